@@ -1,0 +1,477 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (needs /root/reference);
+nothing of the reference (source or bytecode) is written into the repo -- only input /
+expected-output arrays.  Run with:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--large]
+
+What is imported from the reference (all under /root/reference/timit):
+  models/model_ctc.py : CTC_Model, BatchRNN, LayerCNN          (model_ctc.py:13-229)
+  steps/train_ctc.py  : run_epoch                              (train_ctc.py:26-69)
+  utils/data_loader.py: create_input                           (data_loader.py:119-140)
+  utils/ctcDecoder.py : GreedyDecoder, BeamDecoder, Decoder    (ctcDecoder.py:9-192)
+The arithmetic itself lives in torch (2.10.0 CPU here): nn.LSTM/GRU/RNN, BatchNorm1d/2d,
+Conv2d, Linear, LogSoftmax, CTCLoss, Adam -- the fixtures pin that behaviour.
+`editdistance` and `kaldiio` are absent from the image and are stubbed exactly as
+SURVEY.md Appendix C describes.
+"""
+import sys
+sys.dont_write_bytecode = True
+import os, types, json, argparse, io, contextlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+from oracle import synth  # noqa: E402
+
+# ---- stubs for absent third-party modules ------------------------------
+ed = types.ModuleType("editdistance")
+
+
+def _lev(a, b):
+    a, b = list(a), list(b)
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+ed.eval = _lev
+sys.modules["editdistance"] = ed
+sys.modules["kaldiio"] = types.ModuleType("kaldiio")
+sys.path.insert(0, "/root/reference/timit")
+_argv = sys.argv
+sys.argv = [_argv[0]]
+from models.model_ctc import CTC_Model, BatchRNN, LayerCNN  # noqa: E402
+from steps.train_ctc import run_epoch  # noqa: E402
+from utils.data_loader import create_input  # noqa: E402
+from utils.ctcDecoder import GreedyDecoder, BeamDecoder, Decoder  # noqa: E402
+sys.argv = _argv
+
+torch.set_num_threads(8)
+F32 = np.float32
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def save(name, **arrs):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+# ---------------------------------------------------------------------------------------------
+# (1a) recurrent layers: BatchRNN(batch_norm=False, dropout=0) = bare bidirectional nn.{LSTM,GRU,RNN}
+# ---------------------------------------------------------------------------------------------
+def gen_rnn():
+    T, B, I, H = 24, 3, 10, 16
+    for name, cls in (("lstm", nn.LSTM), ("gru", nn.GRU), ("rnn", nn.RNN)):
+        rs = np.random.RandomState(11)
+        layer = BatchRNN(I, H, rnn_type=cls, bidirectional=True, batch_norm=False, dropout=0.0)
+        sd = layer.state_dict()
+        vals = synth.fill_state_dict([(k, v.shape) for k, v in sd.items()], seed=12)
+        layer.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+        layer.train()
+        x = torch.from_numpy(rs.standard_normal((T, B, I)).astype(F32)).requires_grad_(True)
+        dy = torch.from_numpy(rs.standard_normal((T, B, 2 * H)).astype(F32))
+        y = layer(x)
+        y.backward(dy)
+        out = dict(x=t2n(x), dy=t2n(dy), y=t2n(y), dx=t2n(x.grad))
+        for k, p in layer.named_parameters():
+            out["w." + k] = t2n(p)
+            out["g." + k] = t2n(p.grad)
+        save("rnn_" + name, **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# (1b) BatchNorm over (T,B) rows exactly as BatchRNN.forward applies it (model_ctc.py:29-32)
+# ---------------------------------------------------------------------------------------------
+def gen_bn():
+    T, B, C = 13, 5, 24
+    rs = np.random.RandomState(21)
+    bn = nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy((1 + 0.2 * rs.standard_normal(C)).astype(F32)))
+        bn.bias.copy_(torch.from_numpy((0.3 * rs.standard_normal(C)).astype(F32)))
+    out = dict(gamma=t2n(bn.weight), beta=t2n(bn.bias))
+    bn.train()
+    for step in range(2):
+        x = torch.from_numpy((2.0 * rs.standard_normal((T, B, C)) + 0.5).astype(F32)).requires_grad_(True)
+        dy = torch.from_numpy(rs.standard_normal((T, B, C)).astype(F32))
+        bn.zero_grad()
+        y = bn(x.transpose(-1, -2)).transpose(-1, -2)
+        y.backward(dy)
+        out.update({"x%d" % step: t2n(x), "dy%d" % step: t2n(dy), "y%d" % step: t2n(y),
+                    "dx%d" % step: t2n(x.grad), "dgamma%d" % step: t2n(bn.weight.grad),
+                    "dbeta%d" % step: t2n(bn.bias.grad),
+                    "rm%d" % step: t2n(bn.running_mean), "rv%d" % step: t2n(bn.running_var)})
+    bn.eval()
+    xe = torch.from_numpy(rs.standard_normal((T, B, C)).astype(F32))
+    out["x_eval"] = t2n(xe)
+    out["y_eval"] = t2n(bn(xe.transpose(-1, -2)).transpose(-1, -2))
+    save("bn_tb", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# (1c) CNN front-end (LayerCNN x2 + layout shuffle, model_ctc.py:38-68,148-158)
+# ---------------------------------------------------------------------------------------------
+CNN_LAYERS = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
+
+
+def small_cnn_model(rnn_type=nn.LSTM, H=16, layers=1, V=12, act=nn.ReLU, drop=0.0):
+    cnn_param = {"batch_norm": True, "activate_function": act, "layer": CNN_LAYERS}
+    rnn_param = {"rnn_input_size": 40, "rnn_hidden_size": H, "rnn_layers": layers, "rnn_type": rnn_type,
+                 "bidirectional": True, "batch_norm": True}
+    return CTC_Model(add_cnn=True, cnn_param=cnn_param, rnn_param=rnn_param, num_class=V, drop_out=drop)
+
+
+def load_seeded(model, seed):
+    sd = model.state_dict()
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed=seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    return vals
+
+
+def gen_conv():
+    B, T, Fd = 2, 21, 40
+    # NB: the reference can only be constructed with nn.ReLU: LayerCNN passes inplace=True to the
+    # activation class (model_ctc.py:51) and nn.Tanh / nn.Sigmoid raise TypeError on that kwarg.
+    for actname, act in (("relu", nn.ReLU),):
+        rs = np.random.RandomState(31)
+        model = small_cnn_model(act=act)
+        load_seeded(model, 32)
+        model.train()
+        x = torch.from_numpy(rs.standard_normal((B, T, Fd)).astype(F32)).requires_grad_(True)
+        # the reference's own forward code path up to the RNN input (model_ctc.py:148-158)
+        c = model.conv(x.unsqueeze(1))
+        r = c.transpose(1, 2).contiguous()
+        s = r.size()
+        r = r.view(s[0], s[1], s[2] * s[3]).transpose(0, 1).contiguous()
+        d_r = torch.from_numpy(rs.standard_normal(tuple(r.shape)).astype(F32))
+        r.backward(d_r)
+        out = dict(x=t2n(x), conv_out=t2n(c), rnn_in=t2n(r), d_rnn_in=t2n(d_r), dx=t2n(x.grad))
+        for k, p in model.conv.named_parameters():
+            out["w." + k] = t2n(p)
+            out["g." + k] = t2n(p.grad)
+        for k, b in model.conv.named_buffers():
+            out["b." + k] = t2n(b)
+        if actname == "relu":
+            model.eval()
+            with torch.no_grad():
+                c2 = model.conv(x.detach().unsqueeze(1))
+            out["conv_out_eval"] = t2n(c2)
+        save("conv_front_" + actname, **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# (1d) fc = BN1d + Linear(no bias) + log_softmax (model_ctc.py:135-140,165-168)
+# ---------------------------------------------------------------------------------------------
+def gen_fc():
+    T, B, C, V = 9, 4, 32, 62
+    rs = np.random.RandomState(41)
+    rnn_param = {"rnn_input_size": 40, "rnn_hidden_size": C // 2, "rnn_layers": 1, "rnn_type": nn.LSTM,
+                 "bidirectional": True, "batch_norm": True}
+    model = CTC_Model(rnn_param=rnn_param, num_class=V, drop_out=0.0)
+    load_seeded(model, 42)
+    model.train()
+    x = torch.from_numpy(rs.standard_normal((T * B, C)).astype(F32)).requires_grad_(True)
+    z = model.fc(x)
+    lp = model.log_softmax(z.view(T, B, V))
+    dlp = torch.from_numpy(rs.standard_normal((T, B, V)).astype(F32))
+    lp.backward(dlp)
+    _, idx = torch.max(lp, dim=-1)
+    out = dict(x=t2n(x), logits=t2n(z), lp=t2n(lp), dlp=t2n(dlp), dx=t2n(x.grad), argmax=t2n(idx))
+    for k, p in model.fc.named_parameters():
+        out["w." + k] = t2n(p)
+        out["g." + k] = t2n(p.grad)
+    save("fc_lsm", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# (1e) nn.CTCLoss(reduction='sum') as called at train_ctc.py:144,47-48
+# ---------------------------------------------------------------------------------------------
+def gen_ctc():
+    T, B, V = 30, 6, 8
+    rs = np.random.RandomState(51)
+    logits = torch.from_numpy((1.5 * rs.standard_normal((T, B, V))).astype(F32)).requires_grad_(True)
+    targets = np.zeros((B, 7), dtype=np.int64)
+    tgt_len = np.array([5, 7, 0, 3, 6, 1], dtype=np.int64)
+    in_len = np.array([30, 22, 30, 17, 30, 1], dtype=np.int64)
+    targets[0, :5] = [2, 2, 3, 3, 3]            # repeats
+    targets[1, :7] = [1, 5, 7, 6, 6, 2, 4]
+    targets[3, :3] = [4, 5, 4]
+    targets[4, :6] = [3, 3, 3, 3, 3, 3]         # all repeats: needs 11 frames
+    targets[5, :1] = [6]
+    lp = torch.log_softmax(logits, dim=-1)
+    lp.retain_grad()
+    loss_fn = nn.CTCLoss(reduction="sum")
+    tg, il, tl = torch.from_numpy(targets), torch.from_numpy(in_len), torch.from_numpy(tgt_len)
+    loss = loss_fn(lp, tg, il, tl)
+    loss = loss / B
+    loss.backward()
+    nll = nn.CTCLoss(reduction="none")(lp.detach(), tg, il, tl)
+    out = dict(logits=t2n(logits), lp=t2n(lp), targets=targets, in_len=in_len, tgt_len=tgt_len,
+               loss=t2n(loss), nll=t2n(nll), dlp=t2n(lp.grad), dlogits=t2n(logits.grad))
+    # infeasible sample (zero_infinity=False -> +inf loss), kept separate so the finite case stays clean
+    in2 = in_len.copy()
+    in2[4] = 8                                   # 6 repeated labels need 11 frames
+    lp2 = torch.log_softmax(logits.detach(), dim=-1).requires_grad_(True)
+    l2 = loss_fn(lp2, tg, torch.from_numpy(in2), tl) / B
+    l2.backward()
+    nll2 = nn.CTCLoss(reduction="none")(lp2.detach(), tg, torch.from_numpy(in2), tl)
+    out.update(in_len_inf=in2, loss_inf=t2n(l2), nll_inf=t2n(nll2), dlp_inf=t2n(lp2.grad))
+    save("ctc_loss", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# (2) whole model: activations, loss, grads, 3 Adam steps, eval forward
+# ---------------------------------------------------------------------------------------------
+def model_fixture(tag, model, batch, seed_w, steps=3, lr=1e-3, wd=5e-4):
+    vals = load_seeded(model, seed_w)
+    x = torch.from_numpy(batch["x"])
+    frac = torch.from_numpy(batch["frac"])
+    tg = torch.from_numpy(batch["targets"])
+    tl = torch.from_numpy(batch["tgt_len"])
+    B = x.shape[0]
+    loss_fn = nn.CTCLoss(reduction="sum")
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    out = dict(x=batch["x"], frac=batch["frac"], lens=batch["lens"], targets=batch["targets"],
+               tgt_len=batch["tgt_len"], seed_w=np.int64(seed_w))
+    model.train()
+    losses = []
+    for step in range(steps):
+        lp, vis = model(x, visualize=True)
+        out_len = lp.size(0)
+        in_len = (frac * out_len).long()
+        loss = loss_fn(lp, tg, in_len, tl) / B
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["in_len"] = t2n(in_len)
+            out["lp"] = t2n(lp)
+            out["argmax"] = t2n(torch.max(lp, dim=-1)[1])
+            if len(vis) == 4:
+                out["conv_out"] = t2n(vis[1])
+                out["rnn_in"] = t2n(vis[2])
+            for k, p in model.named_parameters():
+                out["g." + k] = t2n(p.grad)
+        losses.append(float(loss.item()))
+        opt.step()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in model.state_dict().items():
+        out["after." + k] = t2n(v)
+    model.eval()
+    with torch.no_grad():
+        lpe = model(x)
+    out["lp_eval_after"] = t2n(lpe)
+    out["argmax_eval_after"] = t2n(torch.max(lpe, dim=-1)[1])
+    save("model_" + tag, **out)
+    return losses
+
+
+def gen_models():
+    V = 62
+    # (a) 2x32 BiLSTM, no CNN
+    b = synth.make_batch(seed=61, B=4, T=48, F=40, V=V, lab_lo=3, lab_hi=8)
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 32, "rnn_layers": 2, "rnn_type": nn.LSTM,
+          "bidirectional": True, "batch_norm": True}
+    print("lstm", model_fixture("lstm2x32", CTC_Model(rnn_param=rp, num_class=V, drop_out=0.0), b, 62))
+    # (b) 2x24 BiGRU
+    rp = dict(rp, rnn_hidden_size=24, rnn_type=nn.GRU)
+    print("gru ", model_fixture("gru2x24", CTC_Model(rnn_param=rp, num_class=V, drop_out=0.0), b, 63))
+    # (c) tanh RNN, unidirectional, no batch_norm (exercises fc.weight naming + 1 direction)
+    rp = dict(rp, rnn_hidden_size=20, rnn_type=nn.RNN, bidirectional=False, batch_norm=False)
+    print("rnn ", model_fixture("rnn2x20_uni_nobn", CTC_Model(rnn_param=rp, num_class=V, drop_out=0.0), b, 64))
+    # (d) CNN + 2x16 BiLSTM; odd T exercises the conv output-size formula
+    b2 = synth.make_batch(seed=65, B=3, T=61, F=40, V=V, lab_lo=3, lab_hi=6)
+    m = small_cnn_model(H=16, layers=2, V=V)
+    print("cnn ", model_fixture("cnn_lstm2x16", m, b2, 66))
+
+
+# ---------------------------------------------------------------------------------------------
+# (3) run_epoch trajectory on the reference's own train loop (train_ctc.py:26-69), cfg1 shape
+# ---------------------------------------------------------------------------------------------
+def gen_run_epoch():
+    V = 62
+    lens = [300, 250, 211, 190, 187, 150, 120, 99]
+    rs = np.random.RandomState(1)
+    feats, labs = [], []
+    for n in lens:
+        feats.append(rs.standard_normal((n, 40)).astype(F32))
+        labs.append(rs.randint(2, V, size=rs.randint(10, 20)).astype(np.int64))
+    batch = create_input([(torch.from_numpy(f), torch.from_numpy(l), "utt%d" % i)
+                          for i, (f, l) in enumerate(zip(feats, labs))])
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 128, "rnn_layers": 2, "rnn_type": nn.LSTM,
+          "bidirectional": True, "batch_norm": True}
+    model = CTC_Model(rnn_param=rp, num_class=V, drop_out=0.0)
+    load_seeded(model, 71)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    loss_fn = nn.CTCLoss(reduction="sum")
+    data = [batch, batch, batch]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        acc, avg = run_epoch(1, model, data, loss_fn, torch.device("cpu"), optimizer=opt, print_every=1,
+                             is_training=True)
+        acc_e, avg_e = run_epoch(1, model, [batch], loss_fn, torch.device("cpu"), optimizer=None,
+                                 print_every=1, is_training=False)
+    log = buf.getvalue()
+    step_losses = [float(l.split("cur_loss = ")[1].split(",")[0]) for l in log.splitlines() if "cur_loss" in l]
+    inputs, frac, targets, tsz, _ = batch
+    save("run_epoch_cfg1", x=t2n(inputs), frac=t2n(frac), targets=t2n(targets), tgt_len=t2n(tsz),
+         lens=np.array(lens), seed_w=np.int64(71), train_acc=np.float64(acc), train_avg_loss=np.float64(avg),
+         eval_acc=np.float64(acc_e), eval_avg_loss=np.float64(avg_e),
+         printed_step_losses=np.array(step_losses, dtype=np.float64))
+    print("run_epoch: train acc %.6f avg %.6f | eval acc %.6f avg %.6f | steps %s" % (acc, avg, acc_e, avg_e, step_losses))
+
+
+# ---------------------------------------------------------------------------------------------
+# (4) length-fraction table: floor(float32(len/Tmax) * T_out) (data_loader.py:137, train_ctc.py:46)
+# ---------------------------------------------------------------------------------------------
+def gen_lengths():
+    rows = []
+    for Tmax in (100, 300, 777, 800, 1200):
+        for T_out in sorted({Tmax, (Tmax + 2 * 1 - 3) // 2 + 1}):
+            lens = np.arange(1, Tmax + 1)
+            frac = torch.zeros(len(lens))
+            for i, n in enumerate(lens):
+                frac[i] = int(n) / Tmax                     # python float -> f32 tensor element
+            frames = (frac.float() * T_out).long().numpy()
+            for n, fr, fv in zip(lens, frames, frac.numpy()):
+                rows.append((int(n), Tmax, T_out, int(fr)))
+    rows = np.array(rows, dtype=np.int64)
+    under = int((rows[:, 3] < (rows[:, 0] * rows[:, 2]) // rows[:, 1]).sum())
+    print("length table: %d rows, %d under-count the exact floor" % (len(rows), under))
+    save("length_table", rows=rows)
+
+
+# ---------------------------------------------------------------------------------------------
+# (5) decoders
+# ---------------------------------------------------------------------------------------------
+def gen_decoders():
+    V = 62
+    i2c = synth.int2char(V)
+    arpa = os.path.join(GOLD, "lm_phone_bg.arpa")
+    synth.write_arpa(arpa, [i2c[i] for i in range(2, V)], seed=7, n_bigrams=600)
+    out = {}
+    meta = {}
+    T, B = 120, 6
+    lens = [120, 97, 64, 110, 33, 81]
+    for regime in ("peaky", "flat"):
+        lp = synth.make_logprobs(seed=81 if regime == "peaky" else 82, T=T, B=B, V=V, regime=regime)
+        lpt = torch.from_numpy(lp)
+        out["lp_" + regime] = lp
+        out["argmax_" + regime] = t2n(torch.max(lpt, dim=-1)[1])
+        g = GreedyDecoder(i2c, space_idx=-1, blank_index=0)
+        meta["greedy_" + regime] = g.decode(lpt, lens)
+        for W in (1, 5, 20):
+            for alpha in (0.0, 0.1):
+                if regime == "flat" and W == 20 and alpha == 0.0:
+                    continue  # slowest combination; (flat,20,0.1) is kept
+                bd = BeamDecoder(i2c, beam_width=W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=alpha)
+                meta["beam_%s_W%d_a%g" % (regime, W, alpha)] = bd.decode(lpt, lens)
+                print("beam", regime, W, alpha, "done")
+    # scoring loop of test_ctc.py:88-109 on the peaky greedy / beam outputs against synthetic labels
+    rs = np.random.RandomState(83)
+    labels = [" ".join(i2c[int(k)] for k in rs.randint(2, V, size=rs.randint(8, 20))) for _ in range(B)]
+    meta["labels"] = labels
+    for key in ("greedy_peaky", "beam_peaky_W5_a0.1"):
+        d = Decoder(i2c, space_idx=-1, blank_index=0)
+        tc = tw = 0
+        for x in range(B):
+            tc += d.cer(meta[key][x], labels[x])
+            tw += d.wer(meta[key][x], labels[x])
+            d.num_word += len(labels[x].split())
+            d.num_char += len(labels[x])
+        meta["score_" + key] = dict(total_cer=tc, total_wer=tw, num_char=d.num_char, num_word=d.num_word,
+                                    CER=float(tc) / d.num_char * 100, WER=float(tw) / d.num_word * 100)
+    # the tiny smoke KAT the reference prints at ctcDecoder.py:195-197
+    meta["kat_convert"] = Decoder("abcde", 1, 2)._convert_to_strings([[1, 2, 1, 0, 3], [1, 2, 1, 1, 1]])
+    meta["lens"] = lens
+    # compute_wer (model_ctc.py:187-202) on the peaky argmax
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 4, "rnn_layers": 1, "rnn_type": nn.LSTM,
+          "bidirectional": True, "batch_norm": False}
+    m = CTC_Model(rnn_param=rp, num_class=V, drop_out=0.0)
+    tg = np.zeros((B, 24), dtype=np.int64)
+    tl = rs.randint(5, 25, size=B)
+    for b in range(B):
+        tg[b, : tl[b]] = rs.randint(2, V, size=tl[b])
+    errs, toks = m.compute_wer(out["argmax_peaky"].T, np.array(lens), tg, tl)
+    out["wer_targets"], out["wer_tgt_len"] = tg, tl
+    meta["compute_wer"] = [int(errs), int(toks)]
+    # legacy KAT matrix (my_863_corpus/steps/BeamSearch.py:130-140; that file does not parse under py3).
+    # Recorded as input data only; expected outputs regenerated with the live timit decoder semantics.
+    kat = np.array([[[0.4, 0.0, 0.6], [0.4, 0.0, 0.6], [0.4, 0.0, 0.6], [0.4, 0.0, 0.6]],
+                    [[0.4, 0.0, 0.6], [0.4, 0.0, 0.6], [0.4, 0.0, 0.6], [0.4, 0.0, 0.6]]], dtype=F32)
+    out["kat_mat"] = kat
+    save("decoders", **out)
+    with open(os.path.join(GOLD, "decoders.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("greedy peaky[0]:", meta["greedy_peaky"][0][:60])
+    print("beam   peaky[0]:", meta["beam_peaky_W5_a0.1"][0][:60])
+
+
+# ---------------------------------------------------------------------------------------------
+# (6) large-shape checksums (BASELINE cfg2/cfg3/cfg4): loss + per-parameter grad norms
+# ---------------------------------------------------------------------------------------------
+def gen_large():
+    res = {}
+    cfgs = {
+        "cfg2": dict(B=32, T=800, V=62, H=320, L=4, rnn=nn.LSTM, cnn=False),
+        "cfg3": dict(B=32, T=800, V=62, H=320, L=4, rnn=nn.LSTM, cnn=True),
+        "cfg4": dict(B=8, T=1200, V=200, H=512, L=5, rnn=nn.GRU, cnn=False),
+    }
+    for name, c in cfgs.items():
+        lab = (60, 100) if name == "cfg4" else (30, 60)
+        b = synth.make_batch(seed=1, B=c["B"], T=c["T"], F=40, V=c["V"], lab_lo=lab[0], lab_hi=lab[1])
+        rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": c["rnn"],
+              "bidirectional": True, "batch_norm": True}
+        if c["cnn"]:
+            cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": CNN_LAYERS}
+            model = CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=0.0)
+        else:
+            model = CTC_Model(rnn_param=rp, num_class=c["V"], drop_out=0.0)
+        load_seeded(model, 91)
+        model.train()
+        x = torch.from_numpy(b["x"])
+        lp = model(x)
+        in_len = (torch.from_numpy(b["frac"]) * lp.size(0)).long()
+        loss = nn.CTCLoss(reduction="sum")(lp, torch.from_numpy(b["targets"]), in_len,
+                                           torch.from_numpy(b["tgt_len"])) / c["B"]
+        loss.backward()
+        r = dict(loss=float(loss.item()), n_params=int(sum(p.numel() for p in model.parameters())),
+                 lp_sum=float(lp.double().sum().item()), lp_abs_mean=float(lp.double().abs().mean().item()),
+                 grad_norm={k: float(p.grad.double().norm().item()) for k, p in model.named_parameters()},
+                 argmax_sum=int(torch.max(lp, dim=-1)[1].sum().item()), shape=dict((k, (v if not isinstance(v, type) else v.__name__)) for k, v in c.items()))
+        res[name] = r
+        print(name, "loss", r["loss"], "params", r["n_params"])
+        with open(os.path.join(GOLD, "large_checksums.json"), "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--large", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
+                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders)
+    if a.large:
+        gen_large()
+    else:
+        for k, fn in steps.items():
+            if a.only and k not in a.only.split(","):
+                continue
+            fn()
