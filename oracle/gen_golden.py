@@ -422,6 +422,19 @@ def gen_decoders():
     print("beam   peaky[0]:", meta["beam_peaky_W5_a0.1"][0][:60])
 
 
+def gen_lm():
+    """get_bi_prob over every (prev,next) class pair from the reference's own LanguageModel (NgramLM.py:65-78)."""
+    import utils.NgramLM as uNgram
+    V = 62
+    i2c = synth.int2char(V)
+    lm = uNgram.LanguageModel(arpa_file=os.path.join(GOLD, "lm_phone_bg.arpa"))
+    tab = np.full((V + 1, V + 1), np.nan)
+    for c1 in range(1, V + 1):
+        for c2 in range(1, V + 1):
+            tab[c1, c2] = lm.get_bi_prob("" if c1 == V else i2c[c1], "" if c2 == V else i2c[c2])
+    save("lm_table", lm_table=tab)
+
+
 # ---------------------------------------------------------------------------------------------
 # (6) large-shape checksums (BASELINE cfg2/cfg3/cfg4): loss + per-parameter grad norms
 # ---------------------------------------------------------------------------------------------
@@ -467,7 +480,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
-                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders)
+                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm)
     if a.large:
         gen_large()
     else:

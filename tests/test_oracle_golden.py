@@ -1,0 +1,189 @@
+"""Pin the oracle (oracle/np_ref.py, oracle/beam_ref.c) against the golden vectors that
+oracle/gen_golden.py captured from the imported reference (torch 2.10 CPU).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_ref as R
+from oracle import beam_ref, synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru", "rnn"])
+def test_rnn_layer(kind):
+    z = load("rnn_" + kind)
+    w = [(z["w.rnn.weight_ih_l0"], z["w.rnn.weight_hh_l0"]),
+         (z["w.rnn.weight_ih_l0_reverse"], z["w.rnn.weight_hh_l0_reverse"])]
+    y, saved = R.birnn_fwd(kind, z["x"], w)
+    assert maxabs(y, z["y"]) < 2e-6
+    dx, grads = R.birnn_bwd(kind, z["x"], w, saved, z["dy"])
+    assert maxabs(dx, z["dx"]) < 5e-6
+    for d, suf in enumerate(["", "_reverse"]):
+        assert maxabs(grads[d][0], z["g.rnn.weight_ih_l0" + suf]) < 2e-5
+        assert maxabs(grads[d][1], z["g.rnn.weight_hh_l0" + suf]) < 2e-5
+
+
+def test_batchnorm_over_tb():
+    z = load("bn_tb")
+    rm, rv = np.zeros_like(z["gamma"], dtype=np.float64), np.ones_like(z["gamma"], dtype=np.float64)
+    for step in range(2):
+        x = z["x%d" % step]
+        T, B, C = x.shape
+        y, mean, var = R.bn_train_fwd(x.reshape(T * B, C), z["gamma"], z["beta"])
+        assert maxabs(y.reshape(T, B, C), z["y%d" % step]) < 3e-6
+        dx, dg, db = R.bn_train_bwd(x.reshape(T * B, C), z["gamma"], mean, var, z["dy%d" % step].reshape(T * B, C))
+        assert maxabs(dx.reshape(T, B, C), z["dx%d" % step]) < 3e-6
+        assert maxabs(dg, z["dgamma%d" % step]) < 2e-5
+        assert maxabs(db, z["dbeta%d" % step]) < 2e-5
+        rm, rv = R.bn_running_update(rm, rv, mean, var, T * B)
+        assert maxabs(rm, z["rm%d" % step]) < 1e-6
+        assert maxabs(rv, z["rv%d" % step]) < 1e-6
+    xe = z["x_eval"]
+    T, B, C = xe.shape
+    ye = R.bn_eval_fwd(xe.reshape(T * B, C), z["gamma"], z["beta"], rm, rv)
+    assert maxabs(ye.reshape(T, B, C), z["y_eval"]) < 3e-6
+
+
+def _conv_front_fwd(z, x):
+    strides = [(1, 2), (2, 2)]
+    acts, stats = [], []
+    h = x[:, None, :, :]
+    for n in range(2):
+        w, b = z["w.%d.conv.weight" % n], z["w.%d.conv.bias" % n]
+        c = R.conv2d_fwd(h, w, b, strides[n], (1, 1))
+        Bn, Cn, Tn, Fn = c.shape
+        c2 = c.transpose(0, 2, 3, 1).reshape(-1, Cn)
+        y, mean, var = R.bn_train_fwd(c2, z["w.%d.batch_norm.weight" % n], z["w.%d.batch_norm.bias" % n])
+        a = np.maximum(y, 0.0).reshape(Bn, Tn, Fn, Cn).transpose(0, 3, 1, 2)
+        acts.append((h, c2, mean, var, y, (Bn, Cn, Tn, Fn)))
+        h = a
+    return h, acts
+
+
+def test_conv_front():
+    z = load("conv_front_relu")
+    out, acts = _conv_front_fwd(z, z["x"].astype(np.float64))
+    assert maxabs(out, z["conv_out"]) < 5e-6
+    r = R.conv_layout_to_rnn(out)
+    assert r.shape == z["rnn_in"].shape and maxabs(r, z["rnn_in"]) < 5e-6
+    # backward
+    strides = [(1, 2), (2, 2)]
+    d = R.conv_layout_from_rnn(z["d_rnn_in"].astype(np.float64), 32)
+    for n in (1, 0):
+        h, c2, mean, var, y, (Bn, Cn, Tn, Fn) = acts[n]
+        d2 = d.transpose(0, 2, 3, 1).reshape(-1, Cn) * (y > 0)
+        dc2, dg, db = R.bn_train_bwd(c2, z["w.%d.batch_norm.weight" % n], mean, var, d2)
+        assert maxabs(dg, z["g.%d.batch_norm.weight" % n]) < 1e-4
+        assert maxabs(db, z["g.%d.batch_norm.bias" % n]) < 1e-4
+        dc = dc2.reshape(Bn, Tn, Fn, Cn).transpose(0, 3, 1, 2)
+        d, dw, dbias = R.conv2d_bwd(h, z["w.%d.conv.weight" % n], strides[n], (1, 1), dc)
+        assert maxabs(dw, z["g.%d.conv.weight" % n]) < 2e-4
+        assert maxabs(dbias, z["g.%d.conv.bias" % n]) < 2e-4
+    assert maxabs(d[:, 0], z["dx"]) < 1e-5
+
+
+def test_fc_logsoftmax_argmax():
+    z = load("fc_lsm")
+    x = z["x"]
+    y, mean, var = R.bn_train_fwd(x, z["w.0.weight"], z["w.0.bias"])
+    logits = y @ z["w.1.weight"].astype(np.float64).T
+    assert maxabs(logits, z["logits"]) < 5e-6
+    T, B, V = z["lp"].shape
+    lp = R.log_softmax(logits.reshape(T, B, V))
+    assert maxabs(lp, z["lp"]) < 5e-6
+    assert np.array_equal(R.argmax_first(z["lp"]), z["argmax"])
+    dlog = R.log_softmax_bwd(lp, z["dlp"].astype(np.float64)).reshape(T * B, V)
+    assert maxabs(dlog.T @ y, z["g.1.weight"]) < 5e-5
+    dy = dlog @ z["w.1.weight"].astype(np.float64)
+    dx, dg, db = R.bn_train_bwd(x, z["w.0.weight"], mean, var, dy)
+    assert maxabs(dx, z["dx"]) < 1e-5
+    assert maxabs(dg, z["g.0.weight"]) < 5e-5
+
+
+def test_ctc_loss_and_grad():
+    z = load("ctc_loss")
+    B = z["lp"].shape[1]
+    nll, grad = R.ctc_loss(z["lp"], z["targets"], z["in_len"], z["tgt_len"])
+    assert np.allclose(nll, z["nll"], rtol=2e-6, atol=2e-5)
+    assert abs(nll.sum() / B - float(z["loss"])) < 1e-4
+    assert maxabs(grad / B, z["dlp"]) < 1e-5   # torch runs the lattice in f32 log-space
+    dlog = R.log_softmax_bwd(z["lp"].astype(np.float64), grad / B)
+    assert maxabs(dlog, z["dlogits"]) < 1e-5
+    # zero beyond each length; rows sum to ~0 after log_softmax backward
+    for b in range(B):
+        assert np.all(grad[z["in_len"][b]:, b] == 0)
+    # infeasible sample -> +inf and NaN rows exactly where torch has them
+    nll2, grad2 = R.ctc_loss(z["lp"], z["targets"], z["in_len_inf"], z["tgt_len"])
+    assert np.isinf(nll2[4]) and np.isinf(z["nll_inf"][4])
+    assert np.array_equal(np.isnan(grad2), np.isnan(z["dlp_inf"]))
+    ok = ~np.isnan(grad2)
+    assert maxabs((grad2 / B)[ok], z["dlp_inf"][ok]) < 1e-5
+
+
+def test_length_table():
+    rows = load("length_table")["rows"]
+    for Tmax in np.unique(rows[:, 1]):
+        for Tout in np.unique(rows[rows[:, 1] == Tmax, 2]):
+            sel = rows[(rows[:, 1] == Tmax) & (rows[:, 2] == Tout)]
+            frac = np.array([np.float32(float(n) / float(Tmax)) for n in sel[:, 0]], dtype=np.float32)
+            assert np.array_equal(R.frames_from_fraction(frac, int(Tout)), sel[:, 3])
+
+
+def test_greedy_and_scoring():
+    z = load("decoders")
+    meta = json.load(open(os.path.join(G, "decoders.json")))
+    i2c = synth.int2char(62)
+    for regime in ("peaky", "flat"):
+        assert np.array_equal(R.argmax_first(z["lp_" + regime]), z["argmax_" + regime])
+        assert R.greedy_strings(z["lp_" + regime], meta["lens"], i2c) == meta["greedy_" + regime]
+    errs, toks = R.compute_wer(z["argmax_peaky"].T, meta["lens"], z["wer_targets"], z["wer_tgt_len"])
+    assert [errs, toks] == meta["compute_wer"]
+    sc = meta["score_greedy_peaky"]
+    tc = sum(R.edit_distance(a, b) for a, b in zip(meta["greedy_peaky"], meta["labels"]))
+    tw = sum(R.edit_distance(a.split(), b.split()) for a, b in zip(meta["greedy_peaky"], meta["labels"]))
+    assert (tc, tw) == (sc["total_cer"], sc["total_wer"])
+
+
+def test_beam_search_strings():
+    z = load("decoders")
+    meta = json.load(open(os.path.join(G, "decoders.json")))
+    i2c = synth.int2char(62)
+    tab = beam_ref.arpa_table(os.path.join(G, "lm_phone_bg.arpa"), i2c)
+    want_tab = load("lm_table")["lm_table"]
+    ok = ~np.isnan(want_tab)
+    assert np.array_equal(ok, ~np.isnan(tab)) and np.array_equal(tab[ok], want_tab[ok])
+    n = 0
+    for key, want in meta.items():
+        if not key.startswith("beam_"):
+            continue
+        _, regime, w, a = key.split("_")
+        lp = z["lp_" + regime]
+        probs = np.exp(lp.astype(np.float32)).transpose(1, 0, 2)   # float32 exp like torch.exp (ctcDecoder.py:190)
+        got = beam_ref.decode_strings(probs, meta["lens"], tab, float(a[1:]), int(w[1:]), i2c)
+        assert got == want, key
+        n += 1
+    assert n >= 10
+
+
+def test_beam_error_paths():
+    i2c = synth.int2char(62)
+    tab = beam_ref.arpa_table(os.path.join(G, "lm_phone_bg.arpa"), i2c)
+    probs = np.full((1, 5, 62), 1e-3, dtype=np.float32)
+    probs[:, :, 0] = 0.95                                   # every frame skipped -> best labelling is ()
+    with pytest.raises(IndexError):
+        beam_ref.decode_strings(probs, [5], tab, 0.1, 5, i2c)
+    probs = np.full((1, 5, 62), 1.0 / 62, dtype=np.float32)
+    probs[0, 2, 7] = 0.0                                    # math.log(0)
+    with pytest.raises(ValueError):
+        beam_ref.decode_strings(probs, [5], tab, 0.1, 5, i2c)
