@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- training-step throughput of the CTC hot path on N x MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg3|cfg4|cfg1] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one synthetic minibatch that is already resident in HBM:
+forward (BN -> BiLSTM x4 -> BN -> Linear -> log_softmax) -> CTC loss (sum)/B -> backward -> one RCCL all-reduce of
+the flat gradient -> fused Adam.  Default workload = BASELINE.json configs[1] ("cfg2": 4x320 BiLSTM + DNN, B=32
+per GPU, T=800, F=40, V=62, dropout 0.1, batch_norm, Adam lr 1e-3 wd 5e-4), weak scaling (fixed per-GPU batch).
+Rank 0 prints ONE JSON line; `value` = acoustic frames/s of the whole job.  `--mode decode` times cfg5 instead
+(beam W=20 + bigram LM over 128 utterances x 800 frames; utterances/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {   # per-GPU shapes
+    "cfg1": dict(B=8, T=300, V=62, H=128, L=2, rnn="LSTM", cnn=False, lab=(10, 35)),
+    "cfg2": dict(B=32, T=800, V=62, H=320, L=4, rnn="LSTM", cnn=False, lab=(30, 60)),
+    "cfg3": dict(B=32, T=800, V=62, H=320, L=4, rnn="LSTM", cnn=True, lab=(30, 60)),
+    "cfg4": dict(B=64, T=1200, V=200, H=512, L=5, rnn="GRU", cnn=False, lab=(60, 100)),
+}
+CNN_LAYERS = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0             # HBM3E spec; ~6300 GB/s measured achievable
+
+
+def gemm_weights(c, feat_in):
+    G = 4 if c["rnn"] == "LSTM" else 3
+    H, L = c["H"], c["L"]
+    w = 0
+    for l in range(L):
+        I = feat_in if l == 0 else 2 * H
+        w += 2 * (G * H * I + G * H * H)
+    return w + 2 * H * c["V"]
+
+
+def build(c, dev, drop_out):
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(nn, c["rnn"]),
+          "bidirectional": True, "batch_norm": True}
+    if c["cnn"]:
+        cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": CNN_LAYERS}
+        m = CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=drop_out)
+    else:
+        m = CTC_Model(rnn_param=rp, num_class=c["V"], drop_out=drop_out)
+    return m.to(dev)
+
+
+def cpu_baseline_train(c, batch, steps=2):
+    """The reference's torch calls re-issued on the host cores (oracle/torch_cpu.py; kind = 'port')."""
+    import torch.nn as tnn
+    from oracle import torch_cpu
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(tnn, c["rnn"]),
+          "bidirectional": True, "batch_norm": True}
+    cp = {"batch_norm": True, "activate_function": tnn.ReLU, "layer": CNN_LAYERS} if c["cnn"] else None
+    torch.manual_seed(1)
+    m = torch_cpu.TorchCpuCTCModel(add_cnn=c["cnn"], cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=0.1)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    x, frac = torch.from_numpy(batch["x"]), torch.from_numpy(batch["frac"])
+    tg, tl = torch.from_numpy(batch["targets"]), torch.from_numpy(batch["tgt_len"])
+    torch_cpu.train_step(m, opt, x, frac, tg, tl)                     # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    for _ in range(steps):
+        torch_cpu.train_step(m, opt, x, frac, tg, tl)
+    dt = (time.time() - t0) / steps
+    return dict(value=c["B"] * c["T"] / dt, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d train steps of the same %dx%dx40 batch through oracle/torch_cpu.py (torch %s CPU, %d threads of %d cores)"
+                       % (steps, c["B"], c["T"], torch.__version__, torch.get_num_threads(), os.cpu_count()),
+                seconds_per_step=dt)
+
+
+def gemm_roofline(dev, c):
+    """HIP-event timing of the dominant MFMA kernel of the step: the time-parallel input projection
+    X[T*B, 2H] * W_ih^T[2H, 4H] (f32 in / f32 accumulate, v_mfma_f32_32x32x2_f32)."""
+    from ctc_pytorch_amd import ops
+    G = 4 if c["rnn"] == "LSTM" else 3
+    M, K, N = c["T"] * c["B"], 2 * c["H"], G * c["H"]
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    C = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        ops.gemm(0, 1, M, N, K, A, K, W, K, C, N)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        ops.gemm(0, 1, M, N, K, A, K, W, K, C, N)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * M * N * K
+    tf = flops / (ms * 1e-3) / 1e12
+    return dict(kernel="gemm_f32_kernel<NT> %dx%dx%d" % (M, N, K), bound="mfma", achieved=tf, peak=PEAK_F32_MFMA_TFLOPS,
+                unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None, us_per_launch=ms * 1e3,
+                algorithmic_flops_per_launch=flops)
+
+
+def recurrence_probe(dev, c):
+    """us per dependent recurrent timestep (one launch = both directions of one layer), forward and backward."""
+    from ctc_pytorch_amd import ops
+    G = 4 if c["rnn"] == "LSTM" else 3
+    cell = {"LSTM": "lstm", "GRU": "gru"}[c["rnn"]]
+    T, B, H = c["T"], c["B"], c["H"]
+    x = torch.randn(T, B, 2 * H, device=dev, requires_grad=True)
+    w = [(torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True),
+         (torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True)]
+    y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
+    y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
+    ev[1].record()
+    y.backward(torch.ones_like(y))
+    ev[2].record()
+    torch.cuda.synchronize()
+    # bytes one forward step launch touches (algorithmic, both directions): W_hh + h_prev + gate slab r/w + c r/w + y
+    step_bytes = 2 * (G * H * H + B * H + 2 * B * G * H + 2 * B * H + B * H) * 4
+    f_us = ev[0].elapsed_time(ev[1]) * 1e3 / T
+    b_us = ev[1].elapsed_time(ev[2]) * 1e3 / T
+    return dict(fwd_layer_us_per_timestep=f_us, bwd_layer_us_per_timestep=b_us, fwd_step_algorithmic_bytes=step_bytes,
+                note="layer time / T, includes the layer's input-projection (fwd) and deferred weight-gradient (bwd) GEMMs")
+
+
+def run_train(args):
+    from ctc_pytorch_amd import nn, parallel
+    from ctc_pytorch_amd.optim import FlatAdam
+    from oracle import synth                      # synthetic inputs only (no arithmetic)
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    c = WORKLOADS[args.workload]
+    torch.manual_seed(1)
+    model = build(c, dev, drop_out=0.1).train()
+    opt = FlatAdam(model, lr=1e-3, weight_decay=5e-4)
+    parallel.broadcast_params(opt.flat)
+    batch = synth.make_batch(seed=1 + rank, B=c["B"], T=c["T"], F=40, V=c["V"], lab_lo=c["lab"][0], lab_hi=c["lab"][1],
+                             full_length=True)
+    x = torch.from_numpy(batch["x"]).to(dev)
+    tg = torch.from_numpy(batch["targets"]).to(dev)
+    tl = torch.from_numpy(batch["tgt_len"]).to(dev)
+    loss_fn = nn.CTCLoss(reduction="sum")
+    global_b = c["B"] * world
+    in_len = None
+    losses = []
+
+    def step():
+        nonlocal in_len
+        out = model(x)
+        if in_len is None:
+            in_len = torch.full((c["B"],), out.size(0), dtype=torch.int64, device=dev)
+        loss = loss_fn(out, tg, in_len, tl) / global_b
+        opt.zero_grad()
+        loss.backward()
+        parallel.allreduce_grads(opt.grad)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(step())
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    last_loss = float(losses[-1]) * world if losses else float("nan")
+    if rank != 0:
+        return
+    frames = c["B"] * c["T"] * world * args.steps
+    value = frames / dt
+    feat_in = 320 if c["cnn"] else 40
+    wts = gemm_weights(c, feat_in)
+    t_frames = c["T"] // 2 if c["cnn"] else c["T"]
+    train_flops_per_step = 3 * 2 * wts * c["B"] * t_frames
+    res = {
+        "metric": "acoustic frames/sec (train), TIMIT-shape 4x320 BiLSTM + CTC" if args.workload == "cfg2" else "acoustic frames/sec (train), " + args.workload,
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d Bi%s + BN + Linear(%d) + CTC, B=%d/GPU, T=%d, F=40%s, dropout 0.1, Adam" % (
+            args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], ", 2-layer CNN front-end" if c["cnn"] else ""),
+            "global_batch": global_b, "seq_len": c["T"], "parallelism": "dp%d" % world, "full_length_utterances": True},
+        "final_loss": last_loss,
+        "model_tflops_per_s": train_flops_per_step * world / (dt / args.steps) / 1e12,
+        "per_gpu_frames_per_s": value / world,
+    }
+    try:
+        res["roofline"] = gemm_roofline(dev, c)
+        res["recurrence"] = recurrence_probe(dev, c)
+    except Exception as e:      # keep the headline line even if a probe fails
+        res["roofline"] = {"error": repr(e)}
+    if not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline_train(c, batch, steps=args.cpu_steps)
+    print(json.dumps(res))
+
+
+def run_decode(args):
+    """cfg5: BeamDecoder W=20 + bigram LM over 128 x (T=800, V=62) log-probs resident in HBM; utterances/s."""
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    from oracle import synth, beam_ref
+    dev = torch.device("cuda", 0)
+    V, T, B, W = 62, 800, 128, 20
+    i2c = synth.int2char(V)
+    arpa = os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")
+    tab = LanguageModel(arpa).table([i2c[i] for i in range(V)])
+    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM, 128 x 800 x 62)", "unit": "utt/s", "n_gpus": 1, "regimes": {}}
+    for regime in ("peaky", "flat"):
+        lp = synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)
+        lens = list(np.random.RandomState(2).randint(400, 801, size=B))
+        x = torch.from_numpy(lp).to(dev)
+        ops.beam_decode(x, lens, tab, 0.1, W)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ids, _, st = ops.beam_decode(x, lens, tab, 0.1, W)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        r = {"value": B / dt, "ms_per_batch": dt * 1e3}
+        nref = 4 if regime == "flat" else 16
+        probs = np.exp(lp[:, :nref, :]).transpose(1, 0, 2)
+        t0 = time.time()
+        want, _, _ = beam_ref.decode_ids(probs, lens[:nref], tab, 0.1, W)
+        r["cpu_baseline"] = {"value": nref / (time.time() - t0), "unit": "utt/s", "cores": 1, "kind": "port",
+                             "sample": "%d utterances through oracle/beam_ref.c (C restatement of BeamSearch.py)" % nref}
+        r["strings_match_oracle"] = [list(map(int, s)) for s in want] == ids[:nref]
+        out["regimes"][regime] = r
+    out["value"] = out["regimes"]["peaky"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="train", choices=["train", "decode"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    a = ap.parse_args()
+    (run_train if a.mode == "train" else run_decode)(a)

@@ -1,0 +1,124 @@
+"""Loader for libctcn.so (the gfx950 HIP kernels behind the C ABI of include/ctcn.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a kernel reports an error
+every op raises (RuntimeError) -- it never silently routes through PyTorch or the oracle.
+
+`build()` cross-compiles all csrc/*.hip for gfx950 with hipcc into ctc_pytorch_amd/libctcn.so (in-tree so
+that it travels with gpurun snapshots).  `import torch` happens before the dlopen on purpose: torch bundles
+its own libamdhip64.so.7 and the dynamic loader then binds libctcn.so to that same runtime (same SONAME),
+so torch streams / device pointers are valid inside the library.
+"""
+import ctypes
+import glob
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the dlopen, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libctcn.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_double, c_size_t, c_u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                      ctypes.c_double, ctypes.c_size_t, ctypes.c_uint64)
+
+# name -> (restype, argtypes); mirrors include/ctcn.h one to one
+P, I, F, D, Z, U = c_void_p, c_int, c_float, c_double, c_size_t, c_u64
+_SIGS = {
+    "ctcn_version": (I, []),
+    "ctcn_last_error": (ctypes.c_char_p, []),
+    "ctcn_device_cus": (I, []),
+    "ctcn_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, F, I, P, Z, P]),
+    "ctcn_transpose01": (I, [P, P, I, I, I, P]),
+    "ctcn_copy_strided4": (I, [P, P, I, I, I, I, Z, Z, Z, Z, P]),
+    "ctcn_relu_fwd": (I, [P, P, Z, P]),
+    "ctcn_relu_bwd": (I, [P, P, P, Z, P]),
+    "ctcn_rnn_scratch_bytes": (Z, [I, I, I, I]),
+    "ctcn_rnn_fwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, Z, P]),
+    "ctcn_rnn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P]),
+    "ctcn_bn_ws_bytes": (Z, [I, I, I]),
+    "ctcn_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, Z, P]),
+    "ctcn_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
+    "ctcn_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P, Z, P]),
+    "ctcn_dropout": (I, [P, P, Z, F, U, U, P]),
+    "ctcn_conv2d_ws_bytes": (Z, [I] * 11),
+    "ctcn_conv2d_fwd": (I, [P, P, P, P] + [I] * 11 + [P]),
+    "ctcn_conv2d_bwd": (I, [P, P, P, P, P, P] + [I] * 11 + [F, P, Z, P]),
+    "ctcn_bctf_to_tbcf": (I, [P, P, I, I, I, I, P]),
+    "ctcn_tbcf_to_bctf": (I, [P, P, I, I, I, I, P]),
+    "ctcn_log_softmax_fwd": (I, [P, P, P, I, I, P]),
+    "ctcn_log_softmax_bwd": (I, [P, P, P, I, I, P]),
+    "ctcn_argmax": (I, [P, P, I, I, P]),
+    "ctcn_ctc_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_ctc_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_sum_f32": (I, [P, P, I, P]),
+    "ctcn_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, P]),
+    "ctcn_greedy_collapse": (I, [P, Z, Z, P, P, P, I, I, I, P]),
+    "ctcn_edit_distance": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_beam_ws_bytes": (Z, [I, I, I, I]),
+    "ctcn_beam_decode": (I, [P, I, P, P, D, I, I, P, P, P, P, I, I, I, P, Z, P]),
+}
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(_CSRC, "*.hip")))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> ctc_pytorch_amd/libctcn.so (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(_CSRC, "*.h")) + [os.path.join(os.path.dirname(_HERE), "include", "ctcn.h")]
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "ctc_pytorch_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+        l = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ctcn_last_error()
+        raise RuntimeError("libctcn %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_WS = {}
+
+
+def workspace(device, nbytes=256 << 20):
+    """Per-device scratch buffer (split-K partials, BN/conv partial sums).  Stream-ordered reuse: every
+    library call consumes its partials before returning control to the same stream's next launch."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf

@@ -1,0 +1,62 @@
+// common.h -- shared helpers for the gfx950 kernels of libctcn.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ctcn.h"
+
+void ctcn_set_error(const char *fmt, ...);
+
+#define CTCN_REQUIRE(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      ctcn_set_error(__VA_ARGS__);       \
+      return CTCN_EINVAL;                \
+    }                                    \
+  } while (0)
+
+#define CTCN_HIP(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      ctcn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+      return CTCN_EHIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+#define CTCN_LAUNCH_CHECK() CTCN_HIP(hipGetLastError())
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t ceil_div_z(size_t a, size_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// round-to-nearest-even f32 -> bf16 (bits)
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}

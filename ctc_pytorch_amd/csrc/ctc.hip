@@ -1,0 +1,341 @@
+// ctc.hip -- log_softmax (+arg-max), CTC alpha/beta lattice and gradient for gfx950.
+//
+// replaces: nn.LogSoftmax(dim=-1) (reference timit/models/model_ctc.py:140,168,181), torch.max(out,-1)
+// (timit/steps/train_ctc.py:51, timit/utils/ctcDecoder.py:163) and nn.CTCLoss(reduction='sum') forward +
+// autograd backward (train_ctc.py:144,47-48,63).  Arithmetic: SURVEY Appendix A.6-A.8; blank = 0,
+// zero_infinity = False (an infeasible utterance gives nll = +inf and NaN gradient rows, as torch).
+//
+// Kernels (all HBM/latency-bound, no MFMA):
+//   log_softmax fwd : one wave per row, lanes over classes, max / sum-exp by wave shuffles; the arg-max
+//                     (lowest index on ties) is taken on the produced log-probs in the same pass.
+//   ctc_alpha/beta  : one workgroup per utterance; the S = 2L+1 lattice states live across the threads,
+//                     alpha_{t-1} / beta_{t+1} in a double-buffered LDS row (neighbour states s-1, s-2 are
+//                     LDS reads), one barrier per frame; the log-prob gather lp[t, ext(s)] of the NEXT frame
+//                     is issued before the current frame's recursion so its latency is hidden.
+//                     alpha is stored (T,B,S) for the backward; beta is folded into it (alpha+beta).
+//   ctc_grad        : fully parallel over (t,b): one wave per frame; blank occupancy by a wave-wide
+//                     log-sum-exp over the even states, label occupancy by a per-class scan of the label
+//                     string (deterministic: fixed order, no atomics).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CTC_THREADS = 256;
+constexpr int CTC_NS = 8;   // lattice states per thread -> S <= 2048 (L <= 1023)
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+template <bool WRITE_LP>
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float *__restrict__ in, float *__restrict__ lp,
+                                                          int32_t *__restrict__ amax, int rows, int V) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *x = in + (size_t)row * V;
+  float m = -INFINITY;
+  for (int c = lane; c < V; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float lse = 0.0f;
+  if (WRITE_LP) {
+    float s = 0.0f;
+    for (int c = lane; c < V; c += 64) s += expf(x[c] - m);
+    s = wave_sum(s);
+    lse = m + logf(s);
+  }
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    const float v = WRITE_LP ? x[c] - lse : x[c];
+    if (WRITE_LP) lp[(size_t)row * V + c] = v;
+    if (better(v, c, bv, bi)) { bv = v; bi = c; }
+  }
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) amax[row] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__restrict__ lp, const float *__restrict__ dlp,
+                                                              float *__restrict__ dx, int rows, int V) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *l = lp + (size_t)row * V, *g = dlp + (size_t)row * V;
+  float s = 0.0f;
+  for (int c = lane; c < V; c += 64) s += g[c];
+  s = wave_sum(s);
+  for (int c = lane; c < V; c += 64) dx[(size_t)row * V + c] = g[c] - expf(l[c]) * s;
+}
+
+__device__ __forceinline__ float lse3(float x0, float x1, float x2) {
+  const float m = fmaxf(x0, fmaxf(x1, x2));
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(x0 - m) + expf(x1 - m) + expf(x2 - m));
+}
+
+// direction: +1 alpha (t = 0..Tb-1, neighbours s-1, s-2), -1 beta (t = Tb-1..0, neighbours s+1, s+2)
+template <int DIR>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
+                                                                  const int64_t *__restrict__ in_len,
+                                                                  const int64_t *__restrict__ tgt_len, float *__restrict__ alpha,
+                                                                  float *__restrict__ nll, int T, int B, int V, int Lmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Smax = 2 * Lmax + 1;
+  const int Tb = (int)in_len[b], L = (int)tgt_len[b];
+  const int S = 2 * L + 1;
+  float *buf0 = smem, *buf1 = smem + Smax;
+  int *ext = reinterpret_cast<int *>(smem + 2 * Smax);
+  for (int s = tid; s < S; s += CTC_THREADS) ext[s] = (s & 1) ? (int)targets[(size_t)b * Lmax + (s >> 1)] : 0;
+  __syncthreads();
+  if (Tb <= 0) {
+    if (DIR > 0 && tid == 0) nll[b] = L == 0 ? 0.0f : INFINITY;
+    return;
+  }
+  // per-thread static state info
+  int my_ext[CTC_NS];
+  bool my_skip[CTC_NS];
+#pragma unroll
+  for (int k = 0; k < CTC_NS; ++k) {
+    const int s = tid + k * CTC_THREADS;
+    my_ext[k] = 0; my_skip[k] = false;
+    if (s < S) {
+      my_ext[k] = ext[s];
+      if (DIR > 0) my_skip[k] = s >= 2 && ext[s] != 0 && ext[s] != ext[s - 2];
+      else my_skip[k] = s + 2 < S && ext[s] != 0 && ext[s] != ext[s + 2];
+    }
+  }
+  const int t_first = DIR > 0 ? 0 : Tb - 1;
+  // frame t_first
+  {
+    const float *lpt = lp + ((size_t)t_first * B + b) * V;
+#pragma unroll
+    for (int k = 0; k < CTC_NS; ++k) {
+      const int s = tid + k * CTC_THREADS;
+      if (s < S) {
+        float v = -INFINITY;
+        if (DIR > 0) { if (s <= 1) v = lpt[my_ext[k]]; }
+        else { if (s >= S - 2) v = lpt[my_ext[k]]; }
+        buf0[s] = v;
+        float *ap = alpha + ((size_t)t_first * B + b) * Smax + s;
+        if (DIR > 0) *ap = v; else *ap += v;
+      }
+    }
+  }
+  __syncthreads();
+  float *prev = buf0, *cur = buf1;
+  float lpn[CTC_NS];   // gathered log-probs of the frame being computed (prefetched one frame ahead)
+  if (Tb > 1) {
+    const int t1 = t_first + DIR;
+    const float *lpt = lp + ((size_t)t1 * B + b) * V;
+#pragma unroll
+    for (int k = 0; k < CTC_NS; ++k) { const int s = tid + k * CTC_THREADS; lpn[k] = s < S ? lpt[my_ext[k]] : 0.0f; }
+  }
+  for (int n = 1; n < Tb; ++n) {
+    const int t = t_first + DIR * n;
+    float lpc[CTC_NS];
+#pragma unroll
+    for (int k = 0; k < CTC_NS; ++k) lpc[k] = lpn[k];
+    if (n + 1 < Tb) {   // prefetch next frame's gather
+      const float *lpt = lp + ((size_t)(t + DIR) * B + b) * V;
+#pragma unroll
+      for (int k = 0; k < CTC_NS; ++k) { const int s = tid + k * CTC_THREADS; lpn[k] = s < S ? lpt[my_ext[k]] : 0.0f; }
+    }
+#pragma unroll
+    for (int k = 0; k < CTC_NS; ++k) {
+      const int s = tid + k * CTC_THREADS;
+      if (s < S) {
+        const float x0 = prev[s];
+        float x1, x2;
+        if (DIR > 0) { x1 = s >= 1 ? prev[s - 1] : -INFINITY; x2 = my_skip[k] ? prev[s - 2] : -INFINITY; }
+        else { x1 = s + 1 < S ? prev[s + 1] : -INFINITY; x2 = my_skip[k] ? prev[s + 2] : -INFINITY; }
+        const float v = lse3(x0, x1, x2) + lpc[k];
+        cur[s] = v;
+        float *ap = alpha + ((size_t)t * B + b) * Smax + s;
+        if (DIR > 0) *ap = v; else *ap += v;
+      }
+    }
+    __syncthreads();
+    float *tmp = prev; prev = cur; cur = tmp;
+  }
+  if (DIR > 0 && tid == 0) {
+    const float l1 = prev[S - 1], l2 = S > 1 ? prev[S - 2] : -INFINITY;
+    const float m = fmaxf(l1, l2);
+    nll[b] = m == -INFINITY ? INFINITY : -(m + logf(expf(l1 - m) + expf(l2 - m)));
+  }
+}
+
+// online log-sum-exp accumulator
+struct Lse {
+  float m, s;
+  __device__ __forceinline__ void add(float x) {
+    if (x == -INFINITY) return;
+    if (x > m) { s = s * expf(m - x) + 1.0f; m = x; }
+    else s += expf(x - m);
+  }
+};
+
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
+                                                       const int64_t *__restrict__ in_len, const int64_t *__restrict__ tgt_len,
+                                                       const float *__restrict__ ab, const float *__restrict__ nll,
+                                                       const float *__restrict__ gscale, float *__restrict__ grad, int T, int B, int V,
+                                                       int Lmax) {
+  const int lane = threadIdx.x & 63;
+  const size_t pair = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= (size_t)T * B) return;
+  const int t = (int)(pair / B), b = (int)(pair - (size_t)t * B);
+  const int Tb = (int)in_len[b], L = (int)tgt_len[b];
+  float *g = grad + pair * V;
+  if (t >= Tb) {
+    for (int c = lane; c < V; c += 64) g[c] = 0.0f;
+    return;
+  }
+  const int Smax = 2 * Lmax + 1;
+  const float *abr = ab + pair * Smax;
+  const float *lpr = lp + pair * V;
+  const float n = nll[b], gs = gscale[0];
+  const int64_t *tg = targets + (size_t)b * Lmax;
+  // blank: even states 0,2,..,2L
+  Lse bl{-INFINITY, 0.0f};
+  for (int j = lane; j <= L; j += 64) bl.add(abr[2 * j]);
+  const float M = wave_max(bl.m);
+  float ssum = bl.m == -INFINITY ? 0.0f : bl.s * expf(bl.m - M);
+  ssum = wave_sum(ssum);
+  const float lcab0 = M == -INFINITY ? -INFINITY : M + logf(ssum);
+  for (int c = lane; c < V; c += 64) {
+    float lcab;
+    if (c == 0) lcab = lcab0;
+    else {
+      Lse a{-INFINITY, 0.0f};
+      for (int j = 0; j < L; ++j)
+        if ((int)tg[j] == c) a.add(abr[2 * j + 1]);
+      lcab = a.m == -INFINITY ? -INFINITY : a.m + logf(a.s);
+    }
+    const float l = lpr[c];
+    g[c] = (expf(l) - expf(lcab + n - l)) * gs;
+  }
+}
+
+__global__ void greedy_collapse_kernel(const int32_t *__restrict__ idx, size_t st_t, size_t st_b, const int32_t *__restrict__ lens,
+                                       int32_t *__restrict__ out_ids, int32_t *__restrict__ out_len, int T, int B, int blank) {
+  // one wave per utterance: 64 frames per iteration, ballot + popcount compaction (order preserving)
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int n = min(max(lens[b], 0), T);
+  int base = 0;
+  for (int t0 = 0; t0 < n; t0 += 64) {
+    const int t = t0 + lane;
+    int k = blank;
+    bool keep = false;
+    if (t < n) {
+      k = idx[t * st_t + b * st_b];
+      keep = k != blank && (t == 0 || k != idx[(t - 1) * st_t + b * st_b]);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (keep) out_ids[(size_t)b * T + base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+    base += __popcll(mask);
+  }
+  if (lane == 0) out_len[b] = base;
+}
+
+// Levenshtein distance between the collapsed prediction a[b,:a_len[b]] (int32) and the label b[b,:b_len[b]] (int64):
+// one lane per utterance, DP row in LDS (row stride ldrow), sequential over the O(La*Lb) cells of its utterance.
+__global__ void edit_distance_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ a_len, const int64_t *__restrict__ bl,
+                                     const int64_t *__restrict__ b_len, int32_t *__restrict__ out, int B, int lda, int ldb, int ldrow) {
+  extern __shared__ int rows[];
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= B) return;
+  int *row = rows + (size_t)threadIdx.x * ldrow;
+  const int la = a_len[u], lb = (int)b_len[u];
+  const int32_t *pa = a + (size_t)u * lda;
+  const int64_t *pb = bl + (size_t)u * ldb;
+  for (int j = 0; j <= lb; ++j) row[j] = j;
+  for (int i = 1; i <= la; ++i) {
+    int diag = row[0];
+    row[0] = i;
+    const int x = pa[i - 1];
+    for (int j = 1; j <= lb; ++j) {
+      const int up = row[j];
+      const int v = min(min(up + 1, row[j - 1] + 1), diag + (x != (int)pb[j - 1]));
+      diag = up;
+      row[j] = v;
+    }
+  }
+  out[u] = row[lb];
+}
+
+}  // namespace
+
+extern "C" int ctcn_edit_distance(const int32_t *a, const int32_t *a_len, const int64_t *b, const int64_t *b_len, int32_t *out,
+                                  int B, int lda, int ldb, int max_b_len, void *stream) {
+  CTCN_REQUIRE(a && a_len && b_len && out && (b || ldb == 0) && B > 0 && max_b_len >= 0, "ctcn_edit_distance: bad args");
+  const int ldrow = max_b_len + 2;
+  int threads = 64;
+  while (threads > 1 && (size_t)threads * ldrow * sizeof(int) > 48 * 1024) threads >>= 1;
+  if ((size_t)threads * ldrow * sizeof(int) > 48 * 1024) { ctcn_set_error("ctcn_edit_distance: label length %d too long", max_b_len); return CTCN_EUNSUPPORTED; }
+  hipLaunchKernelGGL(edit_distance_kernel, dim3(ceil_div(B, threads)), dim3(threads), (size_t)threads * ldrow * sizeof(int),
+                     (hipStream_t)stream, a, a_len, b, b_len, out, B, lda, ldb, ldrow);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_log_softmax_fwd(const float *logits, float *lp, int32_t *argmax, int rows, int V, void *stream) {
+  CTCN_REQUIRE(logits && lp && rows > 0 && V > 0, "ctcn_log_softmax_fwd: bad args");
+  hipLaunchKernelGGL((log_softmax_kernel<true>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, lp, argmax, rows, V);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+extern "C" int ctcn_argmax(const float *lp, int32_t *argmax, int rows, int V, void *stream) {
+  CTCN_REQUIRE(lp && argmax && rows > 0 && V > 0, "ctcn_argmax: bad args");
+  hipLaunchKernelGGL((log_softmax_kernel<false>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, lp, (float *)nullptr, argmax, rows, V);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+extern "C" int ctcn_log_softmax_bwd(const float *lp, const float *dlp, float *dlogits, int rows, int V, void *stream) {
+  CTCN_REQUIRE(lp && dlp && dlogits && rows > 0 && V > 0, "ctcn_log_softmax_bwd: bad args");
+  hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, lp, dlp, dlogits, rows, V);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_ctc_fwd(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len, float *alpha,
+                            float *nll, int T, int B, int V, int Lmax, void *stream) {
+  CTCN_REQUIRE(lp && in_len && tgt_len && alpha && nll && (targets || Lmax == 0), "ctcn_ctc_fwd: null pointer");
+  CTCN_REQUIRE(T > 0 && B > 0 && V > 0 && Lmax >= 0, "ctcn_ctc_fwd: bad dims");
+  if (2 * Lmax + 1 > CTC_THREADS * CTC_NS) { ctcn_set_error("ctcn_ctc_fwd: label length %d > %d unsupported", Lmax, (CTC_THREADS * CTC_NS - 1) / 2); return CTCN_EUNSUPPORTED; }
+  const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
+  hipLaunchKernelGGL((ctc_lattice_kernel<1>), dim3(B), dim3(CTC_THREADS), sm, (hipStream_t)stream, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len, float *alpha,
+                            const float *nll, const float *gscale, float *grad_lp, int T, int B, int V, int Lmax, void *stream) {
+  CTCN_REQUIRE(lp && in_len && tgt_len && alpha && nll && gscale && grad_lp && (targets || Lmax == 0), "ctcn_ctc_bwd: null pointer");
+  CTCN_REQUIRE(T > 0 && B > 0 && V > 0 && Lmax >= 0, "ctcn_ctc_bwd: bad dims");
+  if (2 * Lmax + 1 > CTC_THREADS * CTC_NS) { ctcn_set_error("ctcn_ctc_bwd: label length %d unsupported", Lmax); return CTCN_EUNSUPPORTED; }
+  const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((ctc_lattice_kernel<-1>), dim3(B), dim3(CTC_THREADS), sm, st, lp, targets, in_len, tgt_len, alpha, (float *)nullptr, T, B, V, Lmax);
+  CTCN_LAUNCH_CHECK();
+  const size_t pairs = (size_t)T * B;
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, st, lp, targets, in_len, tgt_len, alpha, nll, gscale, grad_lp, T, B, V, Lmax);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_greedy_collapse(const int32_t *idx, size_t stride_t, size_t stride_b, const int32_t *lens, int32_t *out_ids,
+                                    int32_t *out_len, int T, int B, int blank, void *stream) {
+  CTCN_REQUIRE(idx && lens && out_ids && out_len && T > 0 && B > 0, "ctcn_greedy_collapse: bad args");
+  hipLaunchKernelGGL(greedy_collapse_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, idx, stride_t, stride_b, lens, out_ids, out_len, T, B, blank);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}

@@ -1,0 +1,185 @@
+// elementwise.hip -- dropout (Philox), Adam, small reductions and the CNN<->RNN layout shuffles (gfx950).
+//
+// replaces: nn.Dropout (reference timit/models/model_ctc.py:26,34,58,67), torch.optim.Adam.step
+// (timit/steps/train_ctc.py:145,65), and the transpose/view/transpose sequence of CTC_Model.forward
+// (model_ctc.py:153-158).  All HBM-bound streaming kernels: 16 B per lane, grid-stride, no LDS.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+// Philox4x32-10 (Salmon et al., SC'11): counter = element-group index, key = seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) philox_round(c, k);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
+// y[i] = keep(i) ? x[i]/(1-p) : 0, keep(i) <=> u(i) >= p, u = 24-bit uniform of Philox word (i&3) of group (offset+i)>>2
+__global__ void dropout_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n, float p, float scale,
+                               uint64_t seed, uint64_t offset) {
+  const size_t ngroups = (n + 3) / 4;
+  for (size_t gi = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (size_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(seed, offset + gi, r);
+    const size_t i0 = gi * 4;
+    if (i0 + 3 < n && (((uintptr_t)(x + i0) | (uintptr_t)(y + i0)) & 15) == 0) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + i0);
+      float4 o;
+      o.x = ((r[0] >> 8) * (1.0f / 16777216.0f) >= p) ? v.x * scale : 0.0f;
+      o.y = ((r[1] >> 8) * (1.0f / 16777216.0f) >= p) ? v.y * scale : 0.0f;
+      o.z = ((r[2] >> 8) * (1.0f / 16777216.0f) >= p) ? v.z * scale : 0.0f;
+      o.w = ((r[3] >> 8) * (1.0f / 16777216.0f) >= p) ? v.w * scale : 0.0f;
+      *reinterpret_cast<float4 *>(y + i0) = o;
+    } else {
+      for (int c = 0; c < 4 && i0 + c < n; ++c)
+        y[i0 + c] = ((r[c] >> 8) * (1.0f / 16777216.0f) >= p) ? x[i0 + c] * scale : 0.0f;
+    }
+  }
+}
+
+// torch.optim.Adam (L2-coupled weight decay), SURVEY Appendix A.9
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            size_t n, float step_size, float beta1, float beta2, float eps, float wd, float sqrt_bc2) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    const float gv = g[i] + wd * pv;
+    const float mv = beta1 * m[i] + (1.0f - beta1) * gv;
+    const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+    m[i] = mv; v[i] = vv;
+    p[i] = pv - step_size * (mv / (sqrtf(vv) / sqrt_bc2 + eps));
+  }
+}
+
+__global__ void sum_kernel(const float *__restrict__ x, float *__restrict__ out, int n) {
+  // single workgroup, fixed order: per-thread strided partials (double) -> wave shuffle -> 4 waves
+  __shared__ double s[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += (double)x[i];
+  a = wave_sum_d(a);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(s[0] + s[1] + s[2] + s[3]);
+}
+
+// (B,C,T,F) -> (T,B,C*F): out[((t*B+b)*C + c)*F + f] = in[((b*C+c)*T + t)*F + f]
+__global__ void bctf_to_tbcf_kernel(const float *__restrict__ in, float *__restrict__ out, int B, int C, int T, int F, int to_tbcf) {
+  const size_t total = (size_t)B * C * T * F;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // i enumerates the (T,B,C,F) side so that the strided side is the read (to_tbcf) or the write (from)
+    const int f = i % F;
+    size_t q = i / F;
+    const int c = q % C; q /= C;
+    const int b = q % B;
+    const int t = q / B;
+    const size_t j = (((size_t)b * C + c) * T + t) * F + f;
+    if (to_tbcf) out[i] = in[j]; else out[j] = in[i];
+  }
+}
+
+// generic gather-copy: out contiguous [d0][d1][d2][d3], in element (i0,i1,i2,i3) at in[i0*s0+i1*s1+i2*s2+i3*s3]
+__global__ void copy_strided4_kernel(const float *__restrict__ in, float *__restrict__ out, int d0, int d1, int d2, int d3,
+                                     size_t s0, size_t s1, size_t s2, size_t s3) {
+  const size_t total = (size_t)d0 * d1 * d2 * d3;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int i3 = i % d3;
+    size_t q = i / d3;
+    const int i2 = q % d2; q /= d2;
+    const int i1 = q % d1;
+    const int i0 = q / d1;
+    out[i] = in[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+  }
+}
+
+__global__ void relu_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.0f);
+}
+__global__ void relu_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+}  // namespace
+
+extern "C" int ctcn_copy_strided4(const float *in, float *out, int d0, int d1, int d2, int d3, size_t s0, size_t s1, size_t s2,
+                                  size_t s3, void *stream) {
+  CTCN_REQUIRE(in && out && d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0, "ctcn_copy_strided4: bad args");
+  const size_t total = (size_t)d0 * d1 * d2 * d3;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(copy_strided4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, d0, d1, d2, d3, s0, s1, s2, s3);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+extern "C" int ctcn_relu_fwd(const float *x, float *y, size_t n, void *stream) {
+  CTCN_REQUIRE(x && y, "ctcn_relu_fwd: null pointer");
+  if (n == 0) return CTCN_OK;
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3((int)std::min((size_t)4096, ceil_div_z(n, 256))), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+extern "C" int ctcn_relu_bwd(const float *y, const float *dy, float *dx, size_t n, void *stream) {
+  CTCN_REQUIRE(y && dy && dx, "ctcn_relu_bwd: null pointer");
+  if (n == 0) return CTCN_OK;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)std::min((size_t)4096, ceil_div_z(n, 256))), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uint64_t offset, void *stream) {
+  CTCN_REQUIRE(x && y, "ctcn_dropout: null pointer");
+  CTCN_REQUIRE(p >= 0.0f && p < 1.0f, "ctcn_dropout: p=%f outside [0,1)", (double)p);
+  if (n == 0) return CTCN_OK;
+  const size_t ng = (n + 3) / 4;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(ng, 256));
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, p, 1.0f / (1.0f - p), seed, offset);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, void *stream) {
+  CTCN_REQUIRE(p && g && m && v && step >= 1, "ctcn_adam_step: bad args");
+  if (n == 0) return CTCN_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(n, 256));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)((double)lr / bc1), beta1,
+                     beta2, eps, weight_decay, (float)sqrt(bc2));
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_sum_f32(const float *x, float *out, int n, void *stream) {
+  CTCN_REQUIRE(x && out && n >= 0, "ctcn_sum_f32: bad args");
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_bctf_to_tbcf(const float *in, float *out, int B, int C, int T, int F, void *stream) {
+  CTCN_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && F > 0, "ctcn_bctf_to_tbcf: bad args");
+  const size_t total = (size_t)B * C * T * F;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bctf_to_tbcf_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, B, C, T, F, 1);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+extern "C" int ctcn_tbcf_to_bctf(const float *in, float *out, int B, int C, int T, int F, void *stream) {
+  CTCN_REQUIRE(in && out && B > 0 && C > 0 && T > 0 && F > 0, "ctcn_tbcf_to_bctf: bad args");
+  const size_t total = (size_t)B * C * T * F;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bctf_to_tbcf_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, B, C, T, F, 0);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}

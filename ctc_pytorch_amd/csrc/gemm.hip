@@ -1,0 +1,241 @@
+// gemm.hip -- MFMA GEMM for gfx950 (MI355X).
+//
+// C[M,N] = op(A)[M,K] * op(B)[K,N] + beta*C, row-major, arbitrary M/N/K/strides.
+// replaces: nn.Linear(2H,V,bias=False) (reference timit/models/model_ctc.py:137,166) and the time-parallel
+// input projections X*W_ih^T of nn.LSTM/GRU/RNN (model_ctc.py:33), plus their dgrad/wgrad GEMMs.
+//
+// Design (wave64, 4 SIMDs/CU):
+//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave a 64x64 sub-tile =
+//     2x2 MFMA tiles of v_mfma_f32_32x32x2_f32 (exact f32 == fmaf chain) -> 64 accumulator VGPRs.
+//   * BK=16 K-slab staged through LDS in k-major order ([k][m] / [k][n]) so that a wave's MFMA operand
+//     fetch (lane l reads element (m = l&31, k = l>>5)) is a conflict-free ds_read_b32 of 32 consecutive
+//     floats per half-wave; row pad +4 floats keeps the transposing stores <= 2-way conflicted.
+//   * global -> register -> LDS staging with the next slab's global loads issued before the MFMAs of the
+//     current slab (register prefetch), float4 (16 B/lane) global loads when the operand is 16-B aligned.
+//   * deterministic split-K (grid.z) through a caller-provided workspace + a second reduce pass, used when
+//     the M*N tile grid alone cannot fill the 256 CUs (weight-gradient GEMMs, K = T*B = 25 600).
+//   * XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, so the remap
+//     gives each XCD a contiguous band of M-tiles that share the same B panel in its private L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, PAD = 4;
+
+// ---- global -> registers (8 floats per thread per operand slab) --------------------------------
+// KC: operand element (r, k) at src[(r0+r)*ld + k0+k]  (k contiguous)
+__device__ __forceinline__ void g2r_kc(const float *__restrict__ src, int ld, int r0, int R, int k0, int Kend,
+                                       bool vec, int tid, float (&reg)[8]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + 256 * j;
+    const int r = idx >> 2, kq = (idx & 3) * 4;
+    const int gr = r0 + r, gk = k0 + kq;
+    const float *p = src + (size_t)gr * ld + gk;
+    if (vec && gr < R && gk + 3 < Kend) {
+      const float4 v = *reinterpret_cast<const float4 *>(p);
+      reg[4 * j + 0] = v.x; reg[4 * j + 1] = v.y; reg[4 * j + 2] = v.z; reg[4 * j + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) reg[4 * j + c] = (gr < R && gk + c < Kend) ? p[c] : 0.0f;
+    }
+  }
+}
+__device__ __forceinline__ void r2s_kc(float (*s)[BM + PAD], int tid, const float (&reg)[8]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + 256 * j;
+    const int r = idx >> 2, kq = (idx & 3) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[kq + c][r] = reg[4 * j + c];
+  }
+}
+// MC: operand element (r, k) at src[(k0+k)*ld + r0+r]  (r contiguous)
+__device__ __forceinline__ void g2r_mc(const float *__restrict__ src, int ld, int r0, int R, int k0, int Kend,
+                                       bool vec, int tid, float (&reg)[8]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + 256 * j;
+    const int k = idx >> 5, rq = (idx & 31) * 4;
+    const int gk = k0 + k, gr = r0 + rq;
+    const float *p = src + (size_t)gk * ld + gr;
+    if (vec && gk < Kend && gr + 3 < R) {
+      const float4 v = *reinterpret_cast<const float4 *>(p);
+      reg[4 * j + 0] = v.x; reg[4 * j + 1] = v.y; reg[4 * j + 2] = v.z; reg[4 * j + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) reg[4 * j + c] = (gk < Kend && gr + c < R) ? p[c] : 0.0f;
+    }
+  }
+}
+__device__ __forceinline__ void r2s_mc(float (*s)[BM + PAD], int tid, const float (&reg)[8]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + 256 * j;
+    const int k = idx >> 5, rq = (idx & 31) * 4;
+    *reinterpret_cast<float4 *>(&s[k][rq]) = make_float4(reg[4 * j], reg[4 * j + 1], reg[4 * j + 2], reg[4 * j + 3]);
+  }
+}
+
+// TA: A stored [K][M] (m contiguous).  TB: B stored [N][K] (k contiguous).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ B, int ldb, float *__restrict__ C,
+                                                       int ldc, float beta, int kchunk, float *__restrict__ ws,
+                                                       int tiles_m, int tiles_n, bool vecA, bool vecB) {
+  __shared__ __attribute__((aligned(16))) float sA[BK][BM + PAD];
+  __shared__ __attribute__((aligned(16))) float sB[BK][BN + PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware remap (bijective for any tile count): blocks b, b+8, b+16.. share an XCD/L2.
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;   // consecutive ids walk N first: share the A panel
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  float ra[8], rb[8];
+  auto loadA = [&](int k0) {
+    if (TA) g2r_mc(A, lda, m0, M, k0, kend, vecA, tid, ra);
+    else g2r_kc(A, lda, m0, M, k0, kend, vecA, tid, ra);
+  };
+  auto loadB = [&](int k0) {
+    if (TB) g2r_kc(B, ldb, n0, N, k0, kend, vecB, tid, rb);
+    else g2r_mc(B, ldb, n0, N, k0, kend, vecB, tid, rb);
+  };
+  if (kbeg < kend) {
+    loadA(kbeg);
+    loadB(kbeg);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();   // previous slab fully consumed
+    if (TA) r2s_mc(sA, tid, ra); else r2s_kc(sA, tid, ra);
+    if (TB) r2s_kc(sB, tid, rb); else r2s_mc(sB, tid, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {   // prefetch next slab into registers while the MFMAs run
+      loadA(k0 + BK);
+      loadB(k0 + BK);
+    }
+    const int kl = lane >> 5, ml = lane & 31;
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) {
+      const float a0 = sA[k + kl][wm * 64 + ml], a1 = sA[k + kl][wm * 64 + 32 + ml];
+      const float b0 = sB[k + kl][wn * 64 + ml], b1 = sB[k + kl][wn * 64 + 32 + ml];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float *out = ws ? ws + (size_t)blockIdx.y * M * N : C;
+  const int ldo = ws ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][e];
+          float *p = out + (size_t)row * ldo + col;
+          if (!ws && beta != 0.0f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc,
+                                     int splits, float beta) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * total + i];
+    const size_t m = i / N, n = i - m * N;
+    float *p = C + m * ldc + n;
+    if (beta != 0.0f) s += beta * *p;
+    *p = s;
+  }
+}
+
+__global__ void transpose01_kernel(const float *__restrict__ in, float *__restrict__ out, int A, int B, int C) {
+  // out[b][a][c] = in[a][b][c]
+  const size_t total = (size_t)A * B * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const size_t ab = i / C;
+    const int a = ab % A;     // out index = (b*A + a)*C + c
+    const int b = ab / A;
+    out[i] = in[((size_t)a * B + b) * C + c];
+  }
+}
+
+}  // namespace
+
+extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
+                         int ldb, float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes,
+                         void *stream) {
+  (void)precision;  // bf16-operand mode: see gemm_bf16 (not yet enabled); f32 MFMA is exact
+  CTCN_REQUIRE(M > 0 && N > 0 && K >= 0, "ctcn_gemm: bad dims M=%d N=%d K=%d", M, N, K);
+  CTCN_REQUIRE(A && B && C, "ctcn_gemm: null pointer");
+  CTCN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "ctcn_gemm: leading dim too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
+  const int nt = tiles_m * tiles_n;
+  int splits = 1;
+  if (nt < 256 && K >= 512 && ws && ws_bytes >= (size_t)2 * M * N * sizeof(float)) {
+    splits = ceil_div(512, nt);
+    splits = min(splits, K / 256);
+    splits = min(splits, (int)(ws_bytes / ((size_t)M * N * sizeof(float))));
+    if (splits < 2) splits = 1;
+  }
+  int kchunk = K;
+  if (splits > 1) {
+    kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
+    splits = ceil_div(K, kchunk);
+  }
+  const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+  const bool vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+  float *wsp = splits > 1 ? (float *)ws : nullptr;
+  dim3 grid(nt, splits), block(256);
+#define LAUNCH(TA, TB)                                                                                          \
+  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, \
+                     wsp, tiles_m, tiles_n, vecA, vecB)
+  if (transA) { if (transB) LAUNCH(true, true); else LAUNCH(true, false); }
+  else        { if (transB) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+  CTCN_LAUNCH_CHECK();
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)min((size_t)2048, ceil_div_z(total, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float *)ws, C, M, N, ldc, splits, beta);
+    CTCN_LAUNCH_CHECK();
+  }
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_transpose01(const float *in, float *out, int A, int B, int C, void *stream) {
+  CTCN_REQUIRE(in && out && A > 0 && B > 0 && C > 0, "ctcn_transpose01: bad args");
+  const size_t total = (size_t)A * B * C;
+  const int blocks = (int)min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(transpose01_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, A, B, C);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}

@@ -1,0 +1,239 @@
+// norm.hip -- BatchNorm forward (train / eval) and backward for gfx950, HBM-bound.
+//
+// replaces: nn.BatchNorm1d applied over all T*B rows in BatchRNN.forward (reference
+// timit/models/model_ctc.py:29-32; padded frames included), the fc BatchNorm1d (:136,165-166) and
+// nn.BatchNorm2d + activation(inplace) in LayerCNN.forward (:47,63-64).  Arithmetic: SURVEY Appendix A.3.
+//
+// x is viewed as (outer, C, inner); statistics per channel over outer*inner elements.
+//   inner == 1: rows x C matrix.  Column reductions: a workgroup covers 64 adjacent channels (lanes ->
+//               consecutive channels => coalesced 256-B row segments) x a chunk of rows.
+//   inner  > 1: NCHW.  A workgroup covers one channel x a chunk of the outer dim; lanes run along the
+//               contiguous inner (T*F) dim.
+// Partial sums are float64 and written per chunk; a finalize pass adds them in a fixed order
+// (deterministic, no atomics) and produces mean / rstd / running-stat updates.  The apply and dx passes
+// are single streaming passes (16 B per lane when the shape allows).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+struct Pair { double a, b; };
+
+// value functors --------------------------------------------------------------------------------
+struct StatVal {   // (x, x*x)
+  const float *x;
+  __device__ __forceinline__ Pair operator()(size_t idx, int) const {
+    const double v = x[idx];
+    return {v, v * v};
+  }
+};
+struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu
+  const float *x, *y, *dy, *mean, *rstd;
+  int relu;
+  __device__ __forceinline__ Pair operator()(size_t idx, int c) const {
+    float g = dy[idx];
+    if (relu && !(y[idx] > 0.0f)) g = 0.0f;
+    const float xh = (x[idx] - mean[c]) * rstd[c];
+    return {(double)g, (double)g * (double)xh};
+  }
+};
+
+template <class F>
+__global__ __launch_bounds__(256) void colreduce_rows_kernel(F f, int rows, int C, int rows_per_chunk, double *__restrict__ part) {
+  __shared__ double sa[4][64], sb[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int r = r0 + ry; r < r1; r += 4) {
+      const Pair p = f((size_t)r * C + c, c);
+      a += p.a; b += p.b;
+    }
+  sa[ry][cx] = a; sb[ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    a = sa[0][cx] + sa[1][cx] + sa[2][cx] + sa[3][cx];
+    b = sb[0][cx] + sb[1][cx] + sb[2][cx] + sb[3][cx];
+    part[((size_t)blockIdx.y * C + c) * 2 + 0] = a;
+    part[((size_t)blockIdx.y * C + c) * 2 + 1] = b;
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void colreduce_nchw_kernel(F f, int outer, int C, int inner, int outer_per_chunk, double *__restrict__ part) {
+  __shared__ double sa[4], sb[4];
+  const int c = blockIdx.x;
+  const int o0 = blockIdx.y * outer_per_chunk, o1 = min(outer, o0 + outer_per_chunk);
+  double a = 0.0, b = 0.0;
+  for (int o = o0; o < o1; ++o) {
+    const size_t base = ((size_t)o * C + c) * inner;
+    for (int i = threadIdx.x; i < inner; i += 256) {
+      const Pair p = f(base + i, c);
+      a += p.a; b += p.b;
+    }
+  }
+  a = wave_sum_d(a); b = wave_sum_d(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sa[w] = a; sb[w] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((size_t)blockIdx.y * C + c) * 2 + 0] = sa[0] + sa[1] + sa[2] + sa[3];
+    part[((size_t)blockIdx.y * C + c) * 2 + 1] = sb[0] + sb[1] + sb[2] + sb[3];
+  }
+}
+
+__global__ void bn_finalize_stats_kernel(const double *__restrict__ part, int nchunks, int C, double count, float eps,
+                                         float momentum, float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                         float *__restrict__ rm, float *__restrict__ rv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nchunks; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  const double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm) rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * mean);
+  if (rv) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+  }
+}
+
+__global__ void bn_finalize_bwd_kernel(const double *__restrict__ part, int nchunks, int C, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, float *__restrict__ sums /*[2*C]: sum dy, sum dy*xhat*/,
+                                       float beta_acc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nchunks; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  sums[c] = (float)s; sums[C + c] = (float)ss;
+  if (dbeta) dbeta[c] = (float)s + (beta_acc != 0.0f ? beta_acc * dbeta[c] : 0.0f);
+  if (dgamma) dgamma[c] = (float)ss + (beta_acc != 0.0f ? beta_acc * dgamma[c] : 0.0f);
+}
+
+// y = (x - mean)*rstd*gamma + beta  [relu]
+__global__ void bn_apply_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ rstd_or_var,
+                                float eps, int var_is_variance, size_t total, int C, int inner, int relu) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / inner) % C);
+    const float rs = var_is_variance ? 1.0f / sqrtf(rstd_or_var[c] + eps) : rstd_or_var[c];
+    float v = (x[i] - mean[c]) * rs * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.0f);
+    y[i] = v;
+  }
+}
+
+// dx = gamma*rstd*(dy' - sum(dy')/N - xhat*sum(dy' xhat)/N)
+__global__ void bn_dx_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                             const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+                             const float *__restrict__ sums, float *__restrict__ dx, size_t total, int C, int inner, float inv_n,
+                             int relu) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / inner) % C);
+    float g = dy[i];
+    if (relu && !(y[i] > 0.0f)) g = 0.0f;
+    const float xh = (x[i] - mean[c]) * rstd[c];
+    dx[i] = gamma[c] * rstd[c] * (g - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+  }
+}
+
+int chunks_rows(int rows, int C) {
+  const int colblocks = ceil_div(C, 64);
+  int n = std::max(1, 1024 / colblocks);
+  n = std::min(n, ceil_div(rows, 64));
+  return std::max(n, 1);
+}
+int chunks_nchw(int outer, int C) {
+  int n = std::max(1, 1024 / std::max(C, 1));
+  n = std::min(n, outer);
+  return std::max(n, 1);
+}
+
+template <class F>
+int launch_reduce(F f, int outer, int C, int inner, double *part, int *nchunks_out, hipStream_t st) {
+  if (inner == 1) {
+    const int n = chunks_rows(outer, C);
+    const int rpc = ceil_div(outer, n);
+    const int nn = ceil_div(outer, rpc);
+    hipLaunchKernelGGL((colreduce_rows_kernel<F>), dim3(ceil_div(C, 64), nn), dim3(256), 0, st, f, outer, C, rpc, part);
+    *nchunks_out = nn;
+  } else {
+    const int n = chunks_nchw(outer, C);
+    const int opc = ceil_div(outer, n);
+    const int nn = ceil_div(outer, opc);
+    hipLaunchKernelGGL((colreduce_nchw_kernel<F>), dim3(C, nn), dim3(256), 0, st, f, outer, C, inner, opc, part);
+    *nchunks_out = nn;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t ctcn_bn_ws_bytes(int outer, int C, int inner) {
+  const int n = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C);
+  return align_up((size_t)(n + 1) * C * 2 * sizeof(double), 256) + (size_t)2 * C * sizeof(float);
+}
+
+extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
+                                 float *running_var, float *save_mean, float *save_rstd, int outer, int C, int inner,
+                                 float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && ws, "ctcn_bn_fwd_train: null pointer");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_fwd_train: bad dims");
+  if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_fwd_train: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double *part = (double *)ws;
+  int nchunks = 0;
+  launch_reduce(StatVal{x}, outer, C, inner, part, &nchunks, st);
+  CTCN_LAUNCH_CHECK();
+  const double count = (double)outer * inner;
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nchunks, C, count, eps, momentum,
+                     save_mean, save_rstd, running_mean, running_var);
+  CTCN_LAUNCH_CHECK();
+  const size_t total = (size_t)outer * C * inner;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C,
+                     inner, relu);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_bn_fwd_eval(const float *x, float *y, const float *gamma, const float *beta, const float *running_mean,
+                                const float *running_var, int outer, int C, int inner, float eps, int relu, void *stream) {
+  CTCN_REQUIRE(x && y && gamma && beta && running_mean && running_var, "ctcn_bn_fwd_eval: null pointer");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_fwd_eval: bad dims");
+  const size_t total = (size_t)outer * C * inner;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, running_mean,
+                     running_var, eps, 1, total, C, inner, relu);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_bn_bwd(const float *x, const float *y, const float *dy, const float *gamma, const float *save_mean,
+                           const float *save_rstd, float *dx, float *dgamma, float *dbeta, int outer, int C, int inner,
+                           int relu, float beta_acc, void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && ws, "ctcn_bn_bwd: null pointer");
+  CTCN_REQUIRE(!relu || y, "ctcn_bn_bwd: y required for the fused relu mask");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_bwd: bad dims");
+  if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_bwd: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double *part = (double *)ws;
+  const int nmax = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C);
+  float *sums = (float *)((char *)ws + align_up((size_t)(nmax + 1) * C * 2 * sizeof(double), 256));
+  int nchunks = 0;
+  launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu}, outer, C, inner, part, &nchunks, st);
+  CTCN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nchunks, C, dgamma, dbeta, sums, beta_acc);
+  CTCN_LAUNCH_CHECK();
+  const size_t total = (size_t)outer * C * inner;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, sums, dx, total, C, inner,
+                     (float)(1.0 / ((double)outer * inner)), relu);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}

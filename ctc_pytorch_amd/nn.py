@@ -1,0 +1,178 @@
+"""HIP-backed drop-ins for the `torch.nn` names the reference drivers use.
+
+The reference's train/test scripts do `import torch.nn as nn` and then `from models.model_ctc import *`
+(timit/steps/train_ctc.py:13,16; test_ctc.py:9,13), so whatever `nn` our models.model_ctc exports shadows
+theirs: `nn.CTCLoss(reduction='sum')` (train_ctc.py:144) and `supported_rnn = {'nn.LSTM': nn.LSTM, ...}`
+(:20) resolve to the classes below with the drivers textually unchanged.  Each class subclasses the torch
+module purely as a *parameter container* (same constructor, same init => same-seed equality, identical
+state_dict keys) and replaces `forward` with calls into libctcn.so.  Names not defined here fall through to
+torch.nn (module-level __getattr__).
+"""
+import torch
+import torch.nn as _tnn
+
+from . import ops
+
+Module = _tnn.Module
+Sequential = _tnn.Sequential
+Parameter = _tnn.Parameter
+
+
+def __getattr__(name):          # everything else (init, utils, functional, ...) is plain torch.nn
+    return getattr(_tnn, name)
+
+
+class _RecurrentMixin:
+    _cell = None
+
+    def _check(self):
+        if self.num_layers != 1 or self.bias or self.batch_first or getattr(self, "proj_size", 0):
+            raise NotImplementedError(
+                "ctc_pytorch_amd.nn.%s supports what the reference constructs: num_layers=1, bias=False, "
+                "batch_first=False (model_ctc.py:24-25)" % type(self).__name__)
+        if float(self.dropout) != 0.0:
+            raise NotImplementedError("inter-layer dropout of a 1-layer RNN is a no-op; got dropout=%r" % self.dropout)
+
+    def forward(self, x, hx=None):
+        if hx is not None:
+            raise NotImplementedError("initial state is always zero on the reference path (model_ctc.py:33)")
+        self._check()
+        w1 = (self.weight_ih_l0_reverse, self.weight_hh_l0_reverse) if self.bidirectional else (None, None)
+        y = ops.rnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, w1[0], w1[1], self._cell, self.training)
+        return y, None
+
+    def flatten_parameters(self):
+        return None
+
+
+class LSTM(_RecurrentMixin, _tnn.LSTM):
+    """nn.LSTM(input_size, hidden_size, bidirectional=..., bias=False): gate rows i,f,g,o."""
+    _cell = "lstm"
+
+
+class GRU(_RecurrentMixin, _tnn.GRU):
+    """nn.GRU(..., bias=False): gate rows r,z,n."""
+    _cell = "gru"
+
+
+class RNN(_RecurrentMixin, _tnn.RNN):
+    """nn.RNN(..., bias=False), tanh."""
+    _cell = "tanh"
+
+    def _check(self):
+        super()._check()
+        if self.nonlinearity != "tanh":
+            raise NotImplementedError("only nonlinearity='tanh' (the nn.RNN default the reference uses)")
+
+
+class BatchNorm1d(_tnn.BatchNorm1d):
+    """(N,C) or (N,C,L) input, statistics per channel over N*L -- BatchRNN feeds (T,C,B) views (model_ctc.py:29-32)."""
+
+    fuse_relu = False
+
+    def forward(self, x):
+        if not (self.affine and self.track_running_stats):
+            raise NotImplementedError("affine=True, track_running_stats=True only (nn.BatchNorm1d defaults)")
+        C = self.num_features
+        training = self.training
+        mom = 0.1 if self.momentum is None else self.momentum
+        if training:
+            self.num_batches_tracked += 1
+        if x.dim() == 2:
+            return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], C, 1, training,
+                                  mom, self.eps, self.fuse_relu)
+        if x.dim() != 3 or x.shape[1] != C:
+            raise ValueError("BatchNorm1d expects (N,C) or (N,C,L)")
+        xt = x.transpose(1, 2)                     # (N,L,C)
+        if xt.is_contiguous():                     # the reference's x.transpose(-1,-2) of a (T,B,C) tensor
+            N, Lq = xt.shape[0], xt.shape[1]
+            y = ops.batch_norm(xt, self.weight, self.bias, self.running_mean, self.running_var, N * Lq, C, 1, training, mom,
+                               self.eps, self.fuse_relu)
+            return y.view(N, Lq, C).transpose(1, 2)
+        x = ops.contiguous(x)
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], C, x.shape[2], training,
+                              mom, self.eps, self.fuse_relu)
+
+
+class BatchNorm2d(_tnn.BatchNorm2d):
+    """NCHW, statistics per channel over (B,T,F) (model_ctc.py:47,63)."""
+
+    fuse_relu = False
+
+    def forward(self, x):
+        if not (self.affine and self.track_running_stats):
+            raise NotImplementedError("affine=True, track_running_stats=True only")
+        if x.dim() != 4 or x.shape[1] != self.num_features:
+            raise ValueError("BatchNorm2d expects (B,C,H,W)")
+        if self.training:
+            self.num_batches_tracked += 1
+        mom = 0.1 if self.momentum is None else self.momentum
+        x = ops.contiguous(x)
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], x.shape[1],
+                              x.shape[2] * x.shape[3], self.training, mom, self.eps, self.fuse_relu)
+
+
+class Linear(_tnn.Linear):
+    def forward(self, x):
+        if self.bias is not None:
+            raise NotImplementedError("bias=False only (model_ctc.py:137,139)")
+        shp = x.shape
+        y = ops.linear(x.reshape(-1, shp[-1]), self.weight)
+        return y.view(*shp[:-1], self.out_features)
+
+
+class Conv2d(_tnn.Conv2d):
+    def forward(self, x):
+        if self.groups != 1 or tuple(self.dilation) != (1, 1) or self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise NotImplementedError("plain Conv2d (groups=1, dilation=1, zero padding) only (model_ctc.py:46)")
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+
+
+class ReLU(_tnn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        return ops.relu(x)
+
+
+class Dropout(_tnn.Dropout):
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training)
+
+
+class LogSoftmax(_tnn.Module):
+    def __init__(self, dim=None):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x):
+        if self.dim not in (-1, x.dim() - 1):
+            raise NotImplementedError("LogSoftmax over the last dim only (model_ctc.py:140)")
+        return ops.log_softmax(x)
+
+
+class CTCLoss(_tnn.Module):
+    """nn.CTCLoss(blank=0, reduction='sum', zero_infinity=False) as called at train_ctc.py:144,47."""
+
+    def __init__(self, blank=0, reduction="mean", zero_infinity=False):
+        super().__init__()
+        if blank != 0:
+            raise NotImplementedError("blank index 0 only (data_loader.py:16)")
+        if zero_infinity:
+            raise NotImplementedError("zero_infinity=False only (train_ctc.py:144)")
+        if reduction not in ("sum", "none"):
+            raise NotImplementedError("reduction='sum' (train_ctc.py:144) or 'none'")
+        self.reduction = reduction
+
+    def forward(self, log_probs, targets, input_lengths, target_lengths):
+        return ops.ctc_loss(log_probs, targets, torch.as_tensor(input_lengths), torch.as_tensor(target_lengths), self.reduction)
+
+
+class MaxPool2d(_tnn.Module):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("pooling is configured off on the reference path (ctc_config.yaml:38 `pooling: None`)")
+
+
+MaxPool1d = MaxPool2d

@@ -1,0 +1,569 @@
+"""autograd wrappers around the C ABI of libctcn.so.
+
+Every function here enqueues hand-written gfx950 kernels on torch's current HIP stream; PyTorch is used
+for device memory, autograd bookkeeping and nothing else.  Tensors must live on a ROCm device -- a CPU
+tensor raises (the product has no CPU path; the CPU restatement lives in oracle/ and is test-only).
+"""
+import ctypes
+import threading
+
+import torch
+
+from . import _lib
+
+CELL = {"lstm": 0, "gru": 1, "tanh": 2}
+GATES = {0: 4, 1: 3, 2: 1}
+
+# global numeric mode for the MFMA GEMMs: 0 = exact f32 MFMA, 1 = bf16 operands / f32 accumulate
+_state = threading.local()
+
+
+def set_precision(p):
+    _state.precision = int(p)
+
+
+def get_precision():
+    return getattr(_state, "precision", 0)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ctc_pytorch_amd: tensor on %s -- the HIP path needs a ROCm device tensor "
+                               "(there is no CPU fallback)" % t.device)
+
+
+def _f32c(t):
+    """float32 + contiguous, materialising strided views with the library's own gather kernel."""
+    if t.dtype != torch.float32:
+        raise TypeError("ctc_pytorch_amd: expected float32, got %s" % t.dtype)
+    return t if t.is_contiguous() else contiguous(t)
+
+
+def _gview(p):
+    """Flat-gradient view registered by optim.FlatAdam (backward kernels accumulate into it, beta=1)."""
+    return getattr(p, "_ctcn_grad", None) if p is not None else None
+
+
+def _ws(t):
+    w = _lib.workspace(t.device)
+    return w, ctypes.c_void_p(w.data_ptr()), w.numel()
+
+
+# --------------------------------------------------------------------------------------------------
+# layout
+# --------------------------------------------------------------------------------------------------
+def _copy_strided(src):
+    _need_gpu(src)
+    if src.dim() > 4:
+        raise NotImplementedError("ctc_pytorch_amd.contiguous: rank %d > 4" % src.dim())
+    dims = [1] * (4 - src.dim()) + list(src.shape)
+    strides = [0] * (4 - src.dim()) + list(src.stride())
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    if out.numel():
+        _lib.check(_lib.lib().ctcn_copy_strided4(_ptr(src), _ptr(out), dims[0], dims[1], dims[2], dims[3], strides[0],
+                                                 strides[1], strides[2], strides[3], _lib.stream_ptr()), "copy_strided4")
+    return out
+
+
+class _Contiguous(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _copy_strided(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def contiguous(x):
+    """x.contiguous() through ctcn_copy_strided4 (model_ctc.py:153,158,175)."""
+    if x.is_contiguous():
+        return x
+    if x.dtype != torch.float32:
+        raise TypeError("ctc_pytorch_amd.contiguous: float32 only")
+    return _Contiguous.apply(x)
+
+
+class _BctfToTbcf(torch.autograd.Function):
+    """(B,C,T,F) -> (T,B,C*F): transpose(1,2).view(B,T,C*F).transpose(0,1) of model_ctc.py:153-158 in one pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _f32c(x)
+        B, C, T, Fq = x.shape
+        ctx.shape = (B, C, T, Fq)
+        out = torch.empty((T, B, C * Fq), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ctcn_bctf_to_tbcf(_ptr(x), _ptr(out), B, C, T, Fq, _lib.stream_ptr()), "bctf_to_tbcf")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, T, Fq = ctx.shape
+        g = _f32c(g)
+        out = torch.empty((B, C, T, Fq), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().ctcn_tbcf_to_bctf(_ptr(g), _ptr(out), B, C, T, Fq, _lib.stream_ptr()), "tbcf_to_bctf")
+        return out
+
+
+def bctf_to_tbcf(x):
+    return _BctfToTbcf.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# linear (GEMM)
+# --------------------------------------------------------------------------------------------------
+def gemm(transA, transB, M, N, K, A, lda, Bm, ldb, C, ldc, beta=0.0):
+    _need_gpu(A, Bm, C)
+    w, wp, wn = _ws(C)
+    _lib.check(_lib.lib().ctcn_gemm(int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(Bm), ldb, _ptr(C), ldc, float(beta),
+                                    get_precision(), wp, wn, _lib.stream_ptr()), "gemm")
+    return C
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W^T, W (N,K), no bias  (nn.Linear(bias=False), model_ctc.py:137,166)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_gpu(x, w)
+        ctx.gw_view = _gview(w)
+        x, w = _f32c(x), _f32c(w)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(0, 1, M, N, K, x, K, w, K, y, N)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _f32c(gy)
+        M, K = x.shape
+        N = w.shape[0]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+            gemm(0, 0, M, K, N, gy, N, w, K, gx, K)            # dX = dY * W
+        if ctx.needs_input_grad[1]:
+            if ctx.gw_view is not None:
+                gemm(1, 0, N, K, M, gy, N, x, K, ctx.gw_view, K, beta=1.0)   # dW += dY^T * X into the flat grad buffer
+            else:
+                gw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+                gemm(1, 0, N, K, M, gy, N, x, K, gw, K)        # dW = dY^T * X
+        return gx, gw
+
+
+def linear(x2d, w):
+    return _Linear.apply(x2d, w)
+
+
+# --------------------------------------------------------------------------------------------------
+# recurrent layer
+# --------------------------------------------------------------------------------------------------
+class _RNNLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training):
+        _need_gpu(x, w_ih0, w_hh0, w_ih1, w_hh1)
+        ctx.gviews = [_gview(w) for w in (w_ih0, w_hh0, w_ih1, w_hh1)]
+        x = _f32c(x)
+        ws = [_f32c(w) if w is not None else None for w in (w_ih0, w_hh0, w_ih1, w_hh1)]
+        T, B, I = x.shape
+        G = GATES[cell]
+        H = ws[1].shape[1]
+        dirs = 2 if ws[2] is not None else 1
+        dev = x.device
+        y = torch.empty((T, B, dirs * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((T, B, dirs, G * H), dtype=torch.float32, device=dev)
+        aux = torch.empty((T, B, dirs, H), dtype=torch.float32, device=dev) if cell != 2 else None
+        w, wp, wn = _ws(x)
+        _lib.check(_lib.lib().ctcn_rnn_fwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
+                                           _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
+        ctx.cell, ctx.dims, ctx.has_aux = cell, (T, B, I, H, dirs), aux is not None
+        ctx.consumed = False
+        saved = [x, y, gates] + ([aux] if aux is not None else []) + [t for t in ws if t is not None]
+        ctx.save_for_backward(*saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.consumed:
+            raise RuntimeError("ctc_pytorch_amd RNN layer: backward ran twice (the gate reserve is overwritten in place)")
+        ctx.consumed = True
+        T, B, I, H, dirs = ctx.dims
+        cell = ctx.cell
+        saved = list(ctx.saved_tensors)
+        x, y, gates = saved[:3]
+        k = 3
+        aux = None
+        if ctx.has_aux:
+            aux = saved[3]
+            k = 4
+        wts = saved[k:]
+        w_ih0, w_hh0 = wts[0], wts[1]
+        w_ih1, w_hh1 = (wts[2], wts[3]) if dirs == 2 else (None, None)
+        gy = _f32c(gy)
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gv = ctx.gviews
+        into_flat = gv[0] is not None and gv[1] is not None and (dirs == 1 or (gv[2] is not None and gv[3] is not None))
+        if into_flat:
+            d_ih0, d_hh0, d_ih1, d_hh1 = gv[0], gv[1], (gv[2] if dirs == 2 else None), (gv[3] if dirs == 2 else None)
+        else:
+            d_ih0, d_hh0 = torch.empty_like(w_ih0), torch.empty_like(w_hh0)
+            d_ih1 = torch.empty_like(w_ih1) if dirs == 2 else None
+            d_hh1 = torch.empty_like(w_hh1) if dirs == 2 else None
+        nb = _lib.lib().ctcn_rnn_scratch_bytes(cell, B, H, dirs)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        w, wp, wn = _ws(x)
+        _lib.check(_lib.lib().ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
+                                           _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx), _ptr(d_ih0), _ptr(d_hh0),
+                                           _ptr(d_ih1), _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
+                                           wp, wn, _lib.stream_ptr()), "rnn_bwd")
+        if into_flat:
+            return dx, None, None, None, None, None, None
+        return dx, d_ih0, d_hh0, d_ih1, d_hh1, None, None
+
+
+def rnn_layer(x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training=True):
+    """x (T,B,I) -> y (T,B,dirs*H); cell in {'lstm','gru','tanh'} (nn.LSTM/GRU/RNN, bias=False, model_ctc.py:24-25)."""
+    return _RNNLayer.apply(x, w_ih0, w_hh0, w_ih1, w_hh1, CELL[cell] if isinstance(cell, str) else cell, training)
+
+
+# --------------------------------------------------------------------------------------------------
+# batch norm (+ fused ReLU)
+# --------------------------------------------------------------------------------------------------
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, outer, C, inner, training, momentum, eps, relu):
+        _need_gpu(x, gamma, beta)
+        ctx.gviews = (_gview(gamma), _gview(beta))
+        x = _f32c(x)
+        dev = x.device
+        y = torch.empty_like(x)
+        L = _lib.lib()
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            w, wp, wn = _ws(x)
+            _lib.check(L.ctcn_bn_fwd_train(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(mean), _ptr(rstd),
+                                           outer, C, inner, float(eps), float(momentum), int(relu), wp, wn, _lib.stream_ptr()),
+                       "bn_fwd_train")
+            ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
+            ctx.train_mode = True
+        else:
+            _lib.check(L.ctcn_bn_fwd_eval(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), outer, C, inner, float(eps),
+                                          int(relu), _lib.stream_ptr()), "bn_fwd_eval")
+            ctx.save_for_backward(x, y if relu else None, gamma, rm, rv)
+            ctx.train_mode = False
+        ctx.geom = (outer, C, inner, relu, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        outer, C, inner, relu, eps = ctx.geom
+        x, y, gamma, a, b = ctx.saved_tensors
+        gy = _f32c(gy)
+        dev = x.device
+        if not ctx.train_mode:
+            # eval-mode BN is an affine map: dx = dy' * gamma / sqrt(rv + eps); statistics carry no gradient.
+            raise NotImplementedError("ctc_pytorch_amd: backward through eval-mode BatchNorm is not part of the hot path")
+        dx = torch.empty_like(x)
+        into_flat = ctx.gviews[0] is not None and ctx.gviews[1] is not None
+        if into_flat:
+            dgamma, dbeta = ctx.gviews
+        else:
+            dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        w, wp, wn = _ws(x)
+        _lib.check(_lib.lib().ctcn_bn_bwd(_ptr(x), _ptr(y), _ptr(gy), _ptr(gamma), _ptr(a), _ptr(b), _ptr(dx), _ptr(dgamma),
+                                          _ptr(dbeta), outer, C, inner, int(relu), 1.0 if into_flat else 0.0, wp, wn,
+                                          _lib.stream_ptr()), "bn_bwd")
+        if into_flat:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum=0.1, eps=1e-5, relu=False):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum, eps, relu)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ctcn_relu_fwd(_ptr(x), _ptr(y), x.numel(), _lib.stream_ptr()), "relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _f32c(gy)
+        dx = torch.empty_like(y)
+        _lib.check(_lib.lib().ctcn_relu_bwd(_ptr(y), _ptr(gy), _ptr(dx), y.numel(), _lib.stream_ptr()), "relu_bwd")
+        return dx
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# dropout
+# --------------------------------------------------------------------------------------------------
+_drop_counter = [0]
+
+
+def _next_dropout_stream(n):
+    """(seed, offset): seed follows torch.manual_seed (+ rank so that DP shards decorrelate); the offset
+    advances by the number of Philox groups consumed so that successive calls never reuse counters."""
+    seed = (torch.initial_seed() ^ (0x9E3779B97F4A7C15 * (1 + _rank()))) & 0xFFFFFFFFFFFFFFFF
+    off = _drop_counter[0]
+    _drop_counter[0] += (n + 3) // 4
+    return seed, off
+
+
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _need_gpu(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        seed, off = _next_dropout_stream(x.numel())
+        ctx.rng = (p, seed, off)
+        _lib.check(_lib.lib().ctcn_dropout(_ptr(x), _ptr(y), x.numel(), float(p), seed, off, _lib.stream_ptr()), "dropout")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, seed, off = ctx.rng
+        gy = _f32c(gy)
+        dx = torch.empty_like(gy)
+        _lib.check(_lib.lib().ctcn_dropout(_ptr(gy), _ptr(dx), gy.numel(), float(p), seed, off, _lib.stream_ptr()), "dropout_bwd")
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p == 0.0:
+        return x
+    if p >= 1.0:
+        raise ValueError("dropout p must be < 1")
+    return _Dropout.apply(x, p)
+
+
+# --------------------------------------------------------------------------------------------------
+# conv2d
+# --------------------------------------------------------------------------------------------------
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        _need_gpu(x, w, b)
+        ctx.gviews = (_gview(w), _gview(b))
+        x, w = _f32c(x), _f32c(w)
+        B, Ci, Hi, Wi = x.shape
+        Co, _, kh, kw = w.shape
+        sh, sw = stride
+        ph, pw = padding
+        Ho = (Hi + 2 * ph - kh) // sh + 1
+        Wo = (Wi + 2 * pw - kw) // sw + 1
+        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        ctx.geom = (B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw)
+        _lib.check(_lib.lib().ctcn_conv2d_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(y), *ctx.geom, _lib.stream_ptr()), "conv2d_fwd")
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _f32c(gy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        into_flat = ctx.gviews[0] is not None and (not ctx.has_bias or ctx.gviews[1] is not None)
+        if into_flat:
+            dw, db = ctx.gviews[0], (ctx.gviews[1] if ctx.has_bias else None)
+        else:
+            dw = torch.empty_like(w)
+            db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        ws, wp, wn = _ws(x)
+        _lib.check(_lib.lib().ctcn_conv2d_bwd(_ptr(x), _ptr(w), _ptr(gy), _ptr(dx), _ptr(dw), _ptr(db), *ctx.geom,
+                                              1.0 if into_flat else 0.0, wp, wn, _lib.stream_ptr()), "conv2d_bwd")
+        if into_flat:
+            dw = db = None
+        return dx, dw, db, None, None
+
+
+def conv2d(x, w, b, stride, padding):
+    return _Conv2d.apply(x, w, b, tuple(stride), tuple(padding))
+
+
+# --------------------------------------------------------------------------------------------------
+# log_softmax / argmax / CTC
+# --------------------------------------------------------------------------------------------------
+class _LogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        _need_gpu(z)
+        z = _f32c(z)
+        V = z.shape[-1]
+        rows = z.numel() // V
+        lp = torch.empty_like(z)
+        _lib.check(_lib.lib().ctcn_log_softmax_fwd(_ptr(z), _ptr(lp), None, rows, V, _lib.stream_ptr()), "log_softmax_fwd")
+        ctx.save_for_backward(lp)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g):
+        (lp,) = ctx.saved_tensors
+        g = _f32c(g)
+        V = lp.shape[-1]
+        dz = torch.empty_like(lp)
+        _lib.check(_lib.lib().ctcn_log_softmax_bwd(_ptr(lp), _ptr(g), _ptr(dz), lp.numel() // V, V, _lib.stream_ptr()), "log_softmax_bwd")
+        return dz
+
+
+def log_softmax(z):
+    return _LogSoftmax.apply(z)
+
+
+def argmax_last(lp):
+    """torch.max(lp, -1)[1] (lowest index on ties) as int32 (train_ctc.py:51, ctcDecoder.py:163)."""
+    _need_gpu(lp)
+    lp = _f32c(lp.detach())
+    V = lp.shape[-1]
+    out = torch.empty(lp.shape[:-1], dtype=torch.int32, device=lp.device)
+    _lib.check(_lib.lib().ctcn_argmax(_ptr(lp), _ptr(out), lp.numel() // V, V, _lib.stream_ptr()), "argmax")
+    return out
+
+
+class _CTCLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lp, targets, in_len, tgt_len, reduce_sum):
+        _need_gpu(lp)
+        lp = _f32c(lp)
+        T, B, V = lp.shape
+        dev = lp.device
+        targets = targets.to(device=dev, dtype=torch.int64)
+        if targets.dim() == 1:
+            raise NotImplementedError("ctc_pytorch_amd.CTCLoss: concatenated 1-D targets are not used by the reference "
+                                      "(train_ctc.py:47 passes (B,Lmax)); pass padded 2-D targets")
+        targets = targets.contiguous()
+        in_len = in_len.to(device=dev, dtype=torch.int64).contiguous()
+        tgt_len = tgt_len.to(device=dev, dtype=torch.int64).contiguous()
+        Lmax = targets.shape[1]
+        alpha = torch.empty((T, B, 2 * Lmax + 1), dtype=torch.float32, device=dev)
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        _lib.check(L.ctcn_ctc_fwd(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(nll), T, B, V, Lmax,
+                                  _lib.stream_ptr()), "ctc_fwd")
+        ctx.save_for_backward(lp, targets, in_len, tgt_len, alpha, nll)
+        ctx.dims = (T, B, V, Lmax)
+        ctx.reduce_sum = reduce_sum
+        ctx.consumed = False
+        if not reduce_sum:
+            return nll.clone()
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(L.ctcn_sum_f32(_ptr(nll), _ptr(out), B, _lib.stream_ptr()), "sum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.consumed:
+            raise RuntimeError("ctc_pytorch_amd CTCLoss: backward ran twice (alpha is overwritten with alpha+beta)")
+        ctx.consumed = True
+        lp, targets, in_len, tgt_len, alpha, nll = ctx.saved_tensors
+        T, B, V, Lmax = ctx.dims
+        if not ctx.reduce_sum:
+            raise NotImplementedError("ctc_pytorch_amd.CTCLoss(reduction='none').backward: use reduction='sum' (train_ctc.py:144)")
+        g = g.to(dtype=torch.float32).contiguous()
+        grad = torch.empty_like(lp)
+        _lib.check(_lib.lib().ctcn_ctc_bwd(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(nll), _ptr(g),
+                                           _ptr(grad), T, B, V, Lmax, _lib.stream_ptr()), "ctc_bwd")
+        return grad, None, None, None, None
+
+
+def ctc_loss(lp, targets, in_len, tgt_len, reduction="sum"):
+    if reduction not in ("sum", "none"):
+        raise NotImplementedError("ctc_pytorch_amd.CTCLoss: reduction=%r (the reference uses 'sum', train_ctc.py:144)" % reduction)
+    return _CTCLoss.apply(lp, targets, in_len, tgt_len, reduction == "sum")
+
+
+# --------------------------------------------------------------------------------------------------
+# decode helpers (no autograd)
+# --------------------------------------------------------------------------------------------------
+def greedy_collapse(idx, lens, blank=0, batch_major=False):
+    """idx int32 on device, (T,B) time-major or (B,T) if batch_major (any strides); lens (B)
+    -> (ids (B,T) int32, out_len (B) int32), both on device."""
+    _need_gpu(idx)
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    if batch_major:
+        B, T = idx.shape
+        st_b, st_t = idx.stride()
+    else:
+        T, B = idx.shape
+        st_t, st_b = idx.stride()
+    lens = torch.as_tensor(lens, device=idx.device).to(torch.int32).contiguous()
+    ids = torch.empty((B, T), dtype=torch.int32, device=idx.device)
+    out_len = torch.empty(B, dtype=torch.int32, device=idx.device)
+    _lib.check(_lib.lib().ctcn_greedy_collapse(_ptr(idx), st_t, st_b, _ptr(lens), _ptr(ids), _ptr(out_len), T, B, int(blank),
+                                               _lib.stream_ptr()), "greedy_collapse")
+    return ids, out_len
+
+
+def edit_distance(ids, ids_len, targets, tgt_len):
+    """per-utterance Levenshtein distance (B,) int32 on device (editdistance.eval, model_ctc.py:200)."""
+    _need_gpu(ids)
+    dev = ids.device
+    targets = targets.to(device=dev, dtype=torch.int64).contiguous()
+    tgt_len = tgt_len.to(device=dev, dtype=torch.int64).contiguous()
+    B = ids.shape[0]
+    ldb = targets.shape[1] if targets.dim() == 2 else 0
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().ctcn_edit_distance(_ptr(ids), _ptr(ids_len), _ptr(targets), _ptr(tgt_len), _ptr(out), B, ids.shape[1], ldb,
+                                             max(ldb, 1), _lib.stream_ptr()), "edit_distance")
+    return out
+
+
+def beam_decode(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):
+    """x (T,B,V) float32 device tensor (log-probs, or probabilities if input_is_prob); returns CPU
+    (ids list-of-lists, scores (B,) float64, status (B,) int32).  Synchronises (host result)."""
+    _need_gpu(x_tbv)
+    x = _f32c(x_tbv.detach())
+    T, B, V = x.shape
+    dev = x.device
+    lens_t = torch.as_tensor(lens, dtype=torch.int32, device=dev).contiguous()
+    lm = torch.as_tensor(lm_table, dtype=torch.float64, device=dev).contiguous()
+    if lm.numel() != (V + 1) * (V + 1):
+        raise ValueError("lm table must be (V+1)x(V+1)")
+    L = _lib.lib()
+    nb = L.ctcn_beam_ws_bytes(T, B, V, int(beam_width))
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    out_ids = torch.zeros((B, T), dtype=torch.int32, device=dev)
+    out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    score = torch.zeros(B, dtype=torch.float64, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.check(L.ctcn_beam_decode(_ptr(x), int(bool(input_is_prob)), _ptr(lens_t), _ptr(lm), float(alpha), int(beam_width), int(blank),
+                                  _ptr(out_ids), _ptr(out_len), _ptr(score), _ptr(status), T, B, V, _ptr(ws), ws.numel(),
+                                  _lib.stream_ptr()), "beam_decode")
+    ids_c, len_c = out_ids.cpu().numpy(), out_len.cpu().numpy()
+    return [list(map(int, ids_c[b, : len_c[b]])) for b in range(B)], score.cpu().numpy(), status.cpu().numpy()
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    _need_gpu(p, g, m, v)
+    _lib.check(_lib.lib().ctcn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                         float(eps), float(weight_decay), int(step), _lib.stream_ptr()), "adam_step")

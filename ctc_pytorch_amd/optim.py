@@ -1,0 +1,67 @@
+"""Flat parameter / gradient storage and fused Adam for the HIP path.
+
+replaces: torch.optim.Adam(model.parameters(), lr, weight_decay) as used at the reference's
+timit/steps/train_ctc.py:145,62-65 (L2-coupled weight decay, betas (0.9,0.999), eps 1e-8).
+
+All parameters of the model are re-homed into ONE contiguous float32 buffer and all gradients into a second
+one (288 GB of HBM: no reason to scatter 25 tensors).  The backward kernels of ops.py accumulate weight
+gradients straight into views of the flat gradient buffer (`param._ctcn_grad`), so a training step needs
+  1 memset (zero_grad) + 1 RCCL all-reduce over the flat gradient (data parallel) + 1 fused Adam launch.
+BatchNorm running statistics stay ordinary buffers.
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdam:
+    """Adam over the flattened parameters of `model`; same public surface as torch.optim.Optimizer where the
+    reference touches it: zero_grad(), step(), state_dict(), load_state_dict(), param_groups[i]['lr']."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam: move the model to the ROCm device first (no CPU path)")
+        self.params = params
+        sizes = [p.numel() for p in params]
+        total = sum(sizes)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p, n in zip(params, sizes):
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                g = self.grad[off:off + n].view(p.shape)
+                p._ctcn_grad = g          # ops.py backward kernels accumulate here and return None to autograd
+                p.grad = g
+                off += n
+        self.step_count = 0
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=params)]
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                      self.step_count)
+
+    def state_dict(self):
+        g = self.param_groups[0]
+        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone(),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        for k, v in sd["param_groups"][0].items():
+            self.param_groups[0][k] = v

@@ -1,0 +1,219 @@
+"""Training driver counterpart of the reference's timit/steps/train_ctc.py on the HIP path.
+
+`run_epoch` keeps the reference's signature and semantics (train_ctc.py:26-69): per minibatch forward ->
+length conversion floor(float32(len/Tmax)*T_out) -> CTC loss (sum)/B -> greedy error count BEFORE the update ->
+zero_grad/backward/step; returns (1 - errs/tokens, mean loss).  Differences are only in where work runs:
+arg-max, path collapse and edit distance stay on the GPU (one small D2H of two integers per step instead of
+a (B,T) index matrix + python loops), and the optimiser may be optim.FlatAdam (fused, flat buffers).
+
+`main(conf)` accepts the same YAML keys as timit/conf/ctc_config.yaml and reproduces the dev-loss driven
+LR-halving / best-state rollback / 8-halvings stop rule of train_ctc.py:160-249 without
+visdom (stdout + JSONL).
+"""
+import argparse
+import ast
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from ctc_pytorch_amd import nn, ops, parallel  # noqa: E402
+from ctc_pytorch_amd.models.model_ctc import CTC_Model  # noqa: E402
+from ctc_pytorch_amd.optim import FlatAdam  # noqa: E402
+
+supported_rnn = {"nn.LSTM": nn.LSTM, "nn.GRU": nn.GRU, "nn.RNN": nn.RNN}
+supported_activate = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+
+
+def frames_from_fraction(input_sizes, out_len):
+    """(input_sizes * out_len).long() of train_ctc.py:46 / test_ctc.py:82-83: float32 product, truncation.
+    Host logic on the (B,) CPU vector the loader produced; identical integers to the torch expression."""
+    frac = np.asarray(input_sizes.detach().cpu().numpy() if torch.is_tensor(input_sizes) else input_sizes, dtype=np.float32)
+    return (frac * np.float32(out_len)).astype(np.int64)
+
+
+def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print_every=20, is_training=True,
+              global_batch=None, log=print):
+    model.train() if is_training else model.eval()
+    total_loss = 0.0
+    total_tokens = 0
+    total_errs = 0
+    cur_loss = 0.0
+    n_batches = 0
+    for i, data in enumerate(data_iter):
+        inputs, input_sizes, targets, target_sizes, utt_list = data
+        inputs = inputs.to(device, non_blocking=True)
+        targets_d = targets.to(device, non_blocking=True)
+        target_sizes_d = target_sizes.to(device, non_blocking=True)
+        with torch.set_grad_enabled(is_training):
+            out = model(inputs)
+            out_len, batch_size, _ = out.size()
+            in_len = torch.from_numpy(frames_from_fraction(input_sizes, out_len)).to(device)
+            loss = loss_fn(out, targets_d, in_len, target_sizes_d)
+            loss = loss / (global_batch or batch_size)
+        # greedy error count on the pre-update model, all on device
+        idx = ops.argmax_last(out)                                        # (T,B) int32
+        ids, ids_len = ops.greedy_collapse(idx, in_len, blank=0)
+        dist = ops.edit_distance(ids, ids_len, targets_d, target_sizes_d)
+        if is_training:
+            optimizer.zero_grad()
+            loss.backward()
+            if isinstance(optimizer, FlatAdam):
+                parallel.allreduce_grads(optimizer.grad)
+            optimizer.step()
+        stats = torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]).cpu()
+        lv = float(stats[0])
+        cur_loss += lv
+        total_loss += lv
+        total_errs += int(stats[1])
+        total_tokens += int(stats[2])
+        n_batches = i + 1
+        if (i + 1) % print_every == 0 and is_training:
+            log("Epoch = %d, step = %d, cur_loss = %.4f, total_loss = %.4f, total_wer = %.4f" % (
+                epoch_id, i + 1, cur_loss / print_every, total_loss / (i + 1), total_errs / total_tokens))
+            cur_loss = 0.0
+    average_loss = total_loss / max(n_batches, 1)
+    log("Epoch %d %s done, total_loss: %.4f, total_wer: %.4f" % (epoch_id, "Train" if is_training else "Valid", average_loss,
+                                                                total_errs / max(total_tokens, 1)))
+    return 1 - total_errs / max(total_tokens, 1), average_loss
+
+
+class Config(object):
+    batch_size = 4
+    dropout = 0.1
+
+
+def build_model_from_opts(opts, num_class):
+    rnn_param = {"rnn_input_size": opts.rnn_input_size, "rnn_hidden_size": opts.rnn_hidden_size, "rnn_layers": opts.rnn_layers,
+                 "rnn_type": supported_rnn[opts.rnn_type], "bidirectional": opts.bidirectional, "batch_norm": opts.batch_norm}
+    cnn_param = {}
+    lit = lambda v: ast.literal_eval(v) if isinstance(v, str) else v       # the reference eval()s these YAML strings
+    channel, kernel_size, stride, padding = lit(opts.channel), lit(opts.kernel_size), lit(opts.stride), lit(opts.padding)
+    pooling = lit(opts.pooling)
+    cnn_param["batch_norm"] = opts.batch_norm
+    cnn_param["activate_function"] = supported_activate[opts.activation_function]
+    cnn_param["layer"] = []
+    for layer in range(opts.layers):
+        cnn_param["layer"].append([channel[layer], kernel_size[layer], stride[layer], padding[layer],
+                                   pooling[layer] if pooling is not None else None])
+    return CTC_Model(add_cnn=opts.add_cnn, cnn_param=cnn_param, rnn_param=rnn_param, num_class=num_class, drop_out=opts.drop_out)
+
+
+class LRController:
+    """Dev-loss driven LR halving with best-state rollback (train_ctc.py:160-227)."""
+
+    def __init__(self, end_adjust_acc, decay):
+        self.delta, self.decay = end_adjust_acc, decay
+        self.loss_best = 1000
+        self.loss_best_true = 1000
+        self.adjust_rate_flag = False
+        self.adjust_rate_count = 0
+        self.adjust_time = 0
+        self.acc_best = 0
+        self.stop = False
+        self.model_state = self.op_state = self.best_model_state = self.best_op_state = None
+
+    def begin_epoch(self, optimizer):
+        if self.adjust_rate_flag:
+            self.adjust_rate_flag = False
+            for g in optimizer.param_groups:
+                g["lr"] *= self.decay
+
+    def end_epoch(self, model, optimizer, acc, dev_loss):
+        snap = lambda: (copy.deepcopy(model.state_dict()), copy.deepcopy(optimizer.state_dict()))
+        if dev_loss < (self.loss_best - self.delta):
+            self.loss_best = dev_loss
+            self.loss_best_true = dev_loss
+            self.adjust_rate_count = 0
+            self.model_state, self.op_state = snap()
+        elif dev_loss < self.loss_best + self.delta:
+            self.adjust_rate_count += 1
+            if dev_loss < self.loss_best and dev_loss < self.loss_best_true:
+                self.loss_best_true = dev_loss
+                self.model_state, self.op_state = snap()
+        else:
+            self.adjust_rate_count = 10
+        if acc > self.acc_best:
+            self.acc_best = acc
+            self.best_model_state, self.best_op_state = snap()
+        if self.adjust_rate_count == 10:
+            self.adjust_rate_flag = True
+            self.adjust_time += 1
+            self.adjust_rate_count = 0
+            if self.loss_best > self.loss_best_true:
+                self.loss_best = self.loss_best_true
+            if self.model_state is not None:
+                model.load_state_dict(self.model_state)
+                optimizer.load_state_dict(self.op_state)
+        if self.adjust_time == 8:
+            self.stop = True
+
+
+def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
+    opts = Config()
+    for k, v in conf.items():
+        setattr(opts, k, v)
+    rank, world, local = parallel.init_from_env()
+    device = torch.device("cuda", local)
+    torch.manual_seed(opts.seed)
+    np.random.seed(opts.seed)
+    if train_loader is None:
+        from ctc_pytorch_amd.utils.data_loader import Vocab, SpeechDataset, SpeechDataLoader
+        vocab = Vocab(opts.vocab_file)
+        num_class = vocab.n_words
+        train_loader = SpeechDataLoader(SpeechDataset(vocab, opts.train_scp_path, opts.train_lab_path, opts),
+                                        batch_size=opts.batch_size, shuffle=opts.shuffle_train, num_workers=opts.num_workers)
+        dev_loader = SpeechDataLoader(SpeechDataset(vocab, opts.valid_scp_path, opts.valid_lab_path, opts),
+                                      batch_size=opts.batch_size, shuffle=False, num_workers=opts.num_workers)
+    model = build_model_from_opts(opts, num_class).to(device)
+    log("Number of parameters %d" % sum(p.numel() for p in model.parameters()))
+    loss_fn = nn.CTCLoss(reduction="sum")
+    optimizer = FlatAdam(model, lr=opts.init_lr, weight_decay=opts.weight_decay)
+    parallel.broadcast_params(optimizer.flat)
+    ctl = LRController(opts.end_adjust_acc, opts.lr_decay)
+    loss_results, dev_loss_results, dev_cer_results = [], [], []
+    count = 0
+    start = time.time()
+    while not ctl.stop and count < opts.num_epoches:
+        count += 1
+        ctl.begin_epoch(optimizer)
+        log("Start training epoch: %d, learning_rate: %.5f" % (count, optimizer.param_groups[0]["lr"]))
+        _, loss = run_epoch(count, model, train_loader, loss_fn, device, optimizer=optimizer, print_every=opts.verbose_step,
+                            is_training=True, log=log)
+        acc, dev_loss = run_epoch(count, model, dev_loader, loss_fn, device, optimizer=None, print_every=opts.verbose_step,
+                                  is_training=False, log=log)
+        loss_results.append(loss)
+        dev_loss_results.append(dev_loss)
+        dev_cer_results.append(acc)
+        ctl.end_epoch(model, optimizer, acc, dev_loss)
+        log(json.dumps(dict(epoch=count, train_loss=loss, dev_loss=dev_loss, dev_acc=acc, adjust_time=ctl.adjust_time,
+                            minutes=(time.time() - start) / 60)))
+    if ctl.best_model_state is not None:
+        model.load_state_dict(ctl.best_model_state)
+        optimizer.load_state_dict(ctl.best_op_state)
+    if rank == 0 and getattr(opts, "checkpoint_dir", None):
+        save_dir = os.path.join(opts.checkpoint_dir, opts.exp_name)
+        os.makedirs(save_dir, exist_ok=True)
+        params = {"num_epoches": opts.num_epoches, "end_adjust_acc": opts.end_adjust_acc, "seed": opts.seed, "decay": opts.lr_decay,
+                  "learning_rate": opts.init_lr, "weight_decay": opts.weight_decay, "batch_size": opts.batch_size,
+                  "feature_type": getattr(opts, "feature_type", "fbank"), "n_feats": getattr(opts, "feature_dim", 40), "epoch": count}
+        torch.save(CTC_Model.save_package(model, optimizer=optimizer, epoch=params, loss_results=loss_results,
+                                          dev_loss_results=dev_loss_results, dev_cer_results=dev_cer_results),
+                   os.path.join(save_dir, "ctc_best_model.pkl"))
+    return model, dict(loss=loss_results, dev_loss=dev_loss_results, dev_acc=dev_cer_results)
+
+
+if __name__ == "__main__":
+    import yaml
+    ap = argparse.ArgumentParser(description="cnn_lstm_ctc on MI355X")
+    ap.add_argument("--conf", default="conf/ctc_config.yaml")
+    a = ap.parse_args()
+    main(yaml.safe_load(open(a.conf, "r")))

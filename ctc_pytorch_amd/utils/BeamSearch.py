@@ -1,0 +1,45 @@
+"""CTC prefix beam search -- class surface of the reference's timit/utils/BeamSearch.py (ctcBeamSearch :35-153),
+executed by the gfx950 kernel in csrc/decode.hip (one workgroup per utterance, scores in float64)."""
+import torch
+
+from ctc_pytorch_amd import ops
+
+LOG_ZERO = -99999999.0
+LOG_ONE = 0.0
+
+
+class ctcBeamSearch(object):
+    def __init__(self, classes, beam_width, lm, lm_alpha=0.01, blank_index=0):
+        self.classes = classes
+        self.beamWidth = beam_width
+        self.lm_alpha = lm_alpha
+        self.lm = lm
+        self.blank_index = blank_index
+        self._table = None
+
+    def _lm_table(self):
+        if self._table is None:
+            n = len(self.classes)
+            self._table = self.lm.table([self.classes[i] for i in range(n)], self.blank_index)
+        return self._table
+
+    def decode_ids(self, x_tbv, lens, input_is_prob=False):
+        """x (T,B,V) device tensor -> (list of id lists, float64 scores).  Raises what the reference raises:
+        IndexError when an empty labelling reaches the final LM step (BeamSearch.py:135), ValueError on log(0)."""
+        ids, score, status = ops.beam_decode(x_tbv, lens, self._lm_table(), self.lm_alpha, self.beamWidth, self.blank_index,
+                                             input_is_prob)
+        if (status == 2).any():
+            raise ValueError("math domain error")
+        if (status == 1).any():
+            raise IndexError("tuple index out of range")
+        if (status != 0).any():
+            raise RuntimeError("beam search kernel status %s" % status)
+        return ids, score
+
+    def decode(self, inputs, inputs_list):
+        """inputs: (B,T,V) tensor of probabilities exp(lp) as the reference passes it (ctcDecoder.py:189-191)."""
+        x = inputs.transpose(0, 1)
+        if not x.is_cuda:
+            x = x.to("cuda")
+        ids, _ = self.decode_ids(x, inputs_list, input_is_prob=True)
+        return [" ".join(self.classes[k] for k in seq) for seq in ids]

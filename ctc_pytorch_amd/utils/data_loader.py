@@ -1,0 +1,165 @@
+"""Input pipeline producing the hot path's input contract -- counterpart of the reference's
+timit/utils/data_loader.py (Vocab :13-47, SpeechDataset :50-116, create_input :119-140, SpeechDataLoader
+:148-151) and of the two feature helpers it uses from timit/utils/tools.py (make_context :66-75, skip_feat :77-86).
+
+kaldiio is not available, so Kaldi archives are read by the small binary reader below (uncompressed float /
+double matrices, `scp` entries of the form `utt path:offset`).  Batches have exactly the reference layout:
+(inputs (B,Tmax,F) float32 zero-padded, input_sizes (B) float32 FRACTIONS len/Tmax, targets (B,Lmax) int64
+zero-padded, target_sizes (B) int64, utt_list).
+"""
+import struct
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+
+# ---- Kaldi binary matrix I/O -----------------------------------------------------------------------------
+def _read_token(f):
+    tok = b""
+    while True:
+        c = f.read(1)
+        if c in (b" ", b""):
+            return tok.decode()
+        tok += c
+
+
+def read_kaldi_matrix(path_with_offset):
+    """'file.ark:12345' -> float32 ndarray (rows, cols).  Supports binary 'FM ' and 'DM ' matrices."""
+    if ":" in path_with_offset and not path_with_offset.rsplit(":", 1)[1].strip() == "":
+        path, off = path_with_offset.rsplit(":", 1)
+        off = int(off)
+    else:
+        path, off = path_with_offset, 0
+    with open(path, "rb") as f:
+        f.seek(off)
+        if f.read(2) != b"\0B":
+            raise ValueError("%s: not a binary Kaldi object at offset %d" % (path, off))
+        tok = _read_token(f)
+        if tok not in ("FM", "DM"):
+            raise NotImplementedError("Kaldi matrix type %r (compressed matrices are not supported)" % tok)
+        assert f.read(1) == b"\4"
+        rows = struct.unpack("<i", f.read(4))[0]
+        assert f.read(1) == b"\4"
+        cols = struct.unpack("<i", f.read(4))[0]
+        dt = np.dtype("<f4") if tok == "FM" else np.dtype("<f8")
+        data = np.frombuffer(f.read(rows * cols * dt.itemsize), dtype=dt).reshape(rows, cols)
+    return np.ascontiguousarray(data, dtype=np.float32)
+
+
+def write_kaldi_ark(ark_path, scp_path, mats):
+    """mats: dict utt -> float32 (rows, cols).  Writes a binary ark + scp (as Kaldi copy-feats would)."""
+    with open(ark_path, "wb") as fa, open(scp_path, "w") as fs:
+        for utt, m in mats.items():
+            m = np.ascontiguousarray(m, dtype="<f4")
+            fa.write(utt.encode() + b" ")
+            fs.write("%s %s:%d\n" % (utt, ark_path, fa.tell()))
+            fa.write(b"\0BFM " + b"\4" + struct.pack("<i", m.shape[0]) + b"\4" + struct.pack("<i", m.shape[1]))
+            fa.write(m.tobytes())
+
+
+# ---- feature helpers -------------------------------------------------------------------------------------
+def make_context(feature, left, right):
+    """Splice `left` past and `right` future frames (edge frames repeated) -> (T, (left+1+right)*F)."""
+    if left == 0 and right == 0:
+        return feature
+    T = feature.shape[0]
+    idx = np.arange(T)
+    cols = [feature[np.clip(idx + d, 0, T - 1)] for d in range(-left, right + 1)]
+    return np.hstack(cols)
+
+
+def skip_feat(feature, skip):
+    """Keep every `skip`-th frame starting at 0."""
+    if skip in (0, 1):
+        return feature
+    return feature[::skip]
+
+
+# ---- vocabulary / dataset / collate -----------------------------------------------------------------------
+class Vocab(object):
+    def __init__(self, vocab_file):
+        self.vocab_file = vocab_file
+        self.word2index = {"blank": 0, "UNK": 1}
+        self.index2word = {0: "blank", 1: "UNK"}
+        self.word2count = {}
+        self.n_words = 2
+        self.read_lang()
+
+    def add_sentence(self, sentence):
+        for word in sentence.split(" "):
+            self.add_word(word)
+
+    def add_word(self, word):
+        if word not in self.word2index:
+            self.word2index[word] = self.n_words
+            self.word2count[word] = 1
+            self.index2word[self.n_words] = word
+            self.n_words += 1
+        else:
+            self.word2count[word] += 1
+
+    def read_lang(self):
+        with open(self.vocab_file, "r") as rf:
+            for raw in rf:
+                parts = raw.strip().split(" ")
+                self.add_sentence(" ".join(parts[1:]) if len(parts) > 1 else parts[0])
+
+
+class SpeechDataset(Dataset):
+    def __init__(self, vocab, scp_path, lab_path, opts):
+        self.vocab = vocab
+        self.left_ctx = opts.left_ctx
+        self.right_ctx = opts.right_ctx
+        self.n_skip_frame = opts.n_skip_frame
+        self.n_downsample = opts.n_downsample
+        paths = []
+        with open(scp_path, "r") as rf:
+            for line in rf:
+                utt, path = line.strip().split(" ")
+                paths.append((utt, path))
+        labels = {}
+        unk = vocab.word2index["UNK"]
+        with open(lab_path, "r") as rf:
+            for line in rf:
+                utt, label = line.strip().split(" ", 1)
+                labels[utt] = [vocab.word2index.get(c, unk) for c in label.split()]
+        assert len(paths) == len(labels)
+        self.item = [(path, labels[utt], utt) for utt, path in paths]
+
+    def __getitem__(self, idx):
+        path, label, utt = self.item[idx]
+        feat = skip_feat(make_context(read_kaldi_matrix(path), self.left_ctx, self.right_ctx), self.n_skip_frame)
+        seq_len, dim = feat.shape
+        if seq_len % self.n_downsample != 0:
+            pad_len = self.n_downsample - seq_len % self.n_downsample
+            feat = np.vstack([feat, np.zeros((pad_len, dim), dtype=feat.dtype)])
+        return torch.from_numpy(np.ascontiguousarray(feat)), torch.LongTensor(label), utt
+
+    def __len__(self):
+        return len(self.item)
+
+
+def create_input(batch):
+    tmax = max(x[0].size(0) for x in batch)
+    feat_size = batch[0][0].size(1)
+    lmax = max(x[1].size(0) for x in batch)
+    n = len(batch)
+    data = torch.zeros(n, tmax, feat_size)
+    label = torch.zeros(n, lmax)
+    input_sizes = torch.zeros(n)
+    target_sizes = torch.zeros(n)
+    utt_list = []
+    for i, (feature, lab, utt) in enumerate(batch):
+        data[i, : feature.size(0)] = feature
+        label[i, : lab.size(0)] = lab
+        input_sizes[i] = feature.size(0) / tmax          # python float -> float32 element: the fraction the path consumes
+        target_sizes[i] = lab.size(0)
+        utt_list.append(utt)
+    return data.float(), input_sizes.float(), label.long(), target_sizes.long(), utt_list
+
+
+class SpeechDataLoader(DataLoader):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.collate_fn = create_input

@@ -1,0 +1,176 @@
+/* ctcn.h -- C ABI of libctcn.so: the MI355X (gfx950) CTC acoustic-model hot path.
+ *
+ * The reference (Diamondfan/CTC_pytorch) has no FFI of its own: its seam is the Python class surface
+ * (timit/models/model_ctc.py, timit/utils/ctcDecoder.py, nn.CTCLoss at timit/steps/train_ctc.py:144).
+ * Every entry point below replaces one torch op that surface dispatches; the reference call site it
+ * replaces is cited per function.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, sizes, a HIP stream passed as void* (hipStream_t); no torch types.
+ *   - every function returns int: 0 = OK, <0 = error (CTCN_E*); text via ctcn_last_error() (thread-local).
+ *   - the caller owns every buffer (inputs, outputs, reserve, workspace); the library allocates nothing on
+ *     the device and keeps no pointer past the call; all work is enqueued on `stream` and the call returns
+ *     without synchronising (except where stated).
+ *   - all tensors are dense row-major float32 unless stated; "T,B,C" means time-major (t, b, c).
+ */
+#ifndef CTCN_H
+#define CTCN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTCN_OK 0
+#define CTCN_EINVAL (-1)      /* bad dims / null pointer / misaligned */
+#define CTCN_EHIP (-2)        /* HIP runtime error (message carries hipGetErrorString) */
+#define CTCN_EUNSUPPORTED (-3)
+#define CTCN_EWORKSPACE (-4)  /* workspace too small */
+
+#define CTCN_CELL_LSTM 0 /* gate rows i,f,g,o */
+#define CTCN_CELL_GRU 1  /* gate rows r,z,n */
+#define CTCN_CELL_TANH 2 /* Elman RNN, tanh */
+
+int ctcn_version(void);
+const char *ctcn_last_error(void);
+/* number of CUs of the current device (host query, used to size grids / workspaces) */
+int ctcn_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GEMM (MFMA, f32 in / f32 accumulate: v_mfma_f32_32x32x2_f32; optional bf16-operand mode)
+ * replaces: nn.Linear (model_ctc.py:137,166) and the input-projection part of nn.LSTM/GRU/RNN
+ * (model_ctc.py:33).  C[M,N] = op(A)[M,K] * op(B)[K,N] + beta*C, row-major:
+ *   transA==0: A[m*lda+k]   transA!=0: A[k*lda+m]     transB==0: B[k*ldb+n]   transB!=0: B[n*ldb+k]
+ * ws/ws_bytes: optional split-K workspace (deterministic two-pass reduce); may be NULL/0.
+ * precision: 0 = exact f32 MFMA, 1 = bf16 operands / f32 accumulate. */
+int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+              float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream);
+
+/* out[b,a,c] = in[a,b,c]  (x.transpose(0,1), model_ctc.py:175) */
+int ctcn_transpose01(const float *in, float *out, int A, int B, int C, void *stream);
+/* materialise any <=4-D strided view: out contiguous [d0][d1][d2][d3] = in[i0*s0+i1*s1+i2*s2+i3*s3] (element strides);
+ * the .contiguous() calls of CTC_Model.forward (model_ctc.py:153,158) */
+int ctcn_copy_strided4(const float *in, float *out, int d0, int d1, int d2, int d3, size_t s0, size_t s1, size_t s2,
+                       size_t s3, void *stream);
+/* nn.ReLU when it is not fused into the BatchNorm apply pass (LayerCNN with batch_norm=False, model_ctc.py:64) */
+int ctcn_relu_fwd(const float *x, float *y, size_t n, void *stream);
+int ctcn_relu_bwd(const float *y, const float *dy, float *dx, size_t n, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Recurrent layer, bias-free, 1 layer, 1 or 2 directions, zero initial state, no packing/masking.
+ * replaces: rnn_type(input_size, hidden_size, bidirectional, bias=False)(x)  (model_ctc.py:24-25,33)
+ *   x (T,B,I); w_ih[d] (G*H,I); w_hh[d] (G*H,H); y (T,B,dirs*H) = [fwd | rev]
+ *   gates  (T,B,dirs,G*H): reserve; fwd leaves the saved activations, bwd overwrites it with d(pre-act)
+ *   aux    (T,B,dirs,H)  : reserve; LSTM cell state c / GRU W_hn*h ; unused (may be NULL) for TANH
+ * G = 4 (LSTM) / 3 (GRU) / 1 (TANH).  H must be a multiple of 4. */
+size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs);
+int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
+                 const float *w_hh0, const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux,
+                 int precision, void *ws, size_t ws_bytes, void *stream);
+/* dy (T,B,dirs*H); dx (T,B,I) or NULL; dw_* same shapes as w_*; beta_w: 0 overwrite / 1 accumulate into dw.
+ * scratch: ctcn_rnn_scratch_bytes() bytes (transposed W_hh + carried dh/dc state). */
+int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
+                 const float *w_hh0, const float *w_ih1, const float *w_hh1, const float *y, float *gates,
+                 float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0, float *dw_ih1,
+                 float *dw_hh1, float beta_w, int precision, void *scratch, void *ws, size_t ws_bytes,
+                 void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * BatchNorm, statistics per channel over (outer x inner) elements; x viewed as (outer, C, inner).
+ *   inner==1 : BatchNorm1d over (T*B) rows   (model_ctc.py:29-32, :136,165-166)
+ *   inner>1  : BatchNorm2d on NCHW            (model_ctc.py:47,63)
+ * train fwd: y = gamma*(x-mean)*rstd+beta; saves mean,rstd (C each); updates running stats in place
+ * (momentum 0.1 semantics: rm = (1-mom)*rm + mom*mean; rv uses the unbiased variance).
+ * relu!=0 fuses nn.ReLU (model_ctc.py:64) into the apply pass and its mask into the backward pass.
+ * ws: >= ctcn_bn_ws_bytes(outer, C, inner). */
+size_t ctcn_bn_ws_bytes(int outer, int C, int inner);
+int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
+                      float *running_var, float *save_mean, float *save_rstd, int outer, int C, int inner,
+                      float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream);
+int ctcn_bn_fwd_eval(const float *x, float *y, const float *gamma, const float *beta, const float *running_mean,
+                     const float *running_var, int outer, int C, int inner, float eps, int relu, void *stream);
+/* y is only read when relu!=0 (mask = y>0). dx may alias dy. */
+int ctcn_bn_bwd(const float *x, const float *y, const float *dy, const float *gamma, const float *save_mean,
+                const float *save_rstd, float *dx, float *dgamma, float *dbeta, int outer, int C, int inner,
+                int relu, float beta_acc, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dropout (inverted, Philox4x32-10 counter RNG keyed by (seed, offset + element index)).
+ * replaces: nn.Dropout (model_ctc.py:26,34,58,67).  bwd regenerates the mask from (seed, offset). */
+int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Conv2d (bias) NCHW, direct; replaces nn.Conv2d in LayerCNN (model_ctc.py:46,61).
+ * x (B,Ci,Hi,Wi) w (Co,Ci,kh,kw) y (B,Co,Ho,Wo), Ho=(Hi+2ph-kh)/sh+1.  Co,Ci <= 64, kh*kw <= 25. */
+size_t ctcn_conv2d_ws_bytes(int B, int Ci, int Hi, int Wi, int Co, int kh, int kw, int sh, int sw, int ph, int pw);
+int ctcn_conv2d_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Ci, int Hi, int Wi,
+                    int Co, int kh, int kw, int sh, int sw, int ph, int pw, void *stream);
+int ctcn_conv2d_bwd(const float *x, const float *w, const float *dy, float *dx /*or NULL*/, float *dw,
+                    float *dbias, int B, int Ci, int Hi, int Wi, int Co, int kh, int kw, int sh, int sw, int ph,
+                    int pw, float beta_acc, void *ws, size_t ws_bytes, void *stream);
+/* (B,C,T,F) <-> (T,B,C*F), feature index c*F+f   (model_ctc.py:153-158) */
+int ctcn_bctf_to_tbcf(const float *in, float *out, int B, int C, int T, int F, void *stream);
+int ctcn_tbcf_to_bctf(const float *in, float *out, int B, int C, int T, int F, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * log_softmax over the last dim (+ arg-max, lowest index on ties) and its backward.
+ * replaces: nn.LogSoftmax (model_ctc.py:140,168,181); torch.max(out,-1) (train_ctc.py:51, ctcDecoder.py:163)
+ * argmax (rows) int32 may be NULL. */
+int ctcn_log_softmax_fwd(const float *logits, float *lp, int32_t *argmax, int rows, int V, void *stream);
+int ctcn_log_softmax_bwd(const float *lp, const float *dlp, float *dlogits, int rows, int V, void *stream);
+int ctcn_argmax(const float *lp, int32_t *argmax, int rows, int V, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CTC loss (blank = 0, zero_infinity = False); replaces nn.CTCLoss(reduction='sum') forward/backward
+ * (train_ctc.py:144,47-48,63).  lp (T,B,V) log-probs; targets (B,Lmax) int64 zero-padded;
+ * in_len/tgt_len (B) int64.  alpha: (T,B,2*Lmax+1) reserve.  nll (B): per-utterance negative
+ * log-likelihood (+inf when no alignment exists).
+ * bwd: grad_lp[t,b,c] = gscale[0] * (exp(lp) - exp(logsum_{s:ext(s)=c}(alpha+beta) + nll - lp)) for
+ * t < in_len[b], 0 beyond; gscale is a 1-element DEVICE float (the upstream gradient of the summed loss).
+ * alpha is overwritten with alpha+beta. */
+int ctcn_ctc_fwd(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len,
+                 float *alpha, float *nll, int T, int B, int V, int Lmax, void *stream);
+int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len,
+                 float *alpha, const float *nll, const float *gscale, float *grad_lp, int T, int B, int V,
+                 int Lmax, void *stream);
+/* out[0] = sum_b nll[b]  (deterministic order) */
+int ctcn_sum_f32(const float *x, float *out, int n, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Adam with L2-coupled weight decay over one flat buffer; replaces torch.optim.Adam.step
+ * (train_ctc.py:145,65).  step is the 1-based step count. */
+int ctcn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Greedy decode: collapse of arg-max paths (drop blank, drop frame-to-frame repeats, first lens[b]
+ * frames); replaces GreedyDecoder.decode / CTC_Model.compute_wer inner loops
+ * (ctcDecoder.py:152-166,80-92; model_ctc.py:190-199).  idx int32, element (t,b) at idx[t*stride_t+b*stride_b]
+ * (time-major (T,B): stride_t=B, stride_b=1; batch-major (B,T): stride_t=1, stride_b=T);
+ * out_ids (B,T) int32; out_len (B) int32. */
+int ctcn_greedy_collapse(const int32_t *idx, size_t stride_t, size_t stride_b, const int32_t *lens, int32_t *out_ids,
+                         int32_t *out_len, int T, int B, int blank, void *stream);
+
+/* Levenshtein distance per utterance between collapsed predictions a (B,lda) int32 / a_len (B) int32 and labels
+ * b (B,ldb) int64 / b_len (B) int64 -> out (B) int32; replaces editdistance.eval in CTC_Model.compute_wer
+ * (model_ctc.py:200).  max_b_len >= max(b_len). */
+int ctcn_edit_distance(const int32_t *a, const int32_t *a_len, const int64_t *b, const int64_t *b_len, int32_t *out, int B,
+                       int lda, int ldb, int max_b_len, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CTC prefix beam search with bigram LM; replaces BeamDecoder.decode -> ctcBeamSearch.decode
+ * (ctcDecoder.py:181-192; BeamSearch.py:73-153).  One workgroup per utterance.
+ *   x (T,B,V) float32: log-probs (input_is_prob==0, exp taken on device) or probabilities exp(lp)
+ *   lens (B) int32; lm ((V+1)*(V+1)) float64 ln-probs, row V = '<s>', column V = '</s>'
+ *   out_ids (B,T) int32, out_len (B) int32, out_score (B) float64 (length-normalised prTotal)
+ *   status (B) int32: 0 ok, 1 best labelling empty (reference raises IndexError), 2 log(0) (ValueError)
+ *   ws: >= ctcn_beam_ws_bytes(T,B,V,W) */
+size_t ctcn_beam_ws_bytes(int T, int B, int V, int W);
+int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha,
+                     int W, int blank, int32_t *out_ids, int32_t *out_len, double *out_score, int32_t *status,
+                     int T, int B, int V, void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,512 @@
+"""Parity tests of the HIP path (through the C ABI of libctcn.so) against the oracle and the golden vectors
+captured from the reference.  All tests need the MI355X: run with `pytest -m gpu`.
+
+Tolerances (SURVEY §8a "Parity tolerances", f32-exact MFMA mode): activations / log-probs max-abs <= 1e-5 ..
+1e-4, CTC loss rel <= 1e-5, gradients rel-L2 <= 1e-4, arg-max / greedy / beam strings identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as tnn
+
+from oracle import np_ref as R
+from oracle import beam_ref, synth, torch_cpu
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def gpu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def maxabs(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def test_library_loaded_is_in_tree():
+    from ctc_pytorch_amd import _lib
+    assert _lib.SO_PATH.endswith(os.path.join("ctc_pytorch_amd", "libctcn.so")) and os.path.exists(_lib.SO_PATH)
+    assert _lib.lib().ctcn_version() >= 100
+    assert _lib.lib().ctcn_device_cus() > 0
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 62, 40), (62, 640, 6400), (1280, 40, 512), (33, 17, 5), (300, 257, 130)])
+def test_gemm(dev, ta, tb, M, N, K):
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rs.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    Bm = rs.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    C0 = rs.standard_normal((M, N + 3)).astype(np.float32)
+    want = (A.T if ta else A).astype(np.float64) @ (Bm.T if tb else Bm).astype(np.float64)
+    for beta in (0.0, 1.0):
+        C = gpu(C0, dev)
+        ops.gemm(ta, tb, M, N, K, gpu(A, dev), A.shape[1], gpu(Bm, dev), Bm.shape[1], C, N + 3, beta=beta)
+        got = C.cpu().numpy()
+        ref = want + beta * C0[:, :N]
+        scale = np.abs(A).max() * np.abs(Bm).max() * np.sqrt(K)
+        assert np.max(np.abs(got[:, :N] - ref)) < 2e-6 * scale * 4 + 1e-6, (ta, tb, M, N, K, beta)
+        assert np.array_equal(got[:, N:], C0[:, N:]), "wrote outside ldc window"
+
+
+@pytest.mark.parametrize("kind", ["lstm", "gru", "rnn"])
+def test_rnn_layer_golden(dev, kind):
+    from ctc_pytorch_amd import ops
+    z = load("rnn_" + kind)
+    x = gpu(z["x"], dev).requires_grad_(True)
+    names = ["weight_ih_l0", "weight_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse"]
+    w = [gpu(z["w.rnn." + n], dev).requires_grad_(True) for n in names]
+    y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], {"rnn": "tanh"}.get(kind, kind))
+    assert maxabs(y, z["y"]) < 5e-6
+    y.backward(gpu(z["dy"], dev))
+    assert maxabs(x.grad, z["dx"]) < 2e-5
+    for n, p in zip(names, w):
+        assert maxabs(p.grad, z["g.rnn." + n]) < 1e-4, n
+
+
+@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 37, 32, 40, 320, True), ("gru", 19, 64, 48, 512, True),
+                                            ("lstm", 11, 70, 24, 128, True), ("rnn", 23, 5, 12, 36, False),
+                                            ("gru", 9, 3, 20, 24, True), ("lstm", 6, 16, 640, 20, False)])
+def test_rnn_layer_vs_torch_cpu(dev, kind, T, B, I, H, bi):
+    from ctc_pytorch_amd import ops
+    cls = {"lstm": tnn.LSTM, "gru": tnn.GRU, "rnn": tnn.RNN}[kind]
+    torch.manual_seed(T * 100 + B)
+    ref = cls(I, H, bidirectional=bi, bias=False)
+    x = torch.randn(T, B, I)
+    dy = torch.randn(T, B, (2 if bi else 1) * H)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    yr.backward(dy)
+    names = ["weight_ih_l0", "weight_hh_l0"] + (["weight_ih_l0_reverse", "weight_hh_l0_reverse"] if bi else [])
+    w = [getattr(ref, n).detach().to(dev).requires_grad_(True) for n in names] + ([None, None] if not bi else [])
+    xg = x.to(dev).requires_grad_(True)
+    y = ops.rnn_layer(xg, w[0], w[1], w[2], w[3], {"rnn": "tanh"}.get(kind, kind))
+    assert maxabs(y, yr) < 2e-5
+    y.backward(dy.to(dev))
+    assert rel_l2(xg.grad, xr.grad) < 1e-4
+    for n, p in zip(names, w):
+        assert rel_l2(p.grad, getattr(ref, n).grad) < 1e-4, n
+
+
+def test_rnn_rejects_bad_hidden(dev):
+    from ctc_pytorch_amd import ops
+    x = torch.zeros(3, 2, 5, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.rnn_layer(x, torch.zeros(4 * 6, 5, device=dev), torch.zeros(4 * 6, 6, device=dev), None, None, "lstm")
+
+
+def test_batchnorm_golden(dev):
+    from ctc_pytorch_amd import ops
+    z = load("bn_tb")
+    C = z["gamma"].shape[0]
+    gamma, beta = gpu(z["gamma"], dev).requires_grad_(True), gpu(z["beta"], dev).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    for step in range(2):
+        x = gpu(z["x%d" % step], dev).requires_grad_(True)
+        T, B, _ = x.shape
+        gamma.grad = beta.grad = None
+        y = ops.batch_norm(x, gamma, beta, rm, rv, T * B, C, 1, True)
+        assert maxabs(y, z["y%d" % step]) < 5e-6
+        y.backward(gpu(z["dy%d" % step], dev))
+        assert maxabs(x.grad, z["dx%d" % step]) < 5e-6
+        assert maxabs(gamma.grad, z["dgamma%d" % step]) < 5e-5
+        assert maxabs(beta.grad, z["dbeta%d" % step]) < 5e-5
+        assert maxabs(rm, z["rm%d" % step]) < 1e-6 and maxabs(rv, z["rv%d" % step]) < 1e-6
+    xe = gpu(z["x_eval"], dev)
+    T, B, _ = xe.shape
+    ye = ops.batch_norm(xe, gamma, beta, rm, rv, T * B, C, 1, False)
+    assert maxabs(ye, z["y_eval"]) < 5e-6
+
+
+def test_batchnorm_large_rows_vs_torch(dev):
+    from ctc_pytorch_amd import ops
+    torch.manual_seed(0)
+    x = (torch.randn(800 * 32, 640) * 3 + 1.5)
+    g, b = torch.rand(640) + 0.5, torch.randn(640)
+    dy = torch.randn(800 * 32, 640)
+    bn = tnn.BatchNorm1d(640)
+    with torch.no_grad():
+        bn.weight.copy_(g); bn.bias.copy_(b)
+    xr = x.clone().requires_grad_(True)
+    yr = bn(xr)
+    yr.backward(dy)
+    xg = x.to(dev).requires_grad_(True)
+    gg, bg = g.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(640, device=dev), torch.ones(640, device=dev)
+    y = ops.batch_norm(xg, gg, bg, rm, rv, x.shape[0], 640, 1, True)
+    y.backward(dy.to(dev))
+    assert maxabs(y, yr) < 2e-5 and maxabs(xg.grad, xr.grad) < 2e-5
+    assert rel_l2(gg.grad, bn.weight.grad) < 1e-5 and rel_l2(bg.grad, bn.bias.grad) < 1e-5
+    assert maxabs(rm, bn.running_mean) < 1e-5 and maxabs(rv, bn.running_var) < 1e-5
+
+
+def _load_conv_model(dev):
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    z = load("conv_front_relu")
+    cnn_param = {"batch_norm": True, "activate_function": nn.ReLU,
+                 "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
+    rnn_param = {"rnn_input_size": 40, "rnn_hidden_size": 16, "rnn_layers": 1, "rnn_type": nn.LSTM, "bidirectional": True,
+                 "batch_norm": True}
+    m = CTC_Model(add_cnn=True, cnn_param=cnn_param, rnn_param=rnn_param, num_class=12, drop_out=0.0)
+    sd = m.state_dict()
+    for k in list(sd.keys()):
+        if k.startswith("conv."):
+            kk = k[len("conv."):]
+            src = z["w." + kk] if ("w." + kk) in z.files else None
+            if src is not None:
+                sd[k] = torch.from_numpy(src)
+            # running stats of the fixture are post-step values; start from the defaults instead
+    m.load_state_dict(sd)
+    return m.to(dev), z
+
+
+def test_conv_front_golden(dev):
+    from ctc_pytorch_amd import ops
+    m, z = _load_conv_model(dev)
+    m.train()
+    x = gpu(z["x"], dev).requires_grad_(True)
+    c = m.conv(x.unsqueeze(1))
+    assert maxabs(c, z["conv_out"]) < 2e-5
+    r = ops.bctf_to_tbcf(c)
+    assert tuple(r.shape) == z["rnn_in"].shape and maxabs(r, z["rnn_in"]) < 2e-5
+    r.backward(gpu(z["d_rnn_in"], dev))
+    assert maxabs(x.grad, z["dx"]) < 5e-5
+    for k, p in m.conv.named_parameters():
+        assert maxabs(p.grad, z["g." + k]) < 5e-4 * max(1.0, float(np.abs(z["g." + k]).max())), k
+    for k, bfr in m.conv.named_buffers():
+        if "num_batches" in k:
+            assert int(bfr) == int(z["b." + k])
+        else:
+            assert maxabs(bfr, z["b." + k]) < 1e-5, k
+    m.eval()
+    with torch.no_grad():
+        ce = m.conv(x.detach().unsqueeze(1))
+    assert maxabs(ce, z["conv_out_eval"]) < 2e-5
+
+
+def test_fc_logsoftmax_golden(dev):
+    from ctc_pytorch_amd import ops
+    z = load("fc_lsm")
+    x = gpu(z["x"], dev).requires_grad_(True)
+    g, b = gpu(z["w.0.weight"], dev).requires_grad_(True), gpu(z["w.0.bias"], dev).requires_grad_(True)
+    W = gpu(z["w.1.weight"], dev).requires_grad_(True)
+    C = x.shape[1]
+    T, B, V = z["lp"].shape
+    y = ops.batch_norm(x, g, b, torch.zeros(C, device=dev), torch.ones(C, device=dev), x.shape[0], C, 1, True)
+    logits = ops.linear(y, W)
+    assert maxabs(logits, z["logits"]) < 1e-5
+    lp = ops.log_softmax(logits.view(T, B, V))
+    assert maxabs(lp, z["lp"]) < 1e-5
+    assert np.array_equal(ops.argmax_last(lp).cpu().numpy(), z["argmax"].astype(np.int32))
+    lp.backward(gpu(z["dlp"], dev))
+    assert maxabs(x.grad, z["dx"]) < 2e-5
+    assert maxabs(W.grad, z["g.1.weight"]) < 1e-4 and maxabs(g.grad, z["g.0.weight"]) < 1e-4
+
+
+def test_ctc_golden(dev):
+    from ctc_pytorch_amd import nn, ops
+    z = load("ctc_loss")
+    B = z["lp"].shape[1]
+    logits = gpu(z["logits"], dev).requires_grad_(True)
+    lp = ops.log_softmax(logits)
+    lp.retain_grad()
+    tg, il, tl = gpu(z["targets"], dev), gpu(z["in_len"], dev), gpu(z["tgt_len"], dev)
+    loss = nn.CTCLoss(reduction="sum")(lp, tg, il, tl) / B
+    assert abs(float(loss) - float(z["loss"])) / float(z["loss"]) < 1e-5
+    loss.backward()
+    assert maxabs(lp.grad, z["dlp"]) < 1e-5
+    assert maxabs(logits.grad, z["dlogits"]) < 1e-5
+    nll = nn.CTCLoss(reduction="none")(lp.detach(), tg, il, tl)
+    assert np.allclose(nll.cpu().numpy(), z["nll"], rtol=1e-5, atol=1e-4)
+    # infeasible utterance: +inf loss, NaN gradient rows where torch has them, finite elsewhere
+    lp2 = gpu(z["lp"], dev).requires_grad_(True)
+    il2 = gpu(z["in_len_inf"], dev)
+    l2 = nn.CTCLoss(reduction="sum")(lp2, tg, il2, tl) / B
+    assert np.isinf(float(l2))
+    l2.backward()
+    got = lp2.grad.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(z["dlp_inf"]))
+    ok = ~np.isnan(got)
+    assert np.max(np.abs(got[ok] - z["dlp_inf"][ok])) < 1e-5
+
+
+def test_ctc_vs_torch_cpu_random(dev):
+    from ctc_pytorch_amd import nn, ops
+    T, B, V = 200, 16, 62
+    b = synth.make_batch(seed=9, B=B, T=T, F=4, V=V, lab_lo=10, lab_hi=60)
+    rs = np.random.RandomState(3)
+    logits = torch.from_numpy((2 * rs.standard_normal((T, B, V))).astype(np.float32))
+    tg, tl, il = torch.from_numpy(b["targets"]), torch.from_numpy(b["tgt_len"]), torch.from_numpy(b["lens"])
+    lr = logits.clone().requires_grad_(True)
+    loss_r = tnn.CTCLoss(reduction="sum")(torch.log_softmax(lr, -1), tg, il, tl) / B
+    loss_r.backward()
+    lg = logits.to(dev).requires_grad_(True)
+    loss = nn.CTCLoss(reduction="sum")(ops.log_softmax(lg), tg.to(dev), il.to(dev), tl.to(dev)) / B
+    loss.backward()
+    assert abs(float(loss) - float(loss_r)) / abs(float(loss_r)) < 1e-5
+    assert maxabs(lg.grad, lr.grad) < 2e-5
+    assert float(lg.grad.sum(-1).abs().max()) < 1e-4          # rows sum to zero after log_softmax backward
+
+
+def test_dropout_statistics_and_mask_reuse(dev):
+    from ctc_pytorch_amd import ops
+    x = torch.ones(1 << 20, device=dev, requires_grad=True)
+    y = ops.dropout(x, 0.25, True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.75) < 5e-3
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.75, device=dev))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, y != 0)                   # backward regenerates the same mask
+    y2 = ops.dropout(x, 0.25, True)
+    assert not torch.equal(y2 != 0, y != 0)                   # fresh counters on the next call
+    assert ops.dropout(x, 0.25, False) is x and ops.dropout(x, 0.0, True) is x
+
+
+def test_adam_vs_oracle(dev):
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(4)
+    n = 10007
+    p, g = rs.standard_normal(n).astype(np.float32), rs.standard_normal(n).astype(np.float32)
+    m, v = np.zeros(n), np.zeros(n)
+    pr = p.astype(np.float64)
+    pt, mt, vt = gpu(p, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gs = (g * step).astype(np.float32)
+        pr, m, v = R.adam_step(pr, gs.astype(np.float64), m, v, step, 1e-3, 5e-4)
+        ops.adam_step(pt, gpu(gs, dev), mt, vt, 1e-3, 0.9, 0.999, 1e-8, 5e-4, step)
+    assert maxabs(pt, pr) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole model
+# ---------------------------------------------------------------------------------------------------------
+def _build_model(tag, dev):
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    V = 62
+    base = {"rnn_input_size": 40, "bidirectional": True, "batch_norm": True, "rnn_layers": 2}
+    if tag == "lstm2x32":
+        m = CTC_Model(rnn_param=dict(base, rnn_hidden_size=32, rnn_type=nn.LSTM), num_class=V, drop_out=0.0)
+    elif tag == "gru2x24":
+        m = CTC_Model(rnn_param=dict(base, rnn_hidden_size=24, rnn_type=nn.GRU), num_class=V, drop_out=0.0)
+    elif tag == "rnn2x20_uni_nobn":
+        m = CTC_Model(rnn_param=dict(base, rnn_hidden_size=20, rnn_type=nn.RNN, bidirectional=False, batch_norm=False),
+                      num_class=V, drop_out=0.0)
+    else:
+        cnn_param = {"batch_norm": True, "activate_function": nn.ReLU,
+                     "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
+        m = CTC_Model(add_cnn=True, cnn_param=cnn_param, rnn_param=dict(base, rnn_hidden_size=16, rnn_type=nn.LSTM),
+                      num_class=V, drop_out=0.0)
+    z = load("model_" + tag)
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=int(z["seed_w"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    return m.to(dev), z
+
+
+@pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16"])
+@pytest.mark.parametrize("flat", [True, False])
+def test_model_three_steps_golden(dev, tag, flat):
+    from ctc_pytorch_amd import nn, ops
+    from ctc_pytorch_amd.optim import FlatAdam
+    m, z = _build_model(tag, dev)
+    m.train()
+    x, tg, tl = gpu(z["x"], dev), gpu(z["targets"], dev), gpu(z["tgt_len"], dev)
+    B = x.shape[0]
+    opt = FlatAdam(m, lr=1e-3, weight_decay=5e-4) if flat else torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    loss_fn = nn.CTCLoss(reduction="sum")
+    losses = []
+    for step in range(3):
+        lp, vis = m(x, visualize=True)
+        in_len = torch.from_numpy(R.frames_from_fraction(z["frac"], lp.size(0)))
+        if step == 0:
+            assert np.array_equal(in_len.numpy(), z["in_len"])
+            assert maxabs(lp, z["lp"]) < 5e-5
+            assert np.array_equal(ops.argmax_last(lp).cpu().numpy(), z["argmax"].astype(np.int32))
+            if "rnn_in" in z.files:
+                assert maxabs(vis[1], z["conv_out"]) < 5e-5 and maxabs(vis[2], z["rnn_in"]) < 5e-5
+        loss = loss_fn(lp, tg, in_len.to(dev), tl) / B
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            for k, p in m.named_parameters():
+                assert rel_l2(p.grad, z["g." + k]) < 2e-4 or maxabs(p.grad, z["g." + k]) < 1e-6, k
+        opt.step()
+        losses.append(float(loss))
+    assert np.allclose(losses, z["losses"], rtol=2e-5), (losses, z["losses"])
+    for k, v in m.state_dict().items():
+        want = z["after." + k]
+        if "num_batches" in k:
+            assert int(v) == int(want), k
+        else:
+            assert maxabs(v, want) < 5e-5, k
+    m.eval()
+    with torch.no_grad():
+        lpe = m(x)
+    assert maxabs(lpe, z["lp_eval_after"]) < 2e-4
+    assert np.array_equal(ops.argmax_last(lpe).cpu().numpy(), z["argmax_eval_after"].astype(np.int32))
+
+
+def test_run_epoch_trajectory_golden(dev):
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    from ctc_pytorch_amd.optim import FlatAdam
+    from ctc_pytorch_amd.steps.train_ctc import run_epoch
+    z = load("run_epoch_cfg1")
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 128, "rnn_layers": 2, "rnn_type": nn.LSTM, "bidirectional": True,
+          "batch_norm": True}
+    m = CTC_Model(rnn_param=rp, num_class=62, drop_out=0.0)
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=int(z["seed_w"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    m = m.to(dev)
+    batch = (torch.from_numpy(z["x"]), torch.from_numpy(z["frac"]), torch.from_numpy(z["targets"]),
+             torch.from_numpy(z["tgt_len"]), ["u%d" % i for i in range(8)])
+    opt = FlatAdam(m, lr=1e-3, weight_decay=5e-4)
+    lines = []
+    acc, avg = run_epoch(1, m, [batch, batch, batch], nn.CTCLoss(reduction="sum"), dev, optimizer=opt, print_every=1,
+                         is_training=True, log=lines.append)
+    step_losses = [float(l.split("cur_loss = ")[1].split(",")[0]) for l in lines if "cur_loss" in l]
+    assert np.allclose(step_losses, z["printed_step_losses"], rtol=1e-4), (step_losses, z["printed_step_losses"])
+    assert abs(avg - float(z["train_avg_loss"])) / float(z["train_avg_loss"]) < 1e-4
+    assert abs(acc - float(z["train_acc"])) < 1e-9
+    acc_e, avg_e = run_epoch(1, m, [batch], nn.CTCLoss(reduction="sum"), dev, optimizer=None, is_training=False, log=lines.append)
+    assert abs(avg_e - float(z["eval_avg_loss"])) / float(z["eval_avg_loss"]) < 2e-4
+    assert abs(acc_e - float(z["eval_acc"])) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
+def test_large_shape_checksums(dev, name):
+    """BASELINE.json full-size configs: loss / log-prob checksums / per-parameter gradient norms captured from the
+    reference (cfg4 at B=8 per rank, as one DP shard)."""
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    want = json.load(open(os.path.join(G, "large_checksums.json")))[name]
+    c = want["shape"]
+    lab = (60, 100) if name == "cfg4" else (30, 60)
+    b = synth.make_batch(seed=1, B=c["B"], T=c["T"], F=40, V=c["V"], lab_lo=lab[0], lab_hi=lab[1])
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(nn, c["rnn"]),
+          "bidirectional": True, "batch_norm": True}
+    if c["cnn"]:
+        cp = {"batch_norm": True, "activate_function": nn.ReLU,
+              "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
+        m = CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=0.0)
+    else:
+        m = CTC_Model(rnn_param=rp, num_class=c["V"], drop_out=0.0)
+    assert sum(p.numel() for p in m.parameters()) == want["n_params"]
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=91)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    m = m.to(dev).train()
+    lp = m(gpu(b["x"], dev))
+    in_len = torch.from_numpy(R.frames_from_fraction(b["frac"], lp.size(0))).to(dev)
+    loss = nn.CTCLoss(reduction="sum")(lp, gpu(b["targets"], dev), in_len, gpu(b["tgt_len"], dev)) / c["B"]
+    loss.backward()
+    assert abs(float(loss) - want["loss"]) / want["loss"] < 1e-4, (float(loss), want["loss"])
+    assert abs(float(lp.double().abs().mean()) - want["lp_abs_mean"]) / want["lp_abs_mean"] < 1e-4
+    for k, p in m.named_parameters():
+        gn = float(p.grad.double().norm())
+        assert abs(gn - want["grad_norm"][k]) <= 2e-3 * want["grad_norm"][k] + 1e-6, (k, gn, want["grad_norm"][k])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# decoders
+# ---------------------------------------------------------------------------------------------------------
+def test_greedy_decoder_golden(dev):
+    from ctc_pytorch_amd import nn, ops
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    from ctc_pytorch_amd.utils.ctcDecoder import GreedyDecoder
+    z = load("decoders")
+    meta = json.load(open(os.path.join(G, "decoders.json")))
+    i2c = synth.int2char(62)
+    g = GreedyDecoder(i2c, space_idx=-1, blank_index=0)
+    for regime in ("peaky", "flat"):
+        lp = torch.from_numpy(z["lp_" + regime])            # CPU tensor, as test_ctc.py hands it over
+        assert np.array_equal(ops.argmax_last(lp.to(dev)).cpu().numpy(), z["argmax_" + regime].astype(np.int32))
+        assert g.decode(lp, meta["lens"]) == meta["greedy_" + regime]
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 4, "rnn_layers": 1, "rnn_type": nn.LSTM, "bidirectional": True, "batch_norm": False}
+    m = CTC_Model(rnn_param=rp, num_class=62, drop_out=0.0).to(dev)
+    errs, toks = m.compute_wer(z["argmax_peaky"].T, np.array(meta["lens"]), z["wer_targets"], z["wer_tgt_len"])
+    assert [errs, toks] == meta["compute_wer"]
+    sc = meta["score_greedy_peaky"]
+    dec = g.decode(torch.from_numpy(z["lp_peaky"]), meta["lens"])
+    assert sum(g.cer(a, b) for a, b in zip(dec, meta["labels"])) == sc["total_cer"]
+    assert sum(g.wer(a, b) for a, b in zip(dec, meta["labels"])) == sc["total_wer"]
+
+
+def test_beam_decoder_golden(dev):
+    from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder
+    z = load("decoders")
+    meta = json.load(open(os.path.join(G, "decoders.json")))
+    i2c = synth.int2char(62)
+    arpa = os.path.join(G, "lm_phone_bg.arpa")
+    bad = []
+    for key, want in meta.items():
+        if not key.startswith("beam_"):
+            continue
+        _, regime, w, a = key.split("_")
+        bd = BeamDecoder(i2c, beam_width=int(w[1:]), blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=float(a[1:]))
+        got = bd.decode(torch.from_numpy(z["lp_" + regime]), meta["lens"])
+        if got != want:
+            bad.append((key, [i for i in range(len(want)) if got[i] != want[i]]))
+    assert not bad, bad
+    sc = meta["score_beam_peaky_W5_a0.1"]
+    bd = BeamDecoder(i2c, beam_width=5, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.1)
+    dec = bd.decode(torch.from_numpy(z["lp_peaky"]), meta["lens"])
+    assert sum(bd.cer(a, b) for a, b in zip(dec, meta["labels"])) == sc["total_cer"]
+
+
+@pytest.mark.parametrize("regime,W", [("peaky", 20), ("flat", 8), ("peaky", 3)])
+def test_beam_vs_c_oracle_random(dev, regime, W):
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    V, T, B = 62, 160, 12
+    i2c = synth.int2char(V)
+    lp = synth.make_logprobs(seed=101 + W, T=T, B=B, V=V, regime=regime)
+    lens = list(np.random.RandomState(5).randint(T // 2, T + 1, size=B))
+    tab = LanguageModel(os.path.join(G, "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    lpt = torch.from_numpy(lp)
+    probs = torch.exp(lpt)                                  # float32 exp on CPU, as ctcDecoder.py:190
+    want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, 0.1, W)
+    got, score, st = ops.beam_decode(probs.to(dev), lens, tab, 0.1, W, 0, input_is_prob=True)
+    assert list(st) == list(wst)
+    assert got == [list(map(int, s)) for s in want]
+    assert np.allclose(score, wscore, rtol=1e-12, atol=1e-12)
+    got2, _, _ = ops.beam_decode(lpt.to(dev), lens, tab, 0.1, W, 0, input_is_prob=False)   # device-side exp
+    assert got2 == got
+
+
+def test_beam_error_paths(dev):
+    from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder
+    i2c = synth.int2char(62)
+    bd = BeamDecoder(i2c, beam_width=5, lm_path=os.path.join(G, "lm_phone_bg.arpa"), lm_alpha=0.1)
+    p = np.full((5, 1, 62), 1e-3, dtype=np.float32)
+    p[:, :, 0] = 0.95
+    with pytest.raises(IndexError):
+        bd.decode(torch.log(torch.from_numpy(p)), [5])
+    lp = np.full((5, 1, 62), np.log(1.0 / 62), dtype=np.float32)
+    lp[2, 0, 7] = -200.0                                    # exp underflows to 0 -> math.log(0) in the reference
+    with pytest.raises(ValueError):
+        bd.decode(torch.from_numpy(lp), [5])
+    with pytest.raises(TypeError):
+        BeamDecoder(i2c, beam_width=5)                      # lm_path=None: open(None), as the reference
