@@ -37,46 +37,59 @@ struct RnnArgs {
 };
 
 // Recurrent matmul helper.  acc[mt] (16x16 tile: rows = batch mt*16.., cols = this WG's 16 columns)
-// += A[rows, K] * Bm[16 cols, K]^T, with K split over `ngroups` (wave, k-lane) groups.
+// += A[rows, K] * Bm[16 cols, K]^T.  K is split over the `nwaves` waves of the workgroup (wave w owns the
+// contiguous range [w*16*KQ4, (w+1)*16*KQ4) of every super-chunk of nwaves*16*KQ4 floats) and, inside a wave,
+// over the 4 k-lanes q of the MFMA with a 16-byte interleave: lane (r,q) loads the float4 at
+// k = base + s*16 + q*4, so one load instruction covers a contiguous 64-B segment of each of the 16 rows
+// (16 cache lines per wave-instruction instead of 64) and all loads of the step are in flight at once.
 // A element (row,k) lives at a1[row*ld1 + k] for k < ksplit, else a2[row*ld2 + k - ksplit].
 template <int MT, int KQ4>
 __device__ __forceinline__ void rec_mm(const float *__restrict__ a1, int ld1, int ksplit, const float *__restrict__ a2,
                                        int ld2, int rows, const float *__restrict__ brow, bool bvalid, int K,
-                                       int ngroups, int g, int r, f32x4 (&acc)[MT]) {
-  constexpr int kspan = 4 * KQ4;
-  const int sc_stride = ngroups * kspan;
+                                       int nwaves, int wave, int q, int r, f32x4 (&acc)[MT]) {
+  const int sc_stride = nwaves * 16 * KQ4;
   const int nsc = (K + sc_stride - 1) / sc_stride;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // Every load below is UNCONDITIONAL on a clamped (always valid) address and masked afterwards with a register
+  // select: a predicated load makes hipcc branch around it and wait for it alone, which serialises the operand
+  // fetches of a step into dependent L2 round trips.  Operands are native ext-vector values (not HIP's float4
+  // class) so that the fully unrolled arrays stay in VGPRs instead of scratch.
+  const float *brow_s = bvalid ? brow : a1;
+  const int rmax = rows - 1;
   for (int sc = 0; sc < nsc; ++sc) {
-    const int kb = sc * sc_stride + g * kspan;
-    float4 av[MT][KQ4], bv[KQ4];
+    const int kb = sc * sc_stride + wave * 16 * KQ4 + q * 4;
+    f32x4 av[MT][KQ4], bv[KQ4];
 #pragma unroll
     for (int s = 0; s < KQ4; ++s) {
-      const int k = kb + 4 * s;
-      const bool kin = k < K;
-      bv[s] = (bvalid && kin) ? *reinterpret_cast<const float4 *>(brow + k) : zero;
+      const int k = kb + 16 * s;
+      const int kc = min(k, K - 4);
+      bv[s] = *reinterpret_cast<const f32x4 *>(brow_s + (bvalid ? kc : 0));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int row = mt * 16 + r;
-        const float *p = (k < ksplit) ? a1 + (size_t)row * ld1 + k : a2 + (size_t)row * ld2 + (k - ksplit);
-        av[mt][s] = (kin && row < rows) ? *reinterpret_cast<const float4 *>(p) : zero;
+        const int row = min(mt * 16 + r, rmax);
+        const float *p = (kc < ksplit) ? a1 + (size_t)row * ld1 + kc : a2 + (size_t)row * ld2 + (kc - ksplit);
+        av[mt][s] = *reinterpret_cast<const f32x4 *>(p);
       }
     }
 #pragma unroll
     for (int s = 0; s < KQ4; ++s) {
-      const float b4[4] = {bv[s].x, bv[s].y, bv[s].z, bv[s].w};
+      const bool kin = (kb + 16 * s) < K;
+      bv[s] = (bvalid && kin) ? bv[s] : zero;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float a4[4] = {av[mt][s].x, av[mt][s].y, av[mt][s].z, av[mt][s].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c], b4[c], acc[mt], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; ++mt) av[mt][s] = (kin && mt * 16 + r < rows) ? av[mt][s] : zero;
     }
+#pragma unroll
+    for (int s = 0; s < KQ4; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s][c], bv[s][c], acc[mt], 0, 0, 0);
   }
 }
 
 // Combine the NW per-wave partial tiles through LDS (fixed summation order -> deterministic), at most
-// PW waves per pass so the staging buffer stays <= 32 KiB.  Tile element (row, col) -> outs[row][col].
+// PW waves per pass so the staging buffer stays small.  Tile element (row, col) -> outs[row][col].
 template <int MT, int NW, int PW>
 __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[MT], float *red /*[PW][MT*256]*/,
                                              float (*outs)[17], int tid, int nthreads) {
@@ -106,7 +119,9 @@ __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[MT], float *red 
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward step
+// forward step.  grid = (H/HS, dirs, ceil(B / (16*MT))), 256 threads.
+// The epilogue's global operands (input-projection pre-activations, c_{t-1} / h_{t-1}) are fetched BEFORE the
+// recurrent matmul so that their HBM latency overlaps the operand loads of the matmul.
 // ------------------------------------------------------------------------------------------------
 template <int MT, int KQ4>
 __global__ __launch_bounds__(256) void rnn_fwd_step(RnnArgs p) {
@@ -114,10 +129,10 @@ __global__ __launch_bounds__(256) void rnn_fwd_step(RnnArgs p) {
   __shared__ float red[NW * MT * 256];
   __shared__ float outs[MT * 16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4, g = wave * 4 + q;
-  const int d = blockIdx.y, b0 = blockIdx.z * 64;
+  const int r = lane & 15, q = lane >> 4;
+  const int d = blockIdx.y, b0 = blockIdx.z * (16 * MT);
   const int H = p.H, G = p.G, D = p.D, B = p.B;
-  const int Bc = min(64, B - b0);
+  const int Bc = min(16 * MT, B - b0);
   const int t = d == 0 ? p.step : p.T - 1 - p.step;
   const int tp = p.step == 0 ? -1 : (d == 0 ? t - 1 : t + 1);
   const bool tanh_cell = p.cell == CTCN_CELL_TANH;
@@ -128,65 +143,81 @@ __global__ __launch_bounds__(256) void rnn_fwd_step(RnnArgs p) {
   const float *W = d == 0 ? p.w0 : p.w1;
   const float *brow = W + (size_t)(gate * H + j0 + jj) * H;
 
+  // epilogue work item of this thread (LSTM/GRU: MT*16 rows x 4 units <= 256 items -> one per thread)
+  const int bl = tid / HS, jl = tid - bl * HS;
+  const int j = j0 + jl, b = b0 + bl;
+  const bool item = !tanh_cell && bl < Bc && j < H;
+  const size_t row_t = (size_t)t * B + b;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float prev = 0.0f;   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+  if (item) {
+    const float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < G) pre[k] = gt[k * H + j];
+    if (tp >= 0)
+      prev = p.cell == CTCN_CELL_LSTM ? p.aux[(((size_t)tp * B + b) * D + d) * H + j]
+                                      : p.y[((size_t)tp * B + b) * D * H + d * H + j];
+  }
+
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (tp >= 0) {
     const float *abase = p.y + ((size_t)tp * B + b0) * D * H + d * H;
-    rec_mm<MT, KQ4>(abase, D * H, H, abase, D * H, Bc, brow, bvalid, H, 4 * NW, g, r, acc);
+    rec_mm<MT, KQ4>(abase, D * H, H, abase, D * H, Bc, brow, bvalid, H, NW, wave, q, r, acc);
   }
   reduce_tiles<MT, NW, 4>(acc, red, outs, tid, 256);
 
-  const int items = Bc * HS;
-  for (int it = tid; it < items; it += 256) {
-    const int bl = it / HS, jl = it - bl * HS;
-    const int j = j0 + jl;
-    if (j >= H) continue;
-    const int b = b0 + bl;
-    const size_t row_t = (size_t)t * B + b;
+  if (item) {
     float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
     float *yt = p.y + row_t * D * H + d * H;
     if (p.cell == CTCN_CELL_LSTM) {
-      const float ai = outs[bl][0 * 4 + jl] + gt[0 * H + j];
-      const float af = outs[bl][1 * 4 + jl] + gt[1 * H + j];
-      const float ag = outs[bl][2 * 4 + jl] + gt[2 * H + j];
-      const float ao = outs[bl][3 * 4 + jl] + gt[3 * H + j];
-      const float i_ = sigmoidf_(ai), f_ = sigmoidf_(af), g_ = tanhf(ag), o_ = sigmoidf_(ao);
-      const float cp = tp >= 0 ? p.aux[(((size_t)tp * B + b) * D + d) * H + j] : 0.0f;
-      const float c = f_ * cp + i_ * g_;
+      const float i_ = sigmoidf_(outs[bl][0 * 4 + jl] + pre[0]);
+      const float f_ = sigmoidf_(outs[bl][1 * 4 + jl] + pre[1]);
+      const float g_ = tanhf(outs[bl][2 * 4 + jl] + pre[2]);
+      const float o_ = sigmoidf_(outs[bl][3 * 4 + jl] + pre[3]);
+      const float c = f_ * prev + i_ * g_;
       gt[0 * H + j] = i_; gt[1 * H + j] = f_; gt[2 * H + j] = g_; gt[3 * H + j] = o_;
       p.aux[(row_t * D + d) * H + j] = c;
       yt[j] = o_ * tanhf(c);
-    } else if (p.cell == CTCN_CELL_GRU) {
+    } else {
       const float hn = outs[bl][2 * 4 + jl];
-      const float r_ = sigmoidf_(outs[bl][0 * 4 + jl] + gt[0 * H + j]);
-      const float z_ = sigmoidf_(outs[bl][1 * 4 + jl] + gt[1 * H + j]);
-      const float n_ = tanhf(gt[2 * H + j] + r_ * hn);
-      const float hp = tp >= 0 ? p.y[((size_t)tp * B + b) * D * H + d * H + j] : 0.0f;
+      const float r_ = sigmoidf_(outs[bl][0 * 4 + jl] + pre[0]);
+      const float z_ = sigmoidf_(outs[bl][1 * 4 + jl] + pre[1]);
+      const float n_ = tanhf(pre[2] + r_ * hn);
       gt[0 * H + j] = r_; gt[1 * H + j] = z_; gt[2 * H + j] = n_;
       p.aux[(row_t * D + d) * H + j] = hn;
-      yt[j] = (1.0f - z_) * n_ + z_ * hp;
-    } else {
-      yt[j] = tanhf(outs[bl][jl] + gt[j]);
+      yt[j] = (1.0f - z_) * n_ + z_ * prev;
+    }
+  }
+  if (tanh_cell) {
+    for (int it = tid; it < Bc * 16; it += 256) {
+      const int bl2 = it >> 4, jl2 = it & 15;
+      if (j0 + jl2 >= H) continue;
+      const size_t rt = (size_t)t * B + b0 + bl2;
+      p.y[rt * D * H + d * H + j0 + jl2] = tanhf(outs[bl2][jl2] + p.gates[(rt * D + d) * (size_t)H + j0 + jl2]);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward step (processing order reversed: forward direction walks t = T-1..0)
+// backward step (processing order reversed: the forward direction walks t = T-1..0).
+// grid = (ceil(H/16), dirs, ceil(B/16)), 1024 threads: one 16(batch) x 16(hidden) tile of
+// dh_rec = d(pre-act)_{next} * W_hh per workgroup, K = G*H split over 16 waves.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int KQ4>
+template <int KQ4>
 __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
-  constexpr int NW = 16, PW = 8;
+  constexpr int NW = 16, PW = 8, MT = 1;
   __shared__ float red[PW * MT * 256];
   __shared__ float outs[MT * 16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4, g = wave * 4 + q;
-  const int d = blockIdx.y, b0 = blockIdx.z * 64;
+  const int r = lane & 15, q = lane >> 4;
+  const int d = blockIdx.y, b0 = blockIdx.z * 16;
   const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
-  const int Bc = min(64, B - b0);
+  const int Bc = min(16, B - b0);
   const int GH = G * H;
-  // forward direction: t = T-1-step, next-processed-before = t+1, prev-in-forward-order = t-1
+  // forward direction: t = T-1-step, processed-just-before = t+1, previous-in-forward-order = t-1
   const int t = d == 0 ? T - 1 - p.step : p.step;
   const int tn = p.step == 0 ? -1 : (d == 0 ? t + 1 : t - 1);
   const int tp = d == 0 ? (t > 0 ? t - 1 : -1) : (t < T - 1 ? t + 1 : -1);
@@ -195,70 +226,79 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
   const float *WT = d == 0 ? p.w0 : p.w1;
   const float *brow = WT + (size_t)(j0 + r) * GH;
 
-  f32x4 acc[MT];
+  // epilogue item of this thread and its global operands, fetched ahead of the matmul
+  const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
+  const bool item = tid < 256 && bl < Bc && j < H;
+  const size_t row_t = (size_t)t * B + b;
+  float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f, stv = 0.f;
+  if (item) {
+    const float *gt = p.gates + (row_t * D + d) * (size_t)GH;
+    dyv = p.dy[row_t * D * H + d * H + j];
+    if (p.cell == CTCN_CELL_TANH) {
+      e0 = p.y[row_t * D * H + d * H + j];
+    } else {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 4; ++k)
+        if (k < G) sv[k] = gt[k * H + j];
+      e0 = p.aux[(row_t * D + d) * H + j];                                   // c_t (LSTM) / W_hn h_{t-1} (GRU)
+      if (tp >= 0)
+        e1 = p.cell == CTCN_CELL_LSTM ? p.aux[(((size_t)tp * B + b) * D + d) * H + j]   // c_{t-1}
+                                      : p.y[((size_t)tp * B + b) * D * H + d * H + j];  // h_{t-1}
+      stv = p.state[((size_t)b * D + d) * H + j];
+    }
+  }
+
+  f32x4 acc[MT];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (tn >= 0) {
     const size_t rown = (size_t)tn * B + b0;
     const float *a1 = p.gates + (rown * D + d) * (size_t)GH;
     if (p.cell == CTCN_CELL_GRU) {
       const float *a2 = p.aux + (rown * D + d) * (size_t)H;   // d(W_hn h) = dan * r
-      rec_mm<MT, KQ4>(a1, D * GH, 2 * H, a2, D * H, Bc, brow, bvalid, GH, 4 * NW, g, r, acc);
+      rec_mm<MT, KQ4>(a1, D * GH, 2 * H, a2, D * H, Bc, brow, bvalid, GH, NW, wave, q, r, acc);
     } else {
-      rec_mm<MT, KQ4>(a1, D * GH, GH, a1, D * GH, Bc, brow, bvalid, GH, 4 * NW, g, r, acc);
+      rec_mm<MT, KQ4>(a1, D * GH, GH, a1, D * GH, Bc, brow, bvalid, GH, NW, wave, q, r, acc);
     }
   }
   reduce_tiles<MT, NW, PW>(acc, red, outs, tid, 1024);
 
-  const int bl = tid >> 4, jl = tid & 15, j = j0 + jl;
-  if (bl < Bc && j < H) {
-    const int b = b0 + bl;
-    const size_t row_t = (size_t)t * B + b;
+  if (item) {
     float *gt = p.gates + (row_t * D + d) * (size_t)GH;
-    const float dyv = p.dy[row_t * D * H + d * H + j];
     float dh = dyv + outs[bl][jl];
     if (p.cell == CTCN_CELL_LSTM) {
-      float *st = p.state + ((size_t)b * D + d) * H + j;
-      const float i_ = gt[0 * H + j], f_ = gt[1 * H + j], g_ = gt[2 * H + j], o_ = gt[3 * H + j];
-      const float c = p.aux[(row_t * D + d) * H + j];
-      const float cp = tp >= 0 ? p.aux[(((size_t)tp * B + b) * D + d) * H + j] : 0.0f;
-      const float tc = tanhf(c);
+      const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
+      const float tc = tanhf(e0);
       const float do_ = dh * tc;
-      const float dc = dh * o_ * (1.0f - tc * tc) + *st;
+      const float dc = dh * o_ * (1.0f - tc * tc) + stv;
       gt[0 * H + j] = dc * g_ * i_ * (1.0f - i_);
-      gt[1 * H + j] = dc * cp * f_ * (1.0f - f_);
+      gt[1 * H + j] = dc * e1 * f_ * (1.0f - f_);
       gt[2 * H + j] = dc * i_ * (1.0f - g_ * g_);
       gt[3 * H + j] = do_ * o_ * (1.0f - o_);
-      *st = dc * f_;
+      p.state[((size_t)b * D + d) * H + j] = dc * f_;
     } else if (p.cell == CTCN_CELL_GRU) {
-      float *st = p.state + ((size_t)b * D + d) * H + j;
-      dh += *st;
-      const float r_ = gt[0 * H + j], z_ = gt[1 * H + j], n_ = gt[2 * H + j];
-      float *hnp = p.aux + (row_t * D + d) * H + j;
-      const float hn = *hnp;
-      const float hp = tp >= 0 ? p.y[((size_t)tp * B + b) * D * H + d * H + j] : 0.0f;
+      dh += stv;
+      const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1;
       const float dn = dh * (1.0f - z_);
       const float dz = dh * (hp - n_);
       const float dan = dn * (1.0f - n_ * n_);
       gt[0 * H + j] = dan * hn * r_ * (1.0f - r_);
       gt[1 * H + j] = dz * z_ * (1.0f - z_);
       gt[2 * H + j] = dan;
-      *hnp = dan * r_;
-      *st = dh * z_;
+      p.aux[(row_t * D + d) * H + j] = dan * r_;
+      p.state[((size_t)b * D + d) * H + j] = dh * z_;
     } else {
-      const float yv = p.y[row_t * D * H + d * H + j];
-      gt[j] = dh * (1.0f - yv * yv);
+      gt[j] = dh * (1.0f - e0 * e0);
     }
   }
 }
 
-int pick_kq4(int K, int ngroups, int mt, int budget) {
+int pick_kq4(int K, int nwaves, int mt, int budget) {
   const int cand[4] = {5, 4, 2, 1};
   int best = 1, best_cost = 1 << 30;
   for (int i = 0; i < 4; ++i) {
     const int kq = cand[i];
     if (mt * kq > budget) continue;
-    const int stride = ngroups * 4 * kq;
+    const int stride = nwaves * 16 * kq;
     const int cost = ceil_div(K, stride) * kq;
     if (cost < best_cost) { best_cost = cost; best = kq; }
   }
@@ -266,25 +306,21 @@ int pick_kq4(int K, int ngroups, int mt, int budget) {
 }
 
 template <int MT>
-int launch_fwd(int kq4, dim3 grid, hipStream_t st, const RnnArgs &a) {
+void launch_fwd(int kq4, dim3 grid, hipStream_t st, const RnnArgs &a) {
   switch (kq4) {
     case 5: hipLaunchKernelGGL((rnn_fwd_step<MT, 5>), grid, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((rnn_fwd_step<MT, 4>), grid, dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL((rnn_fwd_step<MT, 2>), grid, dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL((rnn_fwd_step<MT, 1>), grid, dim3(256), 0, st, a); break;
   }
-  return 0;
 }
-template <int MT>
-int launch_bwd(int kq4, dim3 grid, hipStream_t st, const RnnArgs &a) {
-  // 1024-thread workgroups: 128 VGPRs per lane, so MT*KQ4 is capped by pick_kq4's budget (MT=4 -> KQ4<=2)
-  if constexpr (MT <= 2) {
-    if (kq4 == 5) { hipLaunchKernelGGL((rnn_bwd_step<MT, 5>), grid, dim3(1024), 0, st, a); return 0; }
-    if (kq4 == 4) { hipLaunchKernelGGL((rnn_bwd_step<MT, 4>), grid, dim3(1024), 0, st, a); return 0; }
+void launch_bwd(int kq4, dim3 grid, hipStream_t st, const RnnArgs &a) {
+  switch (kq4) {
+    case 5: hipLaunchKernelGGL((rnn_bwd_step<5>), grid, dim3(1024), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((rnn_bwd_step<4>), grid, dim3(1024), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((rnn_bwd_step<2>), grid, dim3(1024), 0, st, a); break;
+    default: hipLaunchKernelGGL((rnn_bwd_step<1>), grid, dim3(1024), 0, st, a); break;
   }
-  if (kq4 >= 2) hipLaunchKernelGGL((rnn_bwd_step<MT, 2>), grid, dim3(1024), 0, st, a);
-  else hipLaunchKernelGGL((rnn_bwd_step<MT, 1>), grid, dim3(1024), 0, st, a);
-  return 0;
 }
 
 int gates_of(int cell) { return cell == CTCN_CELL_LSTM ? 4 : (cell == CTCN_CELL_GRU ? 3 : 1); }
@@ -319,11 +355,9 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   a.cell = cell; a.T = T; a.B = B; a.H = H; a.D = dirs; a.G = G; a.step = 0;
   a.w0 = w_hh0; a.w1 = w_hh1; a.y = y; a.gates = gates; a.aux = aux; a.dy = nullptr; a.state = nullptr;
   const int HS = cell == CTCN_CELL_TANH ? 16 : 4;
-  const int bchunks = ceil_div(B, 64);
-  const int mt = B >= 64 ? 4 : ceil_div(B, 16);
-  const int MT = mt <= 1 ? 1 : (mt == 2 ? 2 : 4);
-  const int kq4 = pick_kq4(H, 16, MT, 20);
-  dim3 grid(ceil_div(H, HS), dirs, bchunks);
+  const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+  const int kq4 = pick_kq4(H, 4, MT, 20);
+  dim3 grid(ceil_div(H, HS), dirs, ceil_div(B, 16 * MT));
   for (int s = 0; s < T; ++s) {
     a.step = s;
     if (MT == 1) launch_fwd<1>(kq4, grid, st, a);
@@ -366,16 +400,11 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   a.cell = cell; a.T = T; a.B = B; a.H = H; a.D = dirs; a.G = G; a.step = 0;
   a.w0 = whhT; a.w1 = whhT + (size_t)GH * H; a.y = const_cast<float *>(y); a.gates = gates; a.aux = aux; a.dy = dy;
   a.state = state;
-  const int bchunks = ceil_div(B, 64);
-  const int mt = B >= 64 ? 4 : ceil_div(B, 16);
-  const int MT = mt <= 1 ? 1 : (mt == 2 ? 2 : 4);
-  const int kq4 = pick_kq4(GH, 64, MT, MT <= 2 ? 10 : 8);
-  dim3 grid(ceil_div(H, 16), dirs, bchunks);
+  const int kq4 = pick_kq4(GH, 16, 1, 5);
+  dim3 grid(ceil_div(H, 16), dirs, ceil_div(B, 16));
   for (int s = 0; s < T; ++s) {
     a.step = s;
-    if (MT == 1) launch_bwd<1>(kq4, grid, st, a);
-    else if (MT == 2) launch_bwd<2>(kq4, grid, st, a);
-    else launch_bwd<4>(kq4, grid, st, a);
+    launch_bwd(kq4, grid, st, a);
   }
   CTCN_LAUNCH_CHECK();
 

@@ -195,7 +195,7 @@ def test_conv_front_golden(dev):
     r.backward(gpu(z["d_rnn_in"], dev))
     assert maxabs(x.grad, z["dx"]) < 5e-5
     for k, p in m.conv.named_parameters():
-        assert maxabs(p.grad, z["g." + k]) < 5e-4 * max(1.0, float(np.abs(z["g." + k]).max())), k
+        assert maxabs(p.grad, z["g." + k]) < 5e-4 * max(1.0, float(np.abs(z["g." + k]).max())), k   # (conv.bias: ~0 on both sides)
     for k, bfr in m.conv.named_buffers():
         if "num_batches" in k:
             assert int(bfr) == int(z["b." + k])
@@ -352,6 +352,11 @@ def test_model_three_steps_golden(dev, tag, flat):
         loss.backward()
         if step == 0:
             for k, p in m.named_parameters():
+                if k.endswith("conv.bias"):
+                    # a bias feeding BatchNorm has an identically-zero gradient in exact arithmetic: both sides hold
+                    # float32 rounding noise (reference ~1e-6), so only its magnitude is checked
+                    assert float(p.grad.abs().max()) < 1e-4, k
+                    continue
                 assert rel_l2(p.grad, z["g." + k]) < 2e-4 or maxabs(p.grad, z["g." + k]) < 1e-6, k
         opt.step()
         losses.append(float(loss))
@@ -360,6 +365,9 @@ def test_model_three_steps_golden(dev, tag, flat):
         want = z["after." + k]
         if "num_batches" in k:
             assert int(v) == int(want), k
+        elif k.endswith("conv.bias"):
+            # its gradient is pure rounding noise (see above) and Adam normalises noise to +-lr per step
+            assert maxabs(v, want) < 3.5e-3, k
         else:
             assert maxabs(v, want) < 5e-5, k
     m.eval()
@@ -426,6 +434,9 @@ def test_large_shape_checksums(dev, name):
     assert abs(float(lp.double().abs().mean()) - want["lp_abs_mean"]) / want["lp_abs_mean"] < 1e-4
     for k, p in m.named_parameters():
         gn = float(p.grad.double().norm())
+        if k.endswith("conv.bias"):        # zero in exact arithmetic (bias -> BatchNorm): rounding noise on both sides
+            assert gn < 0.05
+            continue
         assert abs(gn - want["grad_norm"][k]) <= 2e-3 * want["grad_norm"][k] + 1e-6, (k, gn, want["grad_norm"][k])
 
 

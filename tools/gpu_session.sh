@@ -8,7 +8,7 @@ what="${1:-all}"
 export PYTHONDONTWRITEBYTECODE=1
 if [[ "$what" == "all" || "$what" == "tests" ]]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/summary.log
-  timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 300 -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 300 -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest rc=$?" | tee -a gpurun_out/summary.log
   tail -n 60 gpurun_out/pytest_gpu.log
 fi
