@@ -365,8 +365,9 @@ def test_model_three_steps_golden(dev, tag, flat):
         want = z["after." + k]
         if "num_batches" in k:
             assert int(v) == int(want), k
-        elif k.endswith("conv.bias"):
-            # its gradient is pure rounding noise (see above) and Adam normalises noise to +-lr per step
+        elif k.endswith("conv.bias") or (k.startswith("conv.") and k.endswith("running_mean")):
+            # the bias gradient is pure rounding noise (see above) and Adam normalises noise to +-lr per step; the
+            # BatchNorm running mean right after the conv inherits that drift (0.1 * bias difference per step)
             assert maxabs(v, want) < 3.5e-3, k
         else:
             assert maxabs(v, want) < 5e-5, k
