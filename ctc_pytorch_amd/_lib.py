@@ -29,6 +29,9 @@ _SIGS = {
     "ctcn_version": (I, []),
     "ctcn_last_error": (ctypes.c_char_p, []),
     "ctcn_device_cus": (I, []),
+    "ctcn_set_option": (I, [ctypes.c_char_p, I]),
+    "ctcn_get_option": (I, [ctypes.c_char_p]),
+    "ctcn_set_status_buffer": (I, [P]),
     "ctcn_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, F, I, P, Z, P]),
     "ctcn_transpose01": (I, [P, P, I, I, I, P]),
     "ctcn_copy_strided4": (I, [P, P, I, I, I, I, Z, Z, Z, Z, P]),
@@ -93,6 +96,9 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        env = os.environ.get("CTCN_RNN_PERSISTENT")
+        if env is not None:
+            l.ctcn_set_option(b"rnn_persistent", int(env))
     return _lib
 
 
@@ -108,6 +114,30 @@ def check(rc, what=""):
 
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
+
+
+_STATUS = {}
+
+
+def status_word(device):
+    """Per-device sticky int32 the persistent kernels write on a hand-off timeout (0 = healthy)."""
+    key = (device.type, device.index)
+    t = _STATUS.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _STATUS[key] = t
+        check(lib().ctcn_set_status_buffer(ctypes.c_void_p(t.data_ptr())), "set_status_buffer")
+    return t
+
+
+def check_status(device):
+    """Synchronising health check: raises if a persistent kernel reported a hand-off timeout."""
+    t = _STATUS.get((device.type, device.index))
+    if t is not None:
+        v = int(t.item())
+        if v != 0:
+            t.zero_()
+            raise RuntimeError("libctcn: persistent recurrent kernel reported status %d (in-launch hand-off timed out)" % v)
 
 
 _WS = {}

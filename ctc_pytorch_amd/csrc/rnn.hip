@@ -292,6 +292,270 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
   }
 }
 
+// ================================================================================================
+// Persistent forward recurrence: ONE launch per layer.
+//
+// Measured motivation (tools/mb_step.hip, cfg2).  A per-timestep launch costs 7.2 us = 2.8 us dependent-launch floor
+// + 2.2 us cold operand fetch (the launch boundary invalidates every XCD's L2, so W_hh and h_{t-1} come from the
+// memory side each step) + 2.2 us of work.  A first persistent version that swept 8-byte {value,tag} granules of
+// h_{t-1} straight into MFMA-operand registers ran 5.9 us/step with ZERO retries: the cost was not waiting but the
+// sweep itself (82 KB of half-line sc1 requests per workgroup = 3.1 us; a CU sustains only ~25 B/clk of L1-missing
+// traffic).  This version therefore minimises and coalesces what a workgroup must pull per step:
+//   * a workgroup owns 4*NT hidden units (all gates) of ONE 16-row batch tile, so it needs only that tile of
+//     h_{t-1}: 16 x H floats (20 KB at H=320) -- its W_hh slice lives in VGPRs for all T steps, c/h of its own units
+//     in one register per thread;
+//   * producers publish plain float payload with write-through (sc1) 16-B stores, drain them, then ONE lane stores a
+//     per-(slice) flag = step+1 (hand-off recipe R1 of cdna_hip_programming.md G16: sc1 payload + drained flag, sc1
+//     loads on the consumer side instead of an acquire);
+//   * the consumer polls the H/(4*NT) flags of its (direction, batch tile) with one relaxed sc1 load per lane, then
+//     all 4 waves fetch the tile with fully coalesced sc1 16-B loads (whole 128-B lines, each requested once) into
+//     a row-padded LDS image, from which the MFMA A-operands are read with conflict-free ds_read_b128.
+// Two parity buffers suffice (a workgroup can publish step s+1 only after every producer of its tile published
+// step s, i.e. after all reads of step s-1).  Every spin is bounded: on a timeout the sticky status word is set,
+// the layer output is poisoned with NaN and all workgroups leave.
+// grid = (H/(4*NT), dirs, ceil(B/16)) workgroups x 256 threads, all co-resident (occupancy-checked on the host).
+// ================================================================================================
+struct PersistArgs {
+  RnnArgs a;
+  float *hx;            // fwd: [2 parity][D][btiles][16][H] h payload;  bwd: [2][D][btiles][16][G*H] d(pre-act) payload
+  unsigned *flags;      // [2 parity][D][btiles][nslices]
+  int *status;
+  int spin_limit;
+#ifdef CTCN_PERSIST_STATS
+  long long *stats;   // development instrumentation (tools/mb_step.hip only)
+#endif
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld_sc1_f4(const __amdgpu_buffer_rsrc_t &rs, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);          // aux 16 = sc1: bypass L1
+  return (f32x4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ void st_sc1_f4(const __amdgpu_buffer_rsrc_t &rs, unsigned byte_off, f32x4 v) {
+  const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  __builtin_amdgcn_raw_buffer_store_b128(u, rs, byte_off, 0, 16);                        // write-through
+}
+
+// Wave 0 polls `n` flags (one per lane, strided) until all equal `want`.  Returns false on timeout / global abort.
+__device__ __forceinline__ bool poll_flags(const unsigned *flags, int n, unsigned want, int lane, int spin_limit, int *status) {
+  for (int spins = 0;; ++spins) {
+    bool ok = true;
+    for (int i = lane; i < n; i += 64)
+      ok = ok && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+    if (__all(ok)) return true;
+    if (spins > spin_limit) return false;
+    if ((spins & 255) == 255 && status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <int NT, int KQ4>
+__global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
+  constexpr int NW = 4;
+  const RnnArgs &p = pa.a;
+  extern __shared__ __attribute__((aligned(16))) float dsm[];     // h tile image [16][H+4]
+  __shared__ float red[NW * NT * 256];
+  __shared__ float outs[NT * 16][17];
+  __shared__ float hpub[16][4 * NT < 16 ? 16 : 4 * NT];
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int d = blockIdx.y, bt = blockIdx.z, nbt = gridDim.z, nsl = gridDim.x;
+  const int b0 = bt * 16;
+  const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  const int Bc = min(16, B - b0);
+  const bool tanh_cell = p.cell == CTCN_CELL_TANH;
+  const int HSU = tanh_cell ? 16 : 4 * NT;                 // hidden units owned by this workgroup
+  const int j0 = blockIdx.x * HSU;
+  const int ldh = H + 4;                                   // LDS row stride (floats): rows land 4 banks apart
+  const float *W = d == 0 ? p.w0 : p.w1;
+  const int kb = wave * 16 * KQ4 + q * 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) s_abort = 0;
+
+  // W_hh slice of this lane, resident for the whole sequence: tile nt covers units j0+4nt..+3 (x 4 gates)
+  f32x4 bv[NT][KQ4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int gate = tanh_cell ? 0 : (r >> 2), jj = tanh_cell ? r : (nt * 4 + (r & 3));
+    const bool bvalid = gate < G && (j0 + jj) < H;
+    const float *brow = bvalid ? W + (size_t)(gate * H + j0 + jj) * H : W;
+#pragma unroll
+    for (int s = 0; s < KQ4; ++s) {
+      const int k = kb + 16 * s;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, H - 4));
+      bv[nt][s] = (bvalid && k < H) ? v : zero;
+    }
+  }
+  const size_t tile_f = (size_t)16 * H;                                                         // floats per h tile
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
+
+  // epilogue item of this thread: (row bl, unit jl) fixed for all steps -> c / h of the unit stay in a register
+  const int bl = tid / HSU, jl = tid - bl * HSU;
+  const int j = j0 + jl, b = b0 + bl;
+  const bool item = bl < 16 && bl < Bc && j < H;
+  const int ont = tanh_cell ? 0 : (jl >> 2), ojl = tanh_cell ? jl : (jl & 3);                 // tile / column group of the unit
+  float state = 0.0f;   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+  __syncthreads();
+#ifdef CTCN_PERSIST_STATS
+  long long st_poll = 0, st_fill = 0, st_mm = 0, st_red = 0, st_epi = 0, st_t0 = clock64();
+#endif
+
+  for (int s = 0; s < T; ++s) {
+#ifdef CTCN_PERSIST_STATS
+    const long long c_a = clock64();
+    long long c_p = c_a, c_f = c_a;
+#endif
+    const int t = d == 0 ? s : T - 1 - s;
+    const size_t row_t = (size_t)t * B + b;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (item) {
+      const float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < G) pre[k] = gt[k * H + j];
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero;
+    if (s > 0) {
+      const int par = (s - 1) & 1;
+      if (wave == 0) {
+        const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
+        if (!poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status) && lane == 0) {
+          s_abort = 1;
+          if (pa.status) atomicCAS(pa.status, 0, 101);
+        }
+      }
+      __syncthreads();
+      if (s_abort) break;
+#ifdef CTCN_PERSIST_STATS
+      c_p = clock64();
+#endif
+      // coalesced tile fetch: 16 rows x H floats, whole lines, write-through data read around L1
+      const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
+      const int nf4 = 16 * H / 4;
+      for (int i = tid; i < nf4; i += 256) {
+        const int row = (i * 4) / H, col = i * 4 - row * H;
+        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)i * 16);
+        *reinterpret_cast<f32x4 *>(dsm + row * ldh + col) = v;
+      }
+      __syncthreads();
+#ifdef CTCN_PERSIST_STATS
+      c_f = clock64();
+#endif
+      f32x4 av[KQ4];
+#pragma unroll
+      for (int si = 0; si < KQ4; ++si) {
+        const int k = kb + 16 * si;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(dsm + r * ldh + min(k, H - 4));
+        av[si] = (k < H && r < Bc) ? v : zero;
+      }
+#pragma unroll
+      for (int si = 0; si < KQ4; ++si)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[nt][si][c], acc[nt], 0, 0, 0);
+    }
+#ifdef CTCN_PERSIST_STATS
+    const long long c_b = clock64();
+#endif
+    reduce_tiles<NT, NW, 4>(acc, red, outs, tid, 256);
+#ifdef CTCN_PERSIST_STATS
+    const long long c_c = clock64();
+    st_poll += c_p - c_a; st_fill += c_f - c_p; st_mm += c_b - c_f; st_red += c_c - c_b;
+#endif
+
+    if (item) {
+      float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+      float hval;
+      const float *o = &outs[ont * 16 + bl][0];
+      if (p.cell == CTCN_CELL_LSTM) {
+        const float i_ = sigmoidf_(o[0 * 4 + ojl] + pre[0]);
+        const float f_ = sigmoidf_(o[1 * 4 + ojl] + pre[1]);
+        const float g_ = tanhf(o[2 * 4 + ojl] + pre[2]);
+        const float o_ = sigmoidf_(o[3 * 4 + ojl] + pre[3]);
+        const float c = f_ * state + i_ * g_;
+        hval = o_ * tanhf(c);
+        state = c;
+        gt[0 * H + j] = i_; gt[1 * H + j] = f_; gt[2 * H + j] = g_; gt[3 * H + j] = o_;
+        p.aux[(row_t * D + d) * H + j] = c;
+      } else if (p.cell == CTCN_CELL_GRU) {
+        const float hn = o[2 * 4 + ojl];
+        const float r_ = sigmoidf_(o[0 * 4 + ojl] + pre[0]);
+        const float z_ = sigmoidf_(o[1 * 4 + ojl] + pre[1]);
+        const float n_ = tanhf(pre[2] + r_ * hn);
+        hval = (1.0f - z_) * n_ + z_ * state;
+        state = hval;
+        gt[0 * H + j] = r_; gt[1 * H + j] = z_; gt[2 * H + j] = n_;
+        p.aux[(row_t * D + d) * H + j] = hn;
+      } else {
+        hval = tanhf(o[ojl] + pre[0]);
+      }
+      p.y[row_t * D * H + d * H + j] = hval;
+      hpub[bl][jl] = hval;
+    }
+    __syncthreads();
+    // publish this workgroup's 16 x HSU block of h_t: 16-B write-through stores by wave 0, drained, then the flag
+    if (s + 1 < T && wave == 0) {
+      const int par = s & 1;
+      const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
+      const int per_row = HSU / 4;                               // float4 per row
+      for (int i = lane; i < 16 * per_row; i += 64) {
+        const int row = i / per_row, c4 = i - row * per_row;
+        if (row < Bc && j0 + c4 * 4 < H) {
+          const f32x4 v = {hpub[row][c4 * 4], hpub[row][c4 * 4 + 1], hpub[row][c4 * 4 + 2], hpub[row][c4 * 4 + 3]};
+          st_sc1_f4(rs, tbase + (unsigned)((row * H + j0 + c4 * 4) * 4), v);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the storing wave drains its write-through stores
+      if (lane == 0)
+        __hip_atomic_store(pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef CTCN_PERSIST_STATS
+    st_epi += clock64() - c_c;
+#endif
+  }
+#ifdef CTCN_PERSIST_STATS
+  if (pa.stats && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    pa.stats[0] = st_poll; pa.stats[1] = st_fill; pa.stats[2] = st_mm; pa.stats[3] = st_red; pa.stats[4] = st_epi; pa.stats[5] = clock64() - st_t0;
+  }
+#endif
+  if (s_abort && item) p.y[((size_t)(d == 0 ? T - 1 : 0) * B + b) * D * H + d * H + j] = __uint_as_float(0x7fc00000u);   // poison
+}
+
+// Launch a persistent kernel only if the whole grid is co-resident (occupancy query x CU count, with one block of
+// slack per CU when the API admits more than one: ROCm 7.2 can over-report by one, MI355X_MICROARCH.md).
+template <class Kern, class Args>
+bool launch_resident(Kern kern, dim3 grid, int threads, size_t lds, hipStream_t st, const Args &a) {
+  int per_cu = 0;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu <= 0) return false;
+  const int cus = ctcn_device_cus();
+  const long cap = (long)cus * (per_cu > 1 ? per_cu - 1 : 1) - (per_cu > 1 ? 0 : 8);
+  if ((long)grid.x * grid.y * grid.z > cap) return false;
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
+  return true;
+}
+
+template <int NT>
+bool launch_fwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a) {
+  switch (kq4) {
+    case 1: return launch_resident(rnn_fwd_persist<NT, 1>, grid, 256, lds, st, a);
+    case 2: return launch_resident(rnn_fwd_persist<NT, 2>, grid, 256, lds, st, a);
+    case 3: return launch_resident(rnn_fwd_persist<NT, 3>, grid, 256, lds, st, a);
+    case 4: return launch_resident(rnn_fwd_persist<NT, 4>, grid, 256, lds, st, a);
+    case 5: return launch_resident(rnn_fwd_persist<NT, 5>, grid, 256, lds, st, a);
+    case 6: return launch_resident(rnn_fwd_persist<NT, 6>, grid, 256, lds, st, a);
+    case 8: return launch_resident(rnn_fwd_persist<NT, 8>, grid, 256, lds, st, a);
+    default: return false;
+  }
+}
+
 int pick_kq4(int K, int nwaves, int mt, int budget) {
   const int cand[4] = {5, 4, 2, 1};
   int best = 1, best_cost = 1 << 30;
@@ -356,8 +620,38 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   a.w0 = w_hh0; a.w1 = w_hh1; a.y = y; a.gates = gates; a.aux = aux; a.dy = nullptr; a.state = nullptr;
   const int HS = cell == CTCN_CELL_TANH ? 16 : 4;
   const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-  const int kq4 = pick_kq4(H, 4, MT, 20);
   dim3 grid(ceil_div(H, HS), dirs, ceil_div(B, 16 * MT));
+  if (ctcn_opt_rnn_persistent() && T > 1 && H % 4 == 0) {
+    // persistent recurrence: K = H split over 4 waves x 4 k-lanes x KQ4 float4 (one super-chunk)
+    int kq = ceil_div(H, 64);
+    if (kq == 7) kq = 8;
+    const int NT = cell == CTCN_CELL_TANH ? 1 : (H % 8 == 0 ? 2 : 1);
+    const int HSU = cell == CTCN_CELL_TANH ? 16 : 4 * NT;
+    const int nbt = ceil_div(B, 16), nsl = ceil_div(H, HSU);
+    dim3 pgrid(nsl, dirs, nbt);
+    const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * 16 * H * sizeof(float), 256);
+    const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256);
+    const size_t lds = (size_t)16 * (H + 4) * sizeof(float);
+    if (kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512) {
+      PersistArgs pa;
+      pa.a = a;
+      char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
+      pa.hx = (float *)tail;
+      pa.flags = (unsigned *)(tail + hx_bytes);
+      pa.status = ctcn_status_word();
+      pa.spin_limit = 1 << 22;
+#ifdef CTCN_PERSIST_STATS
+      pa.stats = nullptr;
+#endif
+      CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
+      const bool ok = NT == 1 ? launch_fwd_persist<1>(kq, pgrid, lds, st, pa) : launch_fwd_persist<2>(kq, pgrid, lds, st, pa);
+      if (ok) {
+        CTCN_LAUNCH_CHECK();
+        return CTCN_OK;
+      }
+    }
+  }
+  const int kq4 = pick_kq4(H, 4, MT, 20);
   for (int s = 0; s < T; ++s) {
     a.step = s;
     if (MT == 1) launch_fwd<1>(kq4, grid, st, a);

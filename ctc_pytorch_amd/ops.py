@@ -49,7 +49,18 @@ def _gview(p):
     return getattr(p, "_ctcn_grad", None) if p is not None else None
 
 
+def set_rnn_persistent(flag):
+    """1: persistent recurrent kernels (default); 0: one launch per timestep (ctcn_set_option)."""
+    _lib.check(_lib.lib().ctcn_set_option(b"rnn_persistent", int(bool(flag))), "set_option")
+
+
+def check_health(device=None):
+    """Synchronising check of the sticky status word written by persistent kernels on a hand-off timeout."""
+    _lib.check_status(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+
+
 def _ws(t):
+    _lib.status_word(t.device)
     w = _lib.workspace(t.device)
     return w, ctypes.c_void_p(w.data_ptr()), w.numel()
 

@@ -35,6 +35,13 @@ int ctcn_version(void);
 const char *ctcn_last_error(void);
 /* number of CUs of the current device (host query, used to size grids / workspaces) */
 int ctcn_device_cus(void);
+/* options: "rnn_persistent" = 1 (default): the recurrence of ctcn_rnn_fwd/bwd runs as ONE persistent launch per layer
+ * (W_hh slice resident in VGPRs, h_t handed between workgroups in-launch); 0: one launch per timestep. */
+int ctcn_set_option(const char *name, int value);
+int ctcn_get_option(const char *name);
+/* optional device int that persistent kernels set to a non-zero code if an in-launch hand-off times out (sticky);
+ * the caller zeroes it and reads it at its own synchronisation points. */
+int ctcn_set_status_buffer(int *dev_word);
 
 /* ---------------------------------------------------------------------------------------------------
  * GEMM (MFMA, f32 in / f32 accumulate: v_mfma_f32_32x32x2_f32; optional bf16-operand mode)

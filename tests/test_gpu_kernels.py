@@ -110,6 +110,29 @@ def test_rnn_layer_vs_torch_cpu(dev, kind, T, B, I, H, bi):
         assert rel_l2(p.grad, getattr(ref, n).grad) < 1e-4, n
 
 
+@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 60, 32, 40, 320, True), ("gru", 25, 9, 16, 128, True), ("rnn", 31, 20, 8, 48, False),
+                                            ("lstm", 17, 70, 12, 64, True), ("gru", 12, 64, 24, 512, True)])
+def test_rnn_persistent_equals_per_step_launches(dev, kind, T, B, I, H, bi):
+    """The persistent recurrence (in-launch granule hand-off) and the one-launch-per-timestep path agree."""
+    from ctc_pytorch_amd import ops
+    G = {"lstm": 4, "gru": 3, "rnn": 1}[kind]
+    torch.manual_seed(7)
+    x = torch.randn(T, B, I, device=dev)
+    w = [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)]
+    w += [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)] if bi else [None, None]
+    outs = []
+    try:
+        for flag in (0, 1):
+            ops.set_rnn_persistent(flag)
+            with torch.no_grad():
+                outs.append(ops.rnn_layer(x, w[0], w[1], w[2], w[3], {"rnn": "tanh"}.get(kind, kind)).clone())
+            ops.check_health(dev)
+    finally:
+        ops.set_rnn_persistent(1)
+    assert torch.isfinite(outs[1]).all()
+    assert maxabs(outs[0], outs[1]) < 2e-6
+
+
 def test_rnn_rejects_bad_hidden(dev):
     from ctc_pytorch_amd import ops
     x = torch.zeros(3, 2, 5, device=dev)

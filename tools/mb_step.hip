@@ -1,5 +1,6 @@
 // tools/mb_step.hip -- standalone micro-benchmark of the recurrent step kernels (development aid, not product).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpurun_out/mb_step tools/mb_step.hip ctc_pytorch_amd/csrc/core.hip
+#define CTCN_PERSIST_STATS 1
 #include "../ctc_pytorch_amd/csrc/rnn.hip"
 #include <vector>
 
@@ -48,6 +49,60 @@ __global__ __launch_bounds__(256) void fwd_ld_only(RnnArgs p) {
   for (int i = 0; i < KQ4 * (MT + 1); ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
   if (s == 12345.f) p.y[0] = 1.f;
 }
+
+// instrumented copy of rnn_fwd_step<2,5> (LSTM): wall_clock64 stamps (100 MHz -> 10 ns) of block 0 / wave 0
+__global__ __launch_bounds__(256) void fwd_stamped(RnnArgs p, long long *stamps) {
+  constexpr int NW = 4, MT = 2, KQ4 = 5;
+  __shared__ float red[NW * MT * 256];
+  __shared__ float outs[MT * 16][17];
+  long long ts[8];
+  ts[0] = clock64();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int d = blockIdx.y, b0 = 0, H = p.H, G = p.G, D = p.D, B = p.B, Bc = 32;
+  const int t = d == 0 ? p.step : p.T - 1 - p.step, tp = d == 0 ? t - 1 : t + 1;
+  const int j0 = blockIdx.x * 4, gate = r >> 2, jj = r & 3;
+  const float *W = d == 0 ? p.w0 : p.w1;
+  const float *brow = W + (size_t)(gate * H + j0 + jj) * H;
+  const int bl = tid / 4, jl = tid - bl * 4, j = j0 + jl, b = b0 + bl;
+  const bool item = bl < Bc;
+  const size_t row_t = (size_t)t * B + b;
+  float pre[4] = {0, 0, 0, 0}, prev = 0;
+  if (item) {
+    const float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+    for (int k = 0; k < 4; ++k) pre[k] = gt[k * H + j];
+    prev = p.aux[(((size_t)tp * B + b) * D + d) * H + j];
+  }
+  f32x4 acc[MT];
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *abase = p.y + ((size_t)tp * B + b0) * D * H + d * H;
+  ts[1] = clock64();
+  rec_mm<MT, KQ4>(abase, D * H, H, abase, D * H, Bc, brow, true, H, NW, wave, q, r, acc);
+  asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]));
+  ts[2] = clock64();
+  reduce_tiles<MT, NW, 4>(acc, red, outs, tid, 256);
+  ts[3] = clock64();
+  float hv = 0;
+  if (item) {
+    float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+    float *yt = p.y + row_t * D * H + d * H;
+    const float i_ = sigmoidf_(outs[bl][0 * 4 + jl] + pre[0]);
+    const float f_ = sigmoidf_(outs[bl][1 * 4 + jl] + pre[1]);
+    const float g_ = tanhf(outs[bl][2 * 4 + jl] + pre[2]);
+    const float o_ = sigmoidf_(outs[bl][3 * 4 + jl] + pre[3]);
+    const float c = f_ * prev + i_ * g_;
+    hv = o_ * tanhf(c);
+    asm volatile("" :: "v"(hv));
+    ts[4] = clock64();
+    gt[0 * H + j] = i_; gt[1 * H + j] = f_; gt[2 * H + j] = g_; gt[3 * H + j] = o_;
+    p.aux[(row_t * D + d) * H + j] = c;
+    yt[j] = hv;
+  }
+  ts[5] = clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ts[6] = clock64();
+  if (blockIdx.x == 7 && blockIdx.y == 0 && tid == 0 && p.step == 400)
+    for (int i = 0; i < 7; ++i) stamps[i] = ts[i] - ts[0];
+}
 }  // namespace
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -84,6 +139,35 @@ int main() {
   timeit("fwd matmul+reduce only", [&] { hipLaunchKernelGGL((fwd_mm_only<2, 5>), gf, dim3(256), 0, st, a); }, 1);
   a.w0 = wT; a.w1 = wT + (size_t)G * H * H;
   timeit("bwd full <5> 80x1024", [&] { hipLaunchKernelGGL((rnn_bwd_step<5>), gb, dim3(1024), 0, st, a); }, 1);
+  {
+    long long *stamps, h[8];
+    CK(hipMalloc(&stamps, 64)); CK(hipMemset(stamps, 0, 64));
+    timeit("fwd stamped <2,5>", [&] { hipLaunchKernelGGL(fwd_stamped, gf, dim3(256), 0, st, a, stamps); }, 1);
+    CK(hipMemcpy(h, stamps, 56, hipMemcpyDeviceToHost));
+    printf("  stamps (shader cycles since kernel entry, block 7 wave 0, step 400): prefetch-issued %lld | matmul-done %lld | reduce-done %lld | math-done %lld | stores-issued %lld | stores-acked %lld\n",
+           h[1], h[2], h[3], h[4], h[5], h[6]);
+  }
+  {
+    // persistent forward recurrence with in-kernel phase accounting
+    const int nbt = 2, nsl = H / 8;
+    const size_t hx_bytes = (size_t)2 * D * nbt * 16 * H * 4, fl_bytes = (size_t)2 * D * nbt * nsl * 4;
+    float *hx; unsigned *flags; int *status; long long *stats, h[6];
+    CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, 64));
+    PersistArgs pa; pa.a = a; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
+    dim3 gp(nsl, D, nbt);
+    const size_t lds = (size_t)16 * (H + 4) * 4;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st));
+      hipEventRecord(e0, st);
+      hipLaunchKernelGGL((rnn_fwd_persist<2, 5>), gp, dim3(256), lds, st, pa);
+      hipEventRecord(e1, st); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h, stats, 48, hipMemcpyDeviceToHost));
+    printf("%-44s %8.2f us/step   (status %d)\n", "fwd PERSISTENT <NT=2,5> 160 WGs", ms * 1e3 / T, hs);
+    printf("  per step (cycles), block 7 thread 0: flag poll %.0f | tile fill %.0f | lds+mfma %.0f | reduce %.0f | epilogue+publish %.0f | total %.0f\n",
+           (double)h[0] / T, (double)h[1] / T, (double)h[2] / T, (double)h[3] / T, (double)h[4] / T, (double)h[5] / T);
+  }
   // graph replay of the forward loop: is the host the limiter?
   a.w0 = w; a.w1 = w + (size_t)G * H * H;
   hipGraph_t g; hipGraphExec_t ge;
