@@ -104,9 +104,13 @@ def gemm_roofline(dev, c):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * M * N * K
     tf = flops / (ms * 1e-3) / 1e12
-    return dict(kernel="gemm_f32_kernel<NT> %dx%dx%d" % (M, N, K), bound="mfma", achieved=tf, peak=PEAK_F32_MFMA_TFLOPS,
-                unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS, traffic=None, us_per_launch=ms * 1e3,
-                algorithmic_flops_per_launch=flops)
+    prec = ops.get_precision()
+    # bf16x3 issues 3 bf16 MFMAs per algorithmic product: its ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s
+    peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0 / 3.0
+    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_bf16x3_kernel<NT>") + " %dx%dx%d" % (M, N, K), bound="mfma",
+                achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=None, us_per_launch=ms * 1e3,
+                algorithmic_flops_per_launch=flops,
+                peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
 
 
 def recurrence_probe(dev, c):
@@ -146,6 +150,8 @@ def run_train(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     c = WORKLOADS[args.workload]
+    from ctc_pytorch_amd import ops as _ops
+    _ops.set_precision(args.precision)
     torch.manual_seed(1)
     model = build(c, dev, drop_out=0.1).train()
     opt = FlatAdam(model, lr=1e-3, weight_decay=5e-4)
@@ -198,7 +204,7 @@ def run_train(args):
         "metric": "acoustic frames/sec (train), TIMIT-shape 4x320 BiLSTM + CTC" if args.workload == "cfg2" else "acoustic frames/sec (train), " + args.workload,
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == 0 else "f32 via bf16x3 split-operand MFMA (f32 accumulate)", "data": "synthetic",
         "config": {"workload": "%s: %dx%d Bi%s + BN + Linear(%d) + CTC, B=%d/GPU, T=%d, F=40%s, dropout 0.1, Adam" % (
             args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], ", 2-layer CNN front-end" if c["cnn"] else ""),
             "global_batch": global_b, "seq_len": c["T"], "parallelism": "dp%d" % world, "full_length_utterances": True},
@@ -260,5 +266,7 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="train", choices=["train", "decode"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "0")), choices=[0, 1],
+                    help="0: exact f32 MFMA GEMMs; 1: bf16x3 split-operand MFMA GEMMs (f32-class accuracy)")
     a = ap.parse_args()
     (run_train if a.mode == "train" else run_decode)(a)

@@ -162,6 +162,170 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// precision = 1: split-operand bf16 MFMA ("bf16x3").  Every f32 operand is split on the fly into
+// hi = bf16(x), lo = bf16(x - hi) while it is staged into LDS, and the product is accumulated in f32 as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (3 MFMAs = 96 cycles per 32x32x16 instead of
+// 8 x 64 = 512 cycles of f32 MFMA).  16 mantissa bits per operand -> relative error ~2^-16 per product, i.e.
+// f32-class results (max-abs 1e-5 on unit-scale data) at ~5x the f32-MFMA rate.
+// LDS image: [row][k] with k contiguous (8 bf16 = one ds_read_b128 MFMA fragment), row stride 40 bf16 = 80 B so the
+// 16 lanes of a read group land on 16 distinct 16-B bank slots.
+// ------------------------------------------------------------------------------------------------
+constexpr int XBK = 32, XLD = 40;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(float x, unsigned short &hi, unsigned short &lo) {
+  hi = f2bf(x);
+  lo = f2bf(x - __uint_as_float((unsigned)hi << 16));
+}
+
+// KC: element (r,k) at src[(r0+r)*ld + k0+k];  16 floats per thread: 4 x float4 along k
+__device__ __forceinline__ void x_g2r_kc(const float *__restrict__ src, int ld, int r0, int R, int k0, int Kend, bool vec,
+                                         int tid, float (&reg)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j;
+    const int r = idx >> 3, kq = (idx & 7) * 4;
+    const int gr = r0 + r, gk = k0 + kq;
+    const float *p = src + (size_t)gr * ld + gk;
+    if (vec && gr < R && gk + 3 < Kend) {
+      const float4 v = *reinterpret_cast<const float4 *>(p);
+      reg[4 * j] = v.x; reg[4 * j + 1] = v.y; reg[4 * j + 2] = v.z; reg[4 * j + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) reg[4 * j + c] = (gr < R && gk + c < Kend) ? p[c] : 0.0f;
+    }
+  }
+}
+__device__ __forceinline__ void x_r2s_kc(unsigned short (*sh)[XLD], unsigned short (*sl)[XLD], int tid, const float (&reg)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j;
+    const int r = idx >> 3, kq = (idx & 7) * 4;
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) split_bf16(reg[4 * j + c], h[c], l[c]);
+    *reinterpret_cast<uint2 *>(&sh[r][kq]) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2 *>(&sl[r][kq]) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+// MC: element (r,k) at src[(k0+k)*ld + r0+r];  4 x float4 along r, transposed into the [row][k] image
+__device__ __forceinline__ void x_g2r_mc(const float *__restrict__ src, int ld, int r0, int R, int k0, int Kend, bool vec,
+                                         int tid, float (&reg)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j;
+    const int k = idx >> 5, rq = (idx & 31) * 4;
+    const int gk = k0 + k, gr = r0 + rq;
+    const float *p = src + (size_t)gk * ld + gr;
+    if (vec && gk < Kend && gr + 3 < R) {
+      const float4 v = *reinterpret_cast<const float4 *>(p);
+      reg[4 * j] = v.x; reg[4 * j + 1] = v.y; reg[4 * j + 2] = v.z; reg[4 * j + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) reg[4 * j + c] = (gk < Kend && gr + c < R) ? p[c] : 0.0f;
+    }
+  }
+}
+__device__ __forceinline__ void x_r2s_mc(unsigned short (*sh)[XLD], unsigned short (*sl)[XLD], int tid, const float (&reg)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j;
+    const int k = idx >> 5, rq = (idx & 31) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned short h, l;
+      split_bf16(reg[4 * j + c], h, l);
+      sh[rq + c][k] = h;
+      sl[rq + c][k] = l;
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                          const float *__restrict__ B, int ldb, float *__restrict__ C,
+                                                          int ldc, float beta, int kchunk, float *__restrict__ ws,
+                                                          int tiles_m, int tiles_n, bool vecA, bool vecB) {
+  __shared__ __attribute__((aligned(16))) unsigned short sAh[BM][XLD], sAl[BM][XLD], sBh[BN][XLD], sBl[BN][XLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  float ra[16], rb[16];
+  auto loadA = [&](int k0) {
+    if (TA) x_g2r_mc(A, lda, m0, M, k0, kend, vecA, tid, ra);
+    else x_g2r_kc(A, lda, m0, M, k0, kend, vecA, tid, ra);
+  };
+  auto loadB = [&](int k0) {
+    if (TB) x_g2r_kc(B, ldb, n0, N, k0, kend, vecB, tid, rb);
+    else x_g2r_mc(B, ldb, n0, N, k0, kend, vecB, tid, rb);
+  };
+  if (kbeg < kend) { loadA(kbeg); loadB(kbeg); }
+  for (int k0 = kbeg; k0 < kend; k0 += XBK) {
+    __syncthreads();
+    if (TA) x_r2s_mc(sAh, sAl, tid, ra); else x_r2s_kc(sAh, sAl, tid, ra);
+    if (TB) x_r2s_kc(sBh, sBl, tid, rb); else x_r2s_mc(sBh, sBl, tid, rb);
+    __syncthreads();
+    if (k0 + XBK < kend) { loadA(k0 + XBK); loadB(k0 + XBK); }
+    const int ml = lane & 31, kg = (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < XBK; ks += 16) {
+      bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8_t *>(&sAh[wm * 64 + i * 32 + ml][ks + kg]);
+        al[i] = *reinterpret_cast<const bf16x8_t *>(&sAl[wm * 64 + i * 32 + ml][ks + kg]);
+        bh[i] = *reinterpret_cast<const bf16x8_t *>(&sBh[wn * 64 + i * 32 + ml][ks + kg]);
+        bl[i] = *reinterpret_cast<const bf16x8_t *>(&sBl[wn * 64 + i * 32 + ml][ks + kg]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  float *out = ws ? ws + (size_t)blockIdx.y * M * N : C;
+  const int ldo = ws ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][e];
+          float *p = out + (size_t)row * ldo + col;
+          if (!ws && beta != 0.0f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc,
                                      int splits, float beta) {
   const size_t total = (size_t)M * N;
@@ -192,7 +356,7 @@ __global__ void transpose01_kernel(const float *__restrict__ in, float *__restri
 extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
                          int ldb, float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes,
                          void *stream) {
-  (void)precision;  // bf16-operand mode: see gemm_bf16 (not yet enabled); f32 MFMA is exact
+  CTCN_REQUIRE(precision == 0 || precision == 1, "ctcn_gemm: precision %d (0 = f32 MFMA, 1 = bf16x3 split MFMA)", precision);
   CTCN_REQUIRE(M > 0 && N > 0 && K >= 0, "ctcn_gemm: bad dims M=%d N=%d K=%d", M, N, K);
   CTCN_REQUIRE(A && B && C, "ctcn_gemm: null pointer");
   CTCN_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "ctcn_gemm: leading dim too small");
@@ -208,18 +372,23 @@ extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const floa
   }
   int kchunk = K;
   if (splits > 1) {
-    kchunk = ceil_div(ceil_div(K, splits), BK) * BK;
+    kchunk = ceil_div(ceil_div(K, splits), XBK) * XBK;
     splits = ceil_div(K, kchunk);
   }
   const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
   float *wsp = splits > 1 ? (float *)ws : nullptr;
   dim3 grid(nt, splits), block(256);
-#define LAUNCH(TA, TB)                                                                                          \
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, \
-                     wsp, tiles_m, tiles_n, vecA, vecB)
-  if (transA) { if (transB) LAUNCH(true, true); else LAUNCH(true, false); }
-  else        { if (transB) LAUNCH(false, true); else LAUNCH(false, false); }
+#define LAUNCH(KERN, TA, TB)                                                                             \
+  hipLaunchKernelGGL((KERN<TA, TB>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, wsp, \
+                     tiles_m, tiles_n, vecA, vecB)
+  if (precision == 0) {
+    if (transA) { if (transB) LAUNCH(gemm_f32_kernel, true, true); else LAUNCH(gemm_f32_kernel, true, false); }
+    else        { if (transB) LAUNCH(gemm_f32_kernel, false, true); else LAUNCH(gemm_f32_kernel, false, false); }
+  } else {
+    if (transA) { if (transB) LAUNCH(gemm_bf16x3_kernel, true, true); else LAUNCH(gemm_bf16x3_kernel, true, false); }
+    else        { if (transB) LAUNCH(gemm_bf16x3_kernel, false, true); else LAUNCH(gemm_bf16x3_kernel, false, false); }
+  }
 #undef LAUNCH
   CTCN_LAUNCH_CHECK();
   if (splits > 1) {
