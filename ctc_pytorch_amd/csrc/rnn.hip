@@ -556,6 +556,175 @@ bool launch_fwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const Pe
   }
 }
 
+// ================================================================================================
+// Persistent backward recurrence: ONE launch per layer, same hand-off scheme as rnn_fwd_persist.
+// A workgroup (1024 threads = 16 waves) owns one 16(batch) x 16(hidden) tile of dh_rec = d(pre-act)_{next} * W_hh:
+// its 16 rows of W_hh^T (K = G*H floats each) stay in VGPRs (K split over 16 waves x 4 k-lanes), dc / dh*z of its 256
+// (row, unit) items stay in one register per thread, and per step it pulls only the 16 x K tile of the other
+// workgroups' d(pre-activation) (80 KB at H=320) through a coalesced sc1 fetch into LDS.
+// grid = (ceil(H/16), dirs, ceil(B/16)).
+// ================================================================================================
+template <int KQ4>
+__global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
+  constexpr int NW = 16;
+  const RnnArgs &p = pa.a;
+  extern __shared__ __attribute__((aligned(16))) float dsm[];     // d(pre-act) tile image [16][K+4]
+  __shared__ float red[NW * 256];
+  __shared__ float outs[16][17];
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int d = blockIdx.y, bt = blockIdx.z, nbt = gridDim.z, nsl = gridDim.x;
+  const int b0 = bt * 16, j0 = blockIdx.x * 16;
+  const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  const int Bc = min(16, B - b0);
+  const int K = G * H, ldk = K + 4;
+  const float *WT = d == 0 ? p.w0 : p.w1;
+  const bool bvalid = (j0 + r) < H;
+  const float *brow = bvalid ? WT + (size_t)(j0 + r) * K : WT;
+  const int kb = wave * 16 * KQ4 + q * 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) s_abort = 0;
+
+  f32x4 bv[KQ4];
+#pragma unroll
+  for (int s = 0; s < KQ4; ++s) {
+    const int k = kb + 16 * s;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, K - 4));
+    bv[s] = (bvalid && k < K) ? v : zero;
+  }
+  const size_t tile_f = (size_t)16 * K;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
+
+  const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
+  const bool item = tid < 256 && bl < Bc && j < H;
+  float state = 0.0f;   // carried dc (LSTM) / dh*z (GRU)
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    const int tp = d == 0 ? (t > 0 ? t - 1 : -1) : (t < T - 1 ? t + 1 : -1);
+    const size_t row_t = (size_t)t * B + b;
+    float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f;
+    if (item) {
+      const float *gt = p.gates + (row_t * D + d) * (size_t)K;
+      dyv = p.dy[row_t * D * H + d * H + j];
+      if (p.cell == CTCN_CELL_TANH) {
+        e0 = p.y[row_t * D * H + d * H + j];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < G) sv[k] = gt[k * H + j];
+        e0 = p.aux[(row_t * D + d) * H + j];
+        if (tp >= 0)
+          e1 = p.cell == CTCN_CELL_LSTM ? p.aux[(((size_t)tp * B + b) * D + d) * H + j]
+                                        : p.y[((size_t)tp * B + b) * D * H + d * H + j];
+      }
+    }
+    f32x4 acc[1];
+    acc[0] = zero;
+    if (s > 0) {
+      const int par = (s - 1) & 1;
+      if (wave == 0) {
+        const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
+        if (!poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status) && lane == 0) {
+          s_abort = 1;
+          if (pa.status) atomicCAS(pa.status, 0, 201);
+        }
+      }
+      __syncthreads();
+      if (s_abort) break;
+      const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
+      const int nf4 = 16 * K / 4;
+      for (int i = tid; i < nf4; i += 1024) {
+        const int row = (i * 4) / K, col = i * 4 - row * K;
+        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)i * 16);
+        *reinterpret_cast<f32x4 *>(dsm + row * ldk + col) = v;
+      }
+      __syncthreads();
+      f32x4 av[KQ4];
+#pragma unroll
+      for (int si = 0; si < KQ4; ++si) {
+        const int k = kb + 16 * si;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(dsm + r * ldk + min(k, K - 4));
+        av[si] = (k < K && r < Bc) ? v : zero;
+      }
+      f32x4 acc1 = zero;      // two independent accumulator chains hide the 40-cycle dependent MFMA latency
+#pragma unroll
+      for (int si = 0; si < KQ4; ++si)
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[si][c], acc[0], 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c + 1], bv[si][c + 1], acc1, 0, 0, 0);
+        }
+      acc[0] += acc1;
+    }
+    reduce_tiles<1, NW, NW>(acc, red, outs, tid, 1024);
+
+    const int par = s & 1;
+    float *px = pa.hx + ((((size_t)par * D + d) * nbt + bt) * 16 + bl) * (size_t)K;      // this row of the published tile
+    if (item) {
+      float *gt = p.gates + (row_t * D + d) * (size_t)K;
+      float dh = dyv + outs[bl][jl];
+      float out[4] = {0.f, 0.f, 0.f, 0.f};    // values the next step multiplies by W_hh (published), per gate block
+      if (p.cell == CTCN_CELL_LSTM) {
+        const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
+        const float tc = tanhf(e0);
+        const float do_ = dh * tc;
+        const float dc = dh * o_ * (1.0f - tc * tc) + state;
+        out[0] = dc * g_ * i_ * (1.0f - i_);
+        out[1] = dc * e1 * f_ * (1.0f - f_);
+        out[2] = dc * i_ * (1.0f - g_ * g_);
+        out[3] = do_ * o_ * (1.0f - o_);
+        state = dc * f_;
+        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = out[2]; gt[3 * H + j] = out[3];
+      } else if (p.cell == CTCN_CELL_GRU) {
+        dh += state;
+        const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1;
+        const float dn = dh * (1.0f - z_);
+        const float dz = dh * (hp - n_);
+        const float dan = dn * (1.0f - n_ * n_);
+        out[0] = dan * hn * r_ * (1.0f - r_);
+        out[1] = dz * z_ * (1.0f - z_);
+        out[2] = dan * r_;
+        state = dh * z_;
+        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = dan;
+        p.aux[(row_t * D + d) * H + j] = out[2];
+      } else {
+        out[0] = dh * (1.0f - e0 * e0);
+        gt[j] = out[0];
+      }
+      if (s + 1 < T) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < G)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(px + k * H + j), __float_as_uint(out[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (s + 1 < T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
+}
+
+bool launch_bwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a) {
+  switch (kq4) {
+    case 1: return launch_resident(rnn_bwd_persist<1>, grid, 1024, lds, st, a);
+    case 2: return launch_resident(rnn_bwd_persist<2>, grid, 1024, lds, st, a);
+    case 3: return launch_resident(rnn_bwd_persist<3>, grid, 1024, lds, st, a);
+    case 4: return launch_resident(rnn_bwd_persist<4>, grid, 1024, lds, st, a);
+    case 5: return launch_resident(rnn_bwd_persist<5>, grid, 1024, lds, st, a);
+    case 6: return launch_resident(rnn_bwd_persist<6>, grid, 1024, lds, st, a);
+    case 8: return launch_resident(rnn_bwd_persist<8>, grid, 1024, lds, st, a);
+    default: return false;
+  }
+}
+
 int pick_kq4(int K, int nwaves, int mt, int budget) {
   const int cand[4] = {5, 4, 2, 1};
   int best = 1, best_cost = 1 << 30;
@@ -694,11 +863,35 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   a.cell = cell; a.T = T; a.B = B; a.H = H; a.D = dirs; a.G = G; a.step = 0;
   a.w0 = whhT; a.w1 = whhT + (size_t)GH * H; a.y = const_cast<float *>(y); a.gates = gates; a.aux = aux; a.dy = dy;
   a.state = state;
-  const int kq4 = pick_kq4(GH, 16, 1, 5);
   dim3 grid(ceil_div(H, 16), dirs, ceil_div(B, 16));
-  for (int s = 0; s < T; ++s) {
-    a.step = s;
-    launch_bwd(kq4, grid, st, a);
+  bool done = false;
+  if (ctcn_opt_rnn_persistent() && T > 1) {
+    int kq = ceil_div(GH, 256);
+    if (kq == 7) kq = 8;
+    const size_t hx_bytes = align_up((size_t)2 * dirs * grid.z * 16 * GH * sizeof(float), 256);
+    const size_t fl_bytes = align_up((size_t)2 * dirs * grid.z * grid.x * sizeof(unsigned), 256);
+    const size_t lds = (size_t)16 * (GH + 4) * sizeof(float);
+    if (kq <= 8 && lds <= 120 * 1024 && ws && ws_bytes >= hx_bytes + fl_bytes + 512) {
+      PersistArgs pa;
+      pa.a = a;
+      char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
+      pa.hx = (float *)tail;
+      pa.flags = (unsigned *)(tail + hx_bytes);
+      pa.status = ctcn_status_word();
+      pa.spin_limit = 1 << 22;
+#ifdef CTCN_PERSIST_STATS
+      pa.stats = nullptr;
+#endif
+      CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
+      done = launch_bwd_persist(kq, grid, lds, st, pa);
+    }
+  }
+  if (!done) {
+    const int kq4 = pick_kq4(GH, 16, 1, 5);
+    for (int s = 0; s < T; ++s) {
+      a.step = s;
+      launch_bwd(kq4, grid, st, a);
+    }
   }
   CTCN_LAUNCH_CHECK();
 
