@@ -105,10 +105,18 @@ def gemm_roofline(dev, c):
     flops = 2.0 * M * N * K
     tf = flops / (ms * 1e-3) / 1e12
     prec = ops.get_precision()
+    traffic = None     # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected inside bench.py)
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        key = "gemm_f32_kernel<NT> %dx%dx%d" % (M, N, K)
+        if prec == 0 and key in pm:
+            traffic = pm[key]["hbm_bytes"]
+    except Exception:
+        pass
     # bf16x3 issues 3 bf16 MFMAs per algorithmic product: its ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s
     peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0 / 3.0
     return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_bf16x3_kernel<NT>") + " %dx%dx%d" % (M, N, K), bound="mfma",
-                achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=None, us_per_launch=ms * 1e3,
+                achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic, us_per_launch=ms * 1e3,
                 algorithmic_flops_per_launch=flops,
                 peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
 
