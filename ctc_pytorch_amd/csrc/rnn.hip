@@ -310,6 +310,10 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 //   * the consumer polls the H/(4*NT) flags of its (direction, batch tile) with one relaxed sc1 load per lane, then
 //     all 4 waves fetch the tile with fully coalesced sc1 16-B loads (whole 128-B lines, each requested once) into
 //     a row-padded LDS image, from which the MFMA A-operands are read with conflict-free ds_read_b128.
+// Measured hand-off variants (cfg2 forward, us per step): per-timestep launches 7.1 | 8-B granules swept straight into
+// registers 5.9 | THIS (workgroup flag + 16-B write-through payload, block-wide poll, coalesced LDS fill) 4.9 |
+// per-wave flags, every wave polling its own producers 5.7-5.9 (the extra pollers slow the write-through acks) |
+// coalesced 8-B granule tiles without flags 5.5 (consumers hammer the very lines the producers are writing).
 // Two parity buffers suffice (a workgroup can publish step s+1 only after every producer of its tile published
 // step s, i.e. after all reads of step s-1).  Every spin is bounded: on a timeout the sticky status word is set,
 // the layer output is poisoned with NaN and all workgroups leave.
