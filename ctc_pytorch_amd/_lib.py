@@ -143,7 +143,7 @@ def check_status(device):
 _WS = {}
 
 
-def workspace(device, nbytes=256 << 20):
+def workspace(device, nbytes=1 << 30):
     """Per-device scratch buffer (split-K partials, BN/conv partial sums).  Stream-ordered reuse: every
     library call consumes its partials before returning control to the same stream's next launch."""
     key = (device.type, device.index)

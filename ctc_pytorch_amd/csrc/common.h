@@ -34,6 +34,7 @@ int ctcn_opt_rnn_persistent(void);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t ceil_div_z(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -16,6 +16,8 @@
 //     the M*N tile grid alone cannot fill the 256 CUs (weight-gradient GEMMs, K = T*B = 25 600).
 //   * XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, so the remap
 //     gives each XCD a contiguous band of M-tiles that share the same B panel in its private L2.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -326,6 +328,166 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int M, int N, int K, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// precision = 1, main path: bf16x3 on PRE-SPLIT operand planes.
+//   1. one HBM-bound pass per operand splits the f32 matrix into hi/lo bf16 planes laid out [rows][Kp] with the
+//      contraction index contiguous and zero-padded to a multiple of 64 (the pass transposes when the operand is
+//      stored contraction-major), so that
+//   2. a single "NT" kernel  C[m,n] = sum_k A[m,k] * B[n,k]  serves all four transpose cases with no conversion and
+//      no transposition in its inner loop: 128x128x64 tiles, 16-B global loads -> XOR-swizzled LDS rows of 128 B
+//      (conflict-free ds_write_b128 / ds_read_b128: slot = 8*(row&1) + (chunk ^ ((row>>1)&7))), register prefetch of
+//      the next K-slab, 3 x v_mfma_f32_32x32x16_bf16 per fragment pair (lo*hi, hi*lo, hi*hi), f32 accumulate.
+// ------------------------------------------------------------------------------------------------
+constexpr int PBK = 64;
+
+__global__ void split_rows_kernel(const float *__restrict__ src, int ld, int R, int C, int Cp, unsigned short *__restrict__ hi,
+                                  unsigned short *__restrict__ lo) {
+  // out[r][c] (row stride Cp) = split(src[r*ld + c]), zero for c >= C; 4 elements per thread
+  const size_t total = (size_t)R * (Cp / 4);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (Cp / 4)), c = (int)(i - (size_t)r * (Cp / 4)) * 4;
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = (c + k < C) ? src[(size_t)r * ld + c + k] : 0.0f;
+      split_bf16(v, h[k], l[k]);
+    }
+    *reinterpret_cast<uint2 *>(hi + (size_t)r * Cp + c) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2 *>(lo + (size_t)r * Cp + c) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float *__restrict__ src, int ld, int R, int C, int Rp,
+                                                              unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+  // out[c][r] (row stride Rp) = split(src[r*ld + c]); 64x64 tiles through LDS; zero for r >= R (k padding)
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rp) {
+      unsigned short h, l;
+      split_bf16(t[tx][i], h, l);
+      hi[(size_t)c * Rp + r] = h;
+      lo[(size_t)c * Rp + r] = l;
+    }
+  }
+}
+
+__device__ __forceinline__ int pswz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }   // byte offset in a plane tile
+
+__global__ __launch_bounds__(256) void gemm_planes_nt_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                             const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                             const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
+                                                             int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4][BM * 128];      // Ah | Al | Bh | Bl tiles, 16 KiB each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(Kp, kbeg + kchunk);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // staging map: 128 rows x 8 chunks(16 B) per plane tile = 1024 chunks -> 4 per thread per plane
+  int srow[4], skc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j;
+    srow[j] = idx >> 3;
+    skc[j] = idx & 7;
+  }
+  // element offsets of this thread's 4 chunks in the A-side and B-side planes (rows clamped: out-of-range rows are never stored)
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    offA[j] = (unsigned)min(m0 + srow[j], M - 1) * (unsigned)Kp + skc[j] * 8;
+    offB[j] = (unsigned)min(n0 + srow[j], N - 1) * (unsigned)Kp + skc[j] * 8;
+  }
+  u32x4 pAh[4], pAl[4], pBh[4], pBl[4];      // ext-vector values (arrays of HIP's uint4 class end up in scratch)
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pAh[j] = *reinterpret_cast<const u32x4 *>(Ah + offA[j] + k0);
+      pAl[j] = *reinterpret_cast<const u32x4 *>(Al + offA[j] + k0);
+      pBh[j] = *reinterpret_cast<const u32x4 *>(Bh + offB[j] + k0);
+      pBl[j] = *reinterpret_cast<const u32x4 *>(Bl + offB[j] + k0);
+    }
+  };
+  if (kbeg < kend) gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += PBK) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int so = pswz(srow[j], skc[j]);
+      *reinterpret_cast<u32x4 *>(&sm[0][so]) = pAh[j];
+      *reinterpret_cast<u32x4 *>(&sm[1][so]) = pAl[j];
+      *reinterpret_cast<u32x4 *>(&sm[2][so]) = pBh[j];
+      *reinterpret_cast<u32x4 *>(&sm[3][so]) = pBl[j];
+    }
+    __syncthreads();
+    if (k0 + PBK < kend) gload(k0 + PBK);
+    const int ml = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kc = ks * 2 + g;
+      bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + ml, rb = wn * 64 + i * 32 + ml;
+        ah[i] = *reinterpret_cast<const bf16x8_t *>(&sm[0][pswz(ra, kc)]);
+        al[i] = *reinterpret_cast<const bf16x8_t *>(&sm[1][pswz(ra, kc)]);
+        bh[i] = *reinterpret_cast<const bf16x8_t *>(&sm[2][pswz(rb, kc)]);
+        bl[i] = *reinterpret_cast<const bf16x8_t *>(&sm[3][pswz(rb, kc)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  float *out = ws ? ws + (size_t)blockIdx.y * M * N : C;
+  const int ldo = ws ? N : ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][e];
+          float *p = out + (size_t)row * ldo + col;
+          if (!ws && beta != 0.0f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc,
                                      int splits, float beta) {
   const size_t total = (size_t)M * N;
@@ -374,6 +536,48 @@ extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const floa
   if (splits > 1) {
     kchunk = ceil_div(ceil_div(K, splits), XBK) * XBK;
     splits = ceil_div(K, kchunk);
+  }
+  if (precision == 1 && K >= 64 && ws) {
+    // pre-split planes in the workspace: [Ah | Al | Bh | Bl | split-K partials]
+    const int Kp = ceil_div(K, PBK) * PBK;
+    const size_t a_el = (size_t)M * Kp, b_el = (size_t)N * Kp;
+    const size_t plane_bytes = align_up(2 * (a_el + b_el) * sizeof(unsigned short), 256);
+    if (ws_bytes >= plane_bytes + 256) {
+      unsigned short *ah = (unsigned short *)ws, *al = ah + a_el, *bh = al + a_el, *bl = bh + b_el;
+      float *part = (float *)((char *)ws + plane_bytes);
+      const size_t part_bytes = ws_bytes - plane_bytes;
+      auto split = [&](const float *src, int ld, bool contraction_major, int rows, unsigned short *hi, unsigned short *lo) {
+        if (!contraction_major) {   // src[row*ld + k]
+          const size_t total = (size_t)rows * (Kp / 4);
+          hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min((size_t)8192, ceil_div_z(total, 256))), dim3(256), 0, st, src, ld, rows, K, Kp, hi, lo);
+        } else {                    // src[k*ld + row] -> transpose
+          hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo);
+        }
+      };
+      split(A, lda, transA != 0, M, ah, al);
+      split(B, ldb, transB == 0, N, bh, bl);
+      CTCN_LAUNCH_CHECK();
+      int psplits = 1;
+      if (nt < 256 && Kp >= 1024 && part_bytes >= (size_t)2 * M * N * sizeof(float)) {
+        psplits = std::min(std::min(ceil_div(512, nt), Kp / 512), (int)(part_bytes / ((size_t)M * N * sizeof(float))));
+        if (psplits < 2) psplits = 1;
+      }
+      int pchunk = Kp;
+      if (psplits > 1) {
+        pchunk = ceil_div(ceil_div(Kp, psplits), PBK) * PBK;
+        psplits = ceil_div(Kp, pchunk);
+      }
+      hipLaunchKernelGGL(gemm_planes_nt_kernel, dim3(nt, psplits), dim3(256), 0, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk,
+                         psplits > 1 ? part : (float *)nullptr, tiles_m, tiles_n);
+      CTCN_LAUNCH_CHECK();
+      if (psplits > 1) {
+        const size_t total = (size_t)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min((size_t)2048, ceil_div_z(total, 256))), dim3(256), 0, st, (const float *)part, C, M,
+                           N, ldc, psplits, beta);
+        CTCN_LAUNCH_CHECK();
+      }
+      return CTCN_OK;
+    }
   }
   const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);

@@ -330,7 +330,6 @@ struct PersistArgs {
 #endif
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld_sc1_f4(const __amdgpu_buffer_rsrc_t &rs, unsigned byte_off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);          // aux 16 = sc1: bypass L1

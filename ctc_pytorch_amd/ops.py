@@ -5,7 +5,6 @@ for device memory, autograd bookkeeping and nothing else.  Tensors must live on 
 tensor raises (the product has no CPU path; the CPU restatement lives in oracle/ and is test-only).
 """
 import ctypes
-import threading
 
 import torch
 
@@ -14,16 +13,19 @@ from . import _lib
 CELL = {"lstm": 0, "gru": 1, "tanh": 2}
 GATES = {0: 4, 1: 3, 2: 1}
 
-# global numeric mode for the MFMA GEMMs: 0 = exact f32 MFMA, 1 = bf16 operands / f32 accumulate
-_state = threading.local()
+# process-wide numeric mode of the MFMA GEMMs: 0 = exact f32 MFMA, 1 = bf16x3 split-operand MFMA (f32-class accuracy).
+# A plain module global on purpose: autograd runs backward() on its own worker threads.
+_precision = [0]
 
 
 def set_precision(p):
-    _state.precision = int(p)
+    if int(p) not in (0, 1):
+        raise ValueError("precision must be 0 (f32 MFMA) or 1 (bf16x3 split-operand MFMA)")
+    _precision[0] = int(p)
 
 
 def get_precision():
-    return getattr(_state, "precision", 0)
+    return _precision[0]
 
 
 def _ptr(t):
