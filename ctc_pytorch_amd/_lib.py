@@ -29,6 +29,7 @@ _SIGS = {
     "ctcn_version": (I, []),
     "ctcn_last_error": (ctypes.c_char_p, []),
     "ctcn_device_cus": (I, []),
+    "ctcn_device_xcds": (I, []),
     "ctcn_set_option": (I, [ctypes.c_char_p, I]),
     "ctcn_get_option": (I, [ctypes.c_char_p]),
     "ctcn_set_status_buffer": (I, [P]),
@@ -96,9 +97,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        env = os.environ.get("CTCN_RNN_PERSISTENT")
-        if env is not None:
-            l.ctcn_set_option(b"rnn_persistent", int(env))
+        for var, opt in (("CTCN_RNN_PERSISTENT", b"rnn_persistent"), ("CTCN_HANDOFF", b"handoff")):
+            env = os.environ.get(var)
+            if env is not None:
+                l.ctcn_set_option(opt, int(env))
     return _lib
 
 

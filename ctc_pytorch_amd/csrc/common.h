@@ -11,6 +11,7 @@
 void ctcn_set_error(const char *fmt, ...);
 int *ctcn_status_word(void);      // device int registered with ctcn_set_status_buffer (may be null)
 int ctcn_opt_rnn_persistent(void);
+int ctcn_opt_handoff(void);
 
 #define CTCN_REQUIRE(cond, ...)          \
   do {                                   \

@@ -23,17 +23,21 @@ extern "C" int ctcn_device_cus(void) {
 // rnn_persistent: 1 = persistent recurrent kernels (W_hh resident in VGPRs, in-launch granule hand-off of h_t);
 //                 0 = one launch per timestep.  Both produce the same numbers.
 static int g_opt_rnn_persistent = 1;
+static int g_opt_handoff = 1;
 static int *g_status_dev = nullptr;
 
 extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "rnn_persistent")) { g_opt_rnn_persistent = value; return CTCN_OK; }
+  if (name && !strcmp(name, "handoff")) { g_opt_handoff = value; return CTCN_OK; }
   ctcn_set_error("ctcn_set_option: unknown option %s", name ? name : "(null)");
   return CTCN_EINVAL;
 }
 extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "rnn_persistent")) return g_opt_rnn_persistent;
+  if (name && !strcmp(name, "handoff")) return g_opt_handoff;
   return -1;
 }
 extern "C" int ctcn_set_status_buffer(int *dev_word) { g_status_dev = dev_word; return CTCN_OK; }
 int *ctcn_status_word(void) { return g_status_dev; }
 int ctcn_opt_rnn_persistent(void) { return g_opt_rnn_persistent; }
+int ctcn_opt_handoff(void) { return g_opt_handoff; }

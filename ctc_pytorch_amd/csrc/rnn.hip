@@ -23,10 +23,24 @@
 // Layouts: x (T,B,I); y (T,B,dirs*H); gates (T,B,dirs,G*H); aux (T,B,dirs,H) [LSTM: c_t, GRU: W_hn*h_{t-1}].
 // No packing / masking: all T padded frames are processed, reverse direction starts at t=T-1 (as torch).
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace {
+
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope fence that drains EVERY
+// outstanding global load / store of the wave (s_waitcnt vmcnt(0)); the recurrent kernels keep next-step operand
+// prefetches and reserve stores in flight across their LDS barriers, so they wait for LDS traffic only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Gate activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each): |error| < 3e-7 absolute, a
+// quarter of the instruction count of expf / tanhf + IEEE division -- they sit on the serial path of every timestep.
+__device__ __forceinline__ float act_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float act_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));
+  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
 
 struct RnnArgs {
   int cell, T, B, H, D, G, step;
@@ -103,7 +117,7 @@ __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[MT], float *red 
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[(wl * MT + mt) * 256 + lane * 4 + e] = acc[mt][e];
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < MT * 256; i += nthreads) {
       const int mt = i >> 8, le = i & 255;
       float s = 0.0f;
@@ -114,7 +128,7 @@ __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[MT], float *red 
       float *o = &outs[mt * 16 + (ln >> 4) * 4 + reg][ln & 15];
       *o = pass == 0 ? s : *o + s;
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -173,19 +187,19 @@ __global__ __launch_bounds__(256) void rnn_fwd_step(RnnArgs p) {
     float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
     float *yt = p.y + row_t * D * H + d * H;
     if (p.cell == CTCN_CELL_LSTM) {
-      const float i_ = sigmoidf_(outs[bl][0 * 4 + jl] + pre[0]);
-      const float f_ = sigmoidf_(outs[bl][1 * 4 + jl] + pre[1]);
-      const float g_ = tanhf(outs[bl][2 * 4 + jl] + pre[2]);
-      const float o_ = sigmoidf_(outs[bl][3 * 4 + jl] + pre[3]);
+      const float i_ = act_sigmoid(outs[bl][0 * 4 + jl] + pre[0]);
+      const float f_ = act_sigmoid(outs[bl][1 * 4 + jl] + pre[1]);
+      const float g_ = act_tanh(outs[bl][2 * 4 + jl] + pre[2]);
+      const float o_ = act_sigmoid(outs[bl][3 * 4 + jl] + pre[3]);
       const float c = f_ * prev + i_ * g_;
       gt[0 * H + j] = i_; gt[1 * H + j] = f_; gt[2 * H + j] = g_; gt[3 * H + j] = o_;
       p.aux[(row_t * D + d) * H + j] = c;
-      yt[j] = o_ * tanhf(c);
+      yt[j] = o_ * act_tanh(c);
     } else {
       const float hn = outs[bl][2 * 4 + jl];
-      const float r_ = sigmoidf_(outs[bl][0 * 4 + jl] + pre[0]);
-      const float z_ = sigmoidf_(outs[bl][1 * 4 + jl] + pre[1]);
-      const float n_ = tanhf(pre[2] + r_ * hn);
+      const float r_ = act_sigmoid(outs[bl][0 * 4 + jl] + pre[0]);
+      const float z_ = act_sigmoid(outs[bl][1 * 4 + jl] + pre[1]);
+      const float n_ = act_tanh(pre[2] + r_ * hn);
       gt[0 * H + j] = r_; gt[1 * H + j] = z_; gt[2 * H + j] = n_;
       p.aux[(row_t * D + d) * H + j] = hn;
       yt[j] = (1.0f - z_) * n_ + z_ * prev;
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_step(RnnArgs p) {
       const int bl2 = it >> 4, jl2 = it & 15;
       if (j0 + jl2 >= H) continue;
       const size_t rt = (size_t)t * B + b0 + bl2;
-      p.y[rt * D * H + d * H + j0 + jl2] = tanhf(outs[bl2][jl2] + p.gates[(rt * D + d) * (size_t)H + j0 + jl2]);
+      p.y[rt * D * H + d * H + j0 + jl2] = act_tanh(outs[bl2][jl2] + p.gates[(rt * D + d) * (size_t)H + j0 + jl2]);
     }
   }
 }
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
     float dh = dyv + outs[bl][jl];
     if (p.cell == CTCN_CELL_LSTM) {
       const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
-      const float tc = tanhf(e0);
+      const float tc = act_tanh(e0);
       const float do_ = dh * tc;
       const float dc = dh * o_ * (1.0f - tc * tc) + stv;
       gt[0 * H + j] = dc * g_ * i_ * (1.0f - i_);
@@ -325,6 +339,13 @@ struct PersistArgs {
   unsigned *flags;      // [2 parity][D][btiles][nslices]
   int *status;
   int spin_limit;
+  int local;            // 1: every (direction, batch-tile) group sits on ONE XCD and hands off through that XCD's L2
+                        //    (write-back stores + L1-bypassing loads: ~0.3 us one way); 0: device scope (write-through, ~0.6 us)
+  int nx;               // XCDs of the device (local mode: linear workgroup id i runs on XCD i % nx)
+  int nsl, nbt;         // slices per group, batch tiles
+  int wpx;              // local mode: working workgroups per XCD
+  unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)
+  int hsu;              // forward: hidden units per workgroup (<= 4*NT)
 #ifdef CTCN_PERSIST_STATS
   long long *stats;   // development instrumentation (tools/mb_step.hip only)
 #endif
@@ -340,7 +361,24 @@ __device__ __forceinline__ void st_sc1_f4(const __amdgpu_buffer_rsrc_t &rs, unsi
   __builtin_amdgcn_raw_buffer_store_b128(u, rs, byte_off, 0, 16);                        // write-through
 }
 
-// Wave 0 polls `n` flags (one per lane, strided) until all equal `want`.  Returns false on timeout / global abort.
+__device__ __forceinline__ void st_f4(const __amdgpu_buffer_rsrc_t &rs, unsigned byte_off, f32x4 v, int local) {
+  const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  if (local) __builtin_amdgcn_raw_buffer_store_b128(u, rs, byte_off, 0, 0);              // write-back into this XCD's L2
+  else __builtin_amdgcn_raw_buffer_store_b128(u, rs, byte_off, 0, 16);                   // write-through
+}
+__device__ __forceinline__ void st_f2(const __amdgpu_buffer_rsrc_t &rs, unsigned byte_off, float a, float b, int local) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 u = {__float_as_uint(a), __float_as_uint(b)};
+  if (local) __builtin_amdgcn_raw_buffer_store_b64(u, rs, byte_off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(u, rs, byte_off, 0, 16);
+}
+__device__ __forceinline__ void st_u1(const __amdgpu_buffer_rsrc_t &rs, unsigned byte_off, unsigned v, int local) {
+  if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, byte_off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b32(v, rs, byte_off, 0, 16);
+}
+
+// Wave 0 polls `n` flags (lane-strided relaxed L1-bypassing loads) until all equal `want`; false on timeout / global
+// abort.  Keeping 2-3 polls in flight or pacing them was measured slower (extra traffic delays the flag itself).
 __device__ __forceinline__ bool poll_flags(const unsigned *flags, int n, unsigned want, int lane, int spin_limit, int *status) {
   for (int spins = 0;; ++spins) {
     bool ok = true;
@@ -353,25 +391,49 @@ __device__ __forceinline__ bool poll_flags(const unsigned *flags, int n, unsigne
   }
 }
 
+// Role of a workgroup in a persistent launch.  Device-scope mode: grid (slices, dirs, batch tiles).  XCD-local mode:
+// a 1-D grid of nx * (wpx + spare) workgroups.  The hardware deals workgroups round-robin over the XCDs (starting
+// wherever the previous dispatch stopped), so every XCD receives >= wpx of them; each workgroup reads the XCD it
+// actually runs on (HW_REG_XCC_ID) and draws a ticket there: ticket k on XCD x is slice k % nsl of group
+// (k / nsl) * nx + x, tickets >= wpx (and groups past the end) exit at once.  All slices of a group therefore share
+// one L2 no matter how the dispatcher ordered them; a role that never shows up ends in the bounded-spin abort.
+struct PersistRole { int slice, d, bt; bool active; };
+__device__ __forceinline__ PersistRole persist_role(const PersistArgs &pa, int D, int *s_ticket) {
+  PersistRole r;
+  if (!pa.local) { r.slice = blockIdx.x; r.d = blockIdx.y; r.bt = blockIdx.z; r.active = true; return r; }
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  const int xcd = (int)(x & 15);
+  if (threadIdx.x == 0) *s_ticket = xcd < pa.nx ? (int)atomicAdd(pa.tickets + xcd, 1u) : 0x7fffffff;
+  __syncthreads();
+  const int idx = *s_ticket;
+  const int lg = idx / pa.nsl, group = lg * pa.nx + xcd;
+  r.slice = idx - lg * pa.nsl;
+  r.active = idx < pa.wpx && group < D * pa.nbt;
+  r.d = group % D; r.bt = group / D;
+  return r;
+}
+
 template <int NT, int KQ4>
 __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   constexpr int NW = 4;
   const RnnArgs &p = pa.a;
-  extern __shared__ __attribute__((aligned(16))) float dsm[];     // h tile image [16][H+4]
   __shared__ float red[NW * NT * 256];
   __shared__ float outs[NT * 16][17];
   __shared__ float hpub[16][4 * NT < 16 ? 16 : 4 * NT];
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int d = blockIdx.y, bt = blockIdx.z, nbt = gridDim.z, nsl = gridDim.x;
-  const int b0 = bt * 16;
   const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  __shared__ int s_ticket;
+  const PersistRole role = persist_role(pa, D, &s_ticket);
+  if (!role.active) return;
+  const int d = role.d, bt = role.bt, nbt = pa.nbt, nsl = pa.nsl, slice = role.slice, local = pa.local;
+  const int b0 = bt * 16;
   const int Bc = min(16, B - b0);
   const bool tanh_cell = p.cell == CTCN_CELL_TANH;
-  const int HSU = tanh_cell ? 16 : 4 * NT;                 // hidden units owned by this workgroup
-  const int j0 = blockIdx.x * HSU;
-  const int ldh = H + 4;                                   // LDS row stride (floats): rows land 4 banks apart
+  const int HSU = pa.hsu;                                  // hidden units owned by this workgroup (<= 4*NT; 16 for tanh)
+  const int j0 = slice * HSU;
   const float *W = d == 0 ? p.w0 : p.w1;
   const int kb = wave * 16 * KQ4 + q * 4;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -382,7 +444,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int gate = tanh_cell ? 0 : (r >> 2), jj = tanh_cell ? r : (nt * 4 + (r & 3));
-    const bool bvalid = gate < G && (j0 + jj) < H;
+    const bool bvalid = gate < G && jj < HSU && (j0 + jj) < H;
     const float *brow = bvalid ? W + (size_t)(gate * H + j0 + jj) * H : W;
 #pragma unroll
     for (int s = 0; s < KQ4; ++s) {
@@ -391,8 +453,13 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       bv[nt][s] = (bvalid && k < H) ? v : zero;
     }
   }
-  const size_t tile_f = (size_t)16 * H;                                                         // floats per h tile
+  // published h tile: 16-float column chunks, each stored in MFMA-A lane order [k-quad q][row][4 floats], so that a
+  // consuming lane (row r = lane & 15, quad q = lane >> 4) reads ITS float4 of chunk c at (c * 64 + lane) * 16 bytes:
+  // one fully coalesced 1-KB load per chunk, straight into the MFMA operand registers (no LDS staging, no fill barrier)
+  const int nch = (H + 15) >> 4;
+  const size_t tile_f = (size_t)nch * 256;                                                      // floats per h tile
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
 
   // epilogue item of this thread: (row bl, unit jl) fixed for all steps -> c / h of the unit stay in a register
   const int bl = tid / HSU, jl = tid - bl * HSU;
@@ -400,6 +467,20 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   const bool item = bl < 16 && bl < Bc && j < H;
   const int ont = tanh_cell ? 0 : (jl >> 2), ojl = tanh_cell ? jl : (jl & 3);                 // tile / column group of the unit
   float state = 0.0f;   // c_{t-1} (LSTM) / h_{t-1} (GRU)
+  // Wave roles.  The units' (row, unit) items occupy threads 0 .. 16*HSU-1; when that leaves the last wave without
+  // items it becomes the COMMUNICATION wave: it alone polls the flags, fetches the h tile into LDS and publishes this
+  // workgroup's block, so its in-order vmcnt never queues behind the item waves' operand prefetches and reserve
+  // stores (which then have a whole step to complete).  Otherwise wave 0 does both jobs (correct, slower).
+  const int cw = 16 * HSU <= 192 ? 3 : 0;
+  // x-projection pre-activations of this item, always one step ahead: refilled right after the gate math consumed them
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t gstride = (size_t)B * D * G * H;                       // floats between timesteps of p.gates
+  const float *gitem = p.gates + ((size_t)min(b, B - 1) * D + d) * (size_t)(G * H) + min(j, H - 1);
+  if (item) {
+    const float *gt = gitem + (size_t)(d == 0 ? 0 : T - 1) * gstride;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pre[k] = gt[min(k, G - 1) * H];
+  }
   __syncthreads();
 #ifdef CTCN_PERSIST_STATS
   long long st_poll = 0, st_fill = 0, st_mm = 0, st_red = 0, st_epi = 0, st_t0 = clock64();
@@ -412,49 +493,35 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #endif
     const int t = d == 0 ? s : T - 1 - s;
     const size_t row_t = (size_t)t * B + b;
-    float pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (item) {
-      const float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < G) pre[k] = gt[k * H + j];
-    }
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero;
     if (s > 0) {
       const int par = (s - 1) & 1;
-      if (wave == 0) {
+      if (wave == cw) {
         const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
-        if (!poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status) && lane == 0) {
+        const bool ok = poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status);
+        if (!ok && lane == 0) {
           s_abort = 1;
           if (pa.status) atomicCAS(pa.status, 0, 101);
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (s_abort) break;
 #ifdef CTCN_PERSIST_STATS
       c_p = clock64();
 #endif
-      // coalesced tile fetch: 16 rows x H floats, whole lines, write-through data read around L1
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
-      const int nf4 = 16 * H / 4;
-      for (int i = tid; i < nf4; i += 256) {
-        const int row = (i * 4) / H, col = i * 4 - row * H;
-        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)i * 16);
-        *reinterpret_cast<f32x4 *>(dsm + row * ldh + col) = v;
-      }
-      __syncthreads();
-#ifdef CTCN_PERSIST_STATS
-      c_f = clock64();
-#endif
       f32x4 av[KQ4];
 #pragma unroll
       for (int si = 0; si < KQ4; ++si) {
-        const int k = kb + 16 * si;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(dsm + r * ldh + min(k, H - 4));
+        const int k = kb + 16 * si, c = min(wave * KQ4 + si, nch - 1);
+        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)((c * 64 + lane) * 16));
         av[si] = (k < H && r < Bc) ? v : zero;
       }
+#ifdef CTCN_PERSIST_STATS
+      c_f = clock64();
+#endif
 #pragma unroll
       for (int si = 0; si < KQ4; ++si)
 #pragma unroll
@@ -472,89 +539,125 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     st_poll += c_p - c_a; st_fill += c_f - c_p; st_mm += c_b - c_f; st_red += c_c - c_b;
 #endif
 
+    float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f, sv3 = 0.f, sv4 = 0.f, hval = 0.f;     // values this item stores after the hand-off
     if (item) {
-      float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
-      float hval;
       const float *o = &outs[ont * 16 + bl][0];
       if (p.cell == CTCN_CELL_LSTM) {
-        const float i_ = sigmoidf_(o[0 * 4 + ojl] + pre[0]);
-        const float f_ = sigmoidf_(o[1 * 4 + ojl] + pre[1]);
-        const float g_ = tanhf(o[2 * 4 + ojl] + pre[2]);
-        const float o_ = sigmoidf_(o[3 * 4 + ojl] + pre[3]);
+        const float i_ = act_sigmoid(o[0 * 4 + ojl] + pre[0]);
+        const float f_ = act_sigmoid(o[1 * 4 + ojl] + pre[1]);
+        const float g_ = act_tanh(o[2 * 4 + ojl] + pre[2]);
+        const float o_ = act_sigmoid(o[3 * 4 + ojl] + pre[3]);
         const float c = f_ * state + i_ * g_;
-        hval = o_ * tanhf(c);
+        hval = o_ * act_tanh(c);
         state = c;
-        gt[0 * H + j] = i_; gt[1 * H + j] = f_; gt[2 * H + j] = g_; gt[3 * H + j] = o_;
-        p.aux[(row_t * D + d) * H + j] = c;
+        sv0 = i_; sv1 = f_; sv2 = g_; sv3 = o_; sv4 = c;
       } else if (p.cell == CTCN_CELL_GRU) {
         const float hn = o[2 * 4 + ojl];
-        const float r_ = sigmoidf_(o[0 * 4 + ojl] + pre[0]);
-        const float z_ = sigmoidf_(o[1 * 4 + ojl] + pre[1]);
-        const float n_ = tanhf(pre[2] + r_ * hn);
+        const float r_ = act_sigmoid(o[0 * 4 + ojl] + pre[0]);
+        const float z_ = act_sigmoid(o[1 * 4 + ojl] + pre[1]);
+        const float n_ = act_tanh(pre[2] + r_ * hn);
         hval = (1.0f - z_) * n_ + z_ * state;
         state = hval;
-        gt[0 * H + j] = r_; gt[1 * H + j] = z_; gt[2 * H + j] = n_;
-        p.aux[(row_t * D + d) * H + j] = hn;
+        sv0 = r_; sv1 = z_; sv2 = n_; sv4 = hn;
       } else {
-        hval = tanhf(o[ojl] + pre[0]);
+        hval = act_tanh(o[ojl] + pre[0]);
       }
-      p.y[row_t * D * H + d * H + j] = hval;
       hpub[bl][jl] = hval;
     }
-    __syncthreads();
-    // publish this workgroup's 16 x HSU block of h_t: 16-B write-through stores by wave 0, drained, then the flag
-    if (s + 1 < T && wave == 0) {
+    lds_barrier();
+    // publish this workgroup's 16 x HSU block of h_t: 16-B (8-B when HSU % 4) stores by the communication wave,
+    // drained, then the flag
+    if (s + 1 < T && wave == cw) {
       const int par = s & 1;
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
-      const int per_row = HSU / 4;                               // float4 per row
-      for (int i = lane; i < 16 * per_row; i += 64) {
-        const int row = i / per_row, c4 = i - row * per_row;
-        if (row < Bc && j0 + c4 * 4 < H) {
-          const f32x4 v = {hpub[row][c4 * 4], hpub[row][c4 * 4 + 1], hpub[row][c4 * 4 + 2], hpub[row][c4 * 4 + 3]};
-          st_sc1_f4(rs, tbase + (unsigned)((row * H + j0 + c4 * 4) * 4), v);
+      if ((HSU & 3) == 0) {
+        const int per_row = HSU / 4;                             // float4 per row
+        for (int i = lane; i < 16 * per_row; i += 64) {
+          const int row = i / per_row, c4 = i - row * per_row;
+          if (row < Bc && j0 + c4 * 4 < H) {
+            const f32x4 v = {hpub[row][c4 * 4], hpub[row][c4 * 4 + 1], hpub[row][c4 * 4 + 2], hpub[row][c4 * 4 + 3]};
+            const int col = j0 + c4 * 4;
+            st_f4(rs, tbase + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4) * 4), v, local);
+          }
+        }
+      } else {
+        const int per_row = HSU / 2;                             // float2 per row (HSU and H are even)
+        for (int i = lane; i < 16 * per_row; i += 64) {
+          const int row = i / per_row, c2 = i - row * per_row;
+          const int col = j0 + c2 * 2;
+          if (row < Bc && col < H)
+            st_f2(rs, tbase + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4 + (col & 3)) * 4), hpub[row][c2 * 2], hpub[row][c2 * 2 + 1], local);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the storing wave drains its write-through stores
-      if (lane == 0)
-        __hip_atomic_store(pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the storing wave drains its stores (to L2 / to memory)
+      if (lane == 0) st_u1(rf, (unsigned)(((((size_t)par * D + d) * nbt + bt) * nsl + slice) * 4), (unsigned)(s + 1), local);
+    }
+    // off the critical path (item waves): the reserve (gates, c / hn) and y leave after the hand-off, and the next
+    // step's pre-activations are requested a whole step before the gate math needs them
+    if (item) {
+      float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+      if (p.cell == CTCN_CELL_LSTM) {
+        gt[0 * H + j] = sv0; gt[1 * H + j] = sv1; gt[2 * H + j] = sv2; gt[3 * H + j] = sv3;
+        p.aux[(row_t * D + d) * H + j] = sv4;
+      } else if (p.cell == CTCN_CELL_GRU) {
+        gt[0 * H + j] = sv0; gt[1 * H + j] = sv1; gt[2 * H + j] = sv2;
+        p.aux[(row_t * D + d) * H + j] = sv4;
+      }
+      p.y[row_t * D * H + d * H + j] = hval;
+      if (s + 1 < T) {
+        const float *gn = gitem + (size_t)(d == 0 ? s + 1 : T - 2 - s) * gstride;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pre[k] = gn[min(k, G - 1) * H];
+      }
     }
 #ifdef CTCN_PERSIST_STATS
     st_epi += clock64() - c_c;
 #endif
   }
 #ifdef CTCN_PERSIST_STATS
-  if (pa.stats && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+  if (pa.stats && slice == 7 && d == 0 && bt == 0 && tid == cw * 64) {
     pa.stats[0] = st_poll; pa.stats[1] = st_fill; pa.stats[2] = st_mm; pa.stats[3] = st_red; pa.stats[4] = st_epi; pa.stats[5] = clock64() - st_t0;
   }
 #endif
   if (s_abort && item) p.y[((size_t)(d == 0 ? T - 1 : 0) * B + b) * D * H + d * H + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
-// Launch a persistent kernel only if the whole grid is co-resident (occupancy query x CU count, with one block of
-// slack per CU when the API admits more than one: ROCm 7.2 can over-report by one, MI355X_MICROARCH.md).
-template <class Kern, class Args>
-bool launch_resident(Kern kern, dim3 grid, int threads, size_t lds, hipStream_t st, const Args &a) {
+// Launch a persistent kernel only if every working workgroup is co-resident (occupancy query x CU count, with one
+// block of slack per CU when the API admits more than one: ROCm 7.2 can over-report by one, MI355X_MICROARCH.md).
+// Device-scope mode: the whole 3-D grid against all CUs.  XCD-local mode (a.local): a.nx * wpx workgroups, wpx of
+// them working on each XCD (the rest exit at once), against the CUs of ONE XCD.
+template <class Kern>
+bool launch_resident(Kern kern, dim3 grid, int threads, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   int per_cu = 0;
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu <= 0) return false;
-  const int cus = ctcn_device_cus();
-  const long cap = (long)cus * (per_cu > 1 ? per_cu - 1 : 1) - (per_cu > 1 ? 0 : 8);
-  if ((long)grid.x * grid.y * grid.z > cap) return false;
+  const int cus = a.local ? ctcn_device_cus() / a.nx : ctcn_device_cus();
+  const long cap = (long)cus * (per_cu > 1 ? per_cu - 1 : 1) - (per_cu > 1 ? 0 : (a.local ? 1 : 8));
+  const long need = a.local ? wpx : (long)grid.x * grid.y * grid.z;
+  if (need > cap) return false;
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
   return true;
 }
 
 template <int NT>
-bool launch_fwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a) {
+bool launch_fwd_persist_nt(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (kq4) {
-    case 1: return launch_resident(rnn_fwd_persist<NT, 1>, grid, 256, lds, st, a);
-    case 2: return launch_resident(rnn_fwd_persist<NT, 2>, grid, 256, lds, st, a);
-    case 3: return launch_resident(rnn_fwd_persist<NT, 3>, grid, 256, lds, st, a);
-    case 4: return launch_resident(rnn_fwd_persist<NT, 4>, grid, 256, lds, st, a);
-    case 5: return launch_resident(rnn_fwd_persist<NT, 5>, grid, 256, lds, st, a);
-    case 6: return launch_resident(rnn_fwd_persist<NT, 6>, grid, 256, lds, st, a);
-    case 8: return launch_resident(rnn_fwd_persist<NT, 8>, grid, 256, lds, st, a);
+    case 1: return launch_resident(rnn_fwd_persist<NT, 1>, grid, 256, lds, st, a, wpx);
+    case 2: return launch_resident(rnn_fwd_persist<NT, 2>, grid, 256, lds, st, a, wpx);
+    case 3: return launch_resident(rnn_fwd_persist<NT, 3>, grid, 256, lds, st, a, wpx);
+    case 4: return launch_resident(rnn_fwd_persist<NT, 4>, grid, 256, lds, st, a, wpx);
+    case 5: return launch_resident(rnn_fwd_persist<NT, 5>, grid, 256, lds, st, a, wpx);
+    case 6: return launch_resident(rnn_fwd_persist<NT, 6>, grid, 256, lds, st, a, wpx);
+    case 8: return launch_resident(rnn_fwd_persist<NT, 8>, grid, 256, lds, st, a, wpx);
+    default: return false;
+  }
+}
+bool launch_fwd_persist(int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
+  switch (nt) {
+    case 1: return launch_fwd_persist_nt<1>(kq4, grid, lds, st, a, wpx);
+    case 2: return launch_fwd_persist_nt<2>(kq4, grid, lds, st, a, wpx);
+    case 3: return launch_fwd_persist_nt<3>(kq4, grid, lds, st, a, wpx);
+    case 4: return launch_fwd_persist_nt<4>(kq4, grid, lds, st, a, wpx);
     default: return false;
   }
 }
@@ -567,21 +670,43 @@ bool launch_fwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const Pe
 // workgroups' d(pre-activation) (80 KB at H=320) through a coalesced sc1 fetch into LDS.
 // grid = (ceil(H/16), dirs, ceil(B/16)).
 // ================================================================================================
+// saved forward values of one (row, unit) item at timestep t (tp = the step whose c / h it needs, -1: none)
+__device__ __forceinline__ void bwd_item_loads(const RnnArgs &p, int t, int tp, int b, int d, int j, float sv[4], float &dyv, float &e0, float &e1) {
+  const int H = p.H, G = p.G, D = p.D, B = p.B;
+  const size_t row_t = (size_t)t * B + b;
+  const float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
+  dyv = p.dy[row_t * D * H + d * H + j];
+  e1 = 0.f;
+  if (p.cell == CTCN_CELL_TANH) {
+    e0 = p.y[row_t * D * H + d * H + j];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < G) sv[k] = gt[k * H + j];
+    e0 = p.aux[(row_t * D + d) * H + j];
+    if (tp >= 0)
+      e1 = p.cell == CTCN_CELL_LSTM ? p.aux[(((size_t)tp * B + b) * D + d) * H + j]
+                                    : p.y[((size_t)tp * B + b) * D * H + d * H + j];
+  }
+}
+
 template <int KQ4>
 __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   constexpr int NW = 16;
   const RnnArgs &p = pa.a;
-  extern __shared__ __attribute__((aligned(16))) float dsm[];     // d(pre-act) tile image [16][K+4]
   __shared__ float red[NW * 256];
   __shared__ float outs[16][17];
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int d = blockIdx.y, bt = blockIdx.z, nbt = gridDim.z, nsl = gridDim.x;
-  const int b0 = bt * 16, j0 = blockIdx.x * 16;
   const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  __shared__ int s_ticket;
+  const PersistRole role = persist_role(pa, D, &s_ticket);
+  if (!role.active) return;
+  const int d = role.d, bt = role.bt, nbt = pa.nbt, nsl = pa.nsl, slice = role.slice, local = pa.local;
+  const int b0 = bt * 16, j0 = slice * 16;
   const int Bc = min(16, B - b0);
-  const int K = G * H, ldk = K + 4;
+  const int K = G * H;
   const float *WT = d == 0 ? p.w0 : p.w1;
   const bool bvalid = (j0 + r) < H;
   const float *brow = bvalid ? WT + (size_t)(j0 + r) * K : WT;
@@ -596,60 +721,46 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, K - 4));
     bv[s] = (bvalid && k < K) ? v : zero;
   }
-  const size_t tile_f = (size_t)16 * K;
+  const int nch = (K + 15) >> 4;                     // published tile: 16-column chunks in MFMA-A lane order (see rnn_fwd_persist)
+  const size_t tile_f = (size_t)nch * 256;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
 
   const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
   const bool item = tid < 256 && bl < Bc && j < H;
   float state = 0.0f;   // carried dc (LSTM) / dh*z (GRU)
+  // Wave roles: waves 0..3 hold the 256 (row, unit) items; wave 15 polls the flags and waves 4..15 fetch the tile, so
+  // the item waves' in-order vmcnt only ever sees their own publish stores, reserve stores and next-step operand
+  // loads (requested right after the hand-off, a whole step before the gate math needs them).
+  float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f;
+  if (item) {
+    const int t0 = d == 0 ? T - 1 : 0;
+    bwd_item_loads(p, t0, d == 0 ? (t0 > 0 ? t0 - 1 : -1) : (t0 < T - 1 ? t0 + 1 : -1), b, d, j, sv, dyv, e0, e1);
+  }
   __syncthreads();
 
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? T - 1 - s : s;
-    const int tp = d == 0 ? (t > 0 ? t - 1 : -1) : (t < T - 1 ? t + 1 : -1);
     const size_t row_t = (size_t)t * B + b;
-    float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f;
-    if (item) {
-      const float *gt = p.gates + (row_t * D + d) * (size_t)K;
-      dyv = p.dy[row_t * D * H + d * H + j];
-      if (p.cell == CTCN_CELL_TANH) {
-        e0 = p.y[row_t * D * H + d * H + j];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < G) sv[k] = gt[k * H + j];
-        e0 = p.aux[(row_t * D + d) * H + j];
-        if (tp >= 0)
-          e1 = p.cell == CTCN_CELL_LSTM ? p.aux[(((size_t)tp * B + b) * D + d) * H + j]
-                                        : p.y[((size_t)tp * B + b) * D * H + d * H + j];
-      }
-    }
     f32x4 acc[1];
     acc[0] = zero;
     if (s > 0) {
       const int par = (s - 1) & 1;
-      if (wave == 0) {
+      if (wave == NW - 1) {
         const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
         if (!poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status) && lane == 0) {
           s_abort = 1;
           if (pa.status) atomicCAS(pa.status, 0, 201);
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (s_abort) break;
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
-      const int nf4 = 16 * K / 4;
-      for (int i = tid; i < nf4; i += 1024) {
-        const int row = (i * 4) / K, col = i * 4 - row * K;
-        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)i * 16);
-        *reinterpret_cast<f32x4 *>(dsm + row * ldk + col) = v;
-      }
-      __syncthreads();
       f32x4 av[KQ4];
 #pragma unroll
       for (int si = 0; si < KQ4; ++si) {
-        const int k = kb + 16 * si;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(dsm + r * ldk + min(k, K - 4));
+        const int k = kb + 16 * si, c = min(wave * KQ4 + si, nch - 1);
+        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)((c * 64 + lane) * 16));
         av[si] = (k < K && r < Bc) ? v : zero;
       }
       f32x4 acc1 = zero;      // two independent accumulator chains hide the 40-cycle dependent MFMA latency
@@ -665,14 +776,14 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     reduce_tiles<1, NW, NW>(acc, red, outs, tid, 1024);
 
     const int par = s & 1;
-    float *px = pa.hx + ((((size_t)par * D + d) * nbt + bt) * 16 + bl) * (size_t)K;      // this row of the published tile
+    const unsigned px = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);                 // published tile (bytes)
+    float out[4] = {0.f, 0.f, 0.f, 0.f};      // values the next step multiplies by W_hh (published), per gate block
+    float dan = 0.f;
     if (item) {
-      float *gt = p.gates + (row_t * D + d) * (size_t)K;
       float dh = dyv + outs[bl][jl];
-      float out[4] = {0.f, 0.f, 0.f, 0.f};    // values the next step multiplies by W_hh (published), per gate block
       if (p.cell == CTCN_CELL_LSTM) {
         const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
-        const float tc = tanhf(e0);
+        const float tc = act_tanh(e0);
         const float do_ = dh * tc;
         const float dc = dh * o_ * (1.0f - tc * tc) + state;
         out[0] = dc * g_ * i_ * (1.0f - i_);
@@ -680,52 +791,103 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
         out[2] = dc * i_ * (1.0f - g_ * g_);
         out[3] = do_ * o_ * (1.0f - o_);
         state = dc * f_;
-        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = out[2]; gt[3 * H + j] = out[3];
       } else if (p.cell == CTCN_CELL_GRU) {
         dh += state;
         const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1;
         const float dn = dh * (1.0f - z_);
         const float dz = dh * (hp - n_);
-        const float dan = dn * (1.0f - n_ * n_);
+        dan = dn * (1.0f - n_ * n_);
         out[0] = dan * hn * r_ * (1.0f - r_);
         out[1] = dz * z_ * (1.0f - z_);
         out[2] = dan * r_;
         state = dh * z_;
-        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = dan;
-        p.aux[(row_t * D + d) * H + j] = out[2];
       } else {
         out[0] = dh * (1.0f - e0 * e0);
-        gt[j] = out[0];
       }
       if (s + 1 < T) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < G)
-            __hip_atomic_store(reinterpret_cast<unsigned *>(px + k * H + j), __float_as_uint(out[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (k < G) {
+            const int col = k * H + j;
+            st_u1(rs, px + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + bl) * 4 + (col & 3)) * 4), __float_as_uint(out[k]), local);
+          }
       }
     }
     if (s + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its write-through stores
-      __syncthreads();
-      if (tid == 0)
-        __hip_atomic_store(pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores (to L2 / to memory)
+      lds_barrier();
+      if (tid == 0) st_u1(rf, (unsigned)(((((size_t)par * D + d) * nbt + bt) * nsl + slice) * 4), (unsigned)(s + 1), local);
+    }
+    // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs leaves after the hand-off,
+    // and the next step's saved forward values are requested a whole step ahead
+    if (item) {
+      float *gt = p.gates + (row_t * D + d) * (size_t)K;
+      if (p.cell == CTCN_CELL_LSTM) {
+        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = out[2]; gt[3 * H + j] = out[3];
+      } else if (p.cell == CTCN_CELL_GRU) {
+        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = dan;
+        p.aux[(row_t * D + d) * H + j] = out[2];
+      } else {
+        gt[j] = out[0];
+      }
+      if (s + 1 < T) {
+        const int tn = d == 0 ? T - 2 - s : s + 1;
+        bwd_item_loads(p, tn, d == 0 ? (tn > 0 ? tn - 1 : -1) : (tn < T - 1 ? tn + 1 : -1), b, d, j, sv, dyv, e0, e1);
+      }
     }
   }
   if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
-bool launch_bwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a) {
+bool launch_bwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (kq4) {
-    case 1: return launch_resident(rnn_bwd_persist<1>, grid, 1024, lds, st, a);
-    case 2: return launch_resident(rnn_bwd_persist<2>, grid, 1024, lds, st, a);
-    case 3: return launch_resident(rnn_bwd_persist<3>, grid, 1024, lds, st, a);
-    case 4: return launch_resident(rnn_bwd_persist<4>, grid, 1024, lds, st, a);
-    case 5: return launch_resident(rnn_bwd_persist<5>, grid, 1024, lds, st, a);
-    case 6: return launch_resident(rnn_bwd_persist<6>, grid, 1024, lds, st, a);
-    case 8: return launch_resident(rnn_bwd_persist<8>, grid, 1024, lds, st, a);
+    case 1: return launch_resident(rnn_bwd_persist<1>, grid, 1024, lds, st, a, wpx);
+    case 2: return launch_resident(rnn_bwd_persist<2>, grid, 1024, lds, st, a, wpx);
+    case 3: return launch_resident(rnn_bwd_persist<3>, grid, 1024, lds, st, a, wpx);
+    case 4: return launch_resident(rnn_bwd_persist<4>, grid, 1024, lds, st, a, wpx);
+    case 5: return launch_resident(rnn_bwd_persist<5>, grid, 1024, lds, st, a, wpx);
+    case 6: return launch_resident(rnn_bwd_persist<6>, grid, 1024, lds, st, a, wpx);
+    case 8: return launch_resident(rnn_bwd_persist<8>, grid, 1024, lds, st, a, wpx);
     default: return false;
   }
+}
+
+// XCDs of the current device, if a 64-workgroup probe kernel (reads HW_REG_XCC_ID) finds its workgroups dealt evenly
+// over them; 1 when the XCD-local hand-off cannot be used.  Probed once per device.
+__global__ void xcc_probe_kernel(int *out) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 15);
+}
+extern "C" int ctcn_device_xcds(void) {
+  static int cache[64];
+  static bool have[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+  if (have[dev]) return cache[dev];
+  int nx = 1, h[64];
+  int *buf = nullptr;
+  if (hipMalloc(&buf, sizeof(h)) == hipSuccess) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(64), dim3(64), 0, 0, buf);
+    if (hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      int mx = 0;
+      for (int i = 0; i < 64; ++i) mx = h[i] > mx ? h[i] : mx;
+      nx = mx + 1;
+      int cnt[16] = {0};
+      for (int i = 0; i < 64; ++i) cnt[h[i] & 15]++;
+      for (int x = 0; x < nx; ++x)
+        if (cnt[x] * nx != 64) nx = 1;                                  // not dealt evenly: no XCD-local mode
+      if (nx > 1 && ctcn_device_cus() % nx != 0) nx = 1;
+      if (getenv("CTCN_DEBUG")) {
+        fprintf(stderr, "ctcn_device_xcds: cus %d nx %d xcc:", ctcn_device_cus(), nx);
+        for (int i = 0; i < 64; ++i) fprintf(stderr, " %d", h[i]);
+        fprintf(stderr, "\n");
+      }
+    } else if (getenv("CTCN_DEBUG")) fprintf(stderr, "ctcn_device_xcds: probe copy failed: %s\n", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(buf);
+  }
+  cache[dev] = nx; have[dev] = true;
+  return nx;
 }
 
 int pick_kq4(int K, int nwaves, int mt, int budget) {
@@ -797,14 +959,36 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
     // persistent recurrence: K = H split over 4 waves x 4 k-lanes x KQ4 float4 (one super-chunk)
     int kq = ceil_div(H, 64);
     if (kq == 7) kq = 8;
-    const int NT = cell == CTCN_CELL_TANH ? 1 : (H % 8 == 0 ? 2 : 1);
-    const int HSU = cell == CTCN_CELL_TANH ? 16 : 4 * NT;
-    const int nbt = ceil_div(B, 16), nsl = ceil_div(H, HSU);
-    dim3 pgrid(nsl, dirs, nbt);
-    const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * 16 * H * sizeof(float), 256);
-    const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256);
-    const size_t lds = (size_t)16 * (H + 4) * sizeof(float);
-    if (kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512) {
+    const int nbt = ceil_div(B, 16), groups = dirs * nbt;
+    const size_t lds = 0;
+    // mode 1 = XCD-local (each group's slices on one XCD, hand-off through its L2), mode 0 = device scope
+    // candidates in order of preference: XCD-local hand-off (each group's slices on one XCD, through its L2) with
+    // 8 / 12 / 16 / 4 hidden units per workgroup -- fewer units = less matmul per step, but the group must stay
+    // co-resident on one XCD -- then the device-scope hand-off.  The first one that is co-resident runs.
+    struct Cand { int mode, hsu; };
+    Cand cands[6];
+    int nc = 0;
+    const int nxd = ctcn_opt_handoff() ? ctcn_device_xcds() : 1;
+    if (cell == CTCN_CELL_TANH) {
+      if (nxd > 1) cands[nc++] = {1, 16};
+      cands[nc++] = {0, 16};
+    } else {
+      if (nxd > 1) {
+        if (H % 8 == 0) cands[nc++] = {1, 8};
+        cands[nc++] = {1, 12}; cands[nc++] = {1, 16}; cands[nc++] = {1, 4};
+      }
+      cands[nc++] = {0, H % 8 == 0 ? 8 : 4};
+    }
+    for (int ci = 0; ci < nc && kq <= 8; ++ci) {
+      const int mode = cands[ci].mode, HSU = cands[ci].hsu;
+      const int nx = mode ? nxd : 1;
+      const int NT = cell == CTCN_CELL_TANH ? 1 : ceil_div(HSU, 4);
+      const int nsl = ceil_div(H, HSU);
+      const int wpx = ceil_div(groups, nx) * nsl;
+      const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : dim3(nsl, dirs, nbt);
+      const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * ceil_div(H, 16) * 256 * sizeof(float), 256);
+      const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
+      if (!ws || ws_bytes < hx_bytes + fl_bytes + 512) break;
       PersistArgs pa;
       pa.a = a;
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
@@ -812,12 +996,13 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx;
+      pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
 #endif
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
-      const bool ok = NT == 1 ? launch_fwd_persist<1>(kq, pgrid, lds, st, pa) : launch_fwd_persist<2>(kq, pgrid, lds, st, pa);
-      if (ok) {
+      if (launch_fwd_persist(NT, kq, pgrid, lds, st, pa, wpx)) {
         CTCN_LAUNCH_CHECK();
         return CTCN_OK;
       }
@@ -871,10 +1056,14 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   if (ctcn_opt_rnn_persistent() && T > 1) {
     int kq = ceil_div(GH, 256);
     if (kq == 7) kq = 8;
-    const size_t hx_bytes = align_up((size_t)2 * dirs * grid.z * 16 * GH * sizeof(float), 256);
-    const size_t fl_bytes = align_up((size_t)2 * dirs * grid.z * grid.x * sizeof(unsigned), 256);
-    const size_t lds = (size_t)16 * (GH + 4) * sizeof(float);
-    if (kq <= 8 && lds <= 120 * 1024 && ws && ws_bytes >= hx_bytes + fl_bytes + 512) {
+    const int nbt = grid.z, nsl = grid.x, groups = dirs * nbt;
+    const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * ceil_div(GH, 16) * 256 * sizeof(float), 256);
+    const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
+    const size_t lds = 0;
+    for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
+      const int nx = mode ? ctcn_device_xcds() : 1;
+      if (mode && nx <= 1) continue;
+      const int wpx = ceil_div(groups, nx) * nsl;
       PersistArgs pa;
       pa.a = a;
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
@@ -882,11 +1071,13 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.wpx = wpx;
+      pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
 #endif
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
-      done = launch_bwd_persist(kq, grid, lds, st, pa);
+      done = launch_bwd_persist(kq, mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid, lds, st, pa, wpx);
     }
   }
   if (!done) {

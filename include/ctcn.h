@@ -35,8 +35,12 @@ int ctcn_version(void);
 const char *ctcn_last_error(void);
 /* number of CUs of the current device (host query, used to size grids / workspaces) */
 int ctcn_device_cus(void);
+/* XCDs of the current device when consecutive workgroup ids are dealt round-robin over them (probed once), else 1 */
+int ctcn_device_xcds(void);
 /* options: "rnn_persistent" = 1 (default): the recurrence of ctcn_rnn_fwd/bwd runs as ONE persistent launch per layer
- * (W_hh slice resident in VGPRs, h_t handed between workgroups in-launch); 0: one launch per timestep. */
+ * (W_hh slice resident in VGPRs, h_t handed between workgroups in-launch); 0: one launch per timestep.
+ * "handoff" = 1 (default): persistent launches place each (direction, batch-tile) group on one XCD and hand h_t over
+ * through that XCD's L2 when the device allows it (falls back to 0 otherwise); 0: device-scope write-through hand-off. */
 int ctcn_set_option(const char *name, int value);
 int ctcn_get_option(const char *name);
 /* optional device int that persistent kernels set to a non-zero code if an in-launch hand-off times out (sticky);
