@@ -12,6 +12,7 @@ void ctcn_set_error(const char *fmt, ...);
 int *ctcn_status_word(void);      // device int registered with ctcn_set_status_buffer (may be null)
 int ctcn_opt_rnn_persistent(void);
 int ctcn_opt_handoff(void);
+int ctcn_opt_poll_depth(void);
 
 #define CTCN_REQUIRE(cond, ...)          \
   do {                                   \

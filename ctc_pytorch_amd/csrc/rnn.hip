@@ -42,6 +42,38 @@ __device__ __forceinline__ float act_tanh(float x) {
   return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
+// bf16x3 recurrent matmul (precision = 1): every f32 operand x is carried as hi = bf16(x), lo = bf16(x - hi) and the
+// product accumulates lo*hi + hi*lo + hi*hi in f32 on v_mfma_f32_16x16x32_bf16 (16 cycles per 32 k, against 8 x 32
+// cycles for the same k on the f32 MFMA): the matmul leaves the serial path of the timestep almost entirely.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+union Bf16Pack { u32x4 u; bf16x8_t v; };
+__device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8_t &hi, bf16x8_t &lo) {
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? a[e] : b[e - 4];
+    h[e] = f2bf(x);
+    l[e] = f2bf(x - __uint_as_float(h[e] << 16));
+  }
+  Bf16Pack ph, pl;
+  ph.u = (u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  pl.u = (u32x4){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+  hi = ph.v; lo = pl.v;
+}
+// W operand of one lane: 8 consecutive k of row `brow` (null -> zeros), k beyond K are zeros
+__device__ __forceinline__ void load_w8(const float *brow, int k0, int K, bf16x8_t &hi, bf16x8_t &lo) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float *src = brow ? brow : reinterpret_cast<const float *>(&zero);
+  f32x4 a = zero, b = zero;
+  if (brow) {
+    const f32x4 va = *reinterpret_cast<const f32x4 *>(src + min(k0, K - 4));
+    const f32x4 vb = *reinterpret_cast<const f32x4 *>(src + min(k0 + 4, K - 4));
+    a = k0 < K ? va : zero;
+    b = k0 + 4 < K ? vb : zero;
+  }
+  split8(a, b, hi, lo);
+}
+
 struct RnnArgs {
   int cell, T, B, H, D, G, step;
   const float *w0, *w1;  // fwd: W_hh (G*H,H) per direction; bwd: W_hh^T (H,G*H)
@@ -346,6 +378,7 @@ struct PersistArgs {
   int wpx;              // local mode: working workgroups per XCD
   unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)
   int hsu;              // forward: hidden units per workgroup (<= 4*NT)
+  int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
 #ifdef CTCN_PERSIST_STATS
   long long *stats;   // development instrumentation (tools/mb_step.hip only)
 #endif
@@ -391,6 +424,38 @@ __device__ __forceinline__ bool poll_flags(const unsigned *flags, int n, unsigne
   }
 }
 
+// XCD-local variant for n <= 64 flags (one per lane): DEPTH polls stay in flight, re-issued as each returns, so a flag
+// that lands between two polls is seen after ~RT/DEPTH instead of a full L2 round trip (the flag line lives in this
+// XCD's L2, whose bandwidth the extra polls do not dent; over the fabric the same trick was measured slower).
+template <int DEPTH>
+__device__ __forceinline__ bool poll_flags_pipelined(const unsigned *flags, int n, unsigned want, int lane, int spin_limit, int *status) {
+  const unsigned *p = flags + min(lane, n - 1);
+  const bool idle = lane >= n;
+  unsigned v[DEPTH];
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) {
+    v[i] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i + 1 < DEPTH) __builtin_amdgcn_s_sleep(2);
+  }
+  for (int spins = 0;; ++spins) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      if (__all(idle || v[i] == want)) return true;
+      v[i] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (spins > spin_limit) return false;
+    if ((spins & 63) == 63 && status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  }
+}
+__device__ __forceinline__ bool poll_group(const unsigned *flags, int n, unsigned want, int lane, const PersistArgs &pa) {
+  if (pa.local && n <= 64) {
+    if (pa.poll_depth == 2) return poll_flags_pipelined<2>(flags, n, want, lane, pa.spin_limit, pa.status);
+    if (pa.poll_depth == 3) return poll_flags_pipelined<3>(flags, n, want, lane, pa.spin_limit, pa.status);
+    if (pa.poll_depth >= 4) return poll_flags_pipelined<4>(flags, n, want, lane, pa.spin_limit, pa.status);
+  }
+  return poll_flags(flags, n, want, lane, pa.spin_limit, pa.status);
+}
+
 // Role of a workgroup in a persistent launch.  Device-scope mode: grid (slices, dirs, batch tiles).  XCD-local mode:
 // a 1-D grid of nx * (wpx + spare) workgroups.  The hardware deals workgroups round-robin over the XCDs (starting
 // wherever the previous dispatch stopped), so every XCD receives >= wpx of them; each workgroup reads the XCD it
@@ -414,13 +479,13 @@ __device__ __forceinline__ PersistRole persist_role(const PersistArgs &pa, int D
   return r;
 }
 
-template <int NT, int KQ4>
+template <int NT, int KQ4, int PREC>
 __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   constexpr int NW = 4;
   const RnnArgs &p = pa.a;
   __shared__ float red[NW * NT * 256];
   __shared__ float outs[NT * 16][17];
-  __shared__ float hpub[16][4 * NT < 16 ? 16 : 4 * NT];
+  __shared__ __attribute__((aligned(16))) float hpub[16][16];   // h_t of this workgroup's units: f32 [row][unit], or (precision 1) two bf16 planes [hi|lo][row][unit]
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -440,24 +505,34 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   if (tid == 0) s_abort = 0;
 
   // W_hh slice of this lane, resident for the whole sequence: tile nt covers units j0+4nt..+3 (x 4 gates)
+  constexpr int KB = (KQ4 + 1) / 2;                       // precision 1: 32-k blocks per wave (4 * KB * 32 >= H)
   f32x4 bv[NT][KQ4];
+  bf16x8_t whi[NT][KB], wlo[NT][KB];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int gate = tanh_cell ? 0 : (r >> 2), jj = tanh_cell ? r : (nt * 4 + (r & 3));
     const bool bvalid = gate < G && jj < HSU && (j0 + jj) < H;
     const float *brow = bvalid ? W + (size_t)(gate * H + j0 + jj) * H : W;
+    if constexpr (PREC == 0) {
 #pragma unroll
-    for (int s = 0; s < KQ4; ++s) {
-      const int k = kb + 16 * s;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, H - 4));
-      bv[nt][s] = (bvalid && k < H) ? v : zero;
+      for (int s = 0; s < KQ4; ++s) {
+        const int k = kb + 16 * s;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, H - 4));
+        bv[nt][s] = (bvalid && k < H) ? v : zero;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KB; ++i) load_w8(bvalid ? brow : nullptr, 32 * (wave * KB + i) + 8 * q, H, whi[nt][i], wlo[nt][i]);
     }
   }
   // published h tile: 16-float column chunks, each stored in MFMA-A lane order [k-quad q][row][4 floats], so that a
   // consuming lane (row r = lane & 15, quad q = lane >> 4) reads ITS float4 of chunk c at (c * 64 + lane) * 16 bytes:
   // one fully coalesced 1-KB load per chunk, straight into the MFMA operand registers (no LDS staging, no fill barrier)
-  const int nch = (H + 15) >> 4;
-  const size_t tile_f = (size_t)nch * 256;                                                      // floats per h tile
+  // precision 1: 32-column blocks of two bf16 planes, [block][hi | lo][k-octet q][row][8 bf16]: the lane's hi / lo
+  // MFMA-A fragments of block b sit at b * 2048 + {0, 1024} + lane * 16 bytes (the buffer is zeroed per call, so
+  // rows / columns nobody publishes read as 0)
+  const int nch = PREC == 0 ? (H + 15) >> 4 : (H + 31) >> 5;
+  const size_t tile_f = (size_t)nch * (PREC == 0 ? 256 : 512);                                  // floats per h tile
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
 
@@ -484,6 +559,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   __syncthreads();
 #ifdef CTCN_PERSIST_STATS
   long long st_poll = 0, st_fill = 0, st_mm = 0, st_red = 0, st_epi = 0, st_t0 = clock64();
+  long long st_e1 = 0, st_e2 = 0, st_e3 = 0, st_e4 = 0;   // gate math (to hpub barrier) | publish stores issued | drained | flag + reserve issue
 #endif
 
   for (int s = 0; s < T; ++s) {
@@ -500,7 +576,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       const int par = (s - 1) & 1;
       if (wave == cw) {
         const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
-        const bool ok = poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status);
+        const bool ok = poll_group(fl, nsl, (unsigned)s, lane, pa);
         if (!ok && lane == 0) {
           s_abort = 1;
           if (pa.status) atomicCAS(pa.status, 0, 101);
@@ -512,23 +588,44 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       c_p = clock64();
 #endif
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
-      f32x4 av[KQ4];
+      if constexpr (PREC == 0) {
+        f32x4 av[KQ4];
 #pragma unroll
-      for (int si = 0; si < KQ4; ++si) {
-        const int k = kb + 16 * si, c = min(wave * KQ4 + si, nch - 1);
-        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)((c * 64 + lane) * 16));
-        av[si] = (k < H && r < Bc) ? v : zero;
-      }
+        for (int si = 0; si < KQ4; ++si) {
+          const int k = kb + 16 * si, c = min(wave * KQ4 + si, nch - 1);
+          const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)((c * 64 + lane) * 16));
+          av[si] = (k < H && r < Bc) ? v : zero;
+        }
 #ifdef CTCN_PERSIST_STATS
-      c_f = clock64();
+        c_f = clock64();
 #endif
 #pragma unroll
-      for (int si = 0; si < KQ4; ++si)
+        for (int si = 0; si < KQ4; ++si)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+          for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[nt][si][c], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[nt][si][c], acc[nt], 0, 0, 0);
+      } else {
+        Bf16Pack ah[KB], al[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const unsigned off = tbase + (unsigned)(min(wave * KB + i, nch - 1) * 2048 + lane * 16);   // blocks past the end: W is 0 there
+          ah[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+          al[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
+        }
+#ifdef CTCN_PERSIST_STATS
+        c_f = clock64();
+#endif
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i].v, whi[nt][i], acc[nt], 0, 0, 0);   // small terms first
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, wlo[nt][i], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, whi[nt][i], acc[nt], 0, 0, 0);
+          }
+      }
     }
 #ifdef CTCN_PERSIST_STATS
     const long long c_b = clock64();
@@ -562,34 +659,65 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       } else {
         hval = act_tanh(o[ojl] + pre[0]);
       }
-      hpub[bl][jl] = hval;
+      if constexpr (PREC == 0) {
+        hpub[bl][jl] = hval;
+      } else {
+        unsigned short *hp = reinterpret_cast<unsigned short *>(&hpub[0][0]);
+        const unsigned hi = f2bf(hval);
+        hp[bl * 16 + jl] = (unsigned short)hi;
+        hp[256 + bl * 16 + jl] = f2bf(hval - __uint_as_float(hi << 16));
+      }
     }
+#ifdef CTCN_PERSIST_STATS
+    const long long c_d0 = clock64();
+#endif
     lds_barrier();
-    // publish this workgroup's 16 x HSU block of h_t: 16-B (8-B when HSU % 4) stores by the communication wave,
-    // drained, then the flag
+#ifdef CTCN_PERSIST_STATS
+    const long long c_d = clock64();
+    long long c_e = c_d, c_g = c_d;
+#endif
+    // publish this workgroup's 16 x HSU block of h_t: 16-B stores by the communication wave, drained, then the flag
     if (s + 1 < T && wave == cw) {
       const int par = s & 1;
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
-      if ((HSU & 3) == 0) {
-        const int per_row = HSU / 4;                             // float4 per row
-        for (int i = lane; i < 16 * per_row; i += 64) {
-          const int row = i / per_row, c4 = i - row * per_row;
-          if (row < Bc && j0 + c4 * 4 < H) {
-            const f32x4 v = {hpub[row][c4 * 4], hpub[row][c4 * 4 + 1], hpub[row][c4 * 4 + 2], hpub[row][c4 * 4 + 3]};
-            const int col = j0 + c4 * 4;
-            st_f4(rs, tbase + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4) * 4), v, local);
+      // lanes run row-fastest so that consecutive lanes write consecutive 16-B (8-B) granules of the tile
+      const int row = lane & 15, rest = lane >> 4;
+      if constexpr (PREC == 1) {
+        const unsigned short *hp = reinterpret_cast<const unsigned short *>(&hpub[0][0]);
+        if ((HSU & 7) == 0) {                                      // one 16-B granule = 8 units of one plane
+          const int plane = rest & 1, oct = rest >> 1, col = j0 + oct * 8;
+          if (oct * 8 < HSU && row < Bc && col < H) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(hp + plane * 256 + row * 16 + oct * 8);
+            const unsigned off = tbase + (unsigned)((col >> 5) * 2048 + plane * 1024 + (((col >> 3) & 3) * 16 + row) * 16);
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+          }
+        } else {                                                   // pieces of 4 units (8 B)
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          for (int rr = rest; rr < 2 * (HSU / 4); rr += 4) {
+            const int plane = rr & 1, pc = rr >> 1, col = j0 + pc * 4;
+            if (row < Bc && col < H) {
+              const u32x2 v = *reinterpret_cast<const u32x2 *>(hp + plane * 256 + row * 16 + pc * 4);
+              const unsigned off = tbase + (unsigned)((col >> 5) * 2048 + plane * 1024 + (((col >> 3) & 3) * 16 + row) * 16 + ((col >> 2) & 1) * 8);
+              if (local) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0);
+              else __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 16);
+            }
           }
         }
-      } else {
-        const int per_row = HSU / 2;                             // float2 per row (HSU and H are even)
-        for (int i = lane; i < 16 * per_row; i += 64) {
-          const int row = i / per_row, c2 = i - row * per_row;
-          const int col = j0 + c2 * 2;
-          if (row < Bc && col < H)
-            st_f2(rs, tbase + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4 + (col & 3)) * 4), hpub[row][c2 * 2], hpub[row][c2 * 2 + 1], local);
+      } else {                                                     // f32: one 16-B granule = 4 units (HSU % 4 == 0)
+        const int c4 = rest, col = j0 + c4 * 4;
+        if (c4 * 4 < HSU && row < Bc && col < H) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(&hpub[row][c4 * 4]);
+          st_f4(rs, tbase + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4) * 4), v, local);
         }
       }
+#ifdef CTCN_PERSIST_STATS
+      c_e = clock64();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the storing wave drains its stores (to L2 / to memory)
+#ifdef CTCN_PERSIST_STATS
+      c_g = clock64();
+#endif
       if (lane == 0) st_u1(rf, (unsigned)(((((size_t)par * D + d) * nbt + bt) * nsl + slice) * 4), (unsigned)(s + 1), local);
     }
     // off the critical path (item waves): the reserve (gates, c / hn) and y leave after the hand-off, and the next
@@ -611,12 +739,16 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       }
     }
 #ifdef CTCN_PERSIST_STATS
-    st_epi += clock64() - c_c;
+    const long long c_h = clock64();
+    st_epi += c_h - c_c; st_e1 += c_d - c_c; st_e2 += c_e - c_d; st_e3 += c_g - c_e; st_e4 += c_h - c_g;
+    if (tid == 0) st_e1 += 0;
+    (void)c_d0;
 #endif
   }
 #ifdef CTCN_PERSIST_STATS
   if (pa.stats && slice == 7 && d == 0 && bt == 0 && tid == cw * 64) {
     pa.stats[0] = st_poll; pa.stats[1] = st_fill; pa.stats[2] = st_mm; pa.stats[3] = st_red; pa.stats[4] = st_epi; pa.stats[5] = clock64() - st_t0;
+    pa.stats[6] = st_e1; pa.stats[7] = st_e2; pa.stats[8] = st_e3; pa.stats[9] = st_e4;
   }
 #endif
   if (s_abort && item) p.y[((size_t)(d == 0 ? T - 1 : 0) * B + b) * D * H + d * H + j] = __uint_as_float(0x7fc00000u);   // poison
@@ -639,27 +771,31 @@ bool launch_resident(Kern kern, dim3 grid, int threads, size_t lds, hipStream_t 
   return true;
 }
 
-template <int NT>
+template <int NT, int PREC>
 bool launch_fwd_persist_nt(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (kq4) {
-    case 1: return launch_resident(rnn_fwd_persist<NT, 1>, grid, 256, lds, st, a, wpx);
-    case 2: return launch_resident(rnn_fwd_persist<NT, 2>, grid, 256, lds, st, a, wpx);
-    case 3: return launch_resident(rnn_fwd_persist<NT, 3>, grid, 256, lds, st, a, wpx);
-    case 4: return launch_resident(rnn_fwd_persist<NT, 4>, grid, 256, lds, st, a, wpx);
-    case 5: return launch_resident(rnn_fwd_persist<NT, 5>, grid, 256, lds, st, a, wpx);
-    case 6: return launch_resident(rnn_fwd_persist<NT, 6>, grid, 256, lds, st, a, wpx);
-    case 8: return launch_resident(rnn_fwd_persist<NT, 8>, grid, 256, lds, st, a, wpx);
+    case 1: return launch_resident(rnn_fwd_persist<NT, 1, PREC>, grid, 256, lds, st, a, wpx);
+    case 2: return launch_resident(rnn_fwd_persist<NT, 2, PREC>, grid, 256, lds, st, a, wpx);
+    case 3: return launch_resident(rnn_fwd_persist<NT, 3, PREC>, grid, 256, lds, st, a, wpx);
+    case 4: return launch_resident(rnn_fwd_persist<NT, 4, PREC>, grid, 256, lds, st, a, wpx);
+    case 5: return launch_resident(rnn_fwd_persist<NT, 5, PREC>, grid, 256, lds, st, a, wpx);
+    case 6: return launch_resident(rnn_fwd_persist<NT, 6, PREC>, grid, 256, lds, st, a, wpx);
+    case 8: return launch_resident(rnn_fwd_persist<NT, 8, PREC>, grid, 256, lds, st, a, wpx);
     default: return false;
   }
 }
-bool launch_fwd_persist(int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
+template <int PREC>
+bool launch_fwd_persist_p(int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (nt) {
-    case 1: return launch_fwd_persist_nt<1>(kq4, grid, lds, st, a, wpx);
-    case 2: return launch_fwd_persist_nt<2>(kq4, grid, lds, st, a, wpx);
-    case 3: return launch_fwd_persist_nt<3>(kq4, grid, lds, st, a, wpx);
-    case 4: return launch_fwd_persist_nt<4>(kq4, grid, lds, st, a, wpx);
+    case 1: return launch_fwd_persist_nt<1, PREC>(kq4, grid, lds, st, a, wpx);
+    case 2: return launch_fwd_persist_nt<2, PREC>(kq4, grid, lds, st, a, wpx);
+    case 3: return launch_fwd_persist_nt<3, PREC>(kq4, grid, lds, st, a, wpx);
+    case 4: return launch_fwd_persist_nt<4, PREC>(kq4, grid, lds, st, a, wpx);
     default: return false;
   }
+}
+bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
+  return prec ? launch_fwd_persist_p<1>(nt, kq4, grid, lds, st, a, wpx) : launch_fwd_persist_p<0>(nt, kq4, grid, lds, st, a, wpx);
 }
 
 // ================================================================================================
@@ -690,11 +826,11 @@ __device__ __forceinline__ void bwd_item_loads(const RnnArgs &p, int t, int tp, 
   }
 }
 
-template <int KQ4>
+template <int KQ4, int PREC>
 __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   constexpr int NW = 16;
   const RnnArgs &p = pa.a;
-  __shared__ float red[NW * 256];
+  __shared__ __attribute__((aligned(16))) float red[NW * 256];
   __shared__ float outs[16][17];
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -714,15 +850,23 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   if (tid == 0) s_abort = 0;
 
+  constexpr int KB = (KQ4 + 1) / 2;                  // precision 1: 32-k blocks per wave (16 * KB * 32 >= K)
   f32x4 bv[KQ4];
+  bf16x8_t whi[KB], wlo[KB];
+  if constexpr (PREC == 0) {
 #pragma unroll
-  for (int s = 0; s < KQ4; ++s) {
-    const int k = kb + 16 * s;
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, K - 4));
-    bv[s] = (bvalid && k < K) ? v : zero;
+    for (int s = 0; s < KQ4; ++s) {
+      const int k = kb + 16 * s;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(brow + min(k, K - 4));
+      bv[s] = (bvalid && k < K) ? v : zero;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) load_w8(bvalid ? brow : nullptr, 32 * (wave * KB + i) + 8 * q, K, whi[i], wlo[i]);
   }
-  const int nch = (K + 15) >> 4;                     // published tile: 16-column chunks in MFMA-A lane order (see rnn_fwd_persist)
-  const size_t tile_f = (size_t)nch * 256;
+  // published tile: column chunks in MFMA-A lane order, f32 (precision 0) or hi / lo bf16 planes (see rnn_fwd_persist)
+  const int nch = PREC == 0 ? (K + 15) >> 4 : (K + 31) >> 5;
+  const size_t tile_f = (size_t)nch * (PREC == 0 ? 256 : 512);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
 
@@ -748,7 +892,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
       const int par = (s - 1) & 1;
       if (wave == NW - 1) {
         const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
-        if (!poll_flags(fl, nsl, (unsigned)s, lane, pa.spin_limit, pa.status) && lane == 0) {
+        if (!poll_group(fl, nsl, (unsigned)s, lane, pa) && lane == 0) {
           s_abort = 1;
           if (pa.status) atomicCAS(pa.status, 0, 201);
         }
@@ -756,21 +900,37 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
       lds_barrier();
       if (s_abort) break;
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
-      f32x4 av[KQ4];
+      f32x4 acc1 = zero;      // two independent accumulator chains hide the dependent MFMA latency
+      if constexpr (PREC == 0) {
+        f32x4 av[KQ4];
 #pragma unroll
-      for (int si = 0; si < KQ4; ++si) {
-        const int k = kb + 16 * si, c = min(wave * KQ4 + si, nch - 1);
-        const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)((c * 64 + lane) * 16));
-        av[si] = (k < K && r < Bc) ? v : zero;
-      }
-      f32x4 acc1 = zero;      // two independent accumulator chains hide the 40-cycle dependent MFMA latency
-#pragma unroll
-      for (int si = 0; si < KQ4; ++si)
-#pragma unroll
-        for (int c = 0; c < 4; c += 2) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[si][c], acc[0], 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c + 1], bv[si][c + 1], acc1, 0, 0, 0);
+        for (int si = 0; si < KQ4; ++si) {
+          const int k = kb + 16 * si, c = min(wave * KQ4 + si, nch - 1);
+          const f32x4 v = ld_sc1_f4(rs, tbase + (unsigned)((c * 64 + lane) * 16));
+          av[si] = (k < K && r < Bc) ? v : zero;
         }
+#pragma unroll
+        for (int si = 0; si < KQ4; ++si)
+#pragma unroll
+          for (int c = 0; c < 4; c += 2) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[si][c], acc[0], 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c + 1], bv[si][c + 1], acc1, 0, 0, 0);
+          }
+      } else {
+        Bf16Pack ah[KB], al[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const unsigned off = tbase + (unsigned)(min(wave * KB + i, nch - 1) * 2048 + lane * 16);   // blocks past the end: W is 0 there
+          ah[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+          al[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i].v, whi[i], acc1, 0, 0, 0);                // small terms
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, wlo[i], acc1, 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, whi[i], acc[0], 0, 0, 0);
+        }
+      }
       acc[0] += acc1;
     }
     reduce_tiles<1, NW, NW>(acc, red, outs, tid, 1024);
@@ -804,13 +964,42 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
       } else {
         out[0] = dh * (1.0f - e0 * e0);
       }
+      // stage this workgroup's 16 x 16 x G block in LDS (the reduce buffer is free again) in the granule order of the tile
       if (s + 1 < T) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (k < G) {
-            const int col = k * H + j;
-            st_u1(rs, px + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + bl) * 4 + (col & 3)) * 4), __float_as_uint(out[k]), local);
+            if constexpr (PREC == 0) {
+              red[((k * 4 + (jl >> 2)) * 16 + bl) * 4 + (jl & 3)] = out[k];
+            } else {
+              unsigned short *sp = reinterpret_cast<unsigned short *>(red);
+              const unsigned hi = f2bf(out[k]);
+              sp[((k * 2 + (jl >> 3)) * 16 + bl) * 8 + (jl & 7)] = (unsigned short)hi;
+              sp[(((4 + k) * 2 + (jl >> 3)) * 16 + bl) * 8 + (jl & 7)] = f2bf(out[k] - __uint_as_float(hi << 16));
+            }
           }
+      }
+    }
+    if (s + 1 < T) {
+      lds_barrier();
+      // copy-out by waves 0..3: every lane one 16-B granule, 16 consecutive rows = 256 contiguous bytes of the tile
+      if (tid < 256) {
+        const int row = tid & 15;
+        if constexpr (PREC == 0) {
+          const int k = tid >> 6, qq = (tid >> 4) & 3, col = k * H + j0 + 4 * qq;
+          if (k < G && row < Bc && j0 + 4 * qq < H) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&red[((k * 4 + qq) * 16 + row) * 4]);
+            st_f4(rs, px + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4) * 4), v, local);
+          }
+        } else {
+          const int plane = tid >> 7, k = (tid >> 5) & 3, oct = (tid >> 4) & 1, col = k * H + j0 + 8 * oct;
+          if (k < G && row < Bc && j0 + 8 * oct < H) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(red) + (((plane * 4 + k) * 2 + oct) * 16 + row) * 8);
+            const unsigned off = px + (unsigned)((col >> 5) * 2048 + plane * 1024 + (((col >> 3) & 3) * 16 + row) * 16);
+            if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+          }
+        }
       }
     }
     if (s + 1 < T) {
@@ -839,17 +1028,21 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
-bool launch_bwd_persist(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
+template <int PREC>
+bool launch_bwd_persist_p(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (kq4) {
-    case 1: return launch_resident(rnn_bwd_persist<1>, grid, 1024, lds, st, a, wpx);
-    case 2: return launch_resident(rnn_bwd_persist<2>, grid, 1024, lds, st, a, wpx);
-    case 3: return launch_resident(rnn_bwd_persist<3>, grid, 1024, lds, st, a, wpx);
-    case 4: return launch_resident(rnn_bwd_persist<4>, grid, 1024, lds, st, a, wpx);
-    case 5: return launch_resident(rnn_bwd_persist<5>, grid, 1024, lds, st, a, wpx);
-    case 6: return launch_resident(rnn_bwd_persist<6>, grid, 1024, lds, st, a, wpx);
-    case 8: return launch_resident(rnn_bwd_persist<8>, grid, 1024, lds, st, a, wpx);
+    case 1: return launch_resident(rnn_bwd_persist<1, PREC>, grid, 1024, lds, st, a, wpx);
+    case 2: return launch_resident(rnn_bwd_persist<2, PREC>, grid, 1024, lds, st, a, wpx);
+    case 3: return launch_resident(rnn_bwd_persist<3, PREC>, grid, 1024, lds, st, a, wpx);
+    case 4: return launch_resident(rnn_bwd_persist<4, PREC>, grid, 1024, lds, st, a, wpx);
+    case 5: return launch_resident(rnn_bwd_persist<5, PREC>, grid, 1024, lds, st, a, wpx);
+    case 6: return launch_resident(rnn_bwd_persist<6, PREC>, grid, 1024, lds, st, a, wpx);
+    case 8: return launch_resident(rnn_bwd_persist<8, PREC>, grid, 1024, lds, st, a, wpx);
     default: return false;
   }
+}
+bool launch_bwd_persist(int prec, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
+  return prec ? launch_bwd_persist_p<1>(kq4, grid, lds, st, a, wpx) : launch_bwd_persist_p<0>(kq4, grid, lds, st, a, wpx);
 }
 
 // XCDs of the current device, if a 64-workgroup probe kernel (reads HW_REG_XCC_ID) finds its workgroups dealt evenly
@@ -986,7 +1179,8 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       const int nsl = ceil_div(H, HSU);
       const int wpx = ceil_div(groups, nx) * nsl;
       const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : dim3(nsl, dirs, nbt);
-      const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * ceil_div(H, 16) * 256 * sizeof(float), 256);
+      const int prec = precision == 1 && HSU % 4 == 0 && H % 8 == 0 ? 1 : 0;       // bf16x3 recurrent matmul
+      const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(H, 32) * 512 : ceil_div(H, 16) * 256) * sizeof(float), 256);
       const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
       if (!ws || ws_bytes < hx_bytes + fl_bytes + 512) break;
       PersistArgs pa;
@@ -996,13 +1190,14 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx;
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth();
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
 #endif
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
-      if (launch_fwd_persist(NT, kq, pgrid, lds, st, pa, wpx)) {
+      if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
+      if (launch_fwd_persist(prec, NT, kq, pgrid, lds, st, pa, wpx)) {
         CTCN_LAUNCH_CHECK();
         return CTCN_OK;
       }
@@ -1057,7 +1252,8 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     int kq = ceil_div(GH, 256);
     if (kq == 7) kq = 8;
     const int nbt = grid.z, nsl = grid.x, groups = dirs * nbt;
-    const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * ceil_div(GH, 16) * 256 * sizeof(float), 256);
+    const int prec = precision == 1 && H % 8 == 0 ? 1 : 0;           // bf16x3 recurrent matmul
+    const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
     const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
     const size_t lds = 0;
     for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
@@ -1071,13 +1267,14 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.wpx = wpx;
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth();
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
 #endif
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
-      done = launch_bwd_persist(kq, mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid, lds, st, pa, wpx);
+      if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
+      done = launch_bwd_persist(prec, kq, mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid, lds, st, pa, wpx);
     }
   }
   if (!done) {

@@ -118,6 +118,38 @@ def test_rnn_layer_vs_torch_cpu(dev, kind, T, B, I, H, bi):
         assert rel_l2(p.grad, getattr(ref, n).grad) < 1e-4, n
 
 
+@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 120, 32, 40, 320, True), ("gru", 40, 64, 48, 512, True), ("lstm", 33, 70, 24, 128, True),
+                                            ("rnn", 50, 5, 12, 36, False), ("gru", 30, 3, 20, 24, True), ("lstm", 20, 16, 64, 20, False)])
+def test_rnn_layer_bf16x3_vs_torch_cpu(dev, kind, T, B, I, H, bi):
+    """precision=1: input projection AND the recurrent matmul run as bf16x3 split-operand MFMA (hi/lo planes handed
+    between workgroups); outputs within 1e-4, gradients within 5e-4 rel-L2 of the f32 torch CPU layer (north-star
+    gate 1e-3)."""
+    from ctc_pytorch_amd import ops
+    cls = {"lstm": tnn.LSTM, "gru": tnn.GRU, "rnn": tnn.RNN}[kind]
+    torch.manual_seed(T * 100 + B + 7)
+    ref = cls(I, H, bidirectional=bi, bias=False)
+    x = torch.randn(T, B, I)
+    dy = torch.randn(T, B, (2 if bi else 1) * H)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    yr.backward(dy)
+    names = ["weight_ih_l0", "weight_hh_l0"] + (["weight_ih_l0_reverse", "weight_hh_l0_reverse"] if bi else [])
+    w = [getattr(ref, n).detach().to(dev).requires_grad_(True) for n in names] + ([None, None] if not bi else [])
+    xg = x.to(dev).requires_grad_(True)
+    ops.set_precision(1)
+    try:
+        y = ops.rnn_layer(xg, w[0], w[1], w[2], w[3], {"rnn": "tanh"}.get(kind, kind))
+        y.backward(dy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(0)
+    ops.check_health()
+    assert maxabs(y, yr) < 1e-4
+    assert rel_l2(xg.grad, xr.grad) < 5e-4
+    for n, p in zip(names, w):
+        assert rel_l2(p.grad, getattr(ref, n).grad) < 5e-4, n
+
+
 @pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 60, 32, 40, 320, True), ("gru", 25, 9, 16, 128, True), ("rnn", 31, 20, 8, 48, False),
                                             ("lstm", 17, 70, 12, 64, True), ("gru", 12, 64, 24, 512, True)])
 def test_rnn_persistent_equals_per_step_launches(dev, kind, T, B, I, H, bi):

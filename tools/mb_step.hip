@@ -150,16 +150,16 @@ int main() {
   {
     // persistent forward / backward recurrences with in-kernel phase accounting (forward), device-scope vs XCD-local
     const int nbt = 2, K = G * H;
-    const size_t hx_bytes = (size_t)2 * D * nbt * ((K + 15) / 16) * 256 * 4, fl_bytes = (size_t)2 * D * nbt * 64 * 4 + 256;
-    float *hx; unsigned *flags; int *status; long long *stats, h[6];
-    CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, 64));
+    const size_t hx_bytes = (size_t)2 * D * nbt * ((K + 31) / 32) * 512 * 4, fl_bytes = (size_t)2 * D * nbt * 64 * 4 + 256;
+    float *hx; unsigned *flags; int *status; long long *stats, h[10];
+    CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, 128));
     const int nx = ctcn_device_xcds();
     printf("device XCDs (even deal verified): %d\n", nx);
-    struct Cfg { int local, hsu, nt, fm; } cfgs[] = {{0, 8, 2, 0}, {1, 8, 2, 0}, {1, 10, 3, 0}, {1, 12, 3, 0}, {1, 16, 4, 0}};
+    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{0, 8, 2, 0, 1}, {1, 8, 2, 0, 1}, {1, 8, 2, 0, 2}, {1, 8, 2, 0, 4}, {1, 8, 2, 1, 1}, {1, 8, 2, 1, 2}, {1, 8, 2, 1, 3}, {1, 8, 2, 1, 4}, {1, 12, 3, 1, 4}};
     for (auto &c : cfgs) {
       if (c.local && nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
-      pa.local = c.local; pa.nx = c.local ? nx : 1; pa.nbt = nbt; pa.hsu = c.hsu; pa.nsl = (H + c.hsu - 1) / c.hsu;
+      pa.poll_depth = c.pd; pa.local = c.local; pa.nx = c.local ? nx : 1; pa.nbt = nbt; pa.hsu = c.hsu; pa.nsl = (H + c.hsu - 1) / c.hsu;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
       dim3 gp = c.local ? dim3(pa.nx * (wpx + 4), 1, 1) : dim3(pa.nsl, D, nbt);
@@ -167,21 +167,27 @@ int main() {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st));
         hipEventRecord(e0, st);
-        if (c.nt == 2) hipLaunchKernelGGL((rnn_fwd_persist<2, 5>), gp, dim3(256), lds, st, pa);
-        else if (c.nt == 3) hipLaunchKernelGGL((rnn_fwd_persist<3, 5>), gp, dim3(256), lds, st, pa);
-        else hipLaunchKernelGGL((rnn_fwd_persist<4, 5>), gp, dim3(256), lds, st, pa);
+        if (c.prec) CK(hipMemsetAsync(hx, 0, hx_bytes, st));
+        if (c.nt == 2 && !c.prec) hipLaunchKernelGGL((rnn_fwd_persist<2, 5, 0>), gp, dim3(256), lds, st, pa);
+        else if (c.nt == 3 && !c.prec) hipLaunchKernelGGL((rnn_fwd_persist<3, 5, 0>), gp, dim3(256), lds, st, pa);
+        else if (c.nt == 2) hipLaunchKernelGGL((rnn_fwd_persist<2, 5, 1>), gp, dim3(256), lds, st, pa);
+        else if (c.nt == 3) hipLaunchKernelGGL((rnn_fwd_persist<3, 5, 1>), gp, dim3(256), lds, st, pa);
+        else hipLaunchKernelGGL((rnn_fwd_persist<4, 5, 1>), gp, dim3(256), lds, st, pa);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h, stats, 48, hipMemcpyDeviceToHost));
-      printf("fwd PERSISTENT local=%d HSU=%2d NT=%d  %3d slices/group   %8.2f us/step   (status %d)\n", c.local, c.hsu, c.nt, pa.nsl, ms * 1e3 / T, hs);
+      int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h, stats, 80, hipMemcpyDeviceToHost));
+      printf("fwd PERSISTENT local=%d HSU=%2d NT=%d precision=%d polls=%d  %3d slices/group   %8.2f us/step   (status %d)\n", c.local, c.hsu, c.nt, c.prec, c.pd, pa.nsl, ms * 1e3 / T, hs);
       printf("  per step (cycles), slice 7, communication wave: flag poll+barrier %.0f | operand loads %.0f | mfma %.0f | reduce %.0f | gate math+publish %.0f | total %.0f\n",
              (double)h[0] / T, (double)h[1] / T, (double)h[2] / T, (double)h[3] / T, (double)h[4] / T, (double)h[5] / T);
+      printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
+             (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
     }
-    for (int local = 0; local < 2; ++local) {
+    for (int lp = 0; lp < 5; ++lp) {
+      const int local = lp > 0, prec = lp > 1, pd = lp == 3 ? 2 : (lp == 4 ? 4 : 1);
       if (local && nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = nullptr;
-      pa.local = local; pa.nx = local ? nx : 1; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
+      pa.poll_depth = pd; pa.local = local; pa.nx = local ? nx : 1; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
       dim3 gp = local ? dim3(pa.nx * (wpx + 4), 1, 1) : dim3(pa.nsl, D, nbt);
@@ -189,12 +195,13 @@ int main() {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st));
         hipEventRecord(e0, st);
-        hipLaunchKernelGGL((rnn_bwd_persist<5>), gp, dim3(1024), lds, st, pa);
+        if (prec) { CK(hipMemsetAsync(hx, 0, hx_bytes, st)); hipLaunchKernelGGL((rnn_bwd_persist<5, 1>), gp, dim3(1024), lds, st, pa); }
+        else hipLaunchKernelGGL((rnn_bwd_persist<5, 0>), gp, dim3(1024), lds, st, pa);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost));
-      printf("bwd PERSISTENT local=%d  %3d slices/group   %8.2f us/step   (status %d)\n", local, pa.nsl, ms * 1e3 / T, hs);
+      printf("bwd PERSISTENT local=%d precision=%d polls=%d  %3d slices/group   %8.2f us/step   (status %d)\n", local, prec, pd, pa.nsl, ms * 1e3 / T, hs);
     }
   }
   // graph replay of the forward loop: is the host the limiter?
