@@ -122,7 +122,9 @@ def gemm_roofline(dev, c):
 
 
 def recurrence_probe(dev, c):
-    """us per dependent recurrent timestep (one launch = both directions of one layer), forward and backward."""
+    """HIP-event timing of one BiLSTM layer of the workload.  Two passes: the full layer (input projection +
+    recurrence, recurrence + deferred gradient GEMMs), and -- with the library's `rnn_recurrence_only` measurement option
+    -- the persistent recurrent kernels alone (one launch = T dependent timesteps of both directions)."""
     from ctc_pytorch_amd import ops
     G = 4 if c["rnn"] == "LSTM" else 3
     cell = {"LSTM": "lstm", "GRU": "gru"}[c["rnn"]]
@@ -130,22 +132,35 @@ def recurrence_probe(dev, c):
     x = torch.randn(T, B, 2 * H, device=dev, requires_grad=True)
     w = [(torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True),
          (torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True)]
-    y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
-    y.backward(torch.ones_like(y))
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
-    ev[1].record()
-    y.backward(torch.ones_like(y))
-    ev[2].record()
-    torch.cuda.synchronize()
-    # bytes one forward step launch touches (algorithmic, both directions): W_hh + h_prev + gate slab r/w + c r/w + y
-    step_bytes = 2 * (G * H * H + B * H + 2 * B * G * H + 2 * B * H + B * H) * 4
-    f_us = ev[0].elapsed_time(ev[1]) * 1e3 / T
-    b_us = ev[1].elapsed_time(ev[2]) * 1e3 / T
-    return dict(fwd_layer_us_per_timestep=f_us, bwd_layer_us_per_timestep=b_us, fwd_step_algorithmic_bytes=step_bytes,
-                note="layer time / T, includes the layer's input-projection (fwd) and deferred weight-gradient (bwd) GEMMs")
+    gy = torch.ones(T, B, 2 * H, device=dev)
+
+    def timed(reps):
+        f = b = 0.0
+        for _ in range(reps + 1):                      # first pass warms up
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
+            ev[1].record()
+            y.backward(gy)
+            ev[2].record()
+            torch.cuda.synchronize()
+            f, b = f + ev[0].elapsed_time(ev[1]), b + ev[1].elapsed_time(ev[2])
+            if _ == 0:
+                f = b = 0.0
+        return f * 1e3 / reps, b * 1e3 / reps          # us per layer pass
+
+    lf, lb = timed(3)
+    ops.set_option("rnn_recurrence_only", 1)
+    try:
+        kf, kb = timed(5)
+    finally:
+        ops.set_option("rnn_recurrence_only", 0)
+    ops.check_health()
+    flops = 2.0 * T * 2 * B * (G * H) * H              # recurrent matmul of one launch (both directions)
+    return dict(layer_fwd_us=lf, layer_bwd_us=lb, kernel_fwd_us=kf, kernel_bwd_us=kb, fwd_us_per_timestep=kf / T, bwd_us_per_timestep=kb / T,
+                algorithmic_flops_per_launch=flops,
+                note="kernel_*: persistent recurrent launch alone (T dependent timesteps, both directions; includes its <10 us of memsets / "
+                     "W_hh transposes); layer_*: with the input-projection (fwd) / deferred gradient (bwd) GEMMs")
 
 
 def run_train(args):
@@ -221,8 +236,20 @@ def run_train(args):
         "per_gpu_frames_per_s": value / world,
     }
     try:
-        res["roofline"] = gemm_roofline(dev, c)
-        res["recurrence"] = recurrence_probe(dev, c)
+        # dominant kernel by GPU time (profiles/): the persistent backward recurrence.  It is a chain of T dependent
+        # [B x H] x [H x 4H] products, so its ceiling is the MFMA peak of the arithmetic it uses -- which B = 32 rows and an
+        # 800-step dependence chain cannot approach: the per-timestep cost is two in-XCD L2 hand-offs, not flops.
+        rec = recurrence_probe(dev, c)
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 3.0
+        tf = rec["algorithmic_flops_per_launch"] / (rec["kernel_bwd_us"] * 1e-6) / 1e12
+        res["roofline"] = dict(kernel="rnn_bwd_persist (backward recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (c["rnn"], c["T"]),
+                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=None,
+                               us_per_launch=rec["kernel_bwd_us"], us_per_dependent_step=rec["bwd_us_per_timestep"],
+                               algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],
+                               peak_note=("f32 MFMA 157.3 TFLOP/s" if args.precision == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
+                               + "; latency-bound: see DESIGN.md section 5 for the per-step critical path")
+        res["recurrence"] = rec
+        res["roofline_gemm"] = gemm_roofline(dev, c)
     except Exception as e:      # keep the headline line even if a probe fails
         res["roofline"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
@@ -274,7 +301,7 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="train", choices=["train", "decode"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "0")), choices=[0, 1],
+    ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "1")), choices=[0, 1],
                     help="0: exact f32 MFMA GEMMs; 1: bf16x3 split-operand MFMA GEMMs (f32-class accuracy)")
     a = ap.parse_args()
     (run_train if a.mode == "train" else run_decode)(a)

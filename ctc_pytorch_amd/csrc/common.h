@@ -13,6 +13,7 @@ int *ctcn_status_word(void);      // device int registered with ctcn_set_status_
 int ctcn_opt_rnn_persistent(void);
 int ctcn_opt_handoff(void);
 int ctcn_opt_poll_depth(void);
+int ctcn_opt_recurrence_only(void);   // measurement aid: ctcn_rnn_fwd/bwd skip their GEMMs (results are NOT valid)
 
 #define CTCN_REQUIRE(cond, ...)          \
   do {                                   \
@@ -57,6 +58,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope fence that drains EVERY
+// outstanding global load / store of the wave (s_waitcnt vmcnt(0)); kernels with a serial inner loop (recurrences, the CTC lattice)
+// keep operand prefetches and result stores in flight across their LDS barriers, so they wait for LDS traffic only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // round-to-nearest-even f32 -> bf16 (bits)

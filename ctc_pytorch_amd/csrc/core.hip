@@ -25,12 +25,14 @@ extern "C" int ctcn_device_cus(void) {
 static int g_opt_rnn_persistent = 1;
 static int g_opt_handoff = 1;
 static int g_opt_poll_depth = 2;
+static int g_opt_recurrence_only = 0;
 static int *g_status_dev = nullptr;
 
 extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "rnn_persistent")) { g_opt_rnn_persistent = value; return CTCN_OK; }
   if (name && !strcmp(name, "handoff")) { g_opt_handoff = value; return CTCN_OK; }
   if (name && !strcmp(name, "poll_depth")) { g_opt_poll_depth = value; return CTCN_OK; }
+  if (name && !strcmp(name, "rnn_recurrence_only")) { g_opt_recurrence_only = value ? 1 : 0; return CTCN_OK; }
   ctcn_set_error("ctcn_set_option: unknown option %s", name ? name : "(null)");
   return CTCN_EINVAL;
 }
@@ -38,6 +40,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "rnn_persistent")) return g_opt_rnn_persistent;
   if (name && !strcmp(name, "handoff")) return g_opt_handoff;
   if (name && !strcmp(name, "poll_depth")) return g_opt_poll_depth;
+  if (name && !strcmp(name, "rnn_recurrence_only")) return g_opt_recurrence_only;
   return -1;
 }
 extern "C" int ctcn_set_status_buffer(int *dev_word) { g_status_dev = dev_word; return CTCN_OK; }
@@ -45,3 +48,4 @@ int *ctcn_status_word(void) { return g_status_dev; }
 int ctcn_opt_rnn_persistent(void) { return g_opt_rnn_persistent; }
 int ctcn_opt_handoff(void) { return g_opt_handoff; }
 int ctcn_opt_poll_depth(void) { return g_opt_poll_depth; }
+int ctcn_opt_recurrence_only(void) { return g_opt_recurrence_only; }

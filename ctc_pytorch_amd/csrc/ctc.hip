@@ -74,19 +74,30 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float *__res
   for (int c = lane; c < V; c += 64) dx[(size_t)row * V + c] = g[c] - expf(l[c]) * s;
 }
 
+// log(e^x0 + e^x1 + e^x2) on the hardware exp2 / log2 (1 ulp each): the lattice recursion is a chain of T dependent
+// steps per utterance, so the ~100 instructions of three expf + logf per step were most of its run time.  The sum is in
+// [1, 3], so the log2 result carries an absolute error below 2e-7 per step.
 __device__ __forceinline__ float lse3(float x0, float x1, float x2) {
   const float m = fmaxf(x0, fmaxf(x1, x2));
   if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(x0 - m) + expf(x1 - m) + expf(x2 - m));
+  const float L2E = 1.4426950408889634f;
+  const float sum = __builtin_amdgcn_exp2f((x0 - m) * L2E) + __builtin_amdgcn_exp2f((x1 - m) * L2E) + __builtin_amdgcn_exp2f((x2 - m) * L2E);
+  return m + __builtin_amdgcn_logf(sum) * 0.6931471805599453f;
 }
 
 // direction: +1 alpha (t = 0..Tb-1, neighbours s-1, s-2), -1 beta (t = Tb-1..0, neighbours s+1, s+2)
-template <int DIR>
+// NS = lattice states per thread (host picks the smallest of 1/2/4/8 that covers S = 2L+1 with 256 threads).
+// The recursion is a chain of Tb dependent steps whose per-step work is three LDS reads, one lse3 and one LDS write, so
+// everything else is kept off that chain: the gathered log-probs (and, in the beta pass, the alpha values that
+// alpha + beta overwrites in place) are fetched PF frames ahead into registers, the barrier between steps waits for LDS
+// only, and the alpha / alpha+beta stores are never waited for.
+template <int DIR, int NS>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
                                                                   const int64_t *__restrict__ in_len,
                                                                   const int64_t *__restrict__ tgt_len, float *__restrict__ alpha,
                                                                   float *__restrict__ nll, int T, int B, int V, int Lmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int PF = 4;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Smax = 2 * Lmax + 1;
   const int Tb = (int)in_len[b], L = (int)tgt_len[b];
@@ -100,10 +111,10 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
     return;
   }
   // per-thread static state info
-  int my_ext[CTC_NS];
-  bool my_skip[CTC_NS];
+  int my_ext[NS];
+  bool my_skip[NS];
 #pragma unroll
-  for (int k = 0; k < CTC_NS; ++k) {
+  for (int k = 0; k < NS; ++k) {
     const int s = tid + k * CTC_THREADS;
     my_ext[k] = 0; my_skip[k] = false;
     if (s < S) {
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
   {
     const float *lpt = lp + ((size_t)t_first * B + b) * V;
 #pragma unroll
-    for (int k = 0; k < CTC_NS; ++k) {
+    for (int k = 0; k < NS; ++k) {
       const int s = tid + k * CTC_THREADS;
       if (s < S) {
         float v = -INFINITY;
@@ -131,39 +142,59 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
   }
   __syncthreads();
   float *prev = buf0, *cur = buf1;
-  float lpn[CTC_NS];   // gathered log-probs of the frame being computed (prefetched one frame ahead)
-  if (Tb > 1) {
-    const int t1 = t_first + DIR;
-    const float *lpt = lp + ((size_t)t1 * B + b) * V;
+  float nq[PF][NS], na[PF][NS];      // prefetched frames n0 .. n0+PF-1 of the NEXT chunk: log-prob gather / old alpha
 #pragma unroll
-    for (int k = 0; k < CTC_NS; ++k) { const int s = tid + k * CTC_THREADS; lpn[k] = s < S ? lpt[my_ext[k]] : 0.0f; }
-  }
-  for (int n = 1; n < Tb; ++n) {
-    const int t = t_first + DIR * n;
-    float lpc[CTC_NS];
+  for (int i = 0; i < PF; ++i) {
+    const int t = t_first + DIR * min(1 + i, Tb - 1);
+    const float *lpt = lp + ((size_t)t * B + b) * V;
 #pragma unroll
-    for (int k = 0; k < CTC_NS; ++k) lpc[k] = lpn[k];
-    if (n + 1 < Tb) {   // prefetch next frame's gather
-      const float *lpt = lp + ((size_t)(t + DIR) * B + b) * V;
-#pragma unroll
-      for (int k = 0; k < CTC_NS; ++k) { const int s = tid + k * CTC_THREADS; lpn[k] = s < S ? lpt[my_ext[k]] : 0.0f; }
-    }
-#pragma unroll
-    for (int k = 0; k < CTC_NS; ++k) {
+    for (int k = 0; k < NS; ++k) {
       const int s = tid + k * CTC_THREADS;
-      if (s < S) {
-        const float x0 = prev[s];
-        float x1, x2;
-        if (DIR > 0) { x1 = s >= 1 ? prev[s - 1] : -INFINITY; x2 = my_skip[k] ? prev[s - 2] : -INFINITY; }
-        else { x1 = s + 1 < S ? prev[s + 1] : -INFINITY; x2 = my_skip[k] ? prev[s + 2] : -INFINITY; }
-        const float v = lse3(x0, x1, x2) + lpc[k];
-        cur[s] = v;
-        float *ap = alpha + ((size_t)t * B + b) * Smax + s;
-        if (DIR > 0) *ap = v; else *ap += v;
+      nq[i][k] = s < S ? lpt[my_ext[k]] : 0.0f;
+      na[i][k] = (DIR < 0 && s < S) ? alpha[((size_t)t * B + b) * Smax + s] : 0.0f;
+    }
+  }
+  for (int n0 = 1; n0 < Tb; n0 += PF) {
+    float cq[PF][NS], ca[PF][NS];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) { cq[i][k] = nq[i][k]; ca[i][k] = na[i][k]; }
+    if (n0 + PF < Tb) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int t = t_first + DIR * min(n0 + PF + i, Tb - 1);
+        const float *lpt = lp + ((size_t)t * B + b) * V;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int s = tid + k * CTC_THREADS;
+          nq[i][k] = s < S ? lpt[my_ext[k]] : 0.0f;
+          if (DIR < 0) na[i][k] = s < S ? alpha[((size_t)t * B + b) * Smax + s] : 0.0f;
+        }
       }
     }
-    __syncthreads();
-    float *tmp = prev; prev = cur; cur = tmp;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int n = n0 + i;
+      if (n < Tb) {
+        const int t = t_first + DIR * n;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int s = tid + k * CTC_THREADS;
+          if (s < S) {
+            const float x0 = prev[s];
+            float x1, x2;
+            if (DIR > 0) { x1 = s >= 1 ? prev[s - 1] : -INFINITY; x2 = my_skip[k] ? prev[s - 2] : -INFINITY; }
+            else { x1 = s + 1 < S ? prev[s + 1] : -INFINITY; x2 = my_skip[k] ? prev[s + 2] : -INFINITY; }
+            const float v = lse3(x0, x1, x2) + cq[i][k];
+            cur[s] = v;
+            alpha[((size_t)t * B + b) * Smax + s] = DIR > 0 ? v : ca[i][k] + v;
+          }
+        }
+        lds_barrier();       // LDS only: the alpha stores and the prefetches stay in flight across timesteps
+        float *tmp = prev; prev = cur; cur = tmp;
+      }
+    }
   }
   if (DIR > 0 && tid == 0) {
     const float l1 = prev[S - 1], l2 = S > 1 ? prev[S - 2] : -INFINITY;
@@ -312,7 +343,10 @@ extern "C" int ctcn_ctc_fwd(const float *lp, const int64_t *targets, const int64
   CTCN_REQUIRE(T > 0 && B > 0 && V > 0 && Lmax >= 0, "ctcn_ctc_fwd: bad dims");
   if (2 * Lmax + 1 > CTC_THREADS * CTC_NS) { ctcn_set_error("ctcn_ctc_fwd: label length %d > %d unsupported", Lmax, (CTC_THREADS * CTC_NS - 1) / 2); return CTCN_EUNSUPPORTED; }
   const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
-  hipLaunchKernelGGL((ctc_lattice_kernel<1>), dim3(B), dim3(CTC_THREADS), sm, (hipStream_t)stream, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax);
+  const int ns = ceil_div(2 * Lmax + 1, CTC_THREADS);
+#define CTC_LAUNCH(NS) hipLaunchKernelGGL((ctc_lattice_kernel<1, NS>), dim3(B), dim3(CTC_THREADS), sm, (hipStream_t)stream, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax)
+  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
+#undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
@@ -324,7 +358,10 @@ extern "C" int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64
   if (2 * Lmax + 1 > CTC_THREADS * CTC_NS) { ctcn_set_error("ctcn_ctc_bwd: label length %d unsupported", Lmax); return CTCN_EUNSUPPORTED; }
   const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((ctc_lattice_kernel<-1>), dim3(B), dim3(CTC_THREADS), sm, st, lp, targets, in_len, tgt_len, alpha, (float *)nullptr, T, B, V, Lmax);
+  const int ns = ceil_div(2 * Lmax + 1, CTC_THREADS);
+#define CTC_LAUNCH(NS) hipLaunchKernelGGL((ctc_lattice_kernel<-1, NS>), dim3(B), dim3(CTC_THREADS), sm, st, lp, targets, in_len, tgt_len, alpha, (float *)nullptr, T, B, V, Lmax)
+  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
+#undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
   const size_t pairs = (size_t)T * B;
   hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, st, lp, targets, in_len, tgt_len, alpha, nll, gscale, grad_lp, T, B, V, Lmax);

@@ -29,11 +29,6 @@
 
 namespace {
 
-// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope fence that drains EVERY
-// outstanding global load / store of the wave (s_waitcnt vmcnt(0)); the recurrent kernels keep next-step operand
-// prefetches and reserve stores in flight across their LDS barriers, so they wait for LDS traffic only.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // Gate activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each): |error| < 3e-7 absolute, a
 // quarter of the instruction count of expf / tanhf + IEEE division -- they sit on the serial path of every timestep.
 __device__ __forceinline__ float act_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -1137,7 +1132,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   const int G = gates_of(cell);
   const int GH = G * H;
   const float *w_ih[2] = {w_ih0, w_ih1};
-  for (int d = 0; d < dirs; ++d) {
+  for (int d = 0; d < dirs && !ctcn_opt_recurrence_only(); ++d) {
     int rc = ctcn_gemm(0, 1, T * B, GH, I, x, I, w_ih[d], I, gates + (size_t)d * GH, dirs * GH, 0.0f, precision, ws,
                        ws_bytes, stream);
     if (rc) return rc;
@@ -1288,7 +1283,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
 
   // deferred GEMMs over the d(pre-activation) slab now held in `gates` (and `aux` for the GRU n-gate)
   const int TB = T * B;
-  for (int d = 0; d < dirs; ++d) {
+  for (int d = 0; d < dirs && !ctcn_opt_recurrence_only(); ++d) {
     const float *da = gates + (size_t)d * GH;
     const int ldg = dirs * GH;
     int rc;

@@ -56,6 +56,11 @@ def set_rnn_persistent(flag):
     _lib.check(_lib.lib().ctcn_set_option(b"rnn_persistent", int(bool(flag))), "set_option")
 
 
+def set_option(name, value):
+    """Raw ctcn_set_option (see include/ctcn.h for the option names)."""
+    _lib.check(_lib.lib().ctcn_set_option(name.encode(), int(value)), "set_option")
+
+
 def check_health(device=None):
     """Synchronising check of the sticky status word written by persistent kernels on a hand-off timeout."""
     _lib.check_status(torch.device("cuda", torch.cuda.current_device()) if device is None else device)

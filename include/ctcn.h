@@ -40,7 +40,10 @@ int ctcn_device_xcds(void);
 /* options: "rnn_persistent" = 1 (default): the recurrence of ctcn_rnn_fwd/bwd runs as ONE persistent launch per layer
  * (W_hh slice resident in VGPRs, h_t handed between workgroups in-launch); 0: one launch per timestep.
  * "handoff" = 1 (default): persistent launches place each (direction, batch-tile) group on one XCD and hand h_t over
- * through that XCD's L2 when the device allows it (falls back to 0 otherwise); 0: device-scope write-through hand-off. */
+ * through that XCD's L2 when the device allows it (falls back to 0 otherwise); 0: device-scope write-through hand-off.
+ * "poll_depth" = 2 (default): flag polls kept in flight per polling wave in the XCD-local hand-off (1..4).
+ * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
+ * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */
 int ctcn_set_option(const char *name, int value);
 int ctcn_get_option(const char *name);
 /* optional device int that persistent kernels set to a non-zero code if an in-launch hand-off times out (sticky);
