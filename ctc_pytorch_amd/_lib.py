@@ -41,6 +41,7 @@ _SIGS = {
     "ctcn_rnn_scratch_bytes": (Z, [I, I, I, I]),
     "ctcn_rnn_fwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, Z, P]),
     "ctcn_rnn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P]),
+    "ctcn_rnn_bwd_weights": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, F, I, ctypes.c_uint, P, Z, P]),
     "ctcn_bn_ws_bytes": (Z, [I, I, I]),
     "ctcn_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, Z, P]),
     "ctcn_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
@@ -145,10 +146,11 @@ def check_status(device):
 _WS = {}
 
 
-def workspace(device, nbytes=1 << 30):
+def workspace(device, nbytes=1 << 30, tag="main"):
     """Per-device scratch buffer (split-K partials, BN/conv partial sums).  Stream-ordered reuse: every
-    library call consumes its partials before returning control to the same stream's next launch."""
-    key = (device.type, device.index)
+    library call consumes its partials before returning control to the same stream's next launch.  Calls issued on a
+    second stream use their own buffer (tag)."""
+    key = (device.type, device.index, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -11,6 +11,8 @@
 void ctcn_set_error(const char *fmt, ...);
 int *ctcn_status_word(void);      // device int registered with ctcn_set_status_buffer (may be null)
 int ctcn_opt_rnn_persistent(void);
+int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
+                      int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow);
 int ctcn_opt_handoff(void);
 int ctcn_opt_poll_depth(void);
 int ctcn_opt_recurrence_only(void);   // measurement aid: ctcn_rnn_fwd/bwd skip their GEMMs (results are NOT valid)

@@ -357,11 +357,10 @@ __global__ void split_rows_kernel(const float *__restrict__ src, int ld, int R, 
   }
 }
 
-__global__ __launch_bounds__(256) void split_transpose_kernel(const float *__restrict__ src, int ld, int R, int C, int Rp,
-                                                              unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
-  // out[c][r] (row stride Rp) = split(src[r*ld + c]); 64x64 tiles through LDS; zero for r >= R (k padding)
-  __shared__ float t[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+// out[c][r] (row stride Rp) = split(src[r*ld + c]); 64x64 tiles through LDS; zero for r >= R (k padding)
+__device__ __forceinline__ void split_transpose_tile(float (*t)[65], int bx, int by, const float *__restrict__ src, int ld, int R, int C, int Rp,
+                                                     unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+  const int r0 = by * 64, c0 = bx * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
@@ -379,24 +378,42 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float *__res
   }
 }
 
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float *__restrict__ src, int ld, int R, int C, int Rp,
+                                                              unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+  __shared__ float t[64][65];
+  split_transpose_tile(t, blockIdx.x, blockIdx.y, src, ld, R, C, Rp, hi, lo);
+}
+// XCD-filtered variant (see gemm_planes_nt_queue_kernel): tiles come from an atomic queue, workgroups off `xcd_allow` exit
+__global__ __launch_bounds__(256) void split_transpose_queue_kernel(const float *__restrict__ src, int ld, int R, int C, int Rp,
+                                                                    unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, int tiles_x,
+                                                                    int tiles_y, unsigned xcd_allow, unsigned *__restrict__ queue) {
+  __shared__ float t[64][65];
+  __shared__ int s_item;
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (!((xcd_allow >> (x & 15)) & 1u)) return;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= tiles_x * tiles_y) return;
+    split_transpose_tile(t, item % tiles_x, item / tiles_x, src, ld, R, C, Rp, hi, lo);
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ int pswz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }   // byte offset in a plane tile
 
-__global__ __launch_bounds__(256) void gemm_planes_nt_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
-                                                             const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
-                                                             const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
-                                                             int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char sm[4][BM * 128];      // Ah | Al | Bh | Bl tiles, 16 KiB each
+// one 128x128 output tile (`bid`) of K-split `split`; sm = the workgroup's four 16-KiB plane tiles
+__device__ __forceinline__ void plane_tile(unsigned char (*sm)[BM * 128], int bid, int split, int M, int N, int Kp,
+                                           const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
+                                           const unsigned short *__restrict__ Bh, const unsigned short *__restrict__ Bl,
+                                           float *__restrict__ C, int ldc, float beta, int kchunk, float *__restrict__ ws, int tiles_n) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int nt = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.y * kchunk;
+  const int kbeg = split * kchunk;
   const int kend = min(Kp, kbeg + kchunk);
 
   f32x16 acc[2][2];
@@ -468,7 +485,7 @@ __global__ __launch_bounds__(256) void gemm_planes_nt_kernel(int M, int N, int K
         }
     }
   }
-  float *out = ws ? ws + (size_t)blockIdx.y * M * N : C;
+  float *out = ws ? ws + (size_t)split * M * N : C;
   const int ldo = ws ? N : ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -486,6 +503,44 @@ __global__ __launch_bounds__(256) void gemm_planes_nt_kernel(int M, int N, int K
         }
       }
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_planes_nt_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                             const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                             const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
+                                                             int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4][BM * 128];      // Ah | Al | Bh | Bl tiles, 16 KiB each
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  plane_tile(sm, bid, blockIdx.y, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, kchunk, ws, tiles_n);
+}
+
+// Same GEMM for a side stream that must stay off the XCDs a persistent recurrence is running on: workgroups that wake up
+// on an XCD outside `xcd_allow` (bit x = XCD x, read from HW_REG_XCC_ID) exit at once, the others pull (tile, split)
+// items from an atomic queue until it is empty.  The launch is sized to fill the allowed XCDs, not the tile count.
+__global__ __launch_bounds__(256) void gemm_planes_nt_queue_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                                   const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                                   const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc,
+                                                                   float beta, int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n,
+                                                                   int splits, unsigned xcd_allow, unsigned *__restrict__ queue) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4][BM * 128];
+  __shared__ int s_item;
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (!((xcd_allow >> (x & 15)) & 1u)) return;
+  const int nt = tiles_m * tiles_n, total = nt * splits;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= total) return;
+    plane_tile(sm, item % nt, item / nt, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, kchunk, ws, tiles_n);
+    __syncthreads();
+  }
 }
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc,
@@ -515,9 +570,9 @@ __global__ void transpose01_kernel(const float *__restrict__ in, float *__restri
 
 }  // namespace
 
-extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
-                         int ldb, float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes,
-                         void *stream) {
+// xcd_allow: 0 = whole device; otherwise (precision 1 plane path only) the XCDs the GEMM workgroups may run on
+int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
+                      int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow) {
   CTCN_REQUIRE(precision == 0 || precision == 1, "ctcn_gemm: precision %d (0 = f32 MFMA, 1 = bf16x3 split MFMA)", precision);
   CTCN_REQUIRE(M > 0 && N > 0 && K >= 0, "ctcn_gemm: bad dims M=%d N=%d K=%d", M, N, K);
   CTCN_REQUIRE(A && B && C, "ctcn_gemm: null pointer");
@@ -542,16 +597,24 @@ extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const floa
     const int Kp = ceil_div(K, PBK) * PBK;
     const size_t a_el = (size_t)M * Kp, b_el = (size_t)N * Kp;
     const size_t plane_bytes = align_up(2 * (a_el + b_el) * sizeof(unsigned short), 256);
-    if (ws_bytes >= plane_bytes + 256) {
+    if (ws_bytes >= plane_bytes + 1024) {
       unsigned short *ah = (unsigned short *)ws, *al = ah + a_el, *bh = al + a_el, *bl = bh + b_el;
       float *part = (float *)((char *)ws + plane_bytes);
-      const size_t part_bytes = ws_bytes - plane_bytes;
+      // the last 256 bytes of the workspace hold the work queue of the XCD-filtered variant
+      unsigned *queue = (unsigned *)((char *)ws + ((ws_bytes - 256) & ~(size_t)255));
+      const size_t part_bytes = ws_bytes - plane_bytes - 512;
+      if (xcd_allow) CTCN_HIP(hipMemsetAsync(queue, 0, 16, st));
+      int nq = 0;      // queue words 1, 2: the operand splits
       auto split = [&](const float *src, int ld, bool contraction_major, int rows, unsigned short *hi, unsigned short *lo) {
         if (!contraction_major) {   // src[row*ld + k]
           const size_t total = (size_t)rows * (Kp / 4);
           hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min((size_t)8192, ceil_div_z(total, 256))), dim3(256), 0, st, src, ld, rows, K, Kp, hi, lo);
         } else {                    // src[k*ld + row] -> transpose
-          hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo);
+          if (xcd_allow)
+            hipLaunchKernelGGL(split_transpose_queue_kernel, dim3(8 * ctcn_device_cus()), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, ceil_div(rows, 64),
+                               ceil_div(Kp, 64), xcd_allow, queue + (++nq));
+          else
+            hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo);
         }
       };
       split(A, lda, transA != 0, M, ah, al);
@@ -567,8 +630,13 @@ extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const floa
         pchunk = ceil_div(ceil_div(Kp, psplits), PBK) * PBK;
         psplits = ceil_div(Kp, pchunk);
       }
-      hipLaunchKernelGGL(gemm_planes_nt_kernel, dim3(nt, psplits), dim3(256), 0, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk,
-                         psplits > 1 ? part : (float *)nullptr, tiles_m, tiles_n);
+      if (xcd_allow) {
+        hipLaunchKernelGGL(gemm_planes_nt_queue_kernel, dim3(2 * ctcn_device_cus()), dim3(256), 0, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta,
+                           pchunk, psplits > 1 ? part : (float *)nullptr, tiles_m, tiles_n, psplits, xcd_allow, queue);
+      } else {
+        hipLaunchKernelGGL(gemm_planes_nt_kernel, dim3(nt, psplits), dim3(256), 0, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk,
+                           psplits > 1 ? part : (float *)nullptr, tiles_m, tiles_n);
+      }
       CTCN_LAUNCH_CHECK();
       if (psplits > 1) {
         const size_t total = (size_t)M * N;
@@ -602,6 +670,12 @@ extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const floa
     CTCN_LAUNCH_CHECK();
   }
   return CTCN_OK;
+}
+
+extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
+                         int ldb, float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes,
+                         void *stream) {
+  return ctcn_gemm_on_xcds(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, 0u);
 }
 
 extern "C" int ctcn_transpose01(const float *in, float *out, int A, int B, int C, void *stream) {

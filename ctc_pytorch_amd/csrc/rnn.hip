@@ -1209,6 +1209,50 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   return CTCN_OK;
 }
 
+// The time-parallel GEMMs of the backward pass over the d(pre-activation) slab `gates` (and `aux` for the GRU n-gate):
+// dx = da * W_ih (when dx), and -- when `weights` -- dW_ih = da^T x, dW_hh = da^T h_prev.  xcd_allow != 0 keeps the
+// bf16x3 GEMM workgroups on those XCDs (side stream next to a persistent recurrence).
+static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_ih1,
+                         const float *y, const float *gates, const float *aux, float *dx, float *dw_ih0, float *dw_hh0, float *dw_ih1,
+                         float *dw_hh1, float beta_w, int precision, bool weights, unsigned xcd_allow, void *ws, size_t ws_bytes,
+                         void *stream) {
+  const int G = gates_of(cell), GH = G * H, TB = T * B;
+  const float *w_ih[2] = {w_ih0, w_ih1};
+  float *dw_ih[2] = {dw_ih0, dw_ih1};
+  float *dw_hh[2] = {dw_hh0, dw_hh1};
+  for (int d = 0; d < dirs; ++d) {
+    const float *da = gates + (size_t)d * GH;
+    const int ldg = dirs * GH;
+    int rc;
+    if (dx) {
+      rc = ctcn_gemm_on_xcds(0, 0, TB, I, GH, da, ldg, w_ih[d], I, dx, I, d == 0 ? 0.0f : 1.0f, precision, ws, ws_bytes, stream, xcd_allow);
+      if (rc) return rc;
+    }
+    if (!weights) continue;
+    rc = ctcn_gemm_on_xcds(1, 0, GH, I, TB, da, ldg, x, I, dw_ih[d], I, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
+    if (rc) return rc;
+    // dW_hh = sum_t dgh_t^T h_prev(t);  h_prev(t) = y[t-1] (fwd) / y[t+1] (reverse), zero at the sequence start
+    const int Kh = (T - 1) * B;
+    if (Kh <= 0) {
+      if (beta_w == 0.0f) CTCN_HIP(hipMemsetAsync(dw_hh[d], 0, (size_t)GH * H * sizeof(float), (hipStream_t)stream));
+      continue;
+    }
+    const size_t offA = d == 0 ? (size_t)B : 0, offY = d == 0 ? 0 : (size_t)B;
+    const float *yh = y + (size_t)d * H + offY * dirs * H;
+    if (cell == CTCN_CELL_GRU) {
+      rc = ctcn_gemm_on_xcds(1, 0, 2 * H, H, Kh, da + offA * ldg, ldg, yh, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
+      if (rc) return rc;
+      const float *dn = aux + (size_t)d * H + offA * dirs * H;
+      rc = ctcn_gemm_on_xcds(1, 0, H, H, Kh, dn, dirs * H, yh, dirs * H, dw_hh[d] + (size_t)2 * H * H, H, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
+      if (rc) return rc;
+    } else {
+      rc = ctcn_gemm_on_xcds(1, 0, GH, H, Kh, da + offA * ldg, ldg, yh, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
+      if (rc) return rc;
+    }
+  }
+  return CTCN_OK;
+}
+
 extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
                             const float *w_hh0, const float *w_ih1, const float *w_hh1, const float *y,
                             float *gates, float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0,
@@ -1217,18 +1261,16 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   CTCN_REQUIRE(cell >= 0 && cell <= 2, "ctcn_rnn_bwd: unknown cell %d", cell);
   CTCN_REQUIRE(T > 0 && B > 0 && I > 0 && H > 0 && (dirs == 1 || dirs == 2), "ctcn_rnn_bwd: bad dims");
   if (H % 4 != 0) { ctcn_set_error("ctcn_rnn_bwd: hidden size %d must be a multiple of 4", H); return CTCN_EUNSUPPORTED; }
-  CTCN_REQUIRE(x && w_ih0 && w_hh0 && y && gates && dy && dw_ih0 && dw_hh0 && scratch, "ctcn_rnn_bwd: null pointer");
-  CTCN_REQUIRE(dirs == 1 || (w_ih1 && w_hh1 && dw_ih1 && dw_hh1), "ctcn_rnn_bwd: null pointer (reverse direction)");
+  CTCN_REQUIRE(x && w_ih0 && w_hh0 && y && gates && dy && scratch, "ctcn_rnn_bwd: null pointer");
+  CTCN_REQUIRE((dw_ih0 != nullptr) == (dw_hh0 != nullptr), "ctcn_rnn_bwd: dw_ih0 / dw_hh0 must both be given or both be NULL (weights deferred to ctcn_rnn_bwd_weights)");
+  CTCN_REQUIRE(dirs == 1 || (w_ih1 && w_hh1 && (!dw_ih0 || (dw_ih1 && dw_hh1))), "ctcn_rnn_bwd: null pointer (reverse direction)");
   CTCN_REQUIRE(cell == CTCN_CELL_TANH || aux, "ctcn_rnn_bwd: aux reserve required for LSTM/GRU");
   CTCN_REQUIRE((uintptr_t)gates % 16 == 0 && (uintptr_t)scratch % 16 == 0 && (cell == CTCN_CELL_TANH || (uintptr_t)aux % 16 == 0),
                "ctcn_rnn_bwd: gates / aux / scratch must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int G = gates_of(cell);
   const int GH = G * H;
-  const float *w_ih[2] = {w_ih0, w_ih1};
   const float *w_hh[2] = {w_hh0, w_hh1};
-  float *dw_ih[2] = {dw_ih0, dw_ih1};
-  float *dw_hh[2] = {dw_hh0, dw_hh1};
   float *whhT = (float *)scratch;
   float *state = (float *)((char *)scratch + align_up((size_t)dirs * GH * H * sizeof(float), 256));
   for (int d = 0; d < dirs; ++d) {
@@ -1281,32 +1323,20 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   }
   CTCN_LAUNCH_CHECK();
 
+  if (ctcn_opt_recurrence_only()) return CTCN_OK;
   // deferred GEMMs over the d(pre-activation) slab now held in `gates` (and `aux` for the GRU n-gate)
-  const int TB = T * B;
-  for (int d = 0; d < dirs && !ctcn_opt_recurrence_only(); ++d) {
-    const float *da = gates + (size_t)d * GH;
-    const int ldg = dirs * GH;
-    int rc;
-    if (dx) {
-      rc = ctcn_gemm(0, 0, TB, I, GH, da, ldg, w_ih[d], I, dx, I, d == 0 ? 0.0f : 1.0f, precision, ws, ws_bytes, stream);
-      if (rc) return rc;
-    }
-    rc = ctcn_gemm(1, 0, GH, I, TB, da, ldg, x, I, dw_ih[d], I, beta_w, precision, ws, ws_bytes, stream);
-    if (rc) return rc;
-    // dW_hh = sum_t dgh_t^T h_prev(t);  h_prev(t) = y[t-1] (fwd) / y[t+1] (reverse), zero at the sequence start
-    const int Kh = (T - 1) * B;
-    const size_t offA = d == 0 ? (size_t)B : 0, offY = d == 0 ? 0 : (size_t)B;
-    const float *yh = y + (size_t)d * H + offY * dirs * H;
-    if (cell == CTCN_CELL_GRU) {
-      rc = ctcn_gemm(1, 0, 2 * H, H, Kh, da + offA * ldg, ldg, yh, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream);
-      if (rc) return rc;
-      const float *dn = aux + (size_t)d * H + offA * dirs * H;
-      rc = ctcn_gemm(1, 0, H, H, Kh, dn, dirs * H, yh, dirs * H, dw_hh[d] + (size_t)2 * H * H, H, beta_w, precision, ws, ws_bytes, stream);
-      if (rc) return rc;
-    } else {
-      rc = ctcn_gemm(1, 0, GH, H, Kh, da + offA * ldg, ldg, yh, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream);
-      if (rc) return rc;
-    }
-  }
-  return CTCN_OK;
+  return rnn_bwd_gemms(cell, T, B, I, H, dirs, x, w_ih0, w_ih1, y, gates, aux, dx, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w, precision,
+                       dw_ih0 != nullptr, 0u, ws, ws_bytes, stream);
+}
+
+extern "C" int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *y, const float *gates,
+                                    const float *aux, float *dw_ih0, float *dw_hh0, float *dw_ih1, float *dw_hh1, float beta_w,
+                                    int precision, unsigned xcd_allow, void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(cell >= 0 && cell <= 2, "ctcn_rnn_bwd_weights: unknown cell %d", cell);
+  CTCN_REQUIRE(T > 0 && B > 0 && I > 0 && H > 0 && (dirs == 1 || dirs == 2), "ctcn_rnn_bwd_weights: bad dims");
+  CTCN_REQUIRE(x && y && gates && dw_ih0 && dw_hh0 && (dirs == 1 || (dw_ih1 && dw_hh1)), "ctcn_rnn_bwd_weights: null pointer");
+  CTCN_REQUIRE(cell != CTCN_CELL_GRU || aux, "ctcn_rnn_bwd_weights: aux (d of the GRU n-gate) required");
+  if (ctcn_opt_recurrence_only()) return CTCN_OK;
+  return rnn_bwd_gemms(cell, T, B, I, H, dirs, x, nullptr, nullptr, y, gates, aux, nullptr, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w,
+                       precision, true, xcd_allow, ws, ws_bytes, stream);
 }

@@ -5,6 +5,7 @@ for device memory, autograd bookkeeping and nothing else.  Tensors must live on 
 tensor raises (the product has no CPU path; the CPU restatement lives in oracle/ and is test-only).
 """
 import ctypes
+import os
 
 import torch
 
@@ -66,10 +67,50 @@ def check_health(device=None):
     _lib.check_status(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
 
 
-def _ws(t):
+def _ws(t, tag="main"):
     _lib.status_word(t.device)
-    w = _lib.workspace(t.device)
+    w = _lib.workspace(t.device, tag=tag)
     return w, ctypes.c_void_p(w.data_ptr()), w.numel()
+
+
+# --------------------------------------------------------------------------------------------------
+# weight-gradient side stream
+# --------------------------------------------------------------------------------------------------
+# The weight gradients of a recurrent layer (dW_ih = da^T x, dW_hh = da^T h_prev) have no consumer inside the backward
+# pass, while the next layer's persistent recurrence is a latency-bound kernel that occupies only
+# dirs * ceil(B/16) of the 8 XCDs.  When the gradients go to a flat buffer (optim.FlatAdam) they are therefore issued on
+# a second stream, restricted (ctcn_rnn_bwd_weights' xcd_allow) to the XCDs the recurrence leaves idle, and joined to the
+# main stream when autograd finishes the backward pass.
+_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}}
+
+
+def set_side_stream(flag):
+    """Enable / disable the weight-gradient side stream (default on; env CTCN_SIDE_STREAM=0 disables)."""
+    _side["enabled"] = bool(flag)
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    st = _side["streams"].get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _side["streams"][key] = st
+    return st
+
+
+def _join_side(dev_key):
+    def join():
+        st = _side["pending"].pop(dev_key, None)
+        if st is not None:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+    return join
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for weight gradients still in flight on the side stream (no-op if none)."""
+    keys = list(_side["pending"]) if device is None else [(device.type, device.index)]
+    for k in keys:
+        _join_side(k)()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -240,10 +281,34 @@ class _RNNLayer(torch.autograd.Function):
         nb = _lib.lib().ctcn_rnn_scratch_bytes(cell, B, H, dirs)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         w, wp, wn = _ws(x)
-        _lib.check(_lib.lib().ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
-                                           _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx), _ptr(d_ih0), _ptr(d_hh0),
-                                           _ptr(d_ih1), _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
-                                           wp, wn, _lib.stream_ptr()), "rnn_bwd")
+        L = _lib.lib()
+        # XCDs a persistent recurrence of this shape leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
+        nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
+        allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
+        side = into_flat and _side["enabled"] and get_precision() == 1 and allow != 0 and T > 1
+        if dx is None:
+            allow = 0            # bottom layer: no recurrence follows, its weight GEMMs may use the whole device
+        null = ctypes.c_void_p(None)
+        _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
+                                  _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
+                                  null if side else _ptr(d_ih0), null if side else _ptr(d_hh0), null if side else _ptr(d_ih1),
+                                  null if side else _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
+                                  wp, wn, _lib.stream_ptr()), "rnn_bwd")
+        if side:
+            main, st = torch.cuda.current_stream(dev), _side_stream(dev)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                w2, wp2, wn2 = _ws(x, tag="side")
+                _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0),
+                                                  _ptr(d_hh0), _ptr(d_ih1), _ptr(d_hh1), 1.0, get_precision(), allow, wp2, wn2,
+                                                  st.cuda_stream), "rnn_bwd_weights")
+            for t in (x, y, gates, aux):
+                if t is not None:
+                    t.record_stream(st)             # the caching allocator must not recycle them under the side stream
+            key = (dev.type, dev.index)
+            if key not in _side["pending"]:
+                _side["pending"][key] = st
+                torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if into_flat:
             return dx, None, None, None, None, None, None
         return dx, d_ih0, d_hh0, d_ih1, d_hh1, None, None

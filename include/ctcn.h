@@ -88,6 +88,15 @@ int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x,
                  float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0, float *dw_ih1,
                  float *dw_hh1, float beta_w, int precision, void *scratch, void *ws, size_t ws_bytes,
                  void *stream);
+/* ctcn_rnn_bwd with dw_ih0 == dw_hh0 == NULL runs the recurrence and dx only and leaves d(pre-activation) in gates
+ * (and aux for the GRU n-gate); this call then produces the weight gradients from it: dW_ih = da^T x, dW_hh = da^T h_prev.
+ * It has no consumer inside the backward pass, so the host side issues it on a second stream next to the NEXT layer's
+ * persistent recurrence; xcd_allow != 0 (bit x = XCD x) keeps the bf16x3 GEMM workgroups of precision 1 on those XCDs,
+ * i.e. off the ones the recurrence occupies.  ws must not be shared with calls running concurrently on another stream. */
+int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *y,
+                         const float *gates, const float *aux, float *dw_ih0, float *dw_hh0, float *dw_ih1,
+                         float *dw_hh1, float beta_w, int precision, unsigned xcd_allow, void *ws, size_t ws_bytes,
+                         void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * BatchNorm, statistics per channel over (outer x inner) elements; x viewed as (outer, C, inner).

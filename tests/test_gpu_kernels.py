@@ -342,6 +342,36 @@ def test_ctc_vs_torch_cpu_random(dev):
     assert float(lg.grad.sum(-1).abs().max()) < 1e-4          # rows sum to zero after log_softmax backward
 
 
+@pytest.mark.parametrize("T,B,V,Lmax", [(700, 5, 50, 200), (1200, 3, 30, 520), (9, 7, 12, 3)])
+def test_ctc_long_labels_vs_torch_cpu(dev, T, B, V, Lmax):
+    """Label lengths that need 2 and 4+ lattice states per thread (S = 2L+1 > 256 / > 512), ragged input lengths incl.
+    a 1-frame utterance, repeated labels, and an empty target."""
+    from ctc_pytorch_amd import nn, ops
+    rs = np.random.RandomState(T + Lmax)
+    tl = rs.randint(max(1, Lmax // 2), Lmax + 1, size=B).astype(np.int64)
+    tl[0] = Lmax
+    tl[-1] = 0
+    tg = rs.randint(1, V, size=(B, Lmax)).astype(np.int64)
+    tg[1, : Lmax // 2] = tg[1, 0]                                  # long run of repeats
+    il = np.minimum(T, 2 * tl + rs.randint(1, 40, size=B) + Lmax // 2).astype(np.int64)
+    il[0] = T
+    il[-1] = 1
+    logits = torch.from_numpy((1.5 * rs.standard_normal((T, B, V))).astype(np.float32))
+    lr = logits.clone().requires_grad_(True)
+    loss_r = tnn.CTCLoss(reduction="sum", zero_infinity=False)(torch.log_softmax(lr, -1), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl))
+    loss_r.backward()
+    lg = logits.to(dev).requires_grad_(True)
+    loss = nn.CTCLoss(reduction="sum")(ops.log_softmax(lg), torch.from_numpy(tg).to(dev), torch.from_numpy(il).to(dev), torch.from_numpy(tl).to(dev))
+    loss.backward()
+    assert np.isfinite(float(loss_r))
+    assert abs(float(loss) - float(loss_r)) / abs(float(loss_r)) < 1e-5
+    # alpha / beta reach |3000| here, where one f32 ulp is 2.4e-4: judge both f32 implementations against float64
+    l64 = logits.double().requires_grad_(True)
+    tnn.CTCLoss(reduction="sum")(torch.log_softmax(l64, -1), torch.from_numpy(tg), torch.from_numpy(il), torch.from_numpy(tl)).backward()
+    err_ours, err_torch32 = maxabs(lg.grad.double().cpu(), l64.grad), maxabs(lr.grad.double(), l64.grad)
+    assert err_ours < max(5e-5, 3.0 * err_torch32), (err_ours, err_torch32)
+
+
 def test_dropout_statistics_and_mask_reuse(dev):
     from ctc_pytorch_amd import ops
     x = torch.ones(1 << 20, device=dev, requires_grad=True)
