@@ -121,6 +121,18 @@ def gemm_roofline(dev, c):
                 peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
 
 
+def recurrence_traffic(workload):
+    """HBM bytes per launch of the backward recurrent kernel from the committed rocprofv3 PMC passes (cfg2 only)."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        for k, v in pm.items():
+            if workload == "cfg2" and k.startswith("rnn_bwd_persist"):
+                return v["hbm_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def recurrence_probe(dev, c):
     """HIP-event timing of one BiLSTM layer of the workload.  Two passes: the full layer (input projection +
     recurrence, recurrence + deferred gradient GEMMs), and -- with the library's `rnn_recurrence_only` measurement option
@@ -243,7 +255,7 @@ def run_train(args):
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 3.0
         tf = rec["algorithmic_flops_per_launch"] / (rec["kernel_bwd_us"] * 1e-6) / 1e12
         res["roofline"] = dict(kernel="rnn_bwd_persist (backward recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (c["rnn"], c["T"]),
-                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=None,
+                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=recurrence_traffic(args.workload),
                                us_per_launch=rec["kernel_bwd_us"], us_per_dependent_step=rec["bwd_us_per_timestep"],
                                algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],
                                peak_note=("f32 MFMA 157.3 TFLOP/s" if args.precision == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")

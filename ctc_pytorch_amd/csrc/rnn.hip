@@ -759,7 +759,9 @@ bool launch_resident(Kern kern, dim3 grid, int threads, size_t lds, hipStream_t 
   if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu <= 0) return false;
   const int cus = a.local ? ctcn_device_cus() / a.nx : ctcn_device_cus();
-  const long cap = (long)cus * (per_cu > 1 ? per_cu - 1 : 1) - (per_cu > 1 ? 0 : (a.local ? 1 : 8));
+  // device scope, one workgroup per CU: keep 8 CUs of slack; XCD-local: a group may take every CU of its XCD (nothing else
+  // of this stream runs beside a persistent launch, and a role that cannot become resident ends in the bounded-spin abort)
+  const long cap = (long)cus * (per_cu > 1 ? per_cu - 1 : 1) - (per_cu > 1 || a.local ? 0 : 8);
   const long need = a.local ? wpx : (long)grid.x * grid.y * grid.z;
   if (need > cap) return false;
   hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, a);
