@@ -7,8 +7,9 @@
 // Structure (per layer):
 //   1. time-parallel input projection  Gx = X * W_ih^T  for all T*B rows: one MFMA GEMM per direction
 //      (gemm.hip) written straight into the gate reserve (T,B,dirs,G*H).
-//   2. the serial recurrence: one launch per timestep, both directions in the same launch
-//      (blockIdx.y = direction).  A workgroup owns a slice of hidden units for all batch rows:
+//   2. the serial recurrence: ONE persistent launch per layer (rnn_fwd_persist / rnn_bwd_persist, below) when the grid can
+//      be co-resident, else one launch per timestep (rnn_fwd_step / rnn_bwd_step), both directions in the same launch.
+//      Per-timestep kernels: a workgroup owns a slice of hidden units for all batch rows:
 //        forward : 4 hidden units x 4 gates = one 16-column MFMA N-tile (grid H/4 x dirs = 160 WGs at H=320)
 //        backward: 16 hidden units, K = G*H (grid H/16 x dirs, 16 waves per WG to split the 4x longer K)
 //      The recurrent matmul  h_prev[B,K] * W_slice[16,K]^T  runs on v_mfma_f32_16x16x4_f32 (exact f32).
@@ -334,31 +335,32 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 }
 
 // ================================================================================================
-// Persistent forward recurrence: ONE launch per layer.
+// Persistent forward recurrence: ONE launch per layer (DESIGN.md section 5 has the measured history).
 //
-// Measured motivation (tools/mb_step.hip, cfg2).  A per-timestep launch costs 7.2 us = 2.8 us dependent-launch floor
-// + 2.2 us cold operand fetch (the launch boundary invalidates every XCD's L2, so W_hh and h_{t-1} come from the
-// memory side each step) + 2.2 us of work.  A first persistent version that swept 8-byte {value,tag} granules of
-// h_{t-1} straight into MFMA-operand registers ran 5.9 us/step with ZERO retries: the cost was not waiting but the
-// sweep itself (82 KB of half-line sc1 requests per workgroup = 3.1 us; a CU sustains only ~25 B/clk of L1-missing
-// traffic).  This version therefore minimises and coalesces what a workgroup must pull per step:
-//   * a workgroup owns 4*NT hidden units (all gates) of ONE 16-row batch tile, so it needs only that tile of
-//     h_{t-1}: 16 x H floats (20 KB at H=320) -- its W_hh slice lives in VGPRs for all T steps, c/h of its own units
-//     in one register per thread;
-//   * producers publish plain float payload with write-through (sc1) 16-B stores, drain them, then ONE lane stores a
-//     per-(slice) flag = step+1 (hand-off recipe R1 of cdna_hip_programming.md G16: sc1 payload + drained flag, sc1
-//     loads on the consumer side instead of an acquire);
-//   * the consumer polls the H/(4*NT) flags of its (direction, batch tile) with one relaxed sc1 load per lane, then
-//     all 4 waves fetch the tile with fully coalesced sc1 16-B loads (whole 128-B lines, each requested once) into
-//     a row-padded LDS image, from which the MFMA A-operands are read with conflict-free ds_read_b128.
-// Measured hand-off variants (cfg2 forward, us per step): per-timestep launches 7.1 | 8-B granules swept straight into
-// registers 5.9 | THIS (workgroup flag + 16-B write-through payload, block-wide poll, coalesced LDS fill) 4.9 |
-// per-wave flags, every wave polling its own producers 5.7-5.9 (the extra pollers slow the write-through acks) |
-// coalesced 8-B granule tiles without flags 5.5 (consumers hammer the very lines the producers are writing).
-// Two parity buffers suffice (a workgroup can publish step s+1 only after every producer of its tile published
-// step s, i.e. after all reads of step s-1).  Every spin is bounded: on a timeout the sticky status word is set,
-// the layer output is poisoned with NaN and all workgroups leave.
-// grid = (H/(4*NT), dirs, ceil(B/16)) workgroups x 256 threads, all co-resident (occupancy-checked on the host).
+// A per-timestep launch costs 7.0 us = 2.8 us dependent-launch floor + 2.2 us cold operand fetch (the launch boundary
+// invalidates every XCD's L2) + 2.0 us of work.  Here a workgroup owns `hsu` hidden units (all gates) of ONE 16-row
+// batch tile for the whole sequence: its W_hh slice lives in VGPRs (f32, or hi/lo bf16 planes at precision 1), c / h
+// of its (row, unit) items in one register per thread, and per step it exchanges only h_t with the other workgroups
+// of its (direction, batch tile) GROUP:
+//   * placement: in XCD-local mode all workgroups of a group run on one XCD (persist_role), so the hand-off goes through
+//     that XCD's L2: plain write-back stores, L1-bypassing (sc1) loads; 0.3 us one way instead of 0.6 us across the fabric
+//     with write-through stores (tools/mb_xcd.hip).  Device-scope mode (same code, sc1 stores) is the fallback;
+//   * publish: the items' h_t go through a 1-KB LDS image; ONE communication wave stores them as 16-B granules in the
+//     order the consumers' MFMA lanes read them, drains its stores, then one lane stores the workgroup's flag = step+1;
+//   * consume: the communication wave polls the group's flags (one per lane, 2 polls in flight), a barrier releases the
+//     other waves, and every wave loads its K-slice of the tile with fully coalesced 1-KB loads straight into the MFMA
+//     A-operand registers (no LDS staging);
+//   * everything else stays off that chain: the reserve stores (gates, c, y) and the next step's pre-activation loads are
+//     issued by the item waves after the hand-off; barriers wait for LDS only.
+// Two parity buffers suffice (a workgroup can publish step s+1 only after every producer of its tile published step s,
+// i.e. after all reads of step s-1).  Every spin is bounded: on a timeout the sticky status word is set, the layer
+// output is poisoned with NaN and all workgroups leave.
+// Hand-off variants measured and rejected (cfg2 forward, us per step; THIS = 3.1 f32 / 2.2 bf16x3): per-timestep launches
+// 7.0 | 8-B {value,tag} granules swept into registers 5.9 | device-scope flag + 16-B write-through payload + LDS fill 4.9 |
+// per-wave flags 5.7-5.9 | 8-B granule tiles without flags 5.5 | 16-B {v0,v1,v2,tag} granules swept block-wide 6.9 |
+// 2-3 polls in flight / paced polls over the fabric 5.0-5.7 | buffer_inv sc0 + plain loads: stale L1 lines (incorrect).
+// grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
+// workgroups co-resident (occupancy-checked on the host).
 // ================================================================================================
 struct PersistArgs {
   RnnArgs a;
@@ -800,8 +802,8 @@ bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStr
 // A workgroup (1024 threads = 16 waves) owns one 16(batch) x 16(hidden) tile of dh_rec = d(pre-act)_{next} * W_hh:
 // its 16 rows of W_hh^T (K = G*H floats each) stay in VGPRs (K split over 16 waves x 4 k-lanes), dc / dh*z of its 256
 // (row, unit) items stay in one register per thread, and per step it pulls only the 16 x K tile of the other
-// workgroups' d(pre-activation) (80 KB at H=320) through a coalesced sc1 fetch into LDS.
-// grid = (ceil(H/16), dirs, ceil(B/16)).
+// workgroups' d(pre-activation) (80 KB at H=320), loaded straight into the MFMA operand registers.  Waves 0..3 hold the
+// items and publish (LDS-staged, 16-B granules); wave 15 polls.  grid as rnn_fwd_persist with 16-unit slices.
 // ================================================================================================
 // saved forward values of one (row, unit) item at timestep t (tp = the step whose c / h it needs, -1: none)
 __device__ __forceinline__ void bwd_item_loads(const RnnArgs &p, int t, int tp, int b, int d, int j, float sv[4], float &dyv, float &e0, float &e1) {
