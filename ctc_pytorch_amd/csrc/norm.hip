@@ -87,10 +87,13 @@ __global__ __launch_bounds__(256) void colreduce_nchw_kernel(F f, int outer, int
 __global__ void bn_finalize_stats_kernel(const double *__restrict__ part, int nchunks, int C, double count, float eps,
                                          float momentum, float *__restrict__ mean_out, float *__restrict__ rstd_out,
                                          float *__restrict__ rm, float *__restrict__ rv) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per channel: lanes take the chunk partials k = lane, lane+64, ... in order, then a fixed shuffle tree
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < nchunks; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  for (int k = lane; k < nchunks; k += 64) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  s = wave_sum_d(s); ss = wave_sum_d(ss);
+  if (lane != 0) return;
   const double mean = s / count;
   double var = ss / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -106,10 +109,12 @@ __global__ void bn_finalize_stats_kernel(const double *__restrict__ part, int nc
 __global__ void bn_finalize_bwd_kernel(const double *__restrict__ part, int nchunks, int C, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, float *__restrict__ sums /*[2*C]: sum dy, sum dy*xhat*/,
                                        float beta_acc) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < nchunks; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  for (int k = lane; k < nchunks; k += 64) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  s = wave_sum_d(s); ss = wave_sum_d(ss);
+  if (lane != 0) return;
   sums[c] = (float)s; sums[C + c] = (float)ss;
   if (dbeta) dbeta[c] = (float)s + (beta_acc != 0.0f ? beta_acc * dbeta[c] : 0.0f);
   if (dgamma) dgamma[c] = (float)ss + (beta_acc != 0.0f ? beta_acc * dgamma[c] : 0.0f);
@@ -191,7 +196,7 @@ extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, c
   launch_reduce(StatVal{x}, outer, C, inner, part, &nchunks, st);
   CTCN_LAUNCH_CHECK();
   const double count = (double)outer * inner;
-  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nchunks, C, count, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, count, eps, momentum,
                      save_mean, save_rstd, running_mean, running_var);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
@@ -228,7 +233,7 @@ extern "C" int ctcn_bn_bwd(const float *x, const float *y, const float *dy, cons
   int nchunks = 0;
   launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu}, outer, C, inner, part, &nchunks, st);
   CTCN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nchunks, C, dgamma, dbeta, sums, beta_acc);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, dgamma, dbeta, sums, beta_acc);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
   const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));

@@ -747,6 +747,11 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     pa.stats[0] = st_poll; pa.stats[1] = st_fill; pa.stats[2] = st_mm; pa.stats[3] = st_red; pa.stats[4] = st_epi; pa.stats[5] = clock64() - st_t0;
     pa.stats[6] = st_e1; pa.stats[7] = st_e2; pa.stats[8] = st_e3; pa.stats[9] = st_e4;
   }
+  if (pa.stats && d == 0 && bt == 0 && tid == cw * 64 && slice < 64) {      // per-slice poll / rest split + the CU it ran on
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    pa.stats[16 + slice * 3] = st_poll; pa.stats[17 + slice * 3] = st_fill + st_mm + st_red + st_epi; pa.stats[18 + slice * 3] = hw;
+  }
 #endif
   if (s_abort && item) p.y[((size_t)(d == 0 ? T - 1 : 0) * B + b) * D * H + d * H + j] = __uint_as_float(0x7fc00000u);   // poison
 }

@@ -1,11 +1,12 @@
 // tools/mb_step.hip -- standalone micro-benchmark of the recurrent step kernels (development aid, not product).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpurun_out/mb_step tools/mb_step.hip ctc_pytorch_amd/csrc/core.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/mb_step.bin tools/mb_step.hip ctc_pytorch_amd/csrc/core.hip
 #define CTCN_PERSIST_STATS 1
 #include "../ctc_pytorch_amd/csrc/rnn.hip"
 #include <vector>
 
 extern "C" int ctcn_gemm(int, int, int, int, int, const float *, int, const float *, int, float *, int, float, int, void *, size_t, void *) { return 0; }
 extern "C" int ctcn_transpose01(const float *, float *, int, int, int, void *) { return 0; }
+int ctcn_gemm_on_xcds(int, int, int, int, int, const float *, int, const float *, int, float *, int, float, int, void *, size_t, void *, unsigned) { return 0; }
 
 namespace {
 __global__ void empty_kernel(RnnArgs p) { if (p.T < 0) p.y[0] = 1.f; }
@@ -151,11 +152,11 @@ int main() {
     // persistent forward / backward recurrences with in-kernel phase accounting (forward), device-scope vs XCD-local
     const int nbt = 2, K = G * H;
     const size_t hx_bytes = (size_t)2 * D * nbt * ((K + 31) / 32) * 512 * 4, fl_bytes = (size_t)2 * D * nbt * 64 * 4 + 256;
-    float *hx; unsigned *flags; int *status; long long *stats, h[10];
-    CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, 128));
+    float *hx; unsigned *flags; int *status; long long *stats, h[16 + 64 * 3];
+    CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, sizeof(long long) * (16 + 64 * 3))); CK(hipMemset(stats, 0, sizeof(long long) * (16 + 64 * 3)));
     const int nx = ctcn_device_xcds();
     printf("device XCDs (even deal verified): %d\n", nx);
-    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{0, 8, 2, 0, 1}, {1, 8, 2, 0, 1}, {1, 8, 2, 0, 2}, {1, 8, 2, 0, 4}, {1, 8, 2, 1, 1}, {1, 8, 2, 1, 2}, {1, 8, 2, 1, 3}, {1, 8, 2, 1, 4}, {1, 12, 3, 1, 4}};
+    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{0, 8, 2, 0, 1}, {1, 8, 2, 0, 2}, {1, 8, 2, 1, 2}, {1, 12, 3, 1, 2}, {1, 16, 4, 1, 2}};
     for (auto &c : cfgs) {
       if (c.local && nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
@@ -176,10 +177,18 @@ int main() {
         hipEventRecord(e1, st); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h, stats, 80, hipMemcpyDeviceToHost));
+      int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
       printf("fwd PERSISTENT local=%d HSU=%2d NT=%d precision=%d polls=%d  %3d slices/group   %8.2f us/step   (status %d)\n", c.local, c.hsu, c.nt, c.prec, c.pd, pa.nsl, ms * 1e3 / T, hs);
       printf("  per step (cycles), slice 7, communication wave: flag poll+barrier %.0f | operand loads %.0f | mfma %.0f | reduce %.0f | gate math+publish %.0f | total %.0f\n",
              (double)h[0] / T, (double)h[1] / T, (double)h[2] / T, (double)h[3] / T, (double)h[4] / T, (double)h[5] / T);
+      if (c.local) {
+        printf("    per slice: poll / rest cycles per step [se.sh.cu]:");
+        for (int i = 0; i < pa.nsl; ++i) {
+          const unsigned hw = (unsigned)h[18 + i * 3];
+          printf(" %d:%.0f/%.0f[%u.%u.%u]", i, (double)h[16 + i * 3] / T, (double)h[17 + i * 3] / T, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15);
+        }
+        printf("\n");
+      }
       printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
              (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
     }
