@@ -358,7 +358,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 // Hand-off variants measured and rejected (cfg2 forward, us per step; THIS = 3.1 f32 / 2.2 bf16x3): per-timestep launches
 // 7.0 | 8-B {value,tag} granules swept into registers 5.9 | device-scope flag + 16-B write-through payload + LDS fill 4.9 |
 // per-wave flags 5.7-5.9 | 8-B granule tiles without flags 5.5 | 16-B {v0,v1,v2,tag} granules swept block-wide 6.9 |
-// 2-3 polls in flight / paced polls over the fabric 5.0-5.7 | buffer_inv sc0 + plain loads: stale L1 lines (incorrect).
+// 2-3 polls in flight / paced polls over the fabric 5.0-5.7 | buffer_inv sc0 + plain loads: stale L1 lines (incorrect) |
+// XCD-local, no flags at all: {bf16 hi, lo} words with the step number in the LSBs of lo, every wave re-loading its stale
+// granules: 2.3-2.5, i.e. no gain over flag + data (2.2) -- the re-load traffic of 160 spinning waves delays the stores.
 // grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
 // workgroups co-resident (occupancy-checked on the host).
 // ================================================================================================

@@ -96,7 +96,9 @@ def test_rnn_layer_golden(dev, kind):
 
 @pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 37, 32, 40, 320, True), ("gru", 19, 64, 48, 512, True),
                                             ("lstm", 11, 70, 24, 128, True), ("rnn", 23, 5, 12, 36, False),
-                                            ("gru", 9, 3, 20, 24, True), ("lstm", 6, 16, 640, 20, False)])
+                                            ("gru", 9, 3, 20, 24, True), ("lstm", 6, 16, 640, 20, False),
+                                            ("lstm", 1, 4, 8, 16, True), ("gru", 2, 1, 8, 8, True), ("lstm", 7, 17, 12, 1024, False),
+                                            ("lstm", 5, 200, 16, 64, True), ("rnn", 3, 33, 4, 512, True), ("gru", 12, 130, 8, 40, True)])
 def test_rnn_layer_vs_torch_cpu(dev, kind, T, B, I, H, bi):
     from ctc_pytorch_amd import ops
     cls = {"lstm": tnn.LSTM, "gru": tnn.GRU, "rnn": tnn.RNN}[kind]
@@ -119,7 +121,9 @@ def test_rnn_layer_vs_torch_cpu(dev, kind, T, B, I, H, bi):
 
 
 @pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 120, 32, 40, 320, True), ("gru", 40, 64, 48, 512, True), ("lstm", 33, 70, 24, 128, True),
-                                            ("rnn", 50, 5, 12, 36, False), ("gru", 30, 3, 20, 24, True), ("lstm", 20, 16, 64, 20, False)])
+                                            ("rnn", 50, 5, 12, 36, False), ("gru", 30, 3, 20, 24, True), ("lstm", 20, 16, 64, 20, False),
+                                            ("lstm", 1, 4, 8, 16, True), ("gru", 2, 1, 8, 8, True), ("lstm", 7, 17, 12, 1024, False),
+                                            ("lstm", 5, 200, 16, 64, True), ("rnn", 9, 33, 4, 512, True), ("gru", 12, 130, 8, 40, True)])
 def test_rnn_layer_bf16x3_vs_torch_cpu(dev, kind, T, B, I, H, bi):
     """precision=1: input projection AND the recurrent matmul run as bf16x3 split-operand MFMA (hi/lo planes handed
     between workgroups); outputs within 1e-4, gradients within 5e-4 rel-L2 of the f32 torch CPU layer (north-star
@@ -425,6 +429,47 @@ def _build_model(tag, dev):
     vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=int(z["seed_w"]))
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
     return m.to(dev), z
+
+
+@pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 128, 8, 60), ("GRU", 192, 40, 25)])
+def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T):
+    """precision 1 + FlatAdam: the weight-gradient GEMMs run on the second stream, restricted to the XCDs the next
+    layer's persistent recurrence leaves idle (queue kernels), and are joined when backward ends.  Same flat gradient,
+    bit for bit, as the inline path (same tiles, same split-K order), also over two accumulating backward passes."""
+    from ctc_pytorch_amd import nn, ops
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    from ctc_pytorch_amd.optim import FlatAdam
+    V = 30
+    m = CTC_Model(rnn_param={"rnn_input_size": 40, "bidirectional": True, "batch_norm": True, "rnn_layers": 3, "rnn_hidden_size": H,
+                             "rnn_type": getattr(nn, rnn)}, num_class=V, drop_out=0.0)
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=5)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    m = m.to(dev).train()
+    opt = FlatAdam(m, lr=1e-3)
+    b = synth.make_batch(seed=21, B=B, T=T, F=40, V=V, lab_lo=3, lab_hi=8)
+    x, tg, tl = gpu(b["x"], dev), gpu(b["targets"], dev), gpu(b["tgt_len"], dev)
+    il = torch.full((B,), T, dtype=torch.int64, device=dev)
+    loss_fn = nn.CTCLoss(reduction="sum")
+    flat = next(p for p in m.parameters())._ctcn_grad
+    base = flat.untyped_storage()
+    grads = {}
+    ops.set_precision(1)
+    try:
+        for side in (False, True):
+            ops.set_side_stream(side)
+            opt.zero_grad()
+            for _ in range(2):                              # gradients accumulate (beta = 1) across backward passes
+                loss = loss_fn(m(x), tg, il, tl) / B
+                loss.backward()
+            torch.cuda.synchronize()
+            grads[side] = torch.cat([p._ctcn_grad.reshape(-1) for p in m.parameters()]).clone()
+    finally:
+        ops.set_precision(0)
+        ops.set_side_stream(True)
+    ops.check_health()
+    assert base is not None and torch.isfinite(grads[True]).all()
+    assert float(grads[True].abs().max()) > 0
+    assert torch.equal(grads[True], grads[False])
 
 
 @pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16"])
