@@ -448,11 +448,29 @@ __device__ __forceinline__ bool poll_flags_pipelined(const unsigned *flags, int 
 }
 __device__ __forceinline__ bool poll_group(const unsigned *flags, int n, unsigned want, int lane, const PersistArgs &pa) {
   if (pa.local && n <= 64) {
-    if (pa.poll_depth == 2) return poll_flags_pipelined<2>(flags, n, want, lane, pa.spin_limit, pa.status);
-    if (pa.poll_depth == 3) return poll_flags_pipelined<3>(flags, n, want, lane, pa.spin_limit, pa.status);
-    if (pa.poll_depth >= 4) return poll_flags_pipelined<4>(flags, n, want, lane, pa.spin_limit, pa.status);
+    if ((pa.poll_depth & 255) == 2) return poll_flags_pipelined<2>(flags, n, want, lane, pa.spin_limit, pa.status);
+    if ((pa.poll_depth & 255) == 3) return poll_flags_pipelined<3>(flags, n, want, lane, pa.spin_limit, pa.status);
+    if ((pa.poll_depth & 255) >= 4) return poll_flags_pipelined<4>(flags, n, want, lane, pa.spin_limit, pa.status);
   }
   return poll_flags(flags, n, want, lane, pa.spin_limit, pa.status);
+}
+
+// Item traffic of the persistent kernels (reserve stores, next-step operand loads) goes through buffer instructions: ONE
+// loop-invariant resource per tensor, a per-thread byte offset that never changes, and the timestep as the scalar
+// offset operand -- no 64-bit VGPR address arithmetic and no selects on loaded values in the loop (both made hipcc wait
+// on vmcnt in the middle of the "fire and forget" tail, which put the HBM latency of the reserve traffic on the critical
+// path of every timestep).  The host only takes the persistent path when every tensor is smaller than 4 GB.
+// What is left of that cost is the in-order vmcnt itself: the next step's operand-tile loads of an item wave queue behind
+// its HBM-latency reserve loads (0.3 us per backward step with, 0 without them; warming L2 two steps ahead from the same
+// wave only moves the stall).  Dedicated memory waves would remove it; not done yet.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const float *base, size_t floats) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, base ? (int)(unsigned)(floats * 4) : 0, 0x00020000);
+}
+__device__ __forceinline__ float ld_slab(const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned slab_off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, slab_off, 0));
+}
+__device__ __forceinline__ void st_slab(const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned slab_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off, slab_off, 0);
 }
 
 // Role of a workgroup in a persistent launch.  Device-scope mode: grid (slices, dirs, batch tiles).  XCD-local mode:
@@ -470,7 +488,7 @@ __device__ __forceinline__ PersistRole persist_role(const PersistArgs &pa, int D
   const int xcd = (int)(x & 15);
   if (threadIdx.x == 0) *s_ticket = xcd < pa.nx ? (int)atomicAdd(pa.tickets + xcd, 1u) : 0x7fffffff;
   __syncthreads();
-  const int idx = *s_ticket;
+  const int idx = __builtin_amdgcn_readfirstlane(*s_ticket);   // uniform by construction: keep the role (and every address derived from it) in SGPRs
   const int lg = idx / pa.nsl, group = lg * pa.nx + xcd;
   r.slice = idx - lg * pa.nsl;
   r.active = idx < pa.wpx && group < D * pa.nbt;
@@ -548,12 +566,18 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   const int cw = 16 * HSU <= 192 ? 3 : 0;
   // x-projection pre-activations of this item, always one step ahead: refilled right after the gate math consumed them
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
-  const size_t gstride = (size_t)B * D * G * H;                       // floats between timesteps of p.gates
-  const float *gitem = p.gates + ((size_t)min(b, B - 1) * D + d) * (size_t)(G * H) + min(j, H - 1);
+  // running pointers of this item into the gate slab, the c / hn reserve and y: timestep t of the current step,
+  // advanced by +-one timestep per step (no 64-bit index arithmetic in the loop)
+  const long slab_g = (long)B * D * G * H, slab_h = (long)B * D * H;       // floats per timestep of gates / of aux, y
+  const int bcl = min(b, B - 1), jcl = min(j, H - 1);
+  const unsigned vg0 = (unsigned)(((bcl * D + d) * (G * H) + jcl) * 4);
+  const unsigned vg1 = vg0 + (unsigned)(min(1, G - 1) * H * 4), vg2 = vg0 + (unsigned)(min(2, G - 1) * H * 4), vg3 = vg0 + (unsigned)(min(3, G - 1) * H * 4);
+  const unsigned vh = (unsigned)(((bcl * D + d) * H + jcl) * 4);            // aux (T,B,D,H) and y (T,B,D*H) share it
+  const __amdgpu_buffer_rsrc_t rg = whole_rsrc(p.gates, (size_t)T * slab_g), ra = whole_rsrc(p.aux, (size_t)T * slab_h), ry = whole_rsrc(p.y, (size_t)T * slab_h);
+  const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);            // bytes per timestep slab
   if (item) {
-    const float *gt = gitem + (size_t)(d == 0 ? 0 : T - 1) * gstride;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pre[k] = gt[min(k, G - 1) * H];
+    const unsigned o = (unsigned)(d == 0 ? 0 : T - 1) * sg_b;
+    pre[0] = ld_slab(rg, vg0, o); pre[1] = ld_slab(rg, vg1, o); pre[2] = ld_slab(rg, vg2, o); pre[3] = ld_slab(rg, vg3, o);
   }
   __syncthreads();
 #ifdef CTCN_PERSIST_STATS
@@ -606,24 +630,27 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
             for (int nt = 0; nt < NT; ++nt)
               acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[nt][si][c], acc[nt], 0, 0, 0);
       } else {
-        Bf16Pack ah[KB], al[KB];
+        u32x4 ah[KB], al[KB];                     // plain vectors: a union here made hipcc wait after every second load
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
           const unsigned off = tbase + (unsigned)(min(wave * KB + i, nch - 1) * 2048 + lane * 16);   // blocks past the end: W is 0 there
-          ah[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
-          al[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
+          ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+          al[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
         }
+        __builtin_amdgcn_sched_barrier(0);        // all operand loads in flight before the first MFMA (hipcc otherwise reuses two register sets and serialises them)
 #ifdef CTCN_PERSIST_STATS
         c_f = clock64();
 #endif
 #pragma unroll
-        for (int i = 0; i < KB; ++i)
+        for (int i = 0; i < KB; ++i) {
+          const bf16x8_t ahv = __builtin_bit_cast(bf16x8_t, ah[i]), alv = __builtin_bit_cast(bf16x8_t, al[i]);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i].v, whi[nt][i], acc[nt], 0, 0, 0);   // small terms first
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, wlo[nt][i], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, whi[nt][i], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alv, whi[nt][i], acc[nt], 0, 0, 0);   // small terms first
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, wlo[nt][i], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, whi[nt][i], acc[nt], 0, 0, 0);
           }
+        }
       }
     }
 #ifdef CTCN_PERSIST_STATS
@@ -721,20 +748,19 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     }
     // off the critical path (item waves): the reserve (gates, c / hn) and y leave after the hand-off, and the next
     // step's pre-activations are requested a whole step before the gate math needs them
-    if (item) {
-      float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
-      if (p.cell == CTCN_CELL_LSTM) {
-        gt[0 * H + j] = sv0; gt[1 * H + j] = sv1; gt[2 * H + j] = sv2; gt[3 * H + j] = sv3;
-        p.aux[(row_t * D + d) * H + j] = sv4;
-      } else if (p.cell == CTCN_CELL_GRU) {
-        gt[0 * H + j] = sv0; gt[1 * H + j] = sv1; gt[2 * H + j] = sv2;
-        p.aux[(row_t * D + d) * H + j] = sv4;
-      }
-      p.y[row_t * D * H + d * H + j] = hval;
-      if (s + 1 < T) {
-        const float *gn = gitem + (size_t)(d == 0 ? s + 1 : T - 2 - s) * gstride;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pre[k] = gn[min(k, G - 1) * H];
+    {
+      const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
+      const unsigned on = (unsigned)(s + 1 < T ? (d == 0 ? t + 1 : t - 1) : t) * sg_b;      // past the end: re-read t (unused)
+      if (item) {
+        if (p.cell == CTCN_CELL_LSTM) {
+          st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2); st_slab(rg, vg3, og, sv3);
+          st_slab(ra, vh, oh, sv4);
+        } else if (p.cell == CTCN_CELL_GRU) {
+          st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2);
+          st_slab(ra, vh, oh, sv4);
+        }
+        st_slab(ry, vh, oh, hval);
+        pre[0] = ld_slab(rg, vg0, on); pre[1] = ld_slab(rg, vg1, on); pre[2] = ld_slab(rg, vg2, on); pre[3] = ld_slab(rg, vg3, on);
       }
     }
 #ifdef CTCN_PERSIST_STATS
@@ -812,26 +838,6 @@ bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStr
 // workgroups' d(pre-activation) (80 KB at H=320), loaded straight into the MFMA operand registers.  Waves 0..3 hold the
 // items and publish (LDS-staged, 16-B granules); wave 15 polls.  grid as rnn_fwd_persist with 16-unit slices.
 // ================================================================================================
-// saved forward values of one (row, unit) item at timestep t (tp = the step whose c / h it needs, -1: none)
-__device__ __forceinline__ void bwd_item_loads(const RnnArgs &p, int t, int tp, int b, int d, int j, float sv[4], float &dyv, float &e0, float &e1) {
-  const int H = p.H, G = p.G, D = p.D, B = p.B;
-  const size_t row_t = (size_t)t * B + b;
-  const float *gt = p.gates + (row_t * D + d) * (size_t)(G * H);
-  dyv = p.dy[row_t * D * H + d * H + j];
-  e1 = 0.f;
-  if (p.cell == CTCN_CELL_TANH) {
-    e0 = p.y[row_t * D * H + d * H + j];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < G) sv[k] = gt[k * H + j];
-    e0 = p.aux[(row_t * D + d) * H + j];
-    if (tp >= 0)
-      e1 = p.cell == CTCN_CELL_LSTM ? p.aux[(((size_t)tp * B + b) * D + d) * H + j]
-                                    : p.y[((size_t)tp * B + b) * D * H + d * H + j];
-  }
-}
-
 template <int KQ4, int PREC>
 __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   constexpr int NW = 16;
@@ -879,17 +885,42 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
   const bool item = tid < 256 && bl < Bc && j < H;
   float state = 0.0f;   // carried dc (LSTM) / dh*z (GRU)
-  // Wave roles: waves 0..3 hold the 256 (row, unit) items; wave 15 polls the flags and waves 4..15 fetch the tile, so
-  // the item waves' in-order vmcnt only ever sees their own publish stores, reserve stores and next-step operand
-  // loads (requested right after the hand-off, a whole step before the gate math needs them).
+  // Wave roles: waves 0..3 hold the 256 (row, unit) items and publish; wave 15 (no items) polls the flags, so its
+  // in-order vmcnt never queues behind the item waves' reserve stores and next-step operand loads (requested right
+  // after the hand-off, a whole step before the gate math needs them).
   float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f;
+  // per-thread byte offsets inside one timestep slab (see slab_rsrc); the backward pass walks time in the direction
+  // tdir = -1 for the forward layer direction, +1 for the reverse one
+  const int tdir = d == 0 ? -1 : 1;
+  const long slab_g = (long)B * D * K, slab_h = (long)B * D * H;
+  const int bcl = min(b, B - 1), jcl = min(j, H - 1);
+  const unsigned vg0 = (unsigned)(((bcl * D + d) * K + jcl) * 4);
+  const unsigned vg1 = vg0 + (unsigned)(min(1, G - 1) * H * 4), vg2 = vg0 + (unsigned)(min(2, G - 1) * H * 4), vg3 = vg0 + (unsigned)(min(3, G - 1) * H * 4);
+  const unsigned vh = (unsigned)(((bcl * D + d) * H + jcl) * 4);
+  const bool is_lstm = p.cell == CTCN_CELL_LSTM, is_tanh = p.cell == CTCN_CELL_TANH;
+  // e0: c_t (LSTM) / W_hn h_{t-1} (GRU) / y_t (tanh);  e1: c of the next step in walking order (LSTM) / its y (GRU), 0 when
+  // that step does not exist (applied where e1 is consumed, never as a select on the value in flight)
+  const __amdgpu_buffer_rsrc_t rg = whole_rsrc(p.gates, (size_t)T * slab_g), rdy = whole_rsrc(p.dy, (size_t)T * slab_h);
+  const __amdgpu_buffer_rsrc_t r0 = whole_rsrc(is_tanh ? p.y : p.aux, (size_t)T * slab_h), r1 = whole_rsrc(is_lstm ? p.aux : p.y, (size_t)T * slab_h);
+  const __amdgpu_buffer_rsrc_t ra = whole_rsrc(p.aux, (size_t)T * slab_h);
+  const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);            // bytes per timestep slab
+  bool e1_valid = T > 1 && !is_tanh;
   if (item) {
-    const int t0 = d == 0 ? T - 1 : 0;
-    bwd_item_loads(p, t0, d == 0 ? (t0 > 0 ? t0 - 1 : -1) : (t0 < T - 1 ? t0 + 1 : -1), b, d, j, sv, dyv, e0, e1);
+    const int t0 = d == 0 ? T - 1 : 0, t1 = T > 1 ? t0 + tdir : t0;
+    const unsigned og = (unsigned)t0 * sg_b, oh = (unsigned)t0 * sh_b;
+    sv[0] = ld_slab(rg, vg0, og); sv[1] = ld_slab(rg, vg1, og); sv[2] = ld_slab(rg, vg2, og); sv[3] = ld_slab(rg, vg3, og);
+    dyv = ld_slab(rdy, vh, oh); e0 = ld_slab(r0, vh, oh); e1 = ld_slab(r1, vh, (unsigned)t1 * sh_b);
   }
   __syncthreads();
 
+#ifdef CTCN_PERSIST_STATS
+  long long bt_poll = 0, bt_mm = 0, bt_red = 0, bt_math = 0, bt_copy = 0, bt_tail = 0, bt_t0 = clock64();
+#endif
   for (int s = 0; s < T; ++s) {
+#ifdef CTCN_PERSIST_STATS
+    const long long q_a = clock64();
+    long long q_p = q_a;
+#endif
     const int t = d == 0 ? T - 1 - s : s;
     const size_t row_t = (size_t)t * B + b;
     f32x4 acc[1];
@@ -905,6 +936,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
       }
       lds_barrier();
       if (s_abort) break;
+#ifdef CTCN_PERSIST_STATS
+      q_p = clock64();
+#endif
       const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
       f32x4 acc1 = zero;      // two independent accumulator chains hide the dependent MFMA latency
       if constexpr (PREC == 0) {
@@ -923,23 +957,32 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c + 1], bv[si][c + 1], acc1, 0, 0, 0);
           }
       } else {
-        Bf16Pack ah[KB], al[KB];
+        u32x4 ah[KB], al[KB];
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
           const unsigned off = tbase + (unsigned)(min(wave * KB + i, nch - 1) * 2048 + lane * 16);   // blocks past the end: W is 0 there
-          ah[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
-          al[i].u = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
+          ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+          al[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
         }
+        __builtin_amdgcn_sched_barrier(0);        // all operand loads in flight before the first MFMA
 #pragma unroll
         for (int i = 0; i < KB; ++i) {
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i].v, whi[i], acc1, 0, 0, 0);                // small terms
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, wlo[i], acc1, 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i].v, whi[i], acc[0], 0, 0, 0);
+          const bf16x8_t ahv = __builtin_bit_cast(bf16x8_t, ah[i]), alv = __builtin_bit_cast(bf16x8_t, al[i]);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alv, whi[i], acc1, 0, 0, 0);                    // small terms
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, wlo[i], acc1, 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, whi[i], acc[0], 0, 0, 0);
         }
       }
       acc[0] += acc1;
     }
+#ifdef CTCN_PERSIST_STATS
+    const long long q_m = clock64();
+#endif
     reduce_tiles<1, NW, NW>(acc, red, outs, tid, 1024);
+#ifdef CTCN_PERSIST_STATS
+    const long long q_r = clock64();
+    long long q_e = q_r, q_c = q_r;
+#endif
 
     const int par = s & 1;
     const unsigned px = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);                 // published tile (bytes)
@@ -947,19 +990,20 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     float dan = 0.f;
     if (item) {
       float dh = dyv + outs[bl][jl];
+      const float e1u = e1_valid ? e1 : 0.0f;                 // c / h of a step before the sequence start is 0
       if (p.cell == CTCN_CELL_LSTM) {
         const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
         const float tc = act_tanh(e0);
         const float do_ = dh * tc;
         const float dc = dh * o_ * (1.0f - tc * tc) + state;
         out[0] = dc * g_ * i_ * (1.0f - i_);
-        out[1] = dc * e1 * f_ * (1.0f - f_);
+        out[1] = dc * e1u * f_ * (1.0f - f_);
         out[2] = dc * i_ * (1.0f - g_ * g_);
         out[3] = do_ * o_ * (1.0f - o_);
         state = dc * f_;
       } else if (p.cell == CTCN_CELL_GRU) {
         dh += state;
-        const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1;
+        const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1u;
         const float dn = dh * (1.0f - z_);
         const float dz = dh * (hp - n_);
         dan = dn * (1.0f - n_ * n_);
@@ -988,6 +1032,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     }
     if (s + 1 < T) {
       lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+      q_e = clock64();
+#endif
       // copy-out by waves 0..3: every lane one 16-B granule, 16 consecutive rows = 256 contiguous bytes of the tile
       if (tid < 256) {
         const int row = tid & 15;
@@ -1011,26 +1058,48 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     if (s + 1 < T) {
       if (wave < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores (to L2 / to memory)
       lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+      q_c = clock64();
+#endif
       if (tid == 0) st_u1(rf, (unsigned)(((((size_t)par * D + d) * nbt + bt) * nsl + slice) * 4), (unsigned)(s + 1), local);
     }
     // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs leaves after the hand-off,
     // and the next step's saved forward values are requested a whole step ahead
-    if (item) {
-      float *gt = p.gates + (row_t * D + d) * (size_t)K;
-      if (p.cell == CTCN_CELL_LSTM) {
-        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = out[2]; gt[3 * H + j] = out[3];
-      } else if (p.cell == CTCN_CELL_GRU) {
-        gt[0 * H + j] = out[0]; gt[1 * H + j] = out[1]; gt[2 * H + j] = dan;
-        p.aux[(row_t * D + d) * H + j] = out[2];
-      } else {
-        gt[j] = out[0];
+    {
+      const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
+      const int tn = s + 1 < T ? t + tdir : t, tp = s + 2 < T ? tn + tdir : tn;             // past the end: re-read (unused)
+      const unsigned ogn = (unsigned)tn * sg_b, ohn = (unsigned)tn * sh_b, ohp = (unsigned)tp * sh_b;
+#ifdef CTCN_PERSIST_STATS
+      const bool dbg_no_st = (pa.poll_depth & 512) != 0, dbg_no_ld = (pa.poll_depth & 256) != 0;
+#else
+      constexpr bool dbg_no_st = false, dbg_no_ld = false;
+#endif
+      if (item && !dbg_no_st) {
+        if (is_lstm) {
+          st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, out[2]); st_slab(rg, vg3, og, out[3]);
+        } else if (p.cell == CTCN_CELL_GRU) {
+          st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, dan);
+          st_slab(ra, vh, oh, out[2]);
+        } else {
+          st_slab(rg, vg0, og, out[0]);
+        }
       }
-      if (s + 1 < T) {
-        const int tn = d == 0 ? T - 2 - s : s + 1;
-        bwd_item_loads(p, tn, d == 0 ? (tn > 0 ? tn - 1 : -1) : (tn < T - 1 ? tn + 1 : -1), b, d, j, sv, dyv, e0, e1);
+      if (item && !dbg_no_ld) {
+        sv[0] = ld_slab(rg, vg0, ogn); sv[1] = ld_slab(rg, vg1, ogn); sv[2] = ld_slab(rg, vg2, ogn); sv[3] = ld_slab(rg, vg3, ogn);
+        dyv = ld_slab(rdy, vh, ohn); e0 = ld_slab(r0, vh, ohn); e1 = ld_slab(r1, vh, ohp);
       }
+      e1_valid = s + 2 < T && !is_tanh;
     }
+#ifdef CTCN_PERSIST_STATS
+    { const long long q_z = clock64(); bt_poll += q_p - q_a; bt_mm += q_m - q_p; bt_red += q_r - q_m; bt_math += q_e - q_r; bt_copy += q_c - q_e; bt_tail += q_z - q_c; }
+#endif
   }
+#ifdef CTCN_PERSIST_STATS
+  if (pa.stats && slice == 3 && d == 0 && bt == 0 && (tid == 0 || tid == 960)) {
+    long long *o = pa.stats + (tid == 0 ? 0 : 8);
+    o[0] = bt_poll; o[1] = bt_mm; o[2] = bt_red; o[3] = bt_math; o[4] = bt_copy; o[5] = bt_tail; o[6] = clock64() - bt_t0;
+  }
+#endif
   if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
@@ -1154,7 +1223,9 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   const int HS = cell == CTCN_CELL_TANH ? 16 : 4;
   const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
   dim3 grid(ceil_div(H, HS), dirs, ceil_div(B, 16 * MT));
-  if (ctcn_opt_rnn_persistent() && T > 1 && H % 4 == 0) {
+  // the persistent kernels address each tensor through one 32-bit-offset buffer resource
+  const bool fits32 = (size_t)T * B * dirs * GH * sizeof(float) < ((size_t)1 << 32);
+  if (ctcn_opt_rnn_persistent() && T > 1 && H % 4 == 0 && fits32) {
     // persistent recurrence: K = H split over 4 waves x 4 k-lanes x KQ4 float4 (one super-chunk)
     int kq = ceil_div(H, 64);
     if (kq == 7) kq = 8;
@@ -1296,7 +1367,8 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   a.state = state;
   dim3 grid(ceil_div(H, 16), dirs, ceil_div(B, 16));
   bool done = false;
-  if (ctcn_opt_rnn_persistent() && T > 1) {
+  const bool fits32 = (size_t)T * B * dirs * GH * sizeof(float) < ((size_t)1 << 32);   // one 32-bit-offset resource per tensor
+  if (ctcn_opt_rnn_persistent() && T > 1 && fits32) {
     int kq = ceil_div(GH, 256);
     if (kq == 7) kq = 8;
     const int nbt = grid.z, nsl = grid.x, groups = dirs * nbt;

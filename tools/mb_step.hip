@@ -156,7 +156,7 @@ int main() {
     CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, sizeof(long long) * (16 + 64 * 3))); CK(hipMemset(stats, 0, sizeof(long long) * (16 + 64 * 3)));
     const int nx = ctcn_device_xcds();
     printf("device XCDs (even deal verified): %d\n", nx);
-    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{0, 8, 2, 0, 1}, {1, 8, 2, 0, 2}, {1, 8, 2, 1, 2}, {1, 12, 3, 1, 2}, {1, 16, 4, 1, 2}};
+    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{1, 8, 2, 1, 2}};
     for (auto &c : cfgs) {
       if (c.local && nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
@@ -192,10 +192,10 @@ int main() {
       printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
              (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
     }
-    for (int lp = 0; lp < 5; ++lp) {
-      const int local = lp > 0, prec = lp > 1, pd = lp == 3 ? 2 : (lp == 4 ? 4 : 1);
+    for (int lp = 2; lp < 6; ++lp) {
+      const int local = 1, prec = 1, pd = lp == 2 ? 2 : (lp == 3 ? 2 + 256 : (lp == 4 ? 2 + 512 : 2 + 768));
       if (local && nx <= 1) continue;
-      PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = nullptr;
+      PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
       pa.poll_depth = pd; pa.local = local; pa.nx = local ? nx : 1; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
@@ -210,6 +210,11 @@ int main() {
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
+      for (int wv = 0; wv < 2; ++wv)
+        printf("  bwd per step (cycles), slice 3, %s: poll+barrier %.0f | loads+mfma %.0f | reduce %.0f | gate math+stage+barrier %.0f | copy-out+drain+barrier %.0f | flag+reserve+prefetch issue %.0f | total %.0f\n",
+               wv ? "wave 15 (poller)" : "wave 0 (items)", (double)h[wv * 8 + 0] / T, (double)h[wv * 8 + 1] / T, (double)h[wv * 8 + 2] / T, (double)h[wv * 8 + 3] / T,
+               (double)h[wv * 8 + 4] / T, (double)h[wv * 8 + 5] / T, (double)h[wv * 8 + 6] / T);
       printf("bwd PERSISTENT local=%d precision=%d polls=%d  %3d slices/group   %8.2f us/step   (status %d)\n", local, prec, pd, pa.nsl, ms * 1e3 / T, hs);
     }
   }
