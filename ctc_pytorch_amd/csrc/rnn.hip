@@ -462,7 +462,9 @@ __device__ __forceinline__ bool poll_group(const unsigned *flags, int n, unsigne
 // path of every timestep).  The host only takes the persistent path when every tensor is smaller than 4 GB.
 // What is left of that cost is the in-order vmcnt itself: the next step's operand-tile loads of an item wave queue behind
 // its HBM-latency reserve loads (0.3 us per backward step with, 0 without them; warming L2 two steps ahead from the same
-// wave only moves the stall).  Dedicated memory waves would remove it; not done yet.
+// wave only moves the stall).  Dedicated memory waves (4 matmul-free waves moving the reserve traffic through LDS) were
+// built and measured too: item tail 1400 -> 380 cycles but 3.0 us per step instead of 2.8 -- the cost follows the HBM
+// misses of the CU, not the wave that issues them.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const float *base, size_t floats) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, base ? (int)(unsigned)(floats * 4) : 0, 0x00020000);
 }
