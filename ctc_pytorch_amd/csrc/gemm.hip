@@ -570,6 +570,12 @@ __global__ void transpose01_kernel(const float *__restrict__ in, float *__restri
 
 }  // namespace
 
+// Hint from a caller that issues consecutive GEMMs with the SAME, unmodified A operand on the same stream and workspace
+// (the two directions of a recurrent layer's input projection): the A planes of the previous call are still in the
+// workspace, so the next call skips its split pass when pointer / shape / layout match.  One-shot, per host thread.
+static thread_local struct { const float *A; int lda, M, K, transA; void *ws; hipStream_t st; bool valid, armed; } g_last_a = {};
+void ctcn_gemm_hint_same_a(void) { g_last_a.armed = true; }
+
 // xcd_allow: 0 = whole device; otherwise (precision 1 plane path only) the XCDs the GEMM workgroups may run on
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
                       int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow) {
@@ -617,7 +623,12 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
             hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo);
         }
       };
-      split(A, lda, transA != 0, M, ah, al);
+      const bool same_a = g_last_a.armed && g_last_a.valid && g_last_a.A == A && g_last_a.lda == lda && g_last_a.M == M && g_last_a.K == K &&
+                          g_last_a.transA == transA && g_last_a.ws == ws && g_last_a.st == st && !xcd_allow;
+      g_last_a.armed = false;
+      if (!same_a) split(A, lda, transA != 0, M, ah, al);
+      g_last_a.A = A; g_last_a.lda = lda; g_last_a.M = M; g_last_a.K = K; g_last_a.transA = transA; g_last_a.ws = ws; g_last_a.st = st;
+      g_last_a.valid = !xcd_allow;
       split(B, ldb, transB == 0, N, bh, bl);
       CTCN_LAUNCH_CHECK();
       int psplits = 1;
@@ -647,6 +658,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       return CTCN_OK;
     }
   }
+  g_last_a.valid = false; g_last_a.armed = false;               // not the plane path: nothing to reuse
   const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
   float *wsp = splits > 1 ? (float *)ws : nullptr;

@@ -554,6 +554,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   const size_t tile_f = (size_t)nch * (PREC == 0 ? 256 : 512);                                  // floats per h tile
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
+  // per-parity element / byte offsets of this group's flag row and hand-off tile (kept out of the time loop)
+  const unsigned flg_el[2] = {(unsigned)(((0 * D + d) * nbt + bt) * nsl), (unsigned)(((1 * D + d) * nbt + bt) * nsl)};
+  const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_f * 4), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_f * 4)};
 
   // epilogue item of this thread: (row bl, unit jl) fixed for all steps -> c / h of the unit stay in a register
   const int bl = tid / HSU, jl = tid - bl * HSU;
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     if (s > 0) {
       const int par = (s - 1) & 1;
       if (wave == cw) {
-        const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
+        const unsigned *fl = pa.flags + flg_el[par];
         const bool ok = poll_group(fl, nsl, (unsigned)s, lane, pa);
         if (!ok && lane == 0) {
           s_abort = 1;
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
       c_p = clock64();
 #endif
-      const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
+      const unsigned tbase = tile_b[par];
       if constexpr (PREC == 0) {
         f32x4 av[KQ4];
 #pragma unroll
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     // publish this workgroup's 16 x HSU block of h_t: 16-B stores by the communication wave, drained, then the flag
     if (s + 1 < T && wave == cw) {
       const int par = s & 1;
-      const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
+      const unsigned tbase = tile_b[par];
       // lanes run row-fastest so that consecutive lanes write consecutive 16-B (8-B) granules of the tile
       const int row = lane & 15, rest = lane >> 4;
       if constexpr (PREC == 1) {
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
       c_g = clock64();
 #endif
-      if (lane == 0) st_u1(rf, (unsigned)(((((size_t)par * D + d) * nbt + bt) * nsl + slice) * 4), (unsigned)(s + 1), local);
+      if (lane == 0) st_u1(rf, (flg_el[par] + (unsigned)slice) * 4, (unsigned)(s + 1), local);
     }
     // off the critical path (item waves): the reserve (gates, c / hn) and y leave after the hand-off, and the next
     // step's pre-activations are requested a whole step before the gate math needs them
@@ -883,6 +886,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   const size_t tile_f = (size_t)nch * (PREC == 0 ? 256 : 512);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
+  // per-parity element / byte offsets of this group's flag row and hand-off tile (kept out of the time loop)
+  const unsigned flg_el[2] = {(unsigned)(((0 * D + d) * nbt + bt) * nsl), (unsigned)(((1 * D + d) * nbt + bt) * nsl)};
+  const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_f * 4), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_f * 4)};
 
   const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
   const bool item = tid < 256 && bl < Bc && j < H;
@@ -930,7 +936,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     if (s > 0) {
       const int par = (s - 1) & 1;
       if (wave == NW - 1) {
-        const unsigned *fl = pa.flags + (((size_t)par * D + d) * nbt + bt) * nsl;
+        const unsigned *fl = pa.flags + flg_el[par];
         if (!poll_group(fl, nsl, (unsigned)s, lane, pa) && lane == 0) {
           s_abort = 1;
           if (pa.status) atomicCAS(pa.status, 0, 201);
@@ -941,7 +947,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
       q_p = clock64();
 #endif
-      const unsigned tbase = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);
+      const unsigned tbase = tile_b[par];
       f32x4 acc1 = zero;      // two independent accumulator chains hide the dependent MFMA latency
       if constexpr (PREC == 0) {
         f32x4 av[KQ4];
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 #endif
 
     const int par = s & 1;
-    const unsigned px = (unsigned)(((((size_t)par * D + d) * nbt + bt) * tile_f) * 4);                 // published tile (bytes)
+    const unsigned px = tile_b[par];                                                                // published tile (bytes)
     float out[4] = {0.f, 0.f, 0.f, 0.f};      // values the next step multiplies by W_hh (published), per gate block
     float dan = 0.f;
     if (item) {
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
       q_c = clock64();
 #endif
-      if (tid == 0) st_u1(rf, (unsigned)(((((size_t)par * D + d) * nbt + bt) * nsl + slice) * 4), (unsigned)(s + 1), local);
+      if (tid == 0) st_u1(rf, (flg_el[par] + (unsigned)slice) * 4, (unsigned)(s + 1), local);
     }
     // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs leaves after the hand-off,
     // and the next step's saved forward values are requested a whole step ahead
@@ -1215,6 +1221,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   const int GH = G * H;
   const float *w_ih[2] = {w_ih0, w_ih1};
   for (int d = 0; d < dirs && !ctcn_opt_recurrence_only(); ++d) {
+    if (d > 0) ctcn_gemm_hint_same_a();                 // both directions project the same x: split it into planes once
     int rc = ctcn_gemm(0, 1, T * B, GH, I, x, I, w_ih[d], I, gates + (size_t)d * GH, dirs * GH, 0.0f, precision, ws,
                        ws_bytes, stream);
     if (rc) return rc;
