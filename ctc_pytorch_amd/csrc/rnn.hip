@@ -498,12 +498,21 @@ __device__ __forceinline__ PersistRole persist_role(const PersistArgs &pa, int D
   return r;
 }
 
+// Cross-wave reduction of the persistent kernels: every wave parks its partial C tiles in LDS, ONE barrier, then each item
+// thread adds up the partials of exactly the elements it needs, in wave order (the same fixed order as reduce_tiles, so
+// the sums are bit-identical).  A 16x16 tile occupies 4 row-quads x 96 floats (64 used) and tiles are 400 floats apart:
+// the quads / tiles an item wave touches then fall into disjoint bank groups and every read is conflict-free.
+constexpr int RT_Q = 96, RT_T = 400;
+__device__ __forceinline__ void park_tile(float *red, int slot, int lane, const f32x4 &acc) {
+  *reinterpret_cast<f32x4 *>(red + slot * RT_T + (lane >> 4) * RT_Q + (lane & 15) * 4) = acc;   // C map: col = lane & 15, rows 4*(lane>>4) + 0..3
+}
+__device__ __forceinline__ int parked_at(int row, int col) { return (row >> 2) * RT_Q + col * 4 + (row & 3); }
+
 template <int NT, int KQ4, int PREC>
 __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   constexpr int NW = 4;
   const RnnArgs &p = pa.a;
-  __shared__ float red[NW * NT * 256];
-  __shared__ float outs[NT * 16][17];
+  __shared__ __attribute__((aligned(16))) float red[NW * NT * RT_T];
   __shared__ __attribute__((aligned(16))) float hpub[16][16];   // h_t of this workgroup's units: f32 [row][unit], or (precision 1) two bf16 planes [hi|lo][row][unit]
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -661,7 +670,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
     const long long c_b = clock64();
 #endif
-    reduce_tiles<NT, NW, 4>(acc, red, outs, tid, 256);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) park_tile(red, wave * NT + nt, lane, acc[nt]);
+    lds_barrier();
 #ifdef CTCN_PERSIST_STATS
     const long long c_c = clock64();
     st_poll += c_p - c_a; st_fill += c_f - c_p; st_mm += c_b - c_f; st_red += c_c - c_b;
@@ -669,26 +680,32 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 
     float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f, sv3 = 0.f, sv4 = 0.f, hval = 0.f;     // values this item stores after the hand-off
     if (item) {
-      const float *o = &outs[ont * 16 + bl][0];
+      // recurrent pre-activations of this item: gate g sits in column g*4 + ojl of tile ont (tanh cell: column jl)
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      const float *rp = red + ont * RT_T + parked_at(bl, tanh_cell ? jl : ojl);
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o[g] += rp[w * NT * RT_T + g * 16];          // +4 columns = +16 floats
       if (p.cell == CTCN_CELL_LSTM) {
-        const float i_ = act_sigmoid(o[0 * 4 + ojl] + pre[0]);
-        const float f_ = act_sigmoid(o[1 * 4 + ojl] + pre[1]);
-        const float g_ = act_tanh(o[2 * 4 + ojl] + pre[2]);
-        const float o_ = act_sigmoid(o[3 * 4 + ojl] + pre[3]);
+        const float i_ = act_sigmoid(o[0] + pre[0]);
+        const float f_ = act_sigmoid(o[1] + pre[1]);
+        const float g_ = act_tanh(o[2] + pre[2]);
+        const float o_ = act_sigmoid(o[3] + pre[3]);
         const float c = f_ * state + i_ * g_;
         hval = o_ * act_tanh(c);
         state = c;
         sv0 = i_; sv1 = f_; sv2 = g_; sv3 = o_; sv4 = c;
       } else if (p.cell == CTCN_CELL_GRU) {
-        const float hn = o[2 * 4 + ojl];
-        const float r_ = act_sigmoid(o[0 * 4 + ojl] + pre[0]);
-        const float z_ = act_sigmoid(o[1 * 4 + ojl] + pre[1]);
+        const float hn = o[2];
+        const float r_ = act_sigmoid(o[0] + pre[0]);
+        const float z_ = act_sigmoid(o[1] + pre[1]);
         const float n_ = act_tanh(pre[2] + r_ * hn);
         hval = (1.0f - z_) * n_ + z_ * state;
         state = hval;
         sv0 = r_; sv1 = z_; sv2 = n_; sv4 = hn;
       } else {
-        hval = act_tanh(o[ojl] + pre[0]);
+        hval = act_tanh(o[0] + pre[0]);
       }
       if constexpr (PREC == 0) {
         hpub[bl][jl] = hval;
@@ -847,8 +864,8 @@ template <int KQ4, int PREC>
 __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   constexpr int NW = 16;
   const RnnArgs &p = pa.a;
-  __shared__ __attribute__((aligned(16))) float red[NW * 256];
-  __shared__ float outs[16][17];
+  __shared__ __attribute__((aligned(16))) float red[NW * RT_T];     // parked partial tiles
+  __shared__ __attribute__((aligned(16))) float stage[1024];        // publish stage: 16 x 16 x G block in the granule order of the tile
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -986,7 +1003,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
     const long long q_m = clock64();
 #endif
-    reduce_tiles<1, NW, NW>(acc, red, outs, tid, 1024);
+    park_tile(red, wave, lane, acc[0]);
+    lds_barrier();
 #ifdef CTCN_PERSIST_STATS
     const long long q_r = clock64();
     long long q_e = q_r, q_c = q_r;
@@ -996,8 +1014,14 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     const unsigned px = tile_b[par];                                                                // published tile (bytes)
     float out[4] = {0.f, 0.f, 0.f, 0.f};      // values the next step multiplies by W_hh (published), per gate block
     float dan = 0.f;
+    float rec = 0.0f;                                      // (d(pre-act)_{next} W_hh)[row bl][unit jl], summed in wave order
+    if (tid < 256) {
+      const float *rp = red + parked_at(bl, jl);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) rec += rp[w * RT_T];
+    }
     if (item) {
-      float dh = dyv + outs[bl][jl];
+      float dh = dyv + rec;
       const float e1u = e1_valid ? e1 : 0.0f;                 // c / h of a step before the sequence start is 0
       if (p.cell == CTCN_CELL_LSTM) {
         const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
@@ -1022,15 +1046,15 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
       } else {
         out[0] = dh * (1.0f - e0 * e0);
       }
-      // stage this workgroup's 16 x 16 x G block in LDS (the reduce buffer is free again) in the granule order of the tile
+      // stage this workgroup's 16 x 16 x G block in LDS in the granule order of the tile
       if (s + 1 < T) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (k < G) {
             if constexpr (PREC == 0) {
-              red[((k * 4 + (jl >> 2)) * 16 + bl) * 4 + (jl & 3)] = out[k];
+              stage[((k * 4 + (jl >> 2)) * 16 + bl) * 4 + (jl & 3)] = out[k];
             } else {
-              unsigned short *sp = reinterpret_cast<unsigned short *>(red);
+              unsigned short *sp = reinterpret_cast<unsigned short *>(stage);
               const unsigned hi = f2bf(out[k]);
               sp[((k * 2 + (jl >> 3)) * 16 + bl) * 8 + (jl & 7)] = (unsigned short)hi;
               sp[(((4 + k) * 2 + (jl >> 3)) * 16 + bl) * 8 + (jl & 7)] = f2bf(out[k] - __uint_as_float(hi << 16));
@@ -1049,13 +1073,13 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
         if constexpr (PREC == 0) {
           const int k = tid >> 6, qq = (tid >> 4) & 3, col = k * H + j0 + 4 * qq;
           if (k < G && row < Bc && j0 + 4 * qq < H) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(&red[((k * 4 + qq) * 16 + row) * 4]);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&stage[((k * 4 + qq) * 16 + row) * 4]);
             st_f4(rs, px + (unsigned)(((col >> 4) * 256 + (((col >> 2) & 3) * 16 + row) * 4) * 4), v, local);
           }
         } else {
           const int plane = tid >> 7, k = (tid >> 5) & 3, oct = (tid >> 4) & 1, col = k * H + j0 + 8 * oct;
           if (k < G && row < Bc && j0 + 8 * oct < H) {
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(red) + (((plane * 4 + k) * 2 + oct) * 16 + row) * 8);
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(stage) + (((plane * 4 + k) * 2 + oct) * 16 + row) * 8);
             const unsigned off = px + (unsigned)((col >> 5) * 2048 + plane * 1024 + (((col >> 3) & 3) * 16 + row) * 16);
             if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
