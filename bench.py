@@ -180,6 +180,7 @@ def run_train(args):
     from ctc_pytorch_amd.optim import FlatAdam
     from oracle import synth                      # synthetic inputs only (no arithmetic)
     rank, world, local = parallel.init_from_env()
+    parallel.enable_sync_bn(bool(getattr(args, "sync_bn", False)))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     torch.cuda.set_device(local)
@@ -242,7 +243,8 @@ def run_train(args):
         "dtype": "f32" if args.precision == 0 else "f32 via bf16x3 split-operand MFMA (f32 accumulate)", "data": "synthetic",
         "config": {"workload": "%s: %dx%d Bi%s + BN + Linear(%d) + CTC, B=%d/GPU, T=%d, F=40%s, dropout 0.1, Adam" % (
             args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], ", 2-layer CNN front-end" if c["cnn"] else ""),
-            "global_batch": global_b, "seq_len": c["T"], "parallelism": "dp%d" % world, "full_length_utterances": True},
+            "global_batch": global_b, "seq_len": c["T"], "parallelism": "dp%d" % world, "full_length_utterances": True,
+            "sync_bn": bool(getattr(args, "sync_bn", False))},
         "final_loss": last_loss,
         "model_tflops_per_s": train_flops_per_step * world / (dt / args.steps) / 1e12,
         "per_gpu_frames_per_s": value / world,
@@ -310,6 +312,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over the global batch (N-GPU == 1-GPU math); default: per shard")
     ap.add_argument("--mode", default="train", choices=["train", "decode"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)

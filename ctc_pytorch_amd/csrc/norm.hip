@@ -106,6 +106,16 @@ __global__ void bn_finalize_stats_kernel(const double *__restrict__ part, int nc
   }
 }
 
+// sums[c*2 + {0,1}] = sum over the chunk partials (wave per channel, fixed order): the per-rank half of a synchronised BN
+__global__ void bn_sum_chunks_kernel(const double *__restrict__ part, int nchunks, int C, double *__restrict__ sums) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = lane; k < nchunks; k += 64) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+  s = wave_sum_d(s); ss = wave_sum_d(ss);
+  if (lane == 0) { sums[c * 2] = s; sums[c * 2 + 1] = ss; }
+}
+
 __global__ void bn_finalize_bwd_kernel(const double *__restrict__ part, int nchunks, int C, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, float *__restrict__ sums /*[2*C]: sum dy, sum dy*xhat*/,
                                        float beta_acc) {
@@ -203,6 +213,75 @@ extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, c
   const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C,
                      inner, relu);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+// ---- synchronised BatchNorm (data parallel): statistics over the GLOBAL batch --------------------------------------
+// Each rank computes its per-channel sums (fp64, [C][2]), the host all-reduces them (2*C doubles), and the finish call
+// normalises with the global count.  With one rank the result equals ctcn_bn_fwd_train / ctcn_bn_bwd exactly.
+extern "C" int ctcn_bn_fwd_sums(const float *x, double *sums, int outer, int C, int inner, void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(x && sums && ws, "ctcn_bn_fwd_sums: null pointer");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_fwd_sums: bad dims");
+  if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_fwd_sums: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  int nchunks = 0;
+  launch_reduce(StatVal{x}, outer, C, inner, (double *)ws, &nchunks, st);
+  CTCN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double *)ws, nchunks, C, sums);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_bn_fwd_finish(const float *x, float *y, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                  float *save_mean, float *save_rstd, const double *sums, double count_total, int outer, int C, int inner,
+                                  float eps, float momentum, int relu, void *stream) {
+  CTCN_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && sums, "ctcn_bn_fwd_finish: null pointer");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0 && count_total >= (double)outer * inner, "ctcn_bn_fwd_finish: bad dims / count");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, sums, 1, C, count_total, eps, momentum, save_mean,
+                     save_rstd, running_mean, running_var);
+  CTCN_LAUNCH_CHECK();
+  const size_t total = (size_t)outer * C * inner;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C, inner, relu);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_bn_bwd_sums(const float *x, const float *y, const float *dy, const float *save_mean, const float *save_rstd, double *sums,
+                                int outer, int C, int inner, int relu, void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(x && dy && save_mean && save_rstd && sums && ws, "ctcn_bn_bwd_sums: null pointer");
+  CTCN_REQUIRE(!relu || y, "ctcn_bn_bwd_sums: y required for the fused relu mask");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_bwd_sums: bad dims");
+  if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_bwd_sums: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  int nchunks = 0;
+  launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu}, outer, C, inner, (double *)ws, &nchunks, st);
+  CTCN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double *)ws, nchunks, C, sums);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+// local_sums feed dgamma / dbeta (the gradient all-reduce adds the ranks up later); global_sums and count_total feed dx
+extern "C" int ctcn_bn_bwd_finish(const float *x, const float *y, const float *dy, const float *gamma, const float *save_mean,
+                                  const float *save_rstd, float *dx, float *dgamma, float *dbeta, const double *local_sums,
+                                  const double *global_sums, double count_total, int outer, int C, int inner, int relu, float beta_acc,
+                                  void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && local_sums && global_sums && ws, "ctcn_bn_bwd_finish: null pointer");
+  CTCN_REQUIRE(!relu || y, "ctcn_bn_bwd_finish: y required for the fused relu mask");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0 && count_total >= (double)outer * inner, "ctcn_bn_bwd_finish: bad dims / count");
+  if (ws_bytes < (size_t)4 * C * sizeof(float)) { ctcn_set_error("ctcn_bn_bwd_finish: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  float *scratch = (float *)ws, *sums = scratch + 2 * C;
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, local_sums, 1, C, dgamma, dbeta, scratch, beta_acc);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, global_sums, 1, C, (float *)nullptr, (float *)nullptr, sums, 0.0f);
+  CTCN_LAUNCH_CHECK();
+  const size_t total = (size_t)outer * C * inner;
+  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, sums, dx, total, C, inner,
+                     (float)(1.0 / count_total), relu);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }

@@ -322,6 +322,16 @@ def rnn_layer(x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training=True):
 # --------------------------------------------------------------------------------------------------
 # batch norm (+ fused ReLU)
 # --------------------------------------------------------------------------------------------------
+# Synchronised BatchNorm (data parallel): `_sync_bn["reduce"]` is a callable (sums_tensor, local_count) -> global_count
+# that all-reduces the (C, 2) float64 per-channel sums in place and returns the global element count per channel;
+# parallel.enable_sync_bn() installs the torch.distributed one.  None = per-shard statistics (the fast default).
+_sync_bn = {"reduce": None}
+
+
+def set_sync_bn(reducer):
+    _sync_bn["reduce"] = reducer
+
+
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, outer, C, inner, training, momentum, eps, relu):
@@ -331,7 +341,21 @@ class _BatchNorm(torch.autograd.Function):
         dev = x.device
         y = torch.empty_like(x)
         L = _lib.lib()
-        if training:
+        ctx.sync = None
+        if training and _sync_bn["reduce"] is not None:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            w, wp, wn = _ws(x)
+            _lib.check(L.ctcn_bn_fwd_sums(_ptr(x), _ptr(sums), outer, C, inner, wp, wn, _lib.stream_ptr()), "bn_fwd_sums")
+            total = float(_sync_bn["reduce"](sums, outer * inner))
+            _lib.check(L.ctcn_bn_fwd_finish(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(mean), _ptr(rstd),
+                                            _ptr(sums), total, outer, C, inner, float(eps), float(momentum), int(relu),
+                                            _lib.stream_ptr()), "bn_fwd_finish")
+            ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
+            ctx.train_mode = True
+            ctx.sync = (_sync_bn["reduce"], total)
+        elif training:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
             w, wp, wn = _ws(x)
@@ -365,9 +389,21 @@ class _BatchNorm(torch.autograd.Function):
             dgamma = torch.empty(C, dtype=torch.float32, device=dev)
             dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         w, wp, wn = _ws(x)
-        _lib.check(_lib.lib().ctcn_bn_bwd(_ptr(x), _ptr(y), _ptr(gy), _ptr(gamma), _ptr(a), _ptr(b), _ptr(dx), _ptr(dgamma),
-                                          _ptr(dbeta), outer, C, inner, int(relu), 1.0 if into_flat else 0.0, wp, wn,
-                                          _lib.stream_ptr()), "bn_bwd")
+        if ctx.sync is not None:
+            reducer, total = ctx.sync
+            L = _lib.lib()
+            local = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            _lib.check(L.ctcn_bn_bwd_sums(_ptr(x), _ptr(y), _ptr(gy), _ptr(a), _ptr(b), _ptr(local), outer, C, inner, int(relu), wp, wn,
+                                          _lib.stream_ptr()), "bn_bwd_sums")
+            glob = local.clone()
+            reducer(glob, outer * inner)
+            _lib.check(L.ctcn_bn_bwd_finish(_ptr(x), _ptr(y), _ptr(gy), _ptr(gamma), _ptr(a), _ptr(b), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                            _ptr(local), _ptr(glob), total, outer, C, inner, int(relu), 1.0 if into_flat else 0.0,
+                                            wp, wn, _lib.stream_ptr()), "bn_bwd_finish")
+        else:
+            _lib.check(_lib.lib().ctcn_bn_bwd(_ptr(x), _ptr(y), _ptr(gy), _ptr(gamma), _ptr(a), _ptr(b), _ptr(dx), _ptr(dgamma),
+                                              _ptr(dbeta), outer, C, inner, int(relu), 1.0 if into_flat else 0.0, wp, wn,
+                                              _lib.stream_ptr()), "bn_bwd")
         if into_flat:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None

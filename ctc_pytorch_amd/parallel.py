@@ -46,6 +46,23 @@ def allreduce_grads(flat_grad):
     return flat_grad
 
 
+def _sync_bn_reduce(sums, local_count):
+    """All-reduce of the (C, 2) float64 per-channel BatchNorm sums; returns the global element count per channel.
+    Every rank holds the same padded shard shape (global T_max, equal utterances per rank), so the count is
+    local_count * world_size and needs no second collective."""
+    if world_size() > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return float(local_count) * world_size()
+
+
+def enable_sync_bn(flag=True):
+    """BatchNorm statistics over the GLOBAL batch: N-GPU math equals single-process math on the same
+    global batch, at the price of two tiny (2*C doubles) all-reduces per BatchNorm layer per pass.  Default off:
+    per-shard statistics, the fast documented deviation."""
+    from . import ops
+    ops.set_sync_bn(_sync_bn_reduce if flag else None)
+
+
 def broadcast_params(flat_params, src=0):
     if world_size() > 1:
         dist.broadcast(flat_params, src=src)

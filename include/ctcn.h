@@ -110,6 +110,20 @@ size_t ctcn_bn_ws_bytes(int outer, int C, int inner);
 int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                       float *running_var, float *save_mean, float *save_rstd, int outer, int C, int inner,
                       float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream);
+/* Synchronised BatchNorm for data-parallel training (statistics over the global batch): every rank calls
+ * _sums (per-channel fp64 [C][2]: sum x, sum x^2 / sum dy', sum dy'*xhat), the host all-reduces the 2*C doubles, and
+ * _finish normalises with count_total = global number of elements per channel.  In the backward finish local_sums feed
+ * dgamma / dbeta (the gradient all-reduce adds the ranks up), global_sums feed dx. */
+int ctcn_bn_fwd_sums(const float *x, double *sums, int outer, int C, int inner, void *ws, size_t ws_bytes, void *stream);
+int ctcn_bn_fwd_finish(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, float *save_mean, float *save_rstd, const double *sums, double count_total,
+                       int outer, int C, int inner, float eps, float momentum, int relu, void *stream);
+int ctcn_bn_bwd_sums(const float *x, const float *y, const float *dy, const float *save_mean, const float *save_rstd,
+                     double *sums, int outer, int C, int inner, int relu, void *ws, size_t ws_bytes, void *stream);
+int ctcn_bn_bwd_finish(const float *x, const float *y, const float *dy, const float *gamma, const float *save_mean,
+                       const float *save_rstd, float *dx, float *dgamma, float *dbeta, const double *local_sums,
+                       const double *global_sums, double count_total, int outer, int C, int inner, int relu,
+                       float beta_acc, void *ws, size_t ws_bytes, void *stream);
 int ctcn_bn_fwd_eval(const float *x, float *y, const float *gamma, const float *beta, const float *running_mean,
                      const float *running_var, int outer, int C, int inner, float eps, int relu, void *stream);
 /* y is only read when relu!=0 (mask = y>0). dx may alias dy. */

@@ -6,6 +6,8 @@ Tolerances (SURVEY §8a "Parity tolerances", f32-exact MFMA mode): activations /
 import json
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -256,6 +258,68 @@ def _load_conv_model(dev):
             # running stats of the fixture are post-step values; start from the defaults instead
     m.load_state_dict(sd)
     return m.to(dev), z
+
+
+@pytest.mark.parametrize("rows,C,inner,relu", [(3000, 640, 1, False), (24, 32, 21 * 20, True)])
+def test_sync_batchnorm_two_shards_equal_full_batch(dev, rows, C, inner, relu):
+    """BatchNorm statistics over the GLOBAL batch.  Two 'ranks' hold halves of a batch; their per-channel
+    fp64 sums are added (what the all-reduce does) and each finishes with the global count: outputs, running stats and
+    dx equal the single-process BatchNorm of the whole batch, dgamma / dbeta add up to it."""
+    from ctc_pytorch_amd import _lib, ops
+    L = _lib.lib()
+    rs = np.random.RandomState(rows + C)
+    shape = (rows, C) if inner == 1 else (rows, C, inner)
+    x = torch.from_numpy((rs.standard_normal(shape) * 1.7 + 0.3).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rs.standard_normal(shape).astype(np.float32)).to(dev)
+    g = torch.from_numpy((1 + 0.1 * rs.standard_normal(C)).astype(np.float32)).to(dev)
+    b = torch.from_numpy((0.1 * rs.standard_normal(C)).astype(np.float32)).to(dev)
+    # single process
+    xg, gg, bg = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y = ops.batch_norm(xg, gg, bg, rm, rv, rows, C, inner, True, relu=relu)
+    y.backward(dy)
+    # two shards through the sync path, with a reducer that adds the other shard's sums
+    h = rows // 2
+    parts = [(x[:h].contiguous(), dy[:h].contiguous()), (x[h:].contiguous(), dy[h:].contiguous())]
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    ws = _lib.workspace(dev)
+    wp, wn = ctypes.c_void_p(ws.data_ptr()), ws.numel()
+    st = _lib.stream_ptr()
+    sums = [torch.empty((C, 2), dtype=torch.float64, device=dev) for _ in parts]
+    for (xs, _), sm in zip(parts, sums):
+        _lib.check(L.ctcn_bn_fwd_sums(ptr(xs), ptr(sm), xs.shape[0], C, inner, wp, wn, st), "sums")
+    glob = sums[0] + sums[1]
+    total = float(rows * inner)
+    ys, means, rstds, rms, rvs = [], [], [], [], []
+    for xs, _ in parts:
+        yy, mean, rstd = torch.empty_like(xs), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        _lib.check(L.ctcn_bn_fwd_finish(ptr(xs), ptr(yy), ptr(g), ptr(b), ptr(rm2), ptr(rv2), ptr(mean), ptr(rstd), ptr(glob), total,
+                                        xs.shape[0], C, inner, 1e-5, 0.1, int(relu), st), "finish")
+        ys.append(yy); means.append(mean); rstds.append(rstd); rms.append(rm2); rvs.append(rv2)
+    assert maxabs(torch.cat(ys), y) < 2e-6
+    assert maxabs(rms[0], rm) < 1e-7 and maxabs(rvs[1], rv) < 1e-6 and maxabs(rms[0], rms[1]) == 0
+    lsum = [torch.empty((C, 2), dtype=torch.float64, device=dev) for _ in parts]
+    for (xs, ds), yy, mean, rstd, sm in zip(parts, ys, means, rstds, lsum):
+        _lib.check(L.ctcn_bn_bwd_sums(ptr(xs), ptr(yy), ptr(ds), ptr(mean), ptr(rstd), ptr(sm), xs.shape[0], C, inner, int(relu), wp, wn, st), "bsums")
+    gsum = lsum[0] + lsum[1]
+    dxs, dgs, dbs = [], [], []
+    for (xs, ds), yy, mean, rstd, sm in zip(parts, ys, means, rstds, lsum):
+        dx, dg, db = torch.empty_like(xs), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        _lib.check(L.ctcn_bn_bwd_finish(ptr(xs), ptr(yy), ptr(ds), ptr(g), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), ptr(sm), ptr(gsum),
+                                        total, xs.shape[0], C, inner, int(relu), 0.0, wp, wn, st), "bfinish")
+        dxs.append(dx); dgs.append(dg); dbs.append(db)
+    assert maxabs(torch.cat(dxs), xg.grad) < 2e-6
+    assert rel_l2(dgs[0] + dgs[1], gg.grad) < 1e-6 and rel_l2(dbs[0] + dbs[1], bg.grad) < 1e-6
+    # the autograd path with a 1-rank reducer is the plain BatchNorm
+    ops.set_sync_bn(lambda sm, n: float(n))
+    try:
+        x2, g2, b2 = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y2 = ops.batch_norm(x2, g2, b2, torch.zeros(C, device=dev), torch.ones(C, device=dev), rows, C, inner, True, relu=relu)
+        y2.backward(dy)
+    finally:
+        ops.set_sync_bn(None)
+    assert maxabs(y2, y) < 1e-6 and maxabs(x2.grad, xg.grad) < 1e-6 and rel_l2(g2.grad, gg.grad) < 1e-6
 
 
 def test_conv_front_golden(dev):
