@@ -173,6 +173,9 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
                                         batch_size=opts.batch_size, shuffle=opts.shuffle_train, num_workers=opts.num_workers)
         dev_loader = SpeechDataLoader(SpeechDataset(vocab, opts.valid_scp_path, opts.valid_lab_path, opts),
                                       batch_size=opts.batch_size, shuffle=False, num_workers=opts.num_workers)
+    if device.type == "cuda":
+        from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher
+        train_loader, dev_loader = DevicePrefetcher(train_loader, device), DevicePrefetcher(dev_loader, device)   # async double-buffered H2D
     model = build_model_from_opts(opts, num_class).to(device)
     log("Number of parameters %d" % sum(p.numel() for p in model.parameters()))
     loss_fn = nn.CTCLoss(reduction="sum")

@@ -671,6 +671,69 @@ def test_large_shape_checksums(dev, name):
 # ---------------------------------------------------------------------------------------------------------
 # decoders
 # ---------------------------------------------------------------------------------------------------------
+def test_device_prefetcher_yields_the_loader_batches(dev):
+    """async double-buffered H2D staging; same tensors, same order, targets / sizes on the device."""
+    from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher, create_input
+    rs = np.random.RandomState(4)
+    items = [(torch.from_numpy(rs.standard_normal((int(rs.randint(20, 60)), 40)).astype(np.float32)),
+              torch.from_numpy(rs.randint(1, 30, size=int(rs.randint(3, 9))).astype(np.int64)), "utt%d" % i) for i in range(10)]
+    batches = [create_input(items[i:i + 4]) for i in range(0, 10, 4)]
+    got = list(DevicePrefetcher(batches, dev))
+    assert len(got) == len(batches) == 3
+    for g, w in zip(got, batches):
+        assert g[0].device.type == "cuda" and g[2].device.type == "cuda" and g[3].device.type == "cuda" and g[1].device.type == "cpu"
+        assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2].cpu(), w[2]) and torch.equal(g[3].cpu(), w[3])
+        assert g[4] == w[4]
+    assert list(DevicePrefetcher([], dev)) == []
+
+
+def test_end_to_end_train_checkpoint_decode(dev, tmp_path):
+    """The reference's workflow on a toy corpus, through the drop-in drivers: Kaldi ark/scp + label + vocab files ->
+    steps/train_ctc.main (SpeechDataset, async prefetcher, run_epoch, FlatAdam, LR controller, save_package) ->
+    steps/test_ctc.load_package + decode_and_score with the greedy and the LM beam decoder."""
+    from ctc_pytorch_amd.steps import test_ctc as TE, train_ctc as TR
+    from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder, GreedyDecoder
+    from ctc_pytorch_amd.utils.data_loader import SpeechDataLoader, SpeechDataset, Vocab, write_kaldi_ark
+    rs = np.random.RandomState(7)
+    phones = ["p%d" % i for i in range(8)]
+    proto = rs.standard_normal((len(phones), 40)).astype(np.float32) * 2.0
+    mats, labs = {}, {}
+    for u in range(24):
+        seq = [int(k) for k in rs.randint(0, len(phones), size=int(rs.randint(4, 8)))]
+        frames = [proto[k] + 0.3 * rs.standard_normal(40) for k in seq for _ in range(int(rs.randint(5, 9)))]
+        mats["utt%02d" % u] = np.asarray(frames, dtype=np.float32)
+        labs["utt%02d" % u] = " ".join(phones[k] for k in seq)
+    d = str(tmp_path)
+    write_kaldi_ark(d + "/feats.ark", d + "/feats.scp", mats)
+    open(d + "/text", "w").write("".join("%s %s\n" % kv for kv in labs.items()))
+    open(d + "/vocab", "w").write("".join("%d %s\n" % (i, ph) for i, ph in enumerate(phones)))
+    synth.write_arpa(d + "/lm.arpa", ["UNK"] + phones, seed=3, n_bigrams=40)
+    conf = dict(vocab_file=d + "/vocab", train_scp_path=d + "/feats.scp", train_lab_path=d + "/text", valid_scp_path=d + "/feats.scp",
+                valid_lab_path=d + "/text", left_ctx=0, right_ctx=0, n_skip_frame=1, n_downsample=1, batch_size=8, shuffle_train=False,
+                num_workers=0, rnn_input_size=40, rnn_hidden_size=32, rnn_layers=2, rnn_type="nn.LSTM", bidirectional=True,
+                batch_norm=True, add_cnn=False, layers=2, channel="[(1,32),(32,32)]", kernel_size="[(3,3),(3,3)]", stride="[(1,2),(2,2)]",
+                padding="[(1,1),(1,1)]", pooling="None", activation_function="relu", drop_out=0.0, init_lr=1e-2, weight_decay=0.0,
+                end_adjust_acc=2.0, lr_decay=0.5, num_epoches=6, verbose_step=100, seed=1, checkpoint_dir=d + "/ckpt", exp_name="toy")
+    lines = []
+    model, hist = TR.main(conf, log=lines.append)
+    assert len(hist["loss"]) == 6 and hist["loss"][-1] < 0.6 * hist["loss"][0], hist["loss"]
+    assert hist["dev_acc"][-1] > hist["dev_acc"][0]
+    m2, package = TE.load_package(d + "/ckpt/toy/ctc_best_model.pkl", dev)
+    assert package["epoch"]["epoch"] == 6 and set(m2.state_dict()) == set(model.state_dict())
+    vocab = Vocab(d + "/vocab")
+
+    class O:
+        left_ctx = right_ctx = 0
+        n_skip_frame = n_downsample = 1
+    loader = SpeechDataLoader(SpeechDataset(vocab, d + "/feats.scp", d + "/text", O), batch_size=8, shuffle=False)
+    cer_g, wer_g = TE.decode_and_score(m2, loader, GreedyDecoder(vocab.index2word, space_idx=-1, blank_index=0), vocab.index2word, dev, log=lines.append)
+    cer_b, wer_b = TE.decode_and_score(m2, loader, BeamDecoder(vocab.index2word, beam_width=5, blank_index=0, space_idx=-1, lm_path=d + "/lm.arpa",
+                                                               lm_alpha=0.01), vocab.index2word, dev, log=lines.append)
+    assert 0.0 <= wer_g < 100.0 and np.isfinite(cer_g) and np.isfinite(cer_b) and np.isfinite(wer_b)
+    # the greedy WER of the scoring script equals 1 - accuracy of the training-time on-device PER at the best epoch
+    assert abs(wer_g / 100.0 - (1.0 - max(hist["dev_acc"]))) < 1e-6, (wer_g, hist["dev_acc"])
+
+
 def test_greedy_decoder_golden(dev):
     from ctc_pytorch_amd import nn, ops
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
