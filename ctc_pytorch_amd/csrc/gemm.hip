@@ -80,26 +80,16 @@ __device__ __forceinline__ void r2s_mc(float (*s)[BM + PAD], int tid, const floa
 }
 
 // TA: A stored [K][M] (m contiguous).  TB: B stored [N][K] (k contiguous).
+// one 128x128 output tile (`bid`) of K-split `split`
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
-                                                       const float *__restrict__ B, int ldb, float *__restrict__ C,
-                                                       int ldc, float beta, int kchunk, float *__restrict__ ws,
-                                                       int tiles_m, int tiles_n, bool vecA, bool vecB) {
-  __shared__ __attribute__((aligned(16))) float sA[BK][BM + PAD];
-  __shared__ __attribute__((aligned(16))) float sB[BK][BN + PAD];
+__device__ __forceinline__ void f32_tile(float (*sA)[BM + PAD], float (*sB)[BN + PAD], int bid, int split, int M, int N, int K,
+                                         const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, float *__restrict__ C,
+                                         int ldc, float beta, int kchunk, float *__restrict__ ws, int tiles_n, bool vecA, bool vecB) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware remap (bijective for any tile count): blocks b, b+8, b+16.. share an XCD/L2.
-  const int nt = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;   // consecutive ids walk N first: share the A panel
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.y * kchunk;
+  const int kbeg = split * kchunk;
   const int kend = min(K, kbeg + kchunk);
 
   f32x16 acc[2][2];
@@ -144,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float *out = ws ? ws + (size_t)blockIdx.y * M * N : C;
+  float *out = ws ? ws + (size_t)split * M * N : C;
   const int ldo = ws ? N : ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -162,6 +152,47 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
         }
       }
     }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                       const float *__restrict__ B, int ldb, float *__restrict__ C,
+                                                       int ldc, float beta, int kchunk, float *__restrict__ ws,
+                                                       int tiles_m, int tiles_n, bool vecA, bool vecB) {
+  __shared__ __attribute__((aligned(16))) float sA[BK][BM + PAD];
+  __shared__ __attribute__((aligned(16))) float sB[BK][BN + PAD];
+  // XCD-aware remap (bijective for any tile count): blocks b, b+8, b+16.. share an XCD/L2.
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  f32_tile<TA, TB>(sA, sB, bid, blockIdx.y, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, ws, tiles_n, vecA, vecB);
+}
+
+// XCD-filtered variant for the weight-gradient side stream (see gemm_planes_nt_queue_kernel)
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_queue_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                             const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                                                             float beta, int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n,
+                                                             bool vecA, bool vecB, int splits, unsigned xcd_allow,
+                                                             unsigned *__restrict__ queue) {
+  __shared__ __attribute__((aligned(16))) float sA[BK][BM + PAD];
+  __shared__ __attribute__((aligned(16))) float sB[BK][BN + PAD];
+  __shared__ int s_item;
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (!((xcd_allow >> (x & 15)) & 1u)) return;
+  const int nt = tiles_m * tiles_n, total = nt * splits;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= total) return;
+    f32_tile<TA, TB>(sA, sB, item % nt, item / nt, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, ws, tiles_n, vecA, vecB);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,7 +697,18 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
 #define LAUNCH(KERN, TA, TB)                                                                             \
   hipLaunchKernelGGL((KERN<TA, TB>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, wsp, \
                      tiles_m, tiles_n, vecA, vecB)
-  if (precision == 0) {
+  if (precision == 0 && xcd_allow && ws && ws_bytes >= (size_t)splits * M * N * sizeof(float) * (splits > 1 ? 1 : 0) + 512) {
+    // side stream next to a persistent recurrence: tiles from an atomic queue, workgroups off the allowed XCDs exit
+    unsigned *queue = (unsigned *)((char *)ws + ((ws_bytes - 256) & ~(size_t)255));
+    CTCN_HIP(hipMemsetAsync(queue, 0, 4, st));
+    const dim3 qgrid(2 * ctcn_device_cus());
+#define QLAUNCH(TA, TB)                                                                                              \
+  hipLaunchKernelGGL((gemm_f32_queue_kernel<TA, TB>), qgrid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, wsp, \
+                     tiles_m, tiles_n, vecA, vecB, splits, xcd_allow, queue)
+    if (transA) { if (transB) QLAUNCH(true, true); else QLAUNCH(true, false); }
+    else        { if (transB) QLAUNCH(false, true); else QLAUNCH(false, false); }
+#undef QLAUNCH
+  } else if (precision == 0) {
     if (transA) { if (transB) LAUNCH(gemm_f32_kernel, true, true); else LAUNCH(gemm_f32_kernel, true, false); }
     else        { if (transB) LAUNCH(gemm_f32_kernel, false, true); else LAUNCH(gemm_f32_kernel, false, false); }
   } else {

@@ -285,7 +285,7 @@ class _RNNLayer(torch.autograd.Function):
         # XCDs a persistent recurrence of this shape leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
         nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
         allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
-        side = into_flat and _side["enabled"] and get_precision() == 1 and allow != 0 and T > 1
+        side = into_flat and _side["enabled"] and allow != 0 and T > 1
         if dx is None:
             allow = 0            # bottom layer: no recurrence follows, its weight GEMMs may use the whole device
         null = ctypes.c_void_p(None)

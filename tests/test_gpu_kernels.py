@@ -495,9 +495,10 @@ def _build_model(tag, dev):
     return m.to(dev), z
 
 
+@pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 128, 8, 60), ("GRU", 192, 40, 25)])
-def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T):
-    """precision 1 + FlatAdam: the weight-gradient GEMMs run on the second stream, restricted to the XCDs the next
+def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
+    """FlatAdam, both matmul precisions: the weight-gradient GEMMs run on the second stream, restricted to the XCDs the next
     layer's persistent recurrence leaves idle (queue kernels), and are joined when backward ends.  Same flat gradient,
     bit for bit, as the inline path (same tiles, same split-K order), also over two accumulating backward passes."""
     from ctc_pytorch_amd import nn, ops
@@ -517,7 +518,7 @@ def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T):
     flat = next(p for p in m.parameters())._ctcn_grad
     base = flat.untyped_storage()
     grads = {}
-    ops.set_precision(1)
+    ops.set_precision(prec)
     try:
         for side in (False, True):
             ops.set_side_stream(side)
