@@ -20,8 +20,9 @@ extern "C" int ctcn_device_cus(void) {
 }
 
 // ---- runtime options / sticky device status word ---------------------------------------------------------
-// rnn_persistent: 1 = persistent recurrent kernels (W_hh resident in VGPRs, in-launch granule hand-off of h_t);
-//                 0 = one launch per timestep.  Both produce the same numbers.
+// rnn_persistent: 1 = persistent recurrent kernels (W_hh resident in VGPRs, in-launch flag + tile hand-off of h_t);
+//                 0 = one launch per timestep.  Same arithmetic, same summation order (tests hold them to 2e-6).
+// handoff, poll_depth, rnn_recurrence_only: see include/ctcn.h.
 static int g_opt_rnn_persistent = 1;
 static int g_opt_handoff = 1;
 static int g_opt_poll_depth = 2;

@@ -372,7 +372,7 @@ struct PersistArgs {
   int spin_limit;
   int local;            // 1: every (direction, batch-tile) group sits on ONE XCD and hands off through that XCD's L2
                         //    (write-back stores + L1-bypassing loads: ~0.3 us one way); 0: device scope (write-through, ~0.6 us)
-  int nx;               // XCDs of the device (local mode: linear workgroup id i runs on XCD i % nx)
+  int nx;               // XCDs of the device (local mode: group g lives on XCD g % nx; see persist_role)
   int nsl, nbt;         // slices per group, batch tiles
   int wpx;              // local mode: working workgroups per XCD
   unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)

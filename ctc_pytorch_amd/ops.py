@@ -287,7 +287,8 @@ class _RNNLayer(torch.autograd.Function):
         allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
         side = into_flat and _side["enabled"] and allow != 0 and T > 1
         if dx is None:
-            allow = 0            # bottom layer: no recurrence follows, its weight GEMMs may use the whole device
+            side = False         # bottom layer: no recurrence follows; its weight GEMMs run inline on the main stream, which
+                                 # would otherwise idle while the side stream finishes the layer above
         null = ctypes.c_void_p(None)
         _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
                                   _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
