@@ -360,7 +360,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 // per-wave flags 5.7-5.9 | 8-B granule tiles without flags 5.5 | 16-B {v0,v1,v2,tag} granules swept block-wide 6.9 |
 // 2-3 polls in flight / paced polls over the fabric 5.0-5.7 | buffer_inv sc0 + plain loads: stale L1 lines (incorrect) |
 // XCD-local, no flags at all: {bf16 hi, lo} words with the step number in the LSBs of lo, every wave re-loading its stale
-// granules: 2.3-2.5, i.e. no gain over flag + data (2.2) -- the re-load traffic of 160 spinning waves delays the stores.
+// granules: 2.3-2.5, i.e. no gain over flag + data (2.2) -- the re-load traffic of 160 spinning waves delays the stores |
+// 5 waves per workgroup (16 units = 4 item waves + a communication wave of its own, 20 workgroups per group, one per CU, no
+// stragglers): flag wait 2100 -> 1500 cycles but tile loads and publish longer, 2.05 us either way.
 // grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
 // workgroups co-resident (occupancy-checked on the host).
 // ================================================================================================
