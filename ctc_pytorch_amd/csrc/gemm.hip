@@ -435,47 +435,48 @@ __global__ __launch_bounds__(256) void split_transpose_queue_kernel(const float 
 
 __device__ __forceinline__ int pswz(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }   // byte offset in a plane tile
 
-// one 128x128 output tile (`bid`) of K-split `split`; sm = the workgroup's four 16-KiB plane tiles
-__device__ __forceinline__ void plane_tile(unsigned char (*sm)[BM * 128], int bid, int split, int M, int N, int Kp,
+// One (64*TI) x (64*TJ) output tile (`bid`) of K-split `split`.  2 x 2 waves, each owning (32*TI) x (32*TJ) = TI x TJ
+// MFMA tiles: per 16-k step a wave reads 2*(TI + TJ) fragments from LDS for 3*TI*TJ MFMAs, so the LDS traffic per MFMA
+// falls from 0.67 fragments (TI = TJ = 2) to 0.5 (2 x 4 / 4 x 2) -- the 128x128 kernel is LDS-bound, not MFMA-bound.
+// sm = dynamic LDS: [Ah | Al] (64*TI rows x 128 B each) then [Bh | Bl] (64*TJ rows x 128 B each).
+template <int TI, int TJ>
+__device__ __forceinline__ void plane_tile(unsigned char *sm, int bid, int split, int M, int N, int Kp,
                                            const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
                                            const unsigned short *__restrict__ Bh, const unsigned short *__restrict__ Bl,
                                            float *__restrict__ C, int ldc, float beta, int kchunk, float *__restrict__ ws, int tiles_n) {
+  constexpr int TBM = 64 * TI, TBN = 64 * TJ;
+  constexpr int CA = TBM * 8 / 256, CB = TBN * 8 / 256;              // 16-B staging chunks per thread and plane
+  unsigned char *sAh = sm, *sAl = sm + TBM * 128, *sBh = sm + 2 * TBM * 128, *sBl = sBh + TBN * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TBM, n0 = tn * TBN;
   const int kbeg = split * kchunk;
   const int kend = min(Kp, kbeg + kchunk);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // staging map: 128 rows x 8 chunks(16 B) per plane tile = 1024 chunks -> 4 per thread per plane
-  int srow[4], skc[4];
+  // element offsets of this thread's chunks in the A-side and B-side planes (rows clamped: out-of-range rows are never stored)
+  unsigned offA[CA], offB[CB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = tid + 256 * j;
-    srow[j] = idx >> 3;
-    skc[j] = idx & 7;
-  }
-  // element offsets of this thread's 4 chunks in the A-side and B-side planes (rows clamped: out-of-range rows are never stored)
-  unsigned offA[4], offB[4];
+  for (int j = 0; j < CA; ++j) offA[j] = (unsigned)min(m0 + ((tid + 256 * j) >> 3), M - 1) * (unsigned)Kp + ((tid + 256 * j) & 7) * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    offA[j] = (unsigned)min(m0 + srow[j], M - 1) * (unsigned)Kp + skc[j] * 8;
-    offB[j] = (unsigned)min(n0 + srow[j], N - 1) * (unsigned)Kp + skc[j] * 8;
-  }
-  u32x4 pAh[4], pAl[4], pBh[4], pBl[4];      // ext-vector values (arrays of HIP's uint4 class end up in scratch)
+  for (int j = 0; j < CB; ++j) offB[j] = (unsigned)min(n0 + ((tid + 256 * j) >> 3), N - 1) * (unsigned)Kp + ((tid + 256 * j) & 7) * 8;
+  u32x4 pAh[CA], pAl[CA], pBh[CB], pBl[CB];      // ext-vector values (arrays of HIP's uint4 class end up in scratch)
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CA; ++j) {
       pAh[j] = *reinterpret_cast<const u32x4 *>(Ah + offA[j] + k0);
       pAl[j] = *reinterpret_cast<const u32x4 *>(Al + offA[j] + k0);
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
       pBh[j] = *reinterpret_cast<const u32x4 *>(Bh + offB[j] + k0);
       pBl[j] = *reinterpret_cast<const u32x4 *>(Bl + offB[j] + k0);
     }
@@ -484,12 +485,16 @@ __device__ __forceinline__ void plane_tile(unsigned char (*sm)[BM * 128], int bi
   for (int k0 = kbeg; k0 < kend; k0 += PBK) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int so = pswz(srow[j], skc[j]);
-      *reinterpret_cast<u32x4 *>(&sm[0][so]) = pAh[j];
-      *reinterpret_cast<u32x4 *>(&sm[1][so]) = pAl[j];
-      *reinterpret_cast<u32x4 *>(&sm[2][so]) = pBh[j];
-      *reinterpret_cast<u32x4 *>(&sm[3][so]) = pBl[j];
+    for (int j = 0; j < CA; ++j) {
+      const int so = pswz((tid + 256 * j) >> 3, (tid + 256 * j) & 7);
+      *reinterpret_cast<u32x4 *>(sAh + so) = pAh[j];
+      *reinterpret_cast<u32x4 *>(sAl + so) = pAl[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int so = pswz((tid + 256 * j) >> 3, (tid + 256 * j) & 7);
+      *reinterpret_cast<u32x4 *>(sBh + so) = pBh[j];
+      *reinterpret_cast<u32x4 *>(sBl + so) = pBl[j];
     }
     __syncthreads();
     if (k0 + PBK < kend) gload(k0 + PBK);
@@ -497,20 +502,24 @@ __device__ __forceinline__ void plane_tile(unsigned char (*sm)[BM * 128], int bi
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kc = ks * 2 + g;
-      bf16x8_t ah[2], al[2], bh[2], bl[2];
+      bf16x8_t ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + ml, rb = wn * 64 + i * 32 + ml;
-        ah[i] = *reinterpret_cast<const bf16x8_t *>(&sm[0][pswz(ra, kc)]);
-        al[i] = *reinterpret_cast<const bf16x8_t *>(&sm[1][pswz(ra, kc)]);
-        bh[i] = *reinterpret_cast<const bf16x8_t *>(&sm[2][pswz(rb, kc)]);
-        bl[i] = *reinterpret_cast<const bf16x8_t *>(&sm[3][pswz(rb, kc)]);
+      for (int i = 0; i < TI; ++i) {
+        const int ra = wm * 32 * TI + i * 32 + ml;
+        ah[i] = *reinterpret_cast<const bf16x8_t *>(sAh + pswz(ra, kc));
+        al[i] = *reinterpret_cast<const bf16x8_t *>(sAl + pswz(ra, kc));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TJ; ++j) {
+        const int rb = wn * 32 * TJ + j * 32 + ml;
+        bh[j] = *reinterpret_cast<const bf16x8_t *>(sBh + pswz(rb, kc));
+        bl[j] = *reinterpret_cast<const bf16x8_t *>(sBl + pswz(rb, kc));
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
@@ -519,13 +528,13 @@ __device__ __forceinline__ void plane_tile(unsigned char (*sm)[BM * 128], int bi
   float *out = ws ? ws + (size_t)split * M * N : C;
   const int ldo = ws ? N : ldc;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + wn * 32 * TJ + j * 32 + (lane & 31);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * 32 * TI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) {
           float v = acc[i][j][e];
           float *p = out + (size_t)row * ldo + col;
@@ -536,29 +545,31 @@ __device__ __forceinline__ void plane_tile(unsigned char (*sm)[BM * 128], int bi
     }
 }
 
+template <int TI, int TJ>
 __global__ __launch_bounds__(256) void gemm_planes_nt_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
                                                              const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
                                                              const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
                                                              int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char sm[4][BM * 128];      // Ah | Al | Bh | Bl tiles, 16 KiB each
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];       // Ah | Al | Bh | Bl tiles
   const int nt = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
     const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  plane_tile(sm, bid, blockIdx.y, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, kchunk, ws, tiles_n);
+  plane_tile<TI, TJ>(psm, bid, blockIdx.y, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, kchunk, ws, tiles_n);
 }
 
 // Same GEMM for a side stream that must stay off the XCDs a persistent recurrence is running on: workgroups that wake up
 // on an XCD outside `xcd_allow` (bit x = XCD x, read from HW_REG_XCC_ID) exit at once, the others pull (tile, split)
 // items from an atomic queue until it is empty.  The launch is sized to fill the allowed XCDs, not the tile count.
+template <int TI, int TJ>
 __global__ __launch_bounds__(256) void gemm_planes_nt_queue_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
                                                                    const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
                                                                    const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc,
                                                                    float beta, int kchunk, float *__restrict__ ws, int tiles_m, int tiles_n,
                                                                    int splits, unsigned xcd_allow, unsigned *__restrict__ queue) {
-  __shared__ __attribute__((aligned(16))) unsigned char sm[4][BM * 128];
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   __shared__ int s_item;
   unsigned x;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -569,9 +580,28 @@ __global__ __launch_bounds__(256) void gemm_planes_nt_queue_kernel(int M, int N,
     __syncthreads();
     const int item = s_item;
     if (item >= total) return;
-    plane_tile(sm, item % nt, item / nt, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, kchunk, ws, tiles_n);
+    plane_tile<TI, TJ>(psm, item % nt, item / nt, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, kchunk, ws, tiles_n);
     __syncthreads();
   }
+}
+
+// launch one of the three tile shapes (dynamic LDS = 2 planes x (BM + BN) rows x 128 B)
+template <int TI, int TJ>
+static int launch_planes(bool queued, int nt, int psplits, hipStream_t st, int M, int N, int Kp, const unsigned short *ah, const unsigned short *al,
+                         const unsigned short *bh, const unsigned short *bl, float *C, int ldc, float beta, int pchunk, float *part, int tiles_m,
+                         int tiles_n, unsigned xcd_allow, unsigned *queue) {
+  const size_t lds = (size_t)2 * (64 * TI + 64 * TJ) * 128;
+  if (queued) {
+    auto kern = gemm_planes_nt_queue_kernel<TI, TJ>;
+    if (lds > 64 * 1024) CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(2 * ctcn_device_cus()), dim3(256), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk, part, tiles_m, tiles_n,
+                       psplits, xcd_allow, queue);
+  } else {
+    auto kern = gemm_planes_nt_kernel<TI, TJ>;
+    if (lds > 64 * 1024) CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(nt, psplits), dim3(256), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk, part, tiles_m, tiles_n);
+  }
+  return CTCN_OK;
 }
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc,
@@ -662,9 +692,25 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       g_last_a.valid = !xcd_allow;
       split(B, ldb, transB == 0, N, bh, bl);
       CTCN_LAUNCH_CHECK();
+      // tile shape: 128x128 (two workgroups per CU).  Option gemm_big_tiles: 256x128 / 128x256 tiles (one per CU, 96 KB of LDS)
+      // when they fill the device at least once without more padding -- 25 % fewer LDS fragment reads per MFMA, yet measured
+      // 7 % SLOWER at cfg2 / 4 % at cfg4 (the second resident workgroup hides the staging barriers better), so off by default
+      int shape = 0, ptm = tiles_m, ptn = tiles_n;
+      {
+        const long t22 = (long)tiles_m * tiles_n * 128 * 128;
+        const int m42 = ceil_div(M, 256), n42 = ceil_div(N, 128), m24 = ceil_div(M, 128), n24 = ceil_div(N, 256);
+        const long t42 = (long)m42 * n42 * 256 * 128, t24 = (long)m24 * n24 * 128 * 256;
+        const int min_tiles = ctcn_device_cus();
+        const bool ok42 = m42 * n42 >= min_tiles && t42 <= t22 + t22 / 32, ok24 = m24 * n24 >= min_tiles && t24 <= t22 + t22 / 32;
+        if (ctcn_opt_gemm_big_tiles() && (ok42 || ok24)) {
+          if (ok24 && (!ok42 || t24 <= t42)) { shape = 2; ptm = m24; ptn = n24; }
+          else { shape = 1; ptm = m42; ptn = n42; }
+        }
+      }
+      const int pnt = ptm * ptn;
       int psplits = 1;
-      if (nt < 256 && Kp >= 1024 && part_bytes >= (size_t)2 * M * N * sizeof(float)) {
-        psplits = std::min(std::min(ceil_div(512, nt), Kp / 512), (int)(part_bytes / ((size_t)M * N * sizeof(float))));
+      if (pnt < 256 && Kp >= 1024 && part_bytes >= (size_t)2 * M * N * sizeof(float)) {
+        psplits = std::min(std::min(ceil_div(512, pnt), Kp / 512), (int)(part_bytes / ((size_t)M * N * sizeof(float))));
         if (psplits < 2) psplits = 1;
       }
       int pchunk = Kp;
@@ -672,13 +718,12 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
         pchunk = ceil_div(ceil_div(Kp, psplits), PBK) * PBK;
         psplits = ceil_div(Kp, pchunk);
       }
-      if (xcd_allow) {
-        hipLaunchKernelGGL(gemm_planes_nt_queue_kernel, dim3(2 * ctcn_device_cus()), dim3(256), 0, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta,
-                           pchunk, psplits > 1 ? part : (float *)nullptr, tiles_m, tiles_n, psplits, xcd_allow, queue);
-      } else {
-        hipLaunchKernelGGL(gemm_planes_nt_kernel, dim3(nt, psplits), dim3(256), 0, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk,
-                           psplits > 1 ? part : (float *)nullptr, tiles_m, tiles_n);
-      }
+      float *pp = psplits > 1 ? part : (float *)nullptr;
+      int lrc;
+      if (shape == 1) lrc = launch_planes<4, 2>(xcd_allow != 0, pnt, psplits, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk, pp, ptm, ptn, xcd_allow, queue);
+      else if (shape == 2) lrc = launch_planes<2, 4>(xcd_allow != 0, pnt, psplits, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk, pp, ptm, ptn, xcd_allow, queue);
+      else lrc = launch_planes<2, 2>(xcd_allow != 0, pnt, psplits, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, pchunk, pp, ptm, ptn, xcd_allow, queue);
+      if (lrc) return lrc;
       CTCN_LAUNCH_CHECK();
       if (psplits > 1) {
         const size_t total = (size_t)M * N;

@@ -81,6 +81,33 @@ def test_gemm(dev, ta, tb, M, N, K, prec):
     ops.set_precision(0)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(8192, 1024, 200, 0, 1), (1024, 8192, 136, 0, 1), (8190, 1030, 72, 0, 0), (25600, 640, 1280, 0, 0)])
+def test_gemm_bf16x3_big_tiles_equal_small_tiles(dev, M, N, K, ta, tb):
+    """precision 1: the optional 256x128 / 128x256 workgroup tiles (`gemm_big_tiles`; fewer LDS fragment reads per MFMA,
+    but one workgroup per CU: measured slower, so off by default) accumulate every output element over k in the same
+    order with the same operands as the 128x128 tiling: bit-identical results, both within bf16x3 accuracy of float64."""
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(M % 1000 + K)
+    A = torch.from_numpy(rs.standard_normal((K, M) if ta else (M, K)).astype(np.float32)).to(dev)
+    B = torch.from_numpy(rs.standard_normal((N, K) if tb else (K, N)).astype(np.float32)).to(dev)
+    outs = []
+    ops.set_precision(1)
+    try:
+        for big in (0, 1):
+            ops.set_option("gemm_big_tiles", big)
+            C = torch.full((M, N), float("nan"), device=dev)
+            ops.gemm(ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C, N)
+            outs.append(C)
+    finally:
+        ops.set_option("gemm_big_tiles", 0)
+        ops.set_precision(0)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+    rows = torch.arange(0, M, max(1, M // 64), device=dev)
+    Ad = (A.t() if ta else A)[rows].double()
+    ref = Ad @ (B.t() if tb else B).double()
+    assert float((outs[1][rows].double() - ref).abs().max()) < 2e-4 * (K ** 0.5)
+
+
 @pytest.mark.parametrize("kind", ["lstm", "gru", "rnn"])
 def test_rnn_layer_golden(dev, kind):
     from ctc_pytorch_amd import ops
