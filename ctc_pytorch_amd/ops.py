@@ -307,9 +307,9 @@ class _RNNLayer(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(st)             # the caching allocator must not recycle them under the side stream
             key = (dev.type, dev.index)
-            if key not in _side["pending"]:
-                _side["pending"][key] = st
-                torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
+            _side["pending"][key] = st
+            # one join per layer is harmless and keeps the path safe if an earlier backward pass died before its callback ran
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if into_flat:
             return dx, None, None, None, None, None, None
         return dx, d_ih0, d_hh0, d_ih1, d_hh1, None, None

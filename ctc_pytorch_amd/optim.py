@@ -46,9 +46,11 @@ class FlatAdam:
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=params)]
 
     def zero_grad(self, set_to_none=False):
+        ops.join_side_stream()            # no-op unless weight gradients are still in flight on the side stream
         self.grad.zero_()
 
     def step(self):
+        ops.join_side_stream()
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],

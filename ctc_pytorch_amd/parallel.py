@@ -41,6 +41,9 @@ def shard_range(n_items, rank, world):
 
 def allreduce_grads(flat_grad):
     """SUM all-reduce of the flat gradient buffer (loss is already divided by the GLOBAL batch size)."""
+    if flat_grad.is_cuda:
+        from . import ops
+        ops.join_side_stream()            # weight gradients issued on the side stream must have landed
     if world_size() > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
