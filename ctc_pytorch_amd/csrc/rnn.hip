@@ -1137,6 +1137,257 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
   if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
+// ================================================================================================
+// Persistent backward recurrence, SCATTER formulation (the default).
+//
+// rnn_bwd_persist (above) makes every workgroup pull the whole 16 x G*H tile of d(pre-activation) each step: 80 KB per CU
+// and step at H = 320, i.e. 1250 cycles of its 64 B/clk L2 port before the matmul can finish -- the reason the backward
+// step was 0.65 us slower than the forward one.  Here the product is split the other way: dh_{t-1} = da_t * W_hh, and a
+// workgroup multiplies ITS OWN 16 x (G*16) block of da_t (it has just computed it) by its G*16 rows of W_hh, for all H
+// outputs: nsl partial 16 x 16 tiles, one per owner of 16 hidden units, which it scatters as 1-KB blocks (the MFMA C
+// layout, one 16-B store per lane).  The owner gathers the nsl partials addressed to it (wave w loads sources w, w+16,
+// ...), and the sum over sources runs through the same parked-tile / item-sum code as the sum over waves did before.
+// Per step a CU now reads 1 KB x nsl and writes 1 KB x nsl (20 KB each at H = 320), d(pre-activation) never travels
+// between workgroups (it only goes to the reserve for the deferred GEMMs), and W_hh costs 16 VGPRs per tile.
+// k order inside the 64-wide block: precision 1: two 32-k MFMA blocks, lane octet q -> gate 2*blk + (q >> 1), units
+// 8*(q & 1) .. +7; precision 0: k = gate * 16 + unit, consumed 4 at a time by v_mfma_f32_16x16x4_f32.
+// grid as rnn_bwd_persist; NTW = ceil(nsl / 16) tiles (and source blocks) per wave.
+// ================================================================================================
+template <int NTW, int PREC>
+__global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
+  constexpr int NW = 16;
+  const RnnArgs &p = pa.a;
+  __shared__ __attribute__((aligned(16))) float red[NW * RT_T];        // parked partial tiles (one per wave)
+  __shared__ __attribute__((aligned(16))) float stage[1024];           // this workgroup's da block as MFMA A operand
+  __shared__ int s_abort;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  __shared__ int s_ticket;
+  const PersistRole role = persist_role(pa, D, &s_ticket);
+  if (!role.active) return;
+  const int d = role.d, bt = role.bt, nbt = pa.nbt, nsl = pa.nsl, slice = role.slice, local = pa.local;
+  const int b0 = bt * 16, j0 = slice * 16;
+  const int Bc = min(16, B - b0);
+  const int K = G * H;
+  const float *WT = d == 0 ? p.w0 : p.w1;                               // W_hh^T: row = hidden unit (output n), K columns
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) s_abort = 0;
+  for (int i = tid; i < 1024; i += 1024) stage[i] = 0.0f;              // rows / units nobody owns stay 0
+
+  // W operand of this lane for its NTW output tiles (tile t = the 16 hidden units owned by slice t)
+  bf16x8_t whi[NTW][2], wlo[NTW][2];
+  float wf[NTW][16];
+#pragma unroll
+  for (int tw = 0; tw < NTW; ++tw) {
+    const int n = 16 * (wave + 16 * tw) + r;                           // output unit of this lane's B column
+    const bool nvalid = wave + 16 * tw < nsl && n < H;
+    const float *wrow = WT + (size_t)min(n, H - 1) * K;
+    if constexpr (PREC == 1) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int gate = 2 * blk + (q >> 1), u0 = j0 + 8 * (q & 1);
+        const bool kv = nvalid && gate < G && u0 < H;                  // H % 8 == 0: an octet is valid as a whole
+        load_w8(kv ? wrow + (size_t)gate * H + u0 : nullptr, 0, 8, whi[tw][blk], wlo[tw][blk]);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int kk = 4 * m + q, gate = kk >> 4, unit = j0 + (kk & 15);
+        const float v = wrow[(size_t)min(gate, G - 1) * H + min(unit, H - 1)];
+        wf[tw][m] = (nvalid && gate < G && unit < H) ? v : 0.0f;
+      }
+    }
+  }
+  // partial blocks: [par][d][bt][owner slice][source slice][256 floats in MFMA C order]
+  const size_t tile_f = (size_t)nsl * nsl * 256;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
+  const unsigned flg_el[2] = {(unsigned)(((0 * D + d) * nbt + bt) * nsl), (unsigned)(((1 * D + d) * nbt + bt) * nsl)};
+  const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_f * 4), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_f * 4)};
+
+  const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
+  const bool item = tid < 256 && bl < Bc && j < H;
+  float state = 0.0f;   // carried dc (LSTM) / dh*z (GRU)
+  float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f;
+  const int tdir = d == 0 ? -1 : 1;
+  const long slab_g = (long)B * D * K, slab_h = (long)B * D * H;
+  const int bcl = min(b, B - 1), jcl = min(j, H - 1);
+  const unsigned vg0 = (unsigned)(((bcl * D + d) * K + jcl) * 4);
+  const unsigned vg1 = vg0 + (unsigned)(min(1, G - 1) * H * 4), vg2 = vg0 + (unsigned)(min(2, G - 1) * H * 4), vg3 = vg0 + (unsigned)(min(3, G - 1) * H * 4);
+  const unsigned vh = (unsigned)(((bcl * D + d) * H + jcl) * 4);
+  const bool is_lstm = p.cell == CTCN_CELL_LSTM, is_tanh = p.cell == CTCN_CELL_TANH;
+  const __amdgpu_buffer_rsrc_t rg = whole_rsrc(p.gates, (size_t)T * slab_g), rdy = whole_rsrc(p.dy, (size_t)T * slab_h);
+  const __amdgpu_buffer_rsrc_t r0 = whole_rsrc(is_tanh ? p.y : p.aux, (size_t)T * slab_h), r1 = whole_rsrc(is_lstm ? p.aux : p.y, (size_t)T * slab_h);
+  const __amdgpu_buffer_rsrc_t ra = whole_rsrc(p.aux, (size_t)T * slab_h);
+  const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);
+  bool e1_valid = T > 1 && !is_tanh;
+  if (item) {
+    const int t0 = d == 0 ? T - 1 : 0, t1 = T > 1 ? t0 + tdir : t0;
+    const unsigned og = (unsigned)t0 * sg_b, oh = (unsigned)t0 * sh_b;
+    sv[0] = ld_slab(rg, vg0, og); sv[1] = ld_slab(rg, vg1, og); sv[2] = ld_slab(rg, vg2, og); sv[3] = ld_slab(rg, vg3, og);
+    dyv = ld_slab(rdy, vh, oh); e0 = ld_slab(r0, vh, oh); e1 = ld_slab(r1, vh, (unsigned)t1 * sh_b);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    float rec = 0.0f;                                      // (da_{next} W_hh)[row bl][unit jl]
+    if (s > 0) {
+      const int par = (s - 1) & 1;
+      if (wave == NW - 1) {
+        const unsigned *fl = pa.flags + flg_el[par];
+        if (!poll_group(fl, nsl, (unsigned)s, lane, pa) && lane == 0) {
+          s_abort = 1;
+          if (pa.status) atomicCAS(pa.status, 0, 201);
+        }
+      }
+      lds_barrier();
+      if (s_abort) break;
+      // gather: the partial tiles addressed to this workgroup, sources wave, wave + 16, ... (fixed order)
+      f32x4 g[NTW];
+#pragma unroll
+      for (int tw = 0; tw < NTW; ++tw) {
+        const int src = min(wave + 16 * tw, nsl - 1);
+        g[tw] = ld_sc1_f4(rs, tile_b[par] + (unsigned)(((slice * nsl + src) * 64 + lane) * 16));
+      }
+      f32x4 sum = zero;
+#pragma unroll
+      for (int tw = 0; tw < NTW; ++tw)
+        if (wave + 16 * tw < nsl) sum += g[tw];
+      park_tile(red, wave, lane, sum);
+      lds_barrier();
+      if (tid < 256) {
+        const float *rp = red + parked_at(bl, jl);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) rec += rp[w * RT_T];
+      }
+    }
+
+    float out[4] = {0.f, 0.f, 0.f, 0.f};      // d(pre-activation) the next step multiplies by W_hh, per gate block
+    float dan = 0.f;
+    if (item) {
+      float dh = dyv + rec;
+      const float e1u = e1_valid ? e1 : 0.0f;                 // c / h of a step before the sequence start is 0
+      if (p.cell == CTCN_CELL_LSTM) {
+        const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
+        const float tc = act_tanh(e0);
+        const float do_ = dh * tc;
+        const float dc = dh * o_ * (1.0f - tc * tc) + state;
+        out[0] = dc * g_ * i_ * (1.0f - i_);
+        out[1] = dc * e1u * f_ * (1.0f - f_);
+        out[2] = dc * i_ * (1.0f - g_ * g_);
+        out[3] = do_ * o_ * (1.0f - o_);
+        state = dc * f_;
+      } else if (p.cell == CTCN_CELL_GRU) {
+        dh += state;
+        const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1u;
+        const float dn = dh * (1.0f - z_);
+        const float dz = dh * (hp - n_);
+        dan = dn * (1.0f - n_ * n_);
+        out[0] = dan * hn * r_ * (1.0f - r_);
+        out[1] = dz * z_ * (1.0f - z_);
+        out[2] = dan * r_;
+        state = dh * z_;
+      } else {
+        out[0] = dh * (1.0f - e0 * e0);
+      }
+      if (s + 1 < T) {                                        // A operand of this workgroup's product, in MFMA order
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < G) {
+            if constexpr (PREC == 1) {
+              unsigned short *sp = reinterpret_cast<unsigned short *>(stage);
+              const unsigned hi = f2bf(out[k]);
+              const int o = ((((k >> 1) * 4) + (k & 1) * 2 + (jl >> 3)) * 16 + bl) * 8 + (jl & 7);     // [blk][q][row][8]
+              sp[o] = (unsigned short)hi;
+              sp[1024 + o] = f2bf(out[k] - __uint_as_float(hi << 16));
+            } else {
+              const int kk = k * 16 + jl;                                                              // [m][kq][row]
+              stage[((kk >> 2) * 4 + (kk & 3)) * 16 + bl] = out[k];
+            }
+          }
+      }
+    }
+    if (s + 1 < T) {
+      lds_barrier();
+      const int par = s & 1;
+      f32x4 acc[NTW];
+      if constexpr (PREC == 1) {
+        const unsigned short *sp = reinterpret_cast<const unsigned short *>(stage);
+        bf16x8_t ah[2], al[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          ah[blk] = *reinterpret_cast<const bf16x8_t *>(sp + ((blk * 4 + q) * 16 + r) * 8);
+          al[blk] = *reinterpret_cast<const bf16x8_t *>(sp + 1024 + ((blk * 4 + q) * 16 + r) * 8);
+        }
+#pragma unroll
+        for (int tw = 0; tw < NTW; ++tw) {
+          acc[tw] = zero;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[blk], whi[tw][blk], acc[tw], 0, 0, 0);   // small terms first
+            acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[blk], wlo[tw][blk], acc[tw], 0, 0, 0);
+            acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[blk], whi[tw][blk], acc[tw], 0, 0, 0);
+          }
+        }
+      } else {
+        float af[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) af[m] = stage[(m * 4 + q) * 16 + r];
+#pragma unroll
+        for (int tw = 0; tw < NTW; ++tw) {
+          acc[tw] = zero;
+#pragma unroll
+          for (int m = 0; m < 16; ++m) acc[tw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], wf[tw][m], acc[tw], 0, 0, 0);
+        }
+      }
+      // scatter: tile tw of this wave belongs to owner slice wave + 16*tw; block (owner, source = this slice)
+#pragma unroll
+      for (int tw = 0; tw < NTW; ++tw) {
+        const int owner = wave + 16 * tw;
+        if (owner < nsl) st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its block stores (to L2 / to memory)
+      lds_barrier();
+      if (tid == 0) st_u1(rf, (flg_el[par] + (unsigned)slice) * 4, (unsigned)(s + 1), local);
+    }
+    // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs, next step's saved values
+    {
+      const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
+      const int tn = s + 1 < T ? t + tdir : t, tp = s + 2 < T ? tn + tdir : tn;             // past the end: re-read (unused)
+      const unsigned ogn = (unsigned)tn * sg_b, ohn = (unsigned)tn * sh_b, ohp = (unsigned)tp * sh_b;
+      if (item) {
+        if (is_lstm) {
+          st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, out[2]); st_slab(rg, vg3, og, out[3]);
+        } else if (p.cell == CTCN_CELL_GRU) {
+          st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, dan);
+          st_slab(ra, vh, oh, out[2]);
+        } else {
+          st_slab(rg, vg0, og, out[0]);
+        }
+        sv[0] = ld_slab(rg, vg0, ogn); sv[1] = ld_slab(rg, vg1, ogn); sv[2] = ld_slab(rg, vg2, ogn); sv[3] = ld_slab(rg, vg3, ogn);
+        dyv = ld_slab(rdy, vh, ohn); e0 = ld_slab(r0, vh, ohn); e1 = ld_slab(r1, vh, ohp);
+      }
+      e1_valid = s + 2 < T && !is_tanh;
+    }
+  }
+  if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
+}
+
+template <int PREC>
+bool launch_bwd_scatter_p(int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  switch (ntw) {
+    case 1: return launch_resident(rnn_bwd_scatter<1, PREC>, grid, 1024, 0, st, a, wpx);
+    case 2: return launch_resident(rnn_bwd_scatter<2, PREC>, grid, 1024, 0, st, a, wpx);
+    case 4: return launch_resident(rnn_bwd_scatter<4, PREC>, grid, 1024, 0, st, a, wpx);
+    default: return false;
+  }
+}
+bool launch_bwd_scatter(int prec, int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  return prec ? launch_bwd_scatter_p<1>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<0>(ntw, grid, st, a, wpx);
+}
+
 template <int PREC>
 bool launch_bwd_persist_p(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (kq4) {
@@ -1408,7 +1659,11 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     if (kq == 7) kq = 8;
     const int nbt = grid.z, nsl = grid.x, groups = dirs * nbt;
     const int prec = precision == 1 && H % 8 == 0 ? 1 : 0;           // bf16x3 recurrent matmul
-    const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
+    // scatter formulation (default): partial dh tiles travel, 1 KB per (owner, source) pair; gather formulation: the da tile
+    const bool scatter = ctcn_opt_bwd_scatter() && nsl <= 64;
+    const int ntw = nsl <= 16 ? 1 : (nsl <= 32 ? 2 : 4);
+    const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
+                                    : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
     const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
     const size_t lds = 0;
     for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
@@ -1428,8 +1683,13 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.stats = nullptr;
 #endif
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
-      if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
-      done = launch_bwd_persist(prec, kq, mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid, lds, st, pa, wpx);
+      const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid;
+      if (scatter) {
+        done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
+      } else {
+        if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
+        done = launch_bwd_persist(prec, kq, pgrid, lds, st, pa, wpx);
+      }
     }
   }
   if (!done) {
