@@ -126,7 +126,7 @@ def recurrence_traffic(workload):
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
         for k, v in pm.items():
-            if workload == "cfg2" and k.startswith("rnn_bwd_persist"):
+            if workload == "cfg2" and k.startswith("rnn_bwd_scatter"):
                 return v["hbm_bytes"]
     except Exception:
         pass
@@ -256,7 +256,7 @@ def run_train(args):
         rec = recurrence_probe(dev, c)
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 3.0
         tf = rec["algorithmic_flops_per_launch"] / (rec["kernel_bwd_us"] * 1e-6) / 1e12
-        res["roofline"] = dict(kernel="rnn_bwd_persist (backward recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (c["rnn"], c["T"]),
+        res["roofline"] = dict(kernel="rnn_bwd_scatter (backward recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (c["rnn"], c["T"]),
                                bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=recurrence_traffic(args.workload),
                                us_per_launch=rec["kernel_bwd_us"], us_per_dependent_step=rec["bwd_us_per_timestep"],
                                algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],

@@ -1230,7 +1230,14 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   }
   __syncthreads();
 
+#ifdef CTCN_PERSIST_STATS
+  long long zt[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64();
+#endif
   for (int s = 0; s < T; ++s) {
+#ifdef CTCN_PERSIST_STATS
+    const long long z_a = clock64();
+    long long z_p = z_a, z_g = z_a, z_m = z_a, z_s = z_a, z_d = z_a;
+#endif
     const int t = d == 0 ? T - 1 - s : s;
     float rec = 0.0f;                                      // (da_{next} W_hh)[row bl][unit jl]
     if (s > 0) {
@@ -1244,6 +1251,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
       }
       lds_barrier();
       if (s_abort) break;
+#ifdef CTCN_PERSIST_STATS
+      z_p = clock64();
+#endif
       // gather: the partial tiles addressed to this workgroup, sources wave, wave + 16, ... (fixed order)
       f32x4 g[NTW];
 #pragma unroll
@@ -1257,6 +1267,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         if (wave + 16 * tw < nsl) sum += g[tw];
       park_tile(red, wave, lane, sum);
       lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+      z_g = clock64();
+#endif
       if (tid < 256) {
         const float *rp = red + parked_at(bl, jl);
 #pragma unroll
@@ -1311,6 +1324,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     }
     if (s + 1 < T) {
       lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+      z_m = clock64();
+#endif
       const int par = s & 1;
       f32x4 acc[NTW];
       if constexpr (PREC == 1) {
@@ -1348,8 +1364,14 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         const int owner = wave + 16 * tw;
         if (owner < nsl) st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
       }
+#ifdef CTCN_PERSIST_STATS
+      z_s = clock64();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its block stores (to L2 / to memory)
       lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+      z_d = clock64();
+#endif
       if (tid == 0) st_u1(rf, (flg_el[par] + (unsigned)slice) * 4, (unsigned)(s + 1), local);
     }
     // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs, next step's saved values
@@ -1371,7 +1393,17 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
       }
       e1_valid = s + 2 < T && !is_tanh;
     }
+#ifdef CTCN_PERSIST_STATS
+    { const long long z_z = clock64(); zt[0] += z_p - z_a; zt[1] += z_g - z_p; zt[2] += z_m - z_g; zt[3] += z_s - z_m; zt[4] += z_d - z_s; zt[5] += z_z - z_d; }
+#endif
   }
+#ifdef CTCN_PERSIST_STATS
+  if (pa.stats && slice == 3 && d == 0 && bt == 0 && (tid == 0 || tid == 960)) {
+    long long *o = pa.stats + (tid == 0 ? 0 : 8);
+    for (int i = 0; i < 6; ++i) o[i] = zt[i];
+    o[6] = clock64() - zt0;
+  }
+#endif
   if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 

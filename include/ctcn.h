@@ -42,6 +42,8 @@ int ctcn_device_xcds(void);
  * "handoff" = 1 (default): persistent launches place each (direction, batch-tile) group on one XCD and hand h_t over
  * through that XCD's L2 when the device allows it (falls back to 0 otherwise); 0: device-scope write-through hand-off.
  * "poll_depth" = 2 (default): flag polls kept in flight per polling wave in the XCD-local hand-off (1..4).
+ * "bwd_scatter" = 1 (default): the persistent backward recurrence exchanges partial dh tiles (scatter formulation); 0: every
+ * workgroup gathers the whole d(pre-activation) tile (rnn_bwd_persist).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */

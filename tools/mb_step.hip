@@ -152,7 +152,7 @@ int main() {
   {
     // persistent forward / backward recurrences with in-kernel phase accounting (forward), device-scope vs XCD-local
     const int nbt = 2, K = G * H;
-    const size_t hx_bytes = (size_t)2 * D * nbt * ((K + 31) / 32) * 512 * 4, fl_bytes = (size_t)2 * D * nbt * 64 * 4 + 256;
+    const size_t hx_bytes = (size_t)2 * D * nbt * 32 * 32 * 1024, fl_bytes = (size_t)2 * D * nbt * 64 * 4 + 256;
     float *hx; unsigned *flags; int *status; long long *stats, h[16 + 64 * 3];
     CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, sizeof(long long) * (16 + 64 * 3))); CK(hipMemset(stats, 0, sizeof(long long) * (16 + 64 * 3)));
     const int nx = ctcn_device_xcds();
@@ -193,30 +193,30 @@ int main() {
       printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
              (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
     }
-    for (int lp = 2; lp < 6; ++lp) {
-      const int local = 1, prec = 1, pd = lp == 2 ? 2 : (lp == 3 ? 2 + 256 : (lp == 4 ? 2 + 512 : 2 + 768));
-      if (local && nx <= 1) continue;
+    for (int lp = 0; lp < 2; ++lp) {
+      const int local = 1, prec = 1, pd = 2, scatter = lp;
+      if (nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
-      pa.poll_depth = pd; pa.local = local; pa.nx = local ? nx : 1; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
+      pa.poll_depth = pd; pa.local = local; pa.nx = nx; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
-      dim3 gp = local ? dim3(pa.nx * (wpx + 4), 1, 1) : dim3(pa.nsl, D, nbt);
-      const size_t lds = 0;
+      dim3 gp = dim3(pa.nx * (wpx + 4), 1, 1);
       for (int rep = 0; rep < 2; ++rep) {
-        CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st));
+        CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st)); CK(hipMemsetAsync(hx, 0, hx_bytes, st));
         hipEventRecord(e0, st);
-        if (prec) { CK(hipMemsetAsync(hx, 0, hx_bytes, st)); hipLaunchKernelGGL((rnn_bwd_persist<5, 1>), gp, dim3(1024), lds, st, pa); }
-        else hipLaunchKernelGGL((rnn_bwd_persist<5, 0>), gp, dim3(1024), lds, st, pa);
+        if (scatter) hipLaunchKernelGGL((rnn_bwd_scatter<2, 1>), gp, dim3(1024), 0, st, pa);
+        else hipLaunchKernelGGL((rnn_bwd_persist<5, 1>), gp, dim3(1024), 0, st, pa);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost));
       CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
       for (int wv = 0; wv < 2; ++wv)
-        printf("  bwd per step (cycles), slice 3, %s: poll+barrier %.0f | loads+mfma %.0f | reduce %.0f | gate math+stage+barrier %.0f | copy-out+drain+barrier %.0f | flag+reserve+prefetch issue %.0f | total %.0f\n",
-               wv ? "wave 15 (poller)" : "wave 0 (items)", (double)h[wv * 8 + 0] / T, (double)h[wv * 8 + 1] / T, (double)h[wv * 8 + 2] / T, (double)h[wv * 8 + 3] / T,
+        printf("  bwd %s per step (cycles), slice 3, %s: %s %.0f | %.0f | %.0f | %.0f | %.0f | %.0f | total %.0f\n", scatter ? "SCATTER" : "gather",
+               wv ? "wave 15 (poller)" : "wave 0 (items)", scatter ? "poll+barrier | gather+park+barrier | item sum+math+stage+barrier | lds+mfma+scatter issue | drain+barrier | flag+reserve:" : "phases:",
+               (double)h[wv * 8 + 0] / T, (double)h[wv * 8 + 1] / T, (double)h[wv * 8 + 2] / T, (double)h[wv * 8 + 3] / T,
                (double)h[wv * 8 + 4] / T, (double)h[wv * 8 + 5] / T, (double)h[wv * 8 + 6] / T);
-      printf("bwd PERSISTENT local=%d precision=%d polls=%d  %3d slices/group   %8.2f us/step   (status %d)\n", local, prec, pd, pa.nsl, ms * 1e3 / T, hs);
+      printf("bwd PERSISTENT %s   %8.2f us/step   (status %d)\n", scatter ? "scatter" : "gather", ms * 1e3 / T, hs);
     }
   }
   // graph replay of the forward loop: is the host the limiter?
