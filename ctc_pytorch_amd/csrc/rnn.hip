@@ -1692,7 +1692,9 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     const int nbt = grid.z, nsl = grid.x, groups = dirs * nbt;
     const int prec = precision == 1 && H % 8 == 0 ? 1 : 0;           // bf16x3 recurrent matmul
     // scatter formulation (default): partial dh tiles travel, 1 KB per (owner, source) pair; gather formulation: the da tile
-    const bool scatter = ctcn_opt_bwd_scatter() && nsl <= 64;
+    // measured: scatter wins at H = 320 (2.46 vs 2.68 us per step), ties at H = 128, loses at H = 512 (nsl^2 KB of partial tiles
+    // per group and step) and at precision 0 (f32 MFMA: 32 cycles x 16 per tile on 4 waves per SIMD)
+    const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= 24;
     const int ntw = nsl <= 16 ? 1 : (nsl <= 32 ? 2 : 4);
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
                                     : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
