@@ -1147,6 +1147,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 // outputs: nsl partial 16 x 16 tiles, one per owner of 16 hidden units, which it scatters as 1-KB blocks (the MFMA C
 // layout, one 16-B store per lane).  The owner gathers the nsl partials addressed to it (wave w loads sources w, w+16,
 // ...), and the sum over sources runs through the same parked-tile / item-sum code as the sum over waves did before.
+// Every (owner, source) tile has its own flag, raised by the wave that stored it and polled by the wave that gathers it
+// (waves 4..15: nothing else sits in their vm queue), so a step has two barriers (parked partials, staged A operand).
 // Per step a CU now reads 1 KB x nsl and writes 1 KB x nsl (20 KB each at H = 320), d(pre-activation) never travels
 // between workgroups (it only goes to the reserve for the deferred GEMMs), and W_hh costs 16 VGPRs per tile.
 // k order inside the 64-wide block: precision 1: two 32-k MFMA blocks, lane octet q -> gate 2*blk + (q >> 1), units
@@ -1202,8 +1204,12 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   // partial blocks: [par][d][bt][owner slice][source slice][256 floats in MFMA C order]
   const size_t tile_f = (size_t)nsl * nsl * 256;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * 4), 0x00020000);
-  const unsigned flg_el[2] = {(unsigned)(((0 * D + d) * nbt + bt) * nsl), (unsigned)(((1 * D + d) * nbt + bt) * nsl)};
+  // one flag per (owner, source) block: the wave that stored the block raises it, the wave that gathers it polls it -- no
+  // workgroup-wide flag, hence no barrier between "all producers done" and the loads, none between the stores and the flag
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * nsl * 4), 0x00020000);
+  const unsigned flg_el[2] = {(unsigned)(((0 * D + d) * nbt + bt) * nsl * nsl), (unsigned)(((1 * D + d) * nbt + bt) * nsl * nsl)};
+  constexpr int NGW = 12, NTG = (16 * NTW + NGW - 1) / NGW;          // gathering waves 4..15 (no item traffic in their vm queue), sources per wave
+  const int gw = wave - 4;
   const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_f * 4), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_f * 4)};
 
   const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
@@ -1242,38 +1248,35 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     float rec = 0.0f;                                      // (da_{next} W_hh)[row bl][unit jl]
     if (s > 0) {
       const int par = (s - 1) & 1;
-      if (wave == NW - 1) {
-        const unsigned *fl = pa.flags + flg_el[par];
-        if (!poll_group(fl, nsl, (unsigned)s, lane, pa) && lane == 0) {
-          s_abort = 1;
-          if (pa.status) atomicCAS(pa.status, 0, 201);
+      if (wave >= 4) {
+        // gather: the partial tiles addressed to this workgroup, sources gw, gw + 12, ... (fixed order); each is loaded as
+        // soon as ITS flag shows this step
+        f32x4 sum = zero;
+#pragma unroll
+        for (int tg = 0; tg < NTG; ++tg) {
+          const int src = gw + NGW * tg;
+          if (src < nsl) {
+            const unsigned *fl = pa.flags + flg_el[par] + slice * nsl + src;
+            for (int spins = 0; __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)s; ++spins) {
+              if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (pa.status) atomicCAS(pa.status, 0, 201);        // give up: the launch finishes with a poisoned output
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            sum += ld_sc1_f4(rs, tile_b[par] + (unsigned)(((slice * nsl + src) * 64 + lane) * 16));
+          }
         }
+        park_tile(red, gw, lane, sum);
       }
       lds_barrier();
-      if (s_abort) break;
 #ifdef CTCN_PERSIST_STATS
-      z_p = clock64();
-#endif
-      // gather: the partial tiles addressed to this workgroup, sources wave, wave + 16, ... (fixed order)
-      f32x4 g[NTW];
-#pragma unroll
-      for (int tw = 0; tw < NTW; ++tw) {
-        const int src = min(wave + 16 * tw, nsl - 1);
-        g[tw] = ld_sc1_f4(rs, tile_b[par] + (unsigned)(((slice * nsl + src) * 64 + lane) * 16));
-      }
-      f32x4 sum = zero;
-#pragma unroll
-      for (int tw = 0; tw < NTW; ++tw)
-        if (wave + 16 * tw < nsl) sum += g[tw];
-      park_tile(red, wave, lane, sum);
-      lds_barrier();
-#ifdef CTCN_PERSIST_STATS
-      z_g = clock64();
+      z_p = z_g = clock64();
 #endif
       if (tid < 256) {
         const float *rp = red + parked_at(bl, jl);
 #pragma unroll
-        for (int w = 0; w < NW; ++w) rec += rp[w * RT_T];
+        for (int w = 0; w < NGW; ++w) rec += rp[w * RT_T];
       }
     }
 
@@ -1367,12 +1370,17 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
       z_s = clock64();
 #endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its block stores (to L2 / to memory)
-      lds_barrier();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's block stores have landed (L2 / memory) ...
+      if (lane == 0) {
+#pragma unroll
+        for (int tw = 0; tw < NTW; ++tw) {
+          const int owner = wave + 16 * tw;
+          if (owner < nsl) st_u1(rf, (flg_el[par] + (unsigned)(owner * nsl + slice)) * 4, (unsigned)(s + 1), local);   // ... raise their flags
+        }
+      }
 #ifdef CTCN_PERSIST_STATS
       z_d = clock64();
 #endif
-      if (tid == 0) st_u1(rf, (flg_el[par] + (unsigned)slice) * 4, (unsigned)(s + 1), local);
     }
     // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs, next step's saved values
     {
@@ -1404,7 +1412,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     o[6] = clock64() - zt0;
   }
 #endif
-  if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
+  const bool bad = pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (bad && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
 template <int PREC>
@@ -1698,7 +1707,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     const int ntw = nsl <= 16 ? 1 : (nsl <= 32 ? 2 : 4);
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
                                     : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
-    const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
+    const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * (scatter ? nsl : 1) * sizeof(unsigned), 256) + 256;   // + role tickets
     const size_t lds = 0;
     for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
       const int nx = mode ? ctcn_device_xcds() : 1;

@@ -152,7 +152,7 @@ int main() {
   {
     // persistent forward / backward recurrences with in-kernel phase accounting (forward), device-scope vs XCD-local
     const int nbt = 2, K = G * H;
-    const size_t hx_bytes = (size_t)2 * D * nbt * 32 * 32 * 1024, fl_bytes = (size_t)2 * D * nbt * 64 * 4 + 256;
+    const size_t hx_bytes = (size_t)2 * D * nbt * 32 * 32 * 1024, fl_bytes = (size_t)2 * D * nbt * 32 * 32 * 4 + 256;
     float *hx; unsigned *flags; int *status; long long *stats, h[16 + 64 * 3];
     CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, sizeof(long long) * (16 + 64 * 3))); CK(hipMemset(stats, 0, sizeof(long long) * (16 + 64 * 3)));
     const int nx = ctcn_device_xcds();
