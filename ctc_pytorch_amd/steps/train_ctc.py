@@ -25,7 +25,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from ctc_pytorch_amd import nn, ops, parallel  # noqa: E402
+from ctc_pytorch_amd import _lib, nn, ops, parallel  # noqa: E402
 from ctc_pytorch_amd.models.model_ctc import CTC_Model  # noqa: E402
 from ctc_pytorch_amd.optim import FlatAdam  # noqa: E402
 
@@ -69,7 +69,12 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
             if isinstance(optimizer, FlatAdam):
                 parallel.allreduce_grads(optimizer.grad)
             optimizer.step()
-        stats = torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]).cpu()
+        # one D2H per step: loss, error count, token count and the sticky hand-off status word of the persistent kernels
+        health = _lib.status_word(inputs.device).reshape(1).double() if inputs.is_cuda else torch.zeros(1, dtype=torch.float64)
+        stats = torch.cat([torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]), health]).cpu()
+        if int(stats[3]) != 0:
+            raise RuntimeError("ctc_pytorch_amd: a persistent recurrent kernel gave up waiting for a hand-off (status %d); "
+                               "results of this step are poisoned -- set CTCN_RNN_PERSISTENT=0 to run one launch per timestep" % int(stats[3]))
         lv = float(stats[0])
         cur_loss += lv
         total_loss += lv
