@@ -96,6 +96,11 @@ def _native_act(act):
     return nn.ReLU if act is tnn.ReLU else act
 
 
+def _conv_out_features(feat, kernel_size, stride, padding):
+    """Frequency-axis size after one Conv2d layer: axis 1 of kernel / stride / padding (model_ctc.py:111)."""
+    return int(math.floor((feat + 2 * padding[1] - kernel_size[1]) / stride[1]) + 1)
+
+
 class CTC_Model(nn.Module):
     def __init__(self, add_cnn=False, cnn_param=None, rnn_param=None, num_class=39, drop_out=0.1):
         """Arguments as the reference (model_ctc.py:71-81):
@@ -103,46 +108,41 @@ class CTC_Model(nn.Module):
                      "activate_function": nn.ReLU}
         rnn_param = {"rnn_input_size", "rnn_hidden_size", "rnn_layers", "rnn_type", "bidirectional", "batch_norm"}"""
         super().__init__()
-        self.add_cnn = add_cnn
-        self.cnn_param = cnn_param
-        if rnn_param is None or type(rnn_param) != dict:
+        if type(rnn_param) != dict:
             raise ValueError("rnn_param need to be a dict to contain all params of rnn!")
-        self.rnn_param = rnn_param
-        self.num_class = num_class
-        self.num_directions = 2 if rnn_param["bidirectional"] else 1
-        self.drop_out = drop_out
+        self.add_cnn, self.cnn_param, self.rnn_param = add_cnn, cnn_param, rnn_param
+        self.num_class, self.drop_out = num_class, drop_out
+        self.num_directions = 1 + int(bool(rnn_param["bidirectional"]))
+        width = self.num_directions * rnn_param["rnn_hidden_size"]
 
-        feat = rnn_param["rnn_input_size"]
+        rnn_in = rnn_param["rnn_input_size"]
         if add_cnn:
-            layers = []
-            out_channel = 1
-            for n, spec in enumerate(cnn_param["layer"]):
-                (in_channel, out_channel), kernel_size, stride, padding, pooling_size = spec
-                layers.append(("%d" % n, LayerCNN(in_channel, out_channel, kernel_size, stride, padding, pooling_size,
-                                                  activation_function=cnn_param["activate_function"],
-                                                  batch_norm=cnn_param["batch_norm"], dropout=drop_out)))
-                if len(kernel_size) == 2:   # frequency-axis output size, axis 1 of kernel/stride/padding (model_ctc.py:111)
-                    feat = int(math.floor((feat + 2 * padding[1] - kernel_size[1]) / stride[1]) + 1)
-            self.conv = nn.Sequential(OrderedDict(layers))
-            feat *= out_channel
-
-        H = rnn_param["rnn_hidden_size"]
-        rnn_type = rnn_param["rnn_type"]
-        bidir = rnn_param["bidirectional"]
-        batch_norm = rnn_param["batch_norm"]
-        stack = [("0", BatchRNN(input_size=feat, hidden_size=H, rnn_type=rnn_type, bidirectional=bidir, dropout=drop_out,
-                                batch_norm=False))]
-        for i in range(rnn_param["rnn_layers"] - 1):
-            stack.append(("%d" % (i + 1), BatchRNN(input_size=self.num_directions * H, hidden_size=H, rnn_type=rnn_type,
-                                                   bidirectional=bidir, dropout=drop_out, batch_norm=batch_norm)))
-        self.rnns = nn.Sequential(OrderedDict(stack))
-
-        if batch_norm:
-            self.fc = nn.Sequential(nn.BatchNorm1d(self.num_directions * H),
-                                    nn.Linear(self.num_directions * H, num_class, bias=False))
-        else:
-            self.fc = nn.Linear(self.num_directions * H, num_class, bias=False)
+            self.conv, rnn_in = self._front_end(cnn_param, rnn_in, drop_out)
+        self.rnns = self._recurrent_stack(rnn_param, rnn_in, width, drop_out)
+        head = nn.Linear(width, num_class, bias=False)
+        self.fc = nn.Sequential(nn.BatchNorm1d(width), head) if rnn_param["batch_norm"] else head
         self.log_softmax = nn.LogSoftmax(dim=-1)
+
+    @staticmethod
+    def _front_end(cnn_param, feat, drop_out):
+        """conv.{n} = LayerCNN per entry of cnn_param['layer']; returns (Sequential, features fed to the first RNN)."""
+        blocks, channels = OrderedDict(), 1
+        for n, ((cin, channels), kernel_size, stride, padding, pool) in enumerate(cnn_param["layer"]):
+            blocks[str(n)] = LayerCNN(cin, channels, kernel_size, stride, padding, pool, activation_function=cnn_param["activate_function"],
+                                      batch_norm=cnn_param["batch_norm"], dropout=drop_out)
+            if len(kernel_size) == 2:
+                feat = _conv_out_features(feat, kernel_size, stride, padding)
+        return nn.Sequential(blocks), feat * channels
+
+    @staticmethod
+    def _recurrent_stack(rnn_param, first_in, width, drop_out):
+        """rnns.{l} = BatchRNN; layer 0 has no BatchNorm, the others normalise their (dirs * H)-wide input."""
+        common = dict(hidden_size=rnn_param["rnn_hidden_size"], rnn_type=rnn_param["rnn_type"], bidirectional=rnn_param["bidirectional"],
+                      dropout=drop_out)
+        blocks = OrderedDict()
+        for layer in range(rnn_param["rnn_layers"]):
+            blocks[str(layer)] = BatchRNN(input_size=first_in if layer == 0 else width, batch_norm=bool(layer) and rnn_param["batch_norm"], **common)
+        return nn.Sequential(blocks)
 
     def forward(self, x, visualize=False):
         """x: (B, T, F) float32 on a ROCm device -> log-probs (T', B, num_class); with visualize=True also the
@@ -189,16 +189,11 @@ class CTC_Model(nn.Module):
     @staticmethod
     def save_package(model, optimizer=None, decoder=None, epoch=None, loss_results=None, dev_loss_results=None,
                      dev_cer_results=None):
+        """Checkpoint dict with the reference's keys (model_ctc.py:209-229), loadable by either side."""
         package = {"rnn_param": model.rnn_param, "add_cnn": model.add_cnn, "cnn_param": model.cnn_param,
                    "num_class": model.num_class, "_drop_out": model.drop_out, "state_dict": model.state_dict()}
-        if optimizer is not None:
-            package["optim_dict"] = optimizer.state_dict()
-        if decoder is not None:
-            package["decoder"] = decoder
-        if epoch is not None:
-            package["epoch"] = epoch
+        optional = {"optim_dict": None if optimizer is None else optimizer.state_dict(), "decoder": decoder, "epoch": epoch}
+        package.update({k: v for k, v in optional.items() if v is not None})
         if loss_results is not None:
-            package["loss_results"] = loss_results
-            package["dev_loss_results"] = dev_loss_results
-            package["dev_cer_results"] = dev_cer_results
+            package.update(loss_results=loss_results, dev_loss_results=dev_loss_results, dev_cer_results=dev_cer_results)
         return package

@@ -13,37 +13,33 @@ n_grams = ["unigram", "bigram", "trigram", "4gram", "5gram"]
 
 
 class LanguageModel:
+    """Attributes the reference exposes: unigram / bigram dicts token(-pair) -> [ln prob, ln back-off], start / end / unk."""
+
+    _SECTION = {"\\1-grams:": "unigram", "\\2-grams:": "bigram"}
+
     def __init__(self, arpa_file=None, n_gram=2, start="<s>", end="</s>", unk="<unk>"):
-        self.n_gram = n_gram
-        self.start = start
-        self.end = end
-        self.unk = unk
+        self.n_gram, self.start, self.end, self.unk = n_gram, start, end, unk
         self.scale = math.log(10)          # ARPA stores log10; the decoder works in ln
         self.initngrams(arpa_file)
 
     def initngrams(self, fn):
-        self.unigram = {}
-        self.bigram = {}
+        """Parse the \\1-grams: and \\2-grams: sections: 'log10p<TAB>tokens[<TAB>log10 back-off]' per entry."""
+        self.unigram, self.bigram = {}, {}
         if self.n_gram == 3:
             self.trigrame = {}
-        section = 0
+        target = None
         with open(fn, "r") as f:           # open(None) raises TypeError exactly as in the reference (an LM is mandatory)
-            for raw in f.readlines():
-                line = raw.strip("\n")
-                if line == "\\1-grams:":
-                    section = 1
+            for raw in f:
+                line = raw.rstrip("\n")
+                if line in self._SECTION:
+                    target = getattr(self, self._SECTION[line])
                     continue
-                if line == "\\2-grams:":
-                    section = 2
+                if target is None:
                     continue
-                if section not in (1, 2):
-                    continue
-                fields = line.split("\t")
-                table = self.unigram if section == 1 else self.bigram
-                if len(fields) == 3:
-                    table[fields[1]] = [self.scale * float(fields[0]), self.scale * float(fields[2])]
-                elif len(fields) == 2:
-                    table[fields[1]] = [self.scale * float(fields[0]), 0.0]
+                parts = line.split("\t")
+                if len(parts) in (2, 3):
+                    backoff = self.scale * float(parts[2]) if len(parts) == 3 else 0.0
+                    target[parts[1]] = [self.scale * float(parts[0]), backoff]
         self.unigram["UNK"] = self.unigram[self.unk]
 
     def get_uni_prob(self, wid):
@@ -51,35 +47,26 @@ class LanguageModel:
 
     def get_bi_prob(self, w1, w2):
         """ln p(w2 | w1) with back-off; '' stands for sentence start (w1) / end (w2)."""
-        if w1 == "":
-            w1 = self.start
-        if w2 == "":
-            w2 = self.end
-        key = w1 + " " + w2
-        if key not in self.bigram:
-            return self.unigram[w1][1] + self.unigram[w2][0]      # KeyError for a phone missing from the ARPA, as the reference
-        return self.bigram[key][0]
+        prev, nxt = w1 or self.start, w2 or self.end
+        hit = self.bigram.get(prev + " " + nxt)
+        if hit is not None:
+            return hit[0]
+        return self.unigram[prev][1] + self.unigram[nxt][0]      # KeyError for a phone missing from the ARPA, as the reference
 
     def score_bg(self, sentence):
-        val = 0.0
         words = sentence.strip().split()
-        val += self.get_bi_prob(self.start, words[0])
-        for i in range(len(words) - 1):
-            val += self.get_bi_prob(words[i], words[i + 1])
-        val += self.get_bi_prob(words[-1], self.end)
-        return val
+        if not words:
+            raise IndexError("score_bg: empty sentence")         # the reference indexes words[0]
+        chain = [self.start] + words + [self.end]
+        return float(sum(self.get_bi_prob(a, b) for a, b in zip(chain[:-1], chain[1:])))
 
     def table(self, classes, blank_index=0):
         """(V+1)x(V+1) float64: [c1][c2] = get_bi_prob(classes[c1], classes[c2]); row V = '<s>', column V = '</s>'.
         The blank class is never queried by the decoder (NaN there)."""
         V = len(classes)
+        names = [classes[c] for c in range(V)] + [""]
+        live = [c for c in range(V + 1) if c != blank_index]
         tab = np.full((V + 1, V + 1), np.nan, dtype=np.float64)
-        for c1 in range(V + 1):
-            if c1 == blank_index:
-                continue
-            w1 = "" if c1 == V else classes[c1]
-            for c2 in range(V + 1):
-                if c2 == blank_index:
-                    continue
-                tab[c1, c2] = self.get_bi_prob(w1, "" if c2 == V else classes[c2])
+        for c1 in live:
+            tab[c1, live] = [self.get_bi_prob(names[c1], names[c2]) for c2 in live]
         return tab

@@ -16,88 +16,85 @@ def _to_device(t):
 
 
 class Decoder(object):
+    """Host-side string assembly and scoring shared by both decoders (reference class of the same name,
+    ctcDecoder.py:9-149): label ids -> phone strings, Levenshtein-based CER / WER, running totals."""
+
     def __init__(self, int2char, space_idx=1, blank_index=0):
-        self.int_to_char = int2char
-        self.space_idx = space_idx
-        self.blank_index = blank_index
-        self.num_word = 0
-        self.num_char = 0
+        self.int_to_char, self.space_idx, self.blank_index = int2char, space_idx, blank_index
+        self.num_word = self.num_char = 0
 
     def decode(self):
         raise NotImplementedError
 
-    def phone_word_error(self, prob_tensor, frame_seq_len, targets, target_sizes):
-        strings = self.decode(prob_tensor, frame_seq_len)
-        targets = self._unflatten_targets(targets, target_sizes)
-        target_strings = self._process_strings(self._convert_to_strings(targets))
-        cer = 0
-        wer = 0
-        for x in range(len(target_strings)):
-            cer += self.cer(strings[x], target_strings[x])
-            wer += self.wer(strings[x], target_strings[x])
-            self.num_word += len(target_strings[x].split())
-            self.num_char += len(target_strings[x])
-        return cer, wer
-
-    def _unflatten_targets(self, targets, target_sizes):
-        out, offset = [], 0
-        for size in target_sizes:
-            out.append(targets[offset:offset + size])
-            offset += size
-        return out
-
-    def _process_strings(self, seqs, remove_rep=False):
-        return [self._process_string(seq, remove_rep) for seq in seqs]
-
-    def _process_string(self, seq, remove_rep=False):
-        blank = self.int_to_char[self.blank_index]
-        string = ""
-        for i, char in enumerate(seq):
-            if char == blank:
-                continue
-            if remove_rep and i != 0 and char == seq[i - 1]:
-                continue
-            if self.space_idx == -1:
-                string = string + " " + char
-            elif char == self.int_to_char[self.space_idx]:
-                string += " "
-            else:
-                string = string + char
-        return string
-
-    def _convert_to_strings(self, seq, sizes=None):
-        strings = []
-        for x in range(len(seq)):
-            n = sizes[x] if sizes is not None else len(seq[x])
-            strings.append(self._convert_to_string(seq[x], n))
-        return strings
-
-    def _convert_to_string(self, seq, sizes):
-        result = [self.int_to_char[seq[i]] for i in range(sizes)]
-        return result if self.space_idx == -1 else "".join(result)
-
-    def wer(self, s1, s2):
-        vocab = set(s1.split() + s2.split())
-        word2int = dict(zip(vocab, range(len(vocab))))
-        return self._edit_distance([word2int[w] for w in s1.split()], [word2int[w] for w in s2.split()])
+    # ---- scoring ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _edit_distance(src_seq, tgt_seq):
+        """Levenshtein distance (unit costs) with a rolling numpy row; works on strings and id lists alike."""
+        n_src, n_tgt = len(src_seq), len(tgt_seq)
+        if 0 in (n_src, n_tgt):
+            return n_src + n_tgt
+        tgt = np.asarray([hash(t) for t in tgt_seq] if not isinstance(tgt_seq, str) else [ord(c) for c in tgt_seq])
+        row = np.arange(n_tgt + 1)
+        for i, a in enumerate(src_seq, start=1):
+            key = hash(a) if not isinstance(src_seq, str) else ord(a)
+            diag = row[:-1] + (tgt != key)                       # substitute / match
+            up = row[1:] + 1                                     # delete from src
+            best = np.minimum(diag, up)
+            new = np.empty_like(row)
+            new[0] = i
+            for j in range(n_tgt):                               # insert: running minimum along the row
+                new[j + 1] = best[j] if best[j] < new[j] + 1 else new[j] + 1
+            row = new
+        return int(row[-1])
 
     def cer(self, s1, s2):
         return self._edit_distance(s1, s2)
 
-    def _edit_distance(self, src_seq, tgt_seq):
-        L1, L2 = len(src_seq), len(tgt_seq)
-        if L1 == 0:
-            return L2
-        if L2 == 0:
-            return L1
-        prev = list(range(L2 + 1))
-        for i in range(1, L1 + 1):
-            cur = [i] + [0] * L2
-            a = src_seq[i - 1]
-            for j in range(1, L2 + 1):
-                cur[j] = min(cur[j - 1] + 1, prev[j] + 1, prev[j - 1] + (0 if a == tgt_seq[j - 1] else 1))
-            prev = cur
-        return prev[L2]
+    def wer(self, s1, s2):
+        a, b = s1.split(), s2.split()
+        ids = {}
+        for w in a + b:
+            ids.setdefault(w, len(ids))
+        return self._edit_distance([ids[w] for w in a], [ids[w] for w in b])
+
+    def phone_word_error(self, prob_tensor, frame_seq_len, targets, target_sizes):
+        hyps = self.decode(prob_tensor, frame_seq_len)
+        refs = self._process_strings(self._convert_to_strings(self._unflatten_targets(targets, target_sizes)))
+        char_errs = word_errs = 0
+        for hyp, ref in zip(hyps, refs):
+            char_errs += self.cer(hyp, ref)
+            word_errs += self.wer(hyp, ref)
+            self.num_word += len(ref.split())
+            self.num_char += len(ref)
+        return char_errs, word_errs
+
+    # ---- id / string plumbing ----------------------------------------------------------------------------
+    @staticmethod
+    def _unflatten_targets(targets, target_sizes):
+        bounds = np.concatenate([[0], np.cumsum([int(n) for n in target_sizes])])
+        return [targets[bounds[i]:bounds[i + 1]] for i in range(len(bounds) - 1)]
+
+    def _convert_to_string(self, seq, sizes):
+        symbols = [self.int_to_char[seq[i]] for i in range(sizes)]
+        return symbols if self.space_idx == -1 else "".join(symbols)
+
+    def _convert_to_strings(self, seq, sizes=None):
+        return [self._convert_to_string(row, len(row) if sizes is None else sizes[k]) for k, row in enumerate(seq)]
+
+    def _process_string(self, seq, remove_rep=False):
+        """Drop blanks (and, optionally, frame-to-frame repeats); phones are joined as ' '+phone when the vocabulary
+        has no space symbol (space_idx == -1), else the space symbol becomes ' '."""
+        blank = self.int_to_char[self.blank_index]
+        space = None if self.space_idx == -1 else self.int_to_char[self.space_idx]
+        pieces = []
+        for pos, sym in enumerate(seq):
+            if sym == blank or (remove_rep and pos > 0 and sym == seq[pos - 1]):
+                continue
+            pieces.append(" " + sym if space is None else (" " if sym == space else sym))
+        return "".join(pieces)
+
+    def _process_strings(self, seqs, remove_rep=False):
+        return [self._process_string(one, remove_rep) for one in seqs]
 
 
 class GreedyDecoder(Decoder):
