@@ -216,14 +216,14 @@ def run_train(args):
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(step())
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     _ops.check_health()                # a hand-off timeout in a persistent kernel poisons the step: never report such a run

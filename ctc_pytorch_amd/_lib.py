@@ -61,6 +61,8 @@ _SIGS = {
     "ctcn_argmax": (I, [P, P, I, I, P]),
     "ctcn_ctc_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ctcn_ctc_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_ctc_fwd_both": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_ctc_grad": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "ctcn_sum_f32": (I, [P, P, I, P]),
     "ctcn_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, P]),
     "ctcn_greedy_collapse": (I, [P, Z, Z, P, P, P, I, I, I, P]),

@@ -91,13 +91,14 @@ __device__ __forceinline__ float lse3(float x0, float x1, float x2) {
 // everything else is kept off that chain: the gathered log-probs (and, in the beta pass, the alpha values that
 // alpha + beta overwrites in place) are fetched PF frames ahead into registers, the barrier between steps waits for LDS
 // only, and the alpha / alpha+beta stores are never waited for.
-template <int DIR, int NS>
-__global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
-                                                                  const int64_t *__restrict__ in_len,
-                                                                  const int64_t *__restrict__ tgt_len, float *__restrict__ alpha,
-                                                                  float *__restrict__ nll, int T, int B, int V, int Lmax) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// ADD (beta pass only): accumulate into `alpha` in place (alpha + beta, the one-buffer reserve of ctcn_ctc_fwd / _bwd);
+// otherwise the pass writes its own lattice, which lets alpha and beta run side by side in one launch (ctcn_ctc_fwd_both).
+template <int DIR, int NS, bool ADD>
+__device__ __forceinline__ void ctc_lattice_body(float *smem, const float *__restrict__ lp, const int64_t *__restrict__ targets,
+                                                 const int64_t *__restrict__ in_len, const int64_t *__restrict__ tgt_len,
+                                                 float *__restrict__ alpha, float *__restrict__ nll, int T, int B, int V, int Lmax) {
   constexpr int PF = 4;
+  constexpr bool ACC = DIR < 0 && ADD;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Smax = 2 * Lmax + 1;
   const int Tb = (int)in_len[b], L = (int)tgt_len[b];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
         else { if (s >= S - 2) v = lpt[my_ext[k]]; }
         buf0[s] = v;
         float *ap = alpha + ((size_t)t_first * B + b) * Smax + s;
-        if (DIR > 0) *ap = v; else *ap += v;
+        if (ACC) *ap += v; else *ap = v;
       }
     }
   }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
     for (int k = 0; k < NS; ++k) {
       const int s = tid + k * CTC_THREADS;
       nq[i][k] = s < S ? lpt[my_ext[k]] : 0.0f;
-      na[i][k] = (DIR < 0 && s < S) ? alpha[((size_t)t * B + b) * Smax + s] : 0.0f;
+      na[i][k] = (ACC && s < S) ? alpha[((size_t)t * B + b) * Smax + s] : 0.0f;
     }
   }
   for (int n0 = 1; n0 < Tb; n0 += PF) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
         for (int k = 0; k < NS; ++k) {
           const int s = tid + k * CTC_THREADS;
           nq[i][k] = s < S ? lpt[my_ext[k]] : 0.0f;
-          if (DIR < 0) na[i][k] = s < S ? alpha[((size_t)t * B + b) * Smax + s] : 0.0f;
+          if (ACC) na[i][k] = s < S ? alpha[((size_t)t * B + b) * Smax + s] : 0.0f;
         }
       }
     }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
             else { x1 = s + 1 < S ? prev[s + 1] : -INFINITY; x2 = my_skip[k] ? prev[s + 2] : -INFINITY; }
             const float v = lse3(x0, x1, x2) + cq[i][k];
             cur[s] = v;
-            alpha[((size_t)t * B + b) * Smax + s] = DIR > 0 ? v : ca[i][k] + v;
+            alpha[((size_t)t * B + b) * Smax + s] = ACC ? ca[i][k] + v : v;
           }
         }
         lds_barrier();       // LDS only: the alpha stores and the prefetches stay in flight across timesteps
@@ -203,6 +204,28 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
   }
 }
 
+template <int DIR, int NS>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
+                                                                  const int64_t *__restrict__ in_len,
+                                                                  const int64_t *__restrict__ tgt_len, float *__restrict__ alpha,
+                                                                  float *__restrict__ nll, int T, int B, int V, int Lmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  ctc_lattice_body<DIR, NS, true>(smem, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax);
+}
+
+// alpha (blockIdx.y = 0) and beta (blockIdx.y = 1) of every utterance in one launch: the two passes are independent chains of
+// T dependent steps, so running them side by side halves the latency of the loss (2B workgroups instead of B twice).
+template <int NS>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_lattices_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
+                                                                   const int64_t *__restrict__ in_len,
+                                                                   const int64_t *__restrict__ tgt_len, float *__restrict__ alpha,
+                                                                   float *__restrict__ beta, float *__restrict__ nll, int T, int B, int V,
+                                                                   int Lmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.y == 0) ctc_lattice_body<1, NS, false>(smem, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax);
+  else ctc_lattice_body<-1, NS, false>(smem, lp, targets, in_len, tgt_len, beta, nll, T, B, V, Lmax);
+}
+
 // online log-sum-exp accumulator
 struct Lse {
   float m, s;
@@ -213,9 +236,13 @@ struct Lse {
   }
 };
 
+// SEP: alpha and beta are separate lattices (`ab` = alpha, `bt` = beta) and are added here -- the same single f32 add the
+// in-place beta pass performs, so both reserves give bit-identical gradients.
+template <bool SEP>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
                                                        const int64_t *__restrict__ in_len, const int64_t *__restrict__ tgt_len,
-                                                       const float *__restrict__ ab, const float *__restrict__ nll,
+                                                       const float *__restrict__ ab, const float *__restrict__ bt,
+                                                       const float *__restrict__ nll,
                                                        const float *__restrict__ gscale, float *__restrict__ grad, int T, int B, int V,
                                                        int Lmax) {
   const int lane = threadIdx.x & 63;
@@ -230,12 +257,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__
   }
   const int Smax = 2 * Lmax + 1;
   const float *abr = ab + pair * Smax;
+  const float *btr = SEP ? bt + pair * Smax : nullptr;
+  auto AB = [&](int s) -> float { return SEP ? abr[s] + btr[s] : abr[s]; };
   const float *lpr = lp + pair * V;
   const float n = nll[b], gs = gscale[0];
   const int64_t *tg = targets + (size_t)b * Lmax;
   // blank: even states 0,2,..,2L
   Lse bl{-INFINITY, 0.0f};
-  for (int j = lane; j <= L; j += 64) bl.add(abr[2 * j]);
+  for (int j = lane; j <= L; j += 64) bl.add(AB(2 * j));
   const float M = wave_max(bl.m);
   float ssum = bl.m == -INFINITY ? 0.0f : bl.s * expf(bl.m - M);
   ssum = wave_sum(ssum);
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__
     else {
       Lse a{-INFINITY, 0.0f};
       for (int j = 0; j < L; ++j)
-        if ((int)tg[j] == c) a.add(abr[2 * j + 1]);
+        if ((int)tg[j] == c) a.add(AB(2 * j + 1));
       lcab = a.m == -INFINITY ? -INFINITY : a.m + logf(a.s);
     }
     const float l = lpr[c];
@@ -364,7 +393,34 @@ extern "C" int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64
 #undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
   const size_t pairs = (size_t)T * B;
-  hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, st, lp, targets, in_len, tgt_len, alpha, nll, gscale, grad_lp, T, B, V, Lmax);
+  hipLaunchKernelGGL(ctc_grad_kernel<false>, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, st, lp, targets, in_len, tgt_len, alpha,
+                     (const float *)nullptr, nll, gscale, grad_lp, T, B, V, Lmax);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_ctc_fwd_both(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len, float *alpha,
+                                 float *beta, float *nll, int T, int B, int V, int Lmax, void *stream) {
+  CTCN_REQUIRE(lp && in_len && tgt_len && alpha && beta && nll && (targets || Lmax == 0), "ctcn_ctc_fwd_both: null pointer");
+  CTCN_REQUIRE(T > 0 && B > 0 && V > 0 && Lmax >= 0, "ctcn_ctc_fwd_both: bad dims");
+  if (2 * Lmax + 1 > CTC_THREADS * CTC_NS) { ctcn_set_error("ctcn_ctc_fwd_both: label length %d > %d unsupported", Lmax, (CTC_THREADS * CTC_NS - 1) / 2); return CTCN_EUNSUPPORTED; }
+  const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
+  const int ns = ceil_div(2 * Lmax + 1, CTC_THREADS);
+#define CTC_LAUNCH(NS) hipLaunchKernelGGL((ctc_lattices_kernel<NS>), dim3(B, 2), dim3(CTC_THREADS), sm, (hipStream_t)stream, lp, targets, in_len, tgt_len, alpha, beta, nll, T, B, V, Lmax)
+  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
+#undef CTC_LAUNCH
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_ctc_grad(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len, const float *alpha,
+                             const float *beta, const float *nll, const float *gscale, float *grad_lp, int T, int B, int V, int Lmax,
+                             void *stream) {
+  CTCN_REQUIRE(lp && in_len && tgt_len && alpha && beta && nll && gscale && grad_lp && (targets || Lmax == 0), "ctcn_ctc_grad: null pointer");
+  CTCN_REQUIRE(T > 0 && B > 0 && V > 0 && Lmax >= 0, "ctcn_ctc_grad: bad dims");
+  const size_t pairs = (size_t)T * B;
+  hipLaunchKernelGGL(ctc_grad_kernel<true>, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, (hipStream_t)stream, lp, targets, in_len, tgt_len,
+                     alpha, beta, nll, gscale, grad_lp, T, B, V, Lmax);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }

@@ -81,7 +81,11 @@ def _ws(t, tag="main"):
 # dirs * ceil(B/16) of the 8 XCDs.  When the gradients go to a flat buffer (optim.FlatAdam) they are therefore issued on
 # a second stream, restricted (ctcn_rnn_bwd_weights' xcd_allow) to the XCDs the recurrence leaves idle, and joined to the
 # main stream when autograd finishes the backward pass.
-_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}}
+# The side work of a layer is DEFERRED until the next recurrence below it is about to be launched (or until a join): issued
+# straight away it competes with the critical-path kernels that sit between two recurrences (the input-gradient GEMMs, the
+# BatchNorm / dropout backward), which measured 1.5-10x their stand-alone time in that window; behind the deferral they
+# have the chip to themselves and the side work overlaps with nothing but the recurrence, on the XCDs it leaves idle.
+_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}}
 
 
 def set_side_stream(flag):
@@ -98,19 +102,35 @@ def _side_stream(dev):
     return st
 
 
+def _flush_deferred(dev_key):
+    """Issue the weight-gradient work parked for this device on the side stream, ordered behind everything the main
+    stream holds so far."""
+    fn = _side["deferred"].pop(dev_key, None)
+    if fn is not None:
+        fn()
+
+
+def _join_now(dev_key):
+    _flush_deferred(dev_key)
+    st = _side["pending"].pop(dev_key, None)
+    if st is not None:
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
 def _join_side(dev_key):
+    """End-of-backward callback: join, and forget recurrent layers whose backward never came (a forward pass run with
+    gradients enabled but never differentiated would otherwise leave the count of pending recurrences too high)."""
     def join():
-        st = _side["pending"].pop(dev_key, None)
-        if st is not None:
-            torch.cuda.current_stream(st.device).wait_stream(st)
+        _join_now(dev_key)
+        _side["live"][dev_key] = 0
     return join
 
 
 def join_side_stream(device=None):
     """Make the current stream wait for weight gradients still in flight on the side stream (no-op if none)."""
-    keys = list(_side["pending"]) if device is None else [(device.type, device.index)]
+    keys = list(set(_side["pending"]) | set(_side["deferred"])) if device is None else [(device.type, device.index)]
     for k in keys:
-        _join_side(k)()
+        _join_now(k)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -246,6 +266,12 @@ class _RNNLayer(torch.autograd.Function):
                                            _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
         ctx.cell, ctx.dims, ctx.has_aux = cell, (T, B, I, H, dirs), aux is not None
         ctx.consumed = False
+        # recurrent layers of this device whose backward is still to come (the deferral of the side work needs to know
+        # whether another recurrence will follow in the backward pass)
+        ctx.counted = any(ctx.needs_input_grad)
+        if ctx.counted:
+            key = (dev.type, dev.index)
+            _side["live"][key] = _side["live"].get(key, 0) + 1
         saved = [x, y, gates] + ([aux] if aux is not None else []) + [t for t in ws if t is not None]
         ctx.save_for_backward(*saved)
         return y
@@ -290,24 +316,35 @@ class _RNNLayer(torch.autograd.Function):
             side = False         # bottom layer: no recurrence follows; its weight GEMMs run inline on the main stream, which
                                  # would otherwise idle while the side stream finishes the layer above
         null = ctypes.c_void_p(None)
+        key = (dev.type, dev.index)
+        if ctx.counted:
+            _side["live"][key] = max(0, _side["live"].get(key, 0) - 1)
+        _flush_deferred(key)     # the layer above: its weight GEMMs start together with this layer's recurrence
         _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
                                   _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
                                   null if side else _ptr(d_ih0), null if side else _ptr(d_hh0), null if side else _ptr(d_ih1),
                                   null if side else _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
                                   wp, wn, _lib.stream_ptr()), "rnn_bwd")
         if side:
-            main, st = torch.cuda.current_stream(dev), _side_stream(dev)
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                w2, wp2, wn2 = _ws(x, tag="side")
-                _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0),
-                                                  _ptr(d_hh0), _ptr(d_ih1), _ptr(d_hh1), 1.0, get_precision(), allow, wp2, wn2,
-                                                  st.cuda_stream), "rnn_bwd_weights")
-            for t in (x, y, gates, aux):
-                if t is not None:
-                    t.record_stream(st)             # the caching allocator must not recycle them under the side stream
-            key = (dev.type, dev.index)
-            _side["pending"][key] = st
+            st = _side_stream(dev)
+            prec = get_precision()
+
+            def weights_on_side_stream():
+                st.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(st):
+                    w2, wp2, wn2 = _ws(x, tag="side")
+                    _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0),
+                                                      _ptr(d_hh0), _ptr(d_ih1), _ptr(d_hh1), 1.0, prec, allow, wp2, wn2,
+                                                      st.cuda_stream), "rnn_bwd_weights")
+                for t in (x, y, gates, aux):
+                    if t is not None:
+                        t.record_stream(st)         # the caching allocator must not recycle them under the side stream
+                _side["pending"][key] = st
+
+            if _side["live"].get(key, 0) > 0:
+                _side["deferred"][key] = weights_on_side_stream    # issued when the recurrence of the layer below is launched
+            else:
+                weights_on_side_stream()                           # no recurrence follows: overlap with whatever does
             # one join per layer is harmless and keeps the path safe if an earlier backward pass died before its callback ran
             torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if into_flat:
@@ -587,12 +624,17 @@ class _CTCLoss(torch.autograd.Function):
         alpha = torch.empty((T, B, 2 * Lmax + 1), dtype=torch.float32, device=dev)
         nll = torch.empty(B, dtype=torch.float32, device=dev)
         L = _lib.lib()
-        _lib.check(L.ctcn_ctc_fwd(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(nll), T, B, V, Lmax,
-                                  _lib.stream_ptr()), "ctc_fwd")
-        ctx.save_for_backward(lp, targets, in_len, tgt_len, alpha, nll)
+        if ctx.needs_input_grad[0]:
+            # a gradient will be wanted: beta now, beside alpha, in the same launch (two independent T-step chains)
+            beta = torch.empty_like(alpha)
+            _lib.check(L.ctcn_ctc_fwd_both(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(beta), _ptr(nll),
+                                           T, B, V, Lmax, _lib.stream_ptr()), "ctc_fwd_both")
+            ctx.save_for_backward(lp, targets, in_len, tgt_len, alpha, beta, nll)
+        else:
+            _lib.check(L.ctcn_ctc_fwd(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(nll), T, B, V, Lmax,
+                                      _lib.stream_ptr()), "ctc_fwd")
         ctx.dims = (T, B, V, Lmax)
         ctx.reduce_sum = reduce_sum
-        ctx.consumed = False
         if not reduce_sum:
             return nll.clone()
         out = torch.empty((), dtype=torch.float32, device=dev)
@@ -601,17 +643,14 @@ class _CTCLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.consumed:
-            raise RuntimeError("ctc_pytorch_amd CTCLoss: backward ran twice (alpha is overwritten with alpha+beta)")
-        ctx.consumed = True
-        lp, targets, in_len, tgt_len, alpha, nll = ctx.saved_tensors
+        lp, targets, in_len, tgt_len, alpha, beta, nll = ctx.saved_tensors
         T, B, V, Lmax = ctx.dims
         if not ctx.reduce_sum:
             raise NotImplementedError("ctc_pytorch_amd.CTCLoss(reduction='none').backward: use reduction='sum' (train_ctc.py:144)")
         g = g.to(dtype=torch.float32).contiguous()
         grad = torch.empty_like(lp)
-        _lib.check(_lib.lib().ctcn_ctc_bwd(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(nll), _ptr(g),
-                                           _ptr(grad), T, B, V, Lmax, _lib.stream_ptr()), "ctc_bwd")
+        _lib.check(_lib.lib().ctcn_ctc_grad(_ptr(lp), _ptr(targets), _ptr(in_len), _ptr(tgt_len), _ptr(alpha), _ptr(beta), _ptr(nll),
+                                            _ptr(g), _ptr(grad), T, B, V, Lmax, _lib.stream_ptr()), "ctc_grad")
         return grad, None, None, None, None
 
 

@@ -17,7 +17,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -32,6 +32,15 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+# CTCN_FORCE_COLLECTIVES=1: create the process group and issue every collective even for a single rank, so that the
+# RCCL code path (communicator set-up, stream ordering against the side stream) can be exercised on a 1-GPU box.
+_FORCE = os.environ.get("CTCN_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _collectives_on():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of n_items for `rank` (first n_items % world ranks get one extra)."""
     base, rem = divmod(n_items, world)
@@ -44,7 +53,7 @@ def allreduce_grads(flat_grad):
     if flat_grad.is_cuda:
         from . import ops
         ops.join_side_stream()            # weight gradients issued on the side stream must have landed
-    if world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 
@@ -53,7 +62,7 @@ def _sync_bn_reduce(sums, local_count):
     """All-reduce of the (C, 2) float64 per-channel BatchNorm sums; returns the global element count per channel.
     Every rank holds the same padded shard shape (global T_max, equal utterances per rank), so the count is
     local_count * world_size and needs no second collective."""
-    if world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     return float(local_count) * world_size()
 
@@ -67,13 +76,13 @@ def enable_sync_bn(flag=True):
 
 
 def broadcast_params(flat_params, src=0):
-    if world_size() > 1:
+    if _collectives_on():
         dist.broadcast(flat_params, src=src)
     return flat_params
 
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

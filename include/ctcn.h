@@ -173,6 +173,15 @@ int ctcn_ctc_fwd(const float *lp, const int64_t *targets, const int64_t *in_len,
 int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len,
                  float *alpha, const float *nll, const float *gscale, float *grad_lp, int T, int B, int V,
                  int Lmax, void *stream);
+/* The same loss when a gradient will be wanted (training, train_ctc.py:47 followed by :63): alpha AND beta, each into its
+ * own (T,B,2*Lmax+1) lattice, in ONE launch -- the two passes are independent chains of T dependent steps, so side by
+ * side they cost one chain -- then ctcn_ctc_grad adds them on the fly (the same single f32 add as ctcn_ctc_bwd's
+ * in-place pass: bit-identical gradients) and leaves both lattices untouched. */
+int ctcn_ctc_fwd_both(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len,
+                      float *alpha, float *beta, float *nll, int T, int B, int V, int Lmax, void *stream);
+int ctcn_ctc_grad(const float *lp, const int64_t *targets, const int64_t *in_len, const int64_t *tgt_len,
+                  const float *alpha, const float *beta, const float *nll, const float *gscale, float *grad_lp,
+                  int T, int B, int V, int Lmax, void *stream);
 /* out[0] = sum_b nll[b]  (deterministic order) */
 int ctcn_sum_f32(const float *x, float *out, int n, void *stream);
 

@@ -437,6 +437,43 @@ def test_ctc_vs_torch_cpu_random(dev):
     assert float(lg.grad.sum(-1).abs().max()) < 1e-4          # rows sum to zero after log_softmax backward
 
 
+@pytest.mark.parametrize("T,B,V,lab", [(200, 16, 62, (10, 60)), (64, 5, 20, (1, 30)), (300, 3, 40, (100, 140))])
+def test_ctc_one_launch_lattices_equal_two_pass_reserve(dev, T, B, V, lab):
+    """ctcn_ctc_fwd_both + ctcn_ctc_grad (alpha and beta side by side in one launch: the training path) against
+    ctcn_ctc_fwd + ctcn_ctc_bwd (beta accumulated into the alpha reserve): same nll and gradient, bit for bit; ragged lengths,
+    one infeasible utterance (label longer than the input) included."""
+    from ctc_pytorch_amd import _lib, ops
+    b = synth.make_batch(seed=21, B=B, T=T, F=4, V=V, lab_lo=lab[0], lab_hi=lab[1])
+    rs = np.random.RandomState(4)
+    lp = ops.log_softmax(torch.from_numpy((2 * rs.standard_normal((T, B, V))).astype(np.float32)).to(dev)).contiguous()
+    tg = torch.from_numpy(b["targets"]).to(dev)
+    tl = torch.from_numpy(b["tgt_len"]).to(dev)
+    lens = b["lens"].copy()
+    lens[-1] = min(int(lens[-1]), max(1, int(b["tgt_len"][-1]) - 1))     # no alignment exists: nll = +inf
+    il = torch.from_numpy(lens).to(dev)
+    Lmax = tg.shape[1]
+    L, P, st = _lib.lib(), (lambda t: ctypes.c_void_p(t.data_ptr())), _lib.stream_ptr()
+    gs = torch.full((1,), 1.0 / B, device=dev)
+    a1 = torch.empty((T, B, 2 * Lmax + 1), device=dev)
+    n1, g1 = torch.empty(B, device=dev), torch.empty_like(lp)
+    _lib.check(L.ctcn_ctc_fwd(P(lp), P(tg), P(il), P(tl), P(a1), P(n1), T, B, V, Lmax, st), "ctc_fwd")
+    alpha_only = a1.clone()
+    _lib.check(L.ctcn_ctc_bwd(P(lp), P(tg), P(il), P(tl), P(a1), P(n1), P(gs), P(g1), T, B, V, Lmax, st), "ctc_bwd")
+    a2, b2 = torch.empty_like(a1), torch.empty_like(a1)
+    n2, g2 = torch.empty(B, device=dev), torch.empty_like(lp)
+    _lib.check(L.ctcn_ctc_fwd_both(P(lp), P(tg), P(il), P(tl), P(a2), P(b2), P(n2), T, B, V, Lmax, st), "ctc_fwd_both")
+    _lib.check(L.ctcn_ctc_grad(P(lp), P(tg), P(il), P(tl), P(a2), P(b2), P(n2), P(gs), P(g2), T, B, V, Lmax, st), "ctc_grad")
+    torch.cuda.synchronize()
+    assert bool(torch.isinf(n1[-1])) == (int(b["tgt_len"][-1]) >= 2) and torch.equal(n1, n2)
+    fin = torch.isfinite(n1).cpu().numpy()
+    for i in range(B):                                  # lattice rows the passes define: t < len, s < 2*L+1
+        S, Tb = 2 * int(b["tgt_len"][i]) + 1, int(lens[i])
+        assert torch.equal(alpha_only[:Tb, i, :S], a2[:Tb, i, :S])
+        assert torch.equal(a1[:Tb, i, :S], a2[:Tb, i, :S] + b2[:Tb, i, :S])
+    assert torch.equal(g1[:, fin], g2[:, fin])
+    assert torch.equal(torch.isnan(g1), torch.isnan(g2))
+
+
 @pytest.mark.parametrize("T,B,V,Lmax", [(700, 5, 50, 200), (1200, 3, 30, 520), (9, 7, 12, 3)])
 def test_ctc_long_labels_vs_torch_cpu(dev, T, B, V, Lmax):
     """Label lengths that need 2 and 4+ lattice states per thread (S = 2L+1 > 256 / > 512), ragged input lengths incl.
@@ -840,3 +877,22 @@ def test_beam_error_paths(dev):
         bd.decode(torch.from_numpy(lp), [5])
     with pytest.raises(TypeError):
         BeamDecoder(i2c, beam_width=5)                      # lm_path=None: open(None), as the reference
+
+
+def test_bench_under_torchrun_with_rccl_collectives(dev):
+    """The driver's N>1 launch line, with one rank: torch.distributed.run -> process group on the nccl (= RCCL) backend ->
+    parameter broadcast, flat-gradient all-reduce ordered behind the side stream, sync-BN all-reduces, max-over-ranks.
+    CTCN_FORCE_COLLECTIVES=1 makes the single rank issue every collective (parallel.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CTCN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
+           "--sync-bn", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["steps"] == 2 and res["config"]["sync_bn"] is True
+    assert res["value"] > 0 and np.isfinite(res["final_loss"])
