@@ -1599,8 +1599,8 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
 #endif
-      CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
-      if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
+      if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));      // hand-off tiles | flags | tickets are contiguous
+      else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
       if (launch_fwd_persist(prec, NT, kq, pgrid, lds, st, pa, wpx)) {
         CTCN_LAUNCH_CHECK();
         return CTCN_OK;
@@ -1629,11 +1629,27 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   const float *w_ih[2] = {w_ih0, w_ih1};
   float *dw_ih[2] = {dw_ih0, dw_ih1};
   float *dw_hh[2] = {dw_hh0, dw_hh1};
+  // dx = [da_fwd | da_rev] [W_ih_fwd ; W_ih_rev]: the reserve already holds both directions side by side (row = dirs*GH floats),
+  // so with the two weight matrices stacked in the workspace one K = 2*GH product replaces two K = GH products and the
+  // read-modify-write of dx between them (65 MB each way at cfg2)
+  bool dx_done = false;
+  if (dx && dirs == 2) {
+    const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
+    if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
+      float *wcat = (float *)ws;
+      CTCN_HIP(hipMemcpyAsync(wcat, w_ih0, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+      CTCN_HIP(hipMemcpyAsync(wcat + (size_t)GH * I, w_ih1, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+      int rc = ctcn_gemm_on_xcds(0, 0, TB, I, 2 * GH, gates, 2 * GH, wcat, I, dx, I, 0.0f, precision, (char *)ws + wcat_bytes, ws_bytes - wcat_bytes,
+                                 stream, xcd_allow);
+      if (rc) return rc;
+      dx_done = true;
+    }
+  }
   for (int d = 0; d < dirs; ++d) {
     const float *da = gates + (size_t)d * GH;
     const int ldg = dirs * GH;
     int rc;
-    if (dx) {
+    if (dx && !dx_done) {
       rc = ctcn_gemm_on_xcds(0, 0, TB, I, GH, da, ldg, w_ih[d], I, dx, I, d == 0 ? 0.0f : 1.0f, precision, ws, ws_bytes, stream, xcd_allow);
       if (rc) return rc;
     }

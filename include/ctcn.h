@@ -54,12 +54,13 @@ int ctcn_get_option(const char *name);
 int ctcn_set_status_buffer(int *dev_word);
 
 /* ---------------------------------------------------------------------------------------------------
- * GEMM (MFMA, f32 in / f32 accumulate: v_mfma_f32_32x32x2_f32; optional bf16-operand mode)
+ * GEMM (MFMA, f32 in / f32 accumulate: v_mfma_f32_32x32x2_f32, or bf16x3 split operands: v_mfma_f32_32x32x16_bf16)
  * replaces: nn.Linear (model_ctc.py:137,166) and the input-projection part of nn.LSTM/GRU/RNN
  * (model_ctc.py:33).  C[M,N] = op(A)[M,K] * op(B)[K,N] + beta*C, row-major:
  *   transA==0: A[m*lda+k]   transA!=0: A[k*lda+m]     transB==0: B[k*ldb+n]   transB!=0: B[n*ldb+k]
  * ws/ws_bytes: optional split-K workspace (deterministic two-pass reduce); may be NULL/0.
- * precision: 0 = exact f32 MFMA, 1 = bf16 operands / f32 accumulate. */
+ * precision: 0 = exact f32 MFMA; 1 = each f32 operand split into bf16 hi + lo planes, three bf16 MFMAs per product
+ * (hi*hi + hi*lo + lo*hi), f32 accumulate: ~2^-16 relative operand error instead of bf16's 2^-8. */
 int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
               float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream);
 
