@@ -1538,8 +1538,22 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   const int G = gates_of(cell);
   const int GH = G * H;
   const float *w_ih[2] = {w_ih0, w_ih1};
-  for (int d = 0; d < dirs && !ctcn_opt_recurrence_only(); ++d) {
-    if (d > 0) ctcn_gemm_hint_same_a();                 // both directions project the same x: split it into planes once
+  // both directions project the same x and the gate reserve holds their pre-activations side by side (row = dirs*GH floats):
+  // with the two W_ih stacked in the workspace one N = 2*GH product does the work of two (one pass over x, one launch)
+  bool proj_done = ctcn_opt_recurrence_only();
+  if (!proj_done && dirs == 2) {
+    const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
+    if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
+      float *wcat = (float *)ws;
+      CTCN_HIP(hipMemcpyAsync(wcat, w_ih0, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, st));
+      CTCN_HIP(hipMemcpyAsync(wcat + (size_t)GH * I, w_ih1, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, st));
+      int rc = ctcn_gemm(0, 1, T * B, 2 * GH, I, x, I, wcat, I, gates, 2 * GH, 0.0f, precision, (char *)ws + wcat_bytes, ws_bytes - wcat_bytes, stream);
+      if (rc) return rc;
+      proj_done = true;
+    }
+  }
+  for (int d = 0; d < dirs && !proj_done; ++d) {
+    if (d > 0) ctcn_gemm_hint_same_a();                 // split x into planes once
     int rc = ctcn_gemm(0, 1, T * B, GH, I, x, I, w_ih[d], I, gates + (size_t)d * GH, dirs * GH, 0.0f, precision, ws,
                        ws_bytes, stream);
     if (rc) return rc;
