@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -1177,13 +1178,20 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   if (tid == 0) s_abort = 0;
   for (int i = tid; i < 1024; i += 1024) stage[i] = 0.0f;              // rows / units nobody owns stay 0
 
-  // W operand of this lane for its NTW output tiles (tile t = the 16 hidden units owned by slice t)
+  // Wave roles.  Waves 0..3 hold the (row, unit) items: gate math, the A-operand stage and ALL reserve traffic (loads two
+  // steps ahead, stores never waited for) -- they take no part in the exchange, so no "stores landed" wait ever queues
+  // behind an HBM access.  Waves 4..15 gather the partial tiles addressed to this workgroup, multiply and scatter: wave
+  // 4 + g owns output tiles g, g + 12, ... (tile t = the 16 hidden units of slice t) and nothing else is in its vm queue.
+  constexpr int NGW = 12, NTG = NTW;
+  const int gw = wave - 4;
+  // W operand of this lane for its NTW output tiles
   bf16x8_t whi[NTW][2], wlo[NTW][2];
   float wf[NTW][16];
 #pragma unroll
   for (int tw = 0; tw < NTW; ++tw) {
-    const int n = 16 * (wave + 16 * tw) + r;                           // output unit of this lane's B column
-    const bool nvalid = wave + 16 * tw < nsl && n < H;
+    const int own = wave >= 4 ? gw + NGW * tw : 0;
+    const int n = 16 * own + r;                                        // output unit of this lane's B column
+    const bool nvalid = wave >= 4 && own < nsl && n < H;
     const float *wrow = WT + (size_t)min(n, H - 1) * K;
     if constexpr (PREC == 1) {
 #pragma unroll
@@ -1208,14 +1216,14 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   // workgroup-wide flag, hence no barrier between "all producers done" and the loads, none between the stores and the flag
   const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(pa.flags, 0, (int)((size_t)2 * D * nbt * nsl * nsl * 4), 0x00020000);
   const unsigned flg_el[2] = {(unsigned)(((0 * D + d) * nbt + bt) * nsl * nsl), (unsigned)(((1 * D + d) * nbt + bt) * nsl * nsl)};
-  constexpr int NGW = 12, NTG = (16 * NTW + NGW - 1) / NGW;          // gathering waves 4..15 (no item traffic in their vm queue), sources per wave
-  const int gw = wave - 4;
   const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_f * 4), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_f * 4)};
 
   const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
   const bool item = tid < 256 && bl < Bc && j < H;
   float state = 0.0f;   // carried dc (LSTM) / dh*z (GRU)
-  float sv[4] = {0.f, 0.f, 0.f, 0.f}, dyv = 0.f, e0 = 0.f, e1 = 0.f;
+  // saved activations / dy / c / c_prev of the item, two sets: set (u & 1) holds step u and is refilled for step u + 2 as
+  // soon as step u has consumed it, so a reserve load has two whole steps to return (HBM under the side stream's GEMMs)
+  float sv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dyv[2] = {0.f, 0.f}, e0[2] = {0.f, 0.f}, e1[2] = {0.f, 0.f};
   const int tdir = d == 0 ? -1 : 1;
   const long slab_g = (long)B * D * K, slab_h = (long)B * D * H;
   const int bcl = min(b, B - 1), jcl = min(j, H - 1);
@@ -1227,19 +1235,25 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   const __amdgpu_buffer_rsrc_t r0 = whole_rsrc(is_tanh ? p.y : p.aux, (size_t)T * slab_h), r1 = whole_rsrc(is_lstm ? p.aux : p.y, (size_t)T * slab_h);
   const __amdgpu_buffer_rsrc_t ra = whole_rsrc(p.aux, (size_t)T * slab_h);
   const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);
-  bool e1_valid = T > 1 && !is_tanh;
+  // reserve values of step u (timestep tu; e1 belongs to the timestep of step u + 1) into set `ps`; steps past the end re-read the last one (unused)
+  auto load_set = [&](int u, auto PSC) {
+    constexpr int ps = decltype(PSC)::value;
+    const int uc = min(u, T - 1), tu = d == 0 ? T - 1 - uc : uc, tu1 = uc + 1 < T ? tu + tdir : tu;
+    const unsigned og = (unsigned)tu * sg_b, oh = (unsigned)tu * sh_b;
+    sv[ps][0] = ld_slab(rg, vg0, og); sv[ps][1] = ld_slab(rg, vg1, og); sv[ps][2] = ld_slab(rg, vg2, og); sv[ps][3] = ld_slab(rg, vg3, og);
+    dyv[ps] = ld_slab(rdy, vh, oh); e0[ps] = ld_slab(r0, vh, oh); e1[ps] = ld_slab(r1, vh, (unsigned)tu1 * sh_b);
+  };
   if (item) {
-    const int t0 = d == 0 ? T - 1 : 0, t1 = T > 1 ? t0 + tdir : t0;
-    const unsigned og = (unsigned)t0 * sg_b, oh = (unsigned)t0 * sh_b;
-    sv[0] = ld_slab(rg, vg0, og); sv[1] = ld_slab(rg, vg1, og); sv[2] = ld_slab(rg, vg2, og); sv[3] = ld_slab(rg, vg3, og);
-    dyv = ld_slab(rdy, vh, oh); e0 = ld_slab(r0, vh, oh); e1 = ld_slab(r1, vh, (unsigned)t1 * sh_b);
+    load_set(0, std::integral_constant<int, 0>{});
+    load_set(1, std::integral_constant<int, 1>{});
   }
   __syncthreads();
 
 #ifdef CTCN_PERSIST_STATS
   long long zt[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64();
 #endif
-  for (int s = 0; s < T; ++s) {
+  auto step = [&](const int s, auto PSC) {
+    constexpr int ps = decltype(PSC)::value;
 #ifdef CTCN_PERSIST_STATS
     const long long z_a = clock64();
     long long z_p = z_a, z_g = z_a, z_m = z_a, z_s = z_a, z_d = z_a;
@@ -1283,11 +1297,11 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     float out[4] = {0.f, 0.f, 0.f, 0.f};      // d(pre-activation) the next step multiplies by W_hh, per gate block
     float dan = 0.f;
     if (item) {
-      float dh = dyv + rec;
-      const float e1u = e1_valid ? e1 : 0.0f;                 // c / h of a step before the sequence start is 0
+      float dh = dyv[ps] + rec;
+      const float e1u = (s + 1 < T && !is_tanh) ? e1[ps] : 0.0f;   // c / h of a step before the sequence start is 0
       if (p.cell == CTCN_CELL_LSTM) {
-        const float i_ = sv[0], f_ = sv[1], g_ = sv[2], o_ = sv[3];
-        const float tc = act_tanh(e0);
+        const float i_ = sv[ps][0], f_ = sv[ps][1], g_ = sv[ps][2], o_ = sv[ps][3];
+        const float tc = act_tanh(e0[ps]);
         const float do_ = dh * tc;
         const float dc = dh * o_ * (1.0f - tc * tc) + state;
         out[0] = dc * g_ * i_ * (1.0f - i_);
@@ -1297,7 +1311,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         state = dc * f_;
       } else if (p.cell == CTCN_CELL_GRU) {
         dh += state;
-        const float r_ = sv[0], z_ = sv[1], n_ = sv[2], hn = e0, hp = e1u;
+        const float r_ = sv[ps][0], z_ = sv[ps][1], n_ = sv[ps][2], hn = e0[ps], hp = e1u;
         const float dn = dh * (1.0f - z_);
         const float dz = dh * (hp - n_);
         dan = dn * (1.0f - n_ * n_);
@@ -1306,7 +1320,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         out[2] = dan * r_;
         state = dh * z_;
       } else {
-        out[0] = dh * (1.0f - e0 * e0);
+        out[0] = dh * (1.0f - e0[ps] * e0[ps]);
       }
       if (s + 1 < T) {                                        // A operand of this workgroup's product, in MFMA order
 #pragma unroll
@@ -1331,6 +1345,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
       z_m = clock64();
 #endif
       const int par = s & 1;
+      if (wave >= 4) {
       f32x4 acc[NTW];
       if constexpr (PREC == 1) {
         const unsigned short *sp = reinterpret_cast<const unsigned short *>(stage);
@@ -1361,10 +1376,10 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
           for (int m = 0; m < 16; ++m) acc[tw] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], wf[tw][m], acc[tw], 0, 0, 0);
         }
       }
-      // scatter: tile tw of this wave belongs to owner slice wave + 16*tw; block (owner, source = this slice)
+      // scatter: tile tw of this wave belongs to owner slice gw + 12*tw; block (owner, source = this slice)
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
-        const int owner = wave + 16 * tw;
+        const int owner = gw + NGW * tw;
         if (owner < nsl) st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
       }
 #ifdef CTCN_PERSIST_STATS
@@ -1374,9 +1389,10 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
       if (lane == 0) {
 #pragma unroll
         for (int tw = 0; tw < NTW; ++tw) {
-          const int owner = wave + 16 * tw;
+          const int owner = gw + NGW * tw;
           if (owner < nsl) st_u1(rf, (flg_el[par] + (unsigned)(owner * nsl + slice)) * 4, (unsigned)(s + 1), local);   // ... raise their flags
         }
+      }
       }
 #ifdef CTCN_PERSIST_STATS
       z_d = clock64();
@@ -1385,8 +1401,6 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     // off the critical path (item waves): d(pre-activation) for the deferred dW / dX GEMMs, next step's saved values
     {
       const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
-      const int tn = s + 1 < T ? t + tdir : t, tp = s + 2 < T ? tn + tdir : tn;             // past the end: re-read (unused)
-      const unsigned ogn = (unsigned)tn * sg_b, ohn = (unsigned)tn * sh_b, ohp = (unsigned)tp * sh_b;
       if (item) {
         if (is_lstm) {
           st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, out[2]); st_slab(rg, vg3, og, out[3]);
@@ -1396,14 +1410,16 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         } else {
           st_slab(rg, vg0, og, out[0]);
         }
-        sv[0] = ld_slab(rg, vg0, ogn); sv[1] = ld_slab(rg, vg1, ogn); sv[2] = ld_slab(rg, vg2, ogn); sv[3] = ld_slab(rg, vg3, ogn);
-        dyv = ld_slab(rdy, vh, ohn); e0 = ld_slab(r0, vh, ohn); e1 = ld_slab(r1, vh, ohp);
+        load_set(s + 2, PSC);                                 // this set is free again: refill it for step s + 2
       }
-      e1_valid = s + 2 < T && !is_tanh;
     }
 #ifdef CTCN_PERSIST_STATS
     { const long long z_z = clock64(); zt[0] += z_p - z_a; zt[1] += z_g - z_p; zt[2] += z_m - z_g; zt[3] += z_s - z_m; zt[4] += z_d - z_s; zt[5] += z_z - z_d; }
 #endif
+  };
+  for (int s = 0; s < T; s += 2) {                            // unrolled by two: the reserve set of a step is a compile-time index
+    step(s, std::integral_constant<int, 0>{});
+    if (s + 1 < T) step(s + 1, std::integral_constant<int, 1>{});
   }
 #ifdef CTCN_PERSIST_STATS
   if (pa.stats && slice == 3 && d == 0 && bt == 0 && (tid == 0 || tid == 960)) {
@@ -1692,6 +1708,18 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   return CTCN_OK;
 }
 
+// One-shot event (hipEvent_t) that ctcn_rnn_bwd records on its stream right before it launches the recurrence, i.e. behind
+// its own preparatory memsets / transposes: work that the host wants to run NEXT TO the recurrence on another stream waits
+// for this event -- waiting for "everything before ctcn_rnn_bwd" instead lets it start early and delay those small kernels
+// (measured: a 5 us memset took 116-122 us when the side stream's queue kernels were dispatched first).
+static thread_local void *g_prelaunch_event = nullptr;
+extern "C" int ctcn_set_prelaunch_event(void *event) { g_prelaunch_event = event; return CTCN_OK; }
+static void record_prelaunch(hipStream_t st) {
+  if (!g_prelaunch_event) return;
+  (void)hipEventRecord((hipEvent_t)g_prelaunch_event, st);
+  g_prelaunch_event = nullptr;
+}
+
 extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
                             const float *w_hh0, const float *w_ih1, const float *w_hh1, const float *y,
                             float *gates, float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0,
@@ -1734,7 +1762,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     // measured: scatter wins at H = 320 (2.46 vs 2.68 us per step), ties at H = 128, loses at H = 512 (nsl^2 KB of partial tiles
     // per group and step) and at precision 0 (f32 MFMA: 32 cycles x 16 per tile on 4 waves per SIMD)
     const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= 24;
-    const int ntw = nsl <= 16 ? 1 : (nsl <= 32 ? 2 : 4);
+    const int ntw = nsl <= 12 ? 1 : (nsl <= 24 ? 2 : 4);      // output tiles per scattering wave (12 of them)
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
                                     : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
     const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * (scatter ? nsl : 1) * sizeof(unsigned), 256) + 256;   // + role tickets
@@ -1758,13 +1786,16 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
       const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid;
       if (scatter) {
+        record_prelaunch(st);
         done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
       } else {
         if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
+        record_prelaunch(st);
         done = launch_bwd_persist(prec, kq, pgrid, lds, st, pa, wpx);
       }
     }
   }
+  record_prelaunch(st);          // no-op if a persistent launch already consumed the event
   if (!done) {
     const int kq4 = pick_kq4(GH, 16, 1, 5);
     for (int s = 0; s < T; ++s) {

@@ -85,7 +85,7 @@ def _ws(t, tag="main"):
 # straight away it competes with the critical-path kernels that sit between two recurrences (the input-gradient GEMMs, the
 # BatchNorm / dropout backward), which measured 1.5-10x their stand-alone time in that window; behind the deferral they
 # have the chip to themselves and the side work overlaps with nothing but the recurrence, on the XCDs it leaves idle.
-_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}}
+_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}}
 
 
 def set_side_stream(flag):
@@ -100,6 +100,17 @@ def _side_stream(dev):
         st = torch.cuda.Stream(device=dev)
         _side["streams"][key] = st
     return st
+
+
+def _prelaunch_event(dev):
+    """Per-device event that ctcn_rnn_bwd records right before it launches its recurrence (ctcn_set_prelaunch_event)."""
+    key = (dev.type, dev.index)
+    ev = _side["events"].get(key)
+    if ev is None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))        # materialises the hipEvent_t behind ev.cuda_event
+        _side["events"][key] = ev
+    return ev
 
 
 def _flush_deferred(dev_key):
@@ -319,18 +330,34 @@ class _RNNLayer(torch.autograd.Function):
         key = (dev.type, dev.index)
         if ctx.counted:
             _side["live"][key] = max(0, _side["live"].get(key, 0) - 1)
-        _flush_deferred(key)     # the layer above: its weight GEMMs start together with this layer's recurrence
-        _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
-                                  _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
-                                  null if side else _ptr(d_ih0), null if side else _ptr(d_hh0), null if side else _ptr(d_ih1),
-                                  null if side else _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
-                                  wp, wn, _lib.stream_ptr()), "rnn_bwd")
+        # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right
+        # before that launch, behind its own small preparatory kernels, and the side stream waits for it
+        above, ev = _side["deferred"].pop(key, None), None
+        if above is not None:
+            ev = _prelaunch_event(dev)
+            _lib.check(L.ctcn_set_prelaunch_event(ctypes.c_void_p(ev.cuda_event)), "set_prelaunch_event")
+        try:
+            _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
+                                      _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
+                                      null if side else _ptr(d_ih0), null if side else _ptr(d_hh0), null if side else _ptr(d_ih1),
+                                      null if side else _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
+                                      wp, wn, _lib.stream_ptr()), "rnn_bwd")
+        except Exception:
+            if above is not None:                       # keep the parked work for the join, drop the armed event
+                L.ctcn_set_prelaunch_event(None)
+                _side["deferred"][key] = above
+            raise
+        if above is not None:
+            above(ev)
         if side:
             st = _side_stream(dev)
             prec = get_precision()
 
-            def weights_on_side_stream():
-                st.wait_stream(torch.cuda.current_stream(dev))
+            def weights_on_side_stream(after=None):
+                if after is None:
+                    st.wait_stream(torch.cuda.current_stream(dev))
+                else:
+                    st.wait_event(after)
                 with torch.cuda.stream(st):
                     w2, wp2, wn2 = _ws(x, tag="side")
                     _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0),

@@ -92,6 +92,10 @@ int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x,
                  float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0, float *dw_ih1,
                  float *dw_hh1, float beta_w, int precision, void *scratch, void *ws, size_t ws_bytes,
                  void *stream);
+/* One-shot: the next ctcn_rnn_bwd issued by this host thread records `event` (a hipEvent_t) on its stream immediately before
+ * it launches the recurrence, behind its own preparatory memsets / transposes.  Work meant to run next to that recurrence
+ * on another stream (ctcn_rnn_bwd_weights of the layer above) waits for this event.  NULL clears it. */
+int ctcn_set_prelaunch_event(void *event);
 /* ctcn_rnn_bwd with dw_ih0 == dw_hh0 == NULL runs the recurrence and dx only and leaves d(pre-activation) in gates
  * (and aux for the GRU n-gate); this call then produces the weight gradients from it: dW_ih = da^T x, dW_hh = da^T h_prev.
  * It has no consumer inside the backward pass, so the host side issues it on a second stream next to the NEXT layer's

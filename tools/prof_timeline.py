@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Timeline of the last training step in a rocprofv3 rocpd database: per stream, every kernel with its start offset,
+duration and the idle gap before it; plus per-stream busy / gap totals.  usage: prof_timeline.py results.db [min_gap_us]"""
+import sqlite3
+import sys
+
+db = sys.argv[1]
+min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+cur = sqlite3.connect(db).cursor()
+rows = list(cur.execute("select name, stream_id, start, end from kernels order by start"))
+adam = [i for i, r in enumerate(rows) if r[0].startswith("adam_kernel") or "adam_kernel" in r[0]]
+assert len(adam) >= 2, "need two optimiser steps to delimit one training step"
+lo, hi = adam[-2] + 1, adam[-1] + 1
+step = rows[lo:hi]
+t0, t1 = rows[adam[-2]][3], rows[adam[-1]][3]
+print("# step between the last two adam_kernel ends: %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))
+streams = {}
+for r in step:
+    streams.setdefault(r[1], []).append(r)
+main = max(streams, key=lambda k: len(streams[k]))
+for sid, ks in sorted(streams.items(), key=lambda kv: -len(kv[1])):
+    busy = sum(k[3] - k[2] for k in ks) / 1e3
+    print("## stream %s%s: %d kernels, busy %.1f us" % (sid, " (main)" if sid == main else "", len(ks), busy))
+    prev = t0 if sid == main else ks[0][2]
+    gaps = 0.0
+    for k in ks:
+        gap = (k[2] - prev) / 1e3
+        if sid == main and gap > 0:
+            gaps += gap
+        if sid == main and (gap >= min_gap or (k[3] - k[2]) / 1e3 >= 100):
+            print("%10.1f  gap %7.1f  dur %8.1f  %s" % ((k[2] - t0) / 1e3, gap, (k[3] - k[2]) / 1e3, k[0].replace("(anonymous namespace)::", "")[:70]))
+        prev = max(prev, k[3])
+    if sid == main:
+        print("## main-stream idle inside the step: %.1f us" % gaps)
