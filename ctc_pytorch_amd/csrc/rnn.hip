@@ -381,6 +381,8 @@ struct PersistArgs {
   unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)
   int hsu;              // forward: hidden units per workgroup (<= 4*NT)
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
+  int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
+                        // gathering wave polls the block itself; 0 = stores drained, then a flag per block
 #ifdef CTCN_PERSIST_STATS
   long long *stats;   // development instrumentation (tools/mb_step.hip only)
 #endif
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 // 8*(q & 1) .. +7; precision 0: k = gate * 16 + unit, consumed 4 at a time by v_mfma_f32_16x16x4_f32.
 // grid as rnn_bwd_persist; NTW = ceil(nsl / 16) tiles (and source blocks) per wave.
 // ================================================================================================
-template <int NTW, int PREC>
+template <int NTW, int PREC, bool TAGGED>
 __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   constexpr int NW = 16;
   const RnnArgs &p = pa.a;
@@ -1263,22 +1265,51 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     if (s > 0) {
       const int par = (s - 1) & 1;
       if (wave >= 4) {
-        // gather: the partial tiles addressed to this workgroup, sources gw, gw + 12, ... (fixed order); each is loaded as
-        // soon as ITS flag shows this step
+        // gather: the partial tiles addressed to this workgroup, sources gw, gw + 12, ... (summed in that fixed order)
         f32x4 sum = zero;
+        if constexpr (!TAGGED) {
+          // each block is loaded as soon as ITS flag shows this step
 #pragma unroll
-        for (int tg = 0; tg < NTG; ++tg) {
-          const int src = gw + NGW * tg;
-          if (src < nsl) {
-            const unsigned *fl = pa.flags + flg_el[par] + slice * nsl + src;
-            for (int spins = 0; __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)s; ++spins) {
-              if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                if (pa.status) atomicCAS(pa.status, 0, 201);        // give up: the launch finishes with a poisoned output
-                break;
+          for (int tg = 0; tg < NTG; ++tg) {
+            const int src = gw + NGW * tg;
+            if (src < nsl) {
+              const unsigned *fl = pa.flags + flg_el[par] + slice * nsl + src;
+              for (int spins = 0; __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)s; ++spins) {
+                if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                  if (pa.status) atomicCAS(pa.status, 0, 201);        // give up: the launch finishes with a poisoned output
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
               }
-              __builtin_amdgcn_s_sleep(1);
+              sum += ld_sc1_f4(rs, tile_b[par] + (unsigned)(((slice * nsl + src) * 64 + lane) * 16));
             }
-            sum += ld_sc1_f4(rs, tile_b[par] + (unsigned)(((slice * nsl + src) * 64 + lane) * 16));
+          }
+        } else {
+          // no flags: the blocks themselves are polled, one after the other (polling a wave's two blocks together measured
+          // 4 % slower: the second is nearly always there by the time the first one is).  A producer wrote its block at step
+          // s - 1 with tag ((s-1)>>1 & 1) ^ 1 in the LSB of every float (the buffer starts zeroed and the tag alternates between
+          // the uses of a parity buffer); a block counts once all 256 floats carry the tag, so a half-landed block (any
+          // granularity down to a dword) is simply read again
+          const unsigned tb = ((((unsigned)(s - 1)) >> 1) & 1u) ^ 1u;
+#pragma unroll
+          for (int tg = 0; tg < NTG; ++tg) {
+            const int src = gw + NGW * tg;
+            if (src < nsl) {
+              const unsigned boff = tile_b[par] + (unsigned)(((slice * nsl + src) * 64 + lane) * 16);
+              for (int spins = 0;; ++spins) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 16);
+                const bool okl = ((v.x & v.y & v.z & v.w & 1u) == tb) && (((v.x | v.y | v.z | v.w) & 1u) == tb);
+                if (__builtin_amdgcn_ballot_w64(okl) == ~0ull) {
+                  sum += (f32x4){__uint_as_float(v.x & ~1u), __uint_as_float(v.y & ~1u), __uint_as_float(v.z & ~1u), __uint_as_float(v.w & ~1u)};
+                  break;
+                }
+                if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                  if (pa.status) atomicCAS(pa.status, 0, 202);          // give up: the launch finishes with a poisoned output
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+              }
+            }
           }
         }
         park_tile(red, gw, lane, sum);
@@ -1380,11 +1411,19 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
         const int owner = gw + NGW * tw;
-        if (owner < nsl) st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
+        if (owner < nsl) {
+          if constexpr (TAGGED) {
+            const unsigned tb = ((((unsigned)s) >> 1) & 1u) ^ 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[tw][e] = __uint_as_float((__float_as_uint(acc[tw][e]) & ~1u) | tb);
+          }
+          st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
+        }
       }
 #ifdef CTCN_PERSIST_STATS
       z_s = clock64();
 #endif
+      if constexpr (!TAGGED) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's block stores have landed (L2 / memory) ...
       if (lane == 0) {
 #pragma unroll
@@ -1392,6 +1431,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
           const int owner = gw + NGW * tw;
           if (owner < nsl) st_u1(rf, (flg_el[par] + (unsigned)(owner * nsl + slice)) * 4, (unsigned)(s + 1), local);   // ... raise their flags
         }
+      }
       }
       }
 #ifdef CTCN_PERSIST_STATS
@@ -1432,17 +1472,17 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   if (bad && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
-template <int PREC>
+template <int PREC, bool TAGGED>
 bool launch_bwd_scatter_p(int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (ntw) {
-    case 1: return launch_resident(rnn_bwd_scatter<1, PREC>, grid, 1024, 0, st, a, wpx);
-    case 2: return launch_resident(rnn_bwd_scatter<2, PREC>, grid, 1024, 0, st, a, wpx);
-    case 4: return launch_resident(rnn_bwd_scatter<4, PREC>, grid, 1024, 0, st, a, wpx);
+    case 1: return launch_resident(rnn_bwd_scatter<1, PREC, TAGGED>, grid, 1024, 0, st, a, wpx);
+    case 2: return launch_resident(rnn_bwd_scatter<2, PREC, TAGGED>, grid, 1024, 0, st, a, wpx);
     default: return false;
   }
 }
 bool launch_bwd_scatter(int prec, int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
-  return prec ? launch_bwd_scatter_p<1>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<0>(ntw, grid, st, a, wpx);
+  if (a.tagmode) return prec ? launch_bwd_scatter_p<1, true>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<0, true>(ntw, grid, st, a, wpx);
+  return prec ? launch_bwd_scatter_p<1, false>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<0, false>(ntw, grid, st, a, wpx);
 }
 
 template <int PREC>
@@ -1624,7 +1664,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth();
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
@@ -1778,7 +1818,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth();
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
@@ -1786,6 +1826,8 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
       const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid;
       if (scatter) {
+        pa.tagmode = ctcn_opt_handoff_tags();
+        if (pa.tagmode) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));       // tags start from 0
         record_prelaunch(st);
         done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
       } else {

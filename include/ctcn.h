@@ -44,6 +44,9 @@ int ctcn_device_xcds(void);
  * "poll_depth" = 2 (default): flag polls kept in flight per polling wave in the XCD-local hand-off (1..4).
  * "bwd_scatter" = 1 (default): the persistent backward recurrence exchanges partial dh tiles (scatter formulation); 0: every
  * workgroup gathers the whole d(pre-activation) tile (rnn_bwd_persist).
+ * "handoff_tags" = 1 (default): the scatter formulation hands its partial tiles over WITHOUT flags: every float carries a
+ * step tag in its mantissa LSB (cleared again by the consumer: partial sums lose 1 ulp) and the consumer polls the block itself,
+ * which removes the producer's store drain and the consumer's flag round trip from the per-step chain; 0: drain + one flag per block.
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */
