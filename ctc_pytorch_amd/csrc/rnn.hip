@@ -362,6 +362,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 // 2-3 polls in flight / paced polls over the fabric 5.0-5.7 | buffer_inv sc0 + plain loads: stale L1 lines (incorrect) |
 // XCD-local, no flags at all: {bf16 hi, lo} words with the step number in the LSBs of lo, every wave re-loading its stale
 // granules: 2.3-2.5, i.e. no gain over flag + data (2.2) -- the re-load traffic of 160 spinning waves delays the stores |
+// the same with the bwd_scatter protocol (tag in the LSB of every dword, one chunk polled, the other five fetched together
+// and validated): 2.20 vs 2.03 -- here the polling waves are the item waves, whose polls return behind their own reserve
+// stores / pre-activation loads (in-order vm queue), and six chunks cost six tag reductions per step |
 // 5 waves per workgroup (16 units = 4 item waves + a communication wave of its own, 20 workgroups per group, one per CU, no
 // stragglers): flag wait 2100 -> 1500 cycles but tile loads and publish longer, 2.05 us either way.
 // grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
