@@ -14,6 +14,8 @@ int ctcn_opt_rnn_persistent(void);
 void ctcn_gemm_hint_same_a(void);   // next ctcn_gemm on this thread has the same, unmodified A as the previous one
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
                       int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow);
+int ctcn_gemm_shift_b(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float beta, int precision,
+                      void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, int shift);
 int ctcn_opt_handoff(void);
 int ctcn_opt_poll_depth(void);
 int ctcn_opt_bwd_scatter(void);

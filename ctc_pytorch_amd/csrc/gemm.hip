@@ -389,13 +389,15 @@ __global__ void split_rows_kernel(const float *__restrict__ src, int ld, int R, 
 }
 
 // out[c][r] (row stride Rp) = split(src[r*ld + c]); 64x64 tiles through LDS; zero for r >= R (k padding)
+// shift: output row k takes source row k - shift when that lies in [0, R), zero otherwise (a matrix delayed / advanced by
+// |shift| contraction steps: h_prev of the recurrent weight gradient)
 __device__ __forceinline__ void split_transpose_tile(float (*t)[65], int bx, int by, const float *__restrict__ src, int ld, int R, int C, int Rp,
-                                                     unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+                                                     unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, int shift) {
   const int r0 = by * 64, c0 = bx * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    t[i][tx] = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.0f;
+    const int r = r0 + i - shift, c = c0 + tx;
+    t[i][tx] = (r >= 0 && r < R && r0 + i < R && c < C) ? src[(size_t)r * ld + c] : 0.0f;
   }
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
@@ -410,14 +412,14 @@ __device__ __forceinline__ void split_transpose_tile(float (*t)[65], int bx, int
 }
 
 __global__ __launch_bounds__(256) void split_transpose_kernel(const float *__restrict__ src, int ld, int R, int C, int Rp,
-                                                              unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
+                                                              unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, int shift) {
   __shared__ float t[64][65];
-  split_transpose_tile(t, blockIdx.x, blockIdx.y, src, ld, R, C, Rp, hi, lo);
+  split_transpose_tile(t, blockIdx.x, blockIdx.y, src, ld, R, C, Rp, hi, lo, shift);
 }
 // XCD-filtered variant (see gemm_planes_nt_queue_kernel): tiles come from an atomic queue, workgroups off `xcd_allow` exit
 __global__ __launch_bounds__(256) void split_transpose_queue_kernel(const float *__restrict__ src, int ld, int R, int C, int Rp,
                                                                     unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, int tiles_x,
-                                                                    int tiles_y, unsigned xcd_allow, unsigned *__restrict__ queue) {
+                                                                    int tiles_y, unsigned xcd_allow, unsigned *__restrict__ queue, int shift) {
   __shared__ float t[64][65];
   __shared__ int s_item;
   unsigned x;
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void split_transpose_queue_kernel(const float 
     __syncthreads();
     const int item = s_item;
     if (item >= tiles_x * tiles_y) return;
-    split_transpose_tile(t, item % tiles_x, item / tiles_x, src, ld, R, C, Rp, hi, lo);
+    split_transpose_tile(t, item % tiles_x, item / tiles_x, src, ld, R, C, Rp, hi, lo, shift);
     __syncthreads();
   }
 }
@@ -637,6 +639,7 @@ __global__ void transpose01_kernel(const float *__restrict__ in, float *__restri
 static thread_local struct { const float *A; int lda, M, K, transA; void *ws; hipStream_t st; bool valid, armed; } g_last_a = {};
 void ctcn_gemm_hint_same_a(void) { g_last_a.armed = true; }
 
+static thread_local int g_b_shift = 0;      // one-shot, set by ctcn_gemm_shift_b for the plane path's B split
 // xcd_allow: 0 = whole device; otherwise (precision 1 plane path only) the XCDs the GEMM workgroups may run on
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
                       int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow) {
@@ -672,25 +675,27 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       const size_t part_bytes = ws_bytes - plane_bytes - 512;
       if (xcd_allow) CTCN_HIP(hipMemsetAsync(queue, 0, 16, st));
       int nq = 0;      // queue words 1, 2: the operand splits
-      auto split = [&](const float *src, int ld, bool contraction_major, int rows, unsigned short *hi, unsigned short *lo) {
+      auto split = [&](const float *src, int ld, bool contraction_major, int rows, unsigned short *hi, unsigned short *lo, int shift) {
         if (!contraction_major) {   // src[row*ld + k]
           const size_t total = (size_t)rows * (Kp / 4);
           hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min((size_t)8192, ceil_div_z(total, 256))), dim3(256), 0, st, src, ld, rows, K, Kp, hi, lo);
         } else {                    // src[k*ld + row] -> transpose
           if (xcd_allow)
             hipLaunchKernelGGL(split_transpose_queue_kernel, dim3(8 * ctcn_device_cus()), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, ceil_div(rows, 64),
-                               ceil_div(Kp, 64), xcd_allow, queue + (++nq));
+                               ceil_div(Kp, 64), xcd_allow, queue + (++nq), shift);
           else
-            hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo);
+            hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, shift);
         }
       };
       const bool same_a = g_last_a.armed && g_last_a.valid && g_last_a.A == A && g_last_a.lda == lda && g_last_a.M == M && g_last_a.K == K &&
-                          g_last_a.transA == transA && g_last_a.ws == ws && g_last_a.st == st && !xcd_allow;
+                          g_last_a.transA == transA && g_last_a.ws == ws && g_last_a.st == st;
       g_last_a.armed = false;
-      if (!same_a) split(A, lda, transA != 0, M, ah, al);
+      if (!same_a) split(A, lda, transA != 0, M, ah, al, 0);
       g_last_a.A = A; g_last_a.lda = lda; g_last_a.M = M; g_last_a.K = K; g_last_a.transA = transA; g_last_a.ws = ws; g_last_a.st = st;
-      g_last_a.valid = !xcd_allow;
-      split(B, ldb, transB == 0, N, bh, bl);
+      g_last_a.valid = true;
+      const int bshift = g_b_shift;
+      g_b_shift = 0;
+      split(B, ldb, transB == 0, N, bh, bl, bshift);
       CTCN_LAUNCH_CHECK();
       // tile shape: 128x128 (two workgroups per CU).  Option gemm_big_tiles: 256x128 / 128x256 tiles (one per CU, 96 KB of LDS)
       // when they fill the device at least once without more padding -- 25 % fewer LDS fragment reads per MFMA, yet measured
@@ -769,6 +774,28 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
     CTCN_LAUNCH_CHECK();
   }
   return CTCN_OK;
+}
+
+// C = A^T * shift_k(B) for contraction-major A (K x M) and B (K x N): B_eff[k] = B[k - shift] when 0 <= k - shift < K, else 0 --
+// the recurrent weight gradient dW_hh = da^T h_prev with h_prev = y delayed (forward direction) or advanced (reverse) by one
+// timestep.  On the bf16x3 plane path the shift is applied while B is split, so that A = da^T keeps the SAME K window as in
+// dW_ih = da^T x and its planes can be reused (ctcn_gemm_hint_same_a); elsewhere the window is narrowed instead.
+int ctcn_gemm_shift_b(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float beta, int precision,
+                      void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, int shift) {
+  const int as = shift < 0 ? -shift : shift;
+  CTCN_REQUIRE(as < K, "ctcn_gemm_shift_b: |shift| %d >= K %d", as, K);
+  const int Kp = ceil_div(K, PBK) * PBK;
+  const size_t plane_bytes = align_up(2 * ((size_t)M * Kp + (size_t)N * Kp) * sizeof(unsigned short), 256);
+  const bool plane = precision == 1 && K >= 64 && ws && ws_bytes >= plane_bytes + 1024;
+  if (!plane) {
+    g_last_a.armed = false;
+    const float *A2 = shift > 0 ? A + (size_t)as * lda : A, *B2 = shift < 0 ? B + (size_t)as * ldb : B;
+    return ctcn_gemm_on_xcds(1, 0, M, N, K - as, A2, lda, B2, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow);
+  }
+  g_b_shift = shift;
+  const int rc = ctcn_gemm_on_xcds(1, 0, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow);
+  g_b_shift = 0;
+  return rc;
 }
 
 extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,

@@ -1744,7 +1744,10 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
       rc = ctcn_gemm_on_xcds(1, 0, H, H, Kh, dn, dirs * H, yh, dirs * H, dw_hh[d] + (size_t)2 * H * H, H, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
       if (rc) return rc;
     } else {
-      rc = ctcn_gemm_on_xcds(1, 0, GH, H, Kh, da + offA * ldg, ldg, yh, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
+      // same A = da^T over the same K = T*B window as dW_ih above (its bf16 planes are reused); h_prev = y shifted by one timestep
+      ctcn_gemm_hint_same_a();
+      rc = ctcn_gemm_shift_b(GH, H, TB, da, ldg, y + (size_t)d * H, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream, xcd_allow,
+                             d == 0 ? B : -B);
       if (rc) return rc;
     }
   }

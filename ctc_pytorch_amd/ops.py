@@ -85,12 +85,15 @@ def _ws(t, tag="main"):
 # straight away it competes with the critical-path kernels that sit between two recurrences (the input-gradient GEMMs, the
 # BatchNorm / dropout backward), which measured 1.5-10x their stand-alone time in that window; behind the deferral they
 # have the chip to themselves and the side work overlaps with nothing but the recurrence, on the XCDs it leaves idle.
-_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}}
+_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": 1 << 21}
 
 
-def set_side_stream(flag):
-    """Enable / disable the weight-gradient side stream (default on; env CTCN_SIDE_STREAM=0 disables)."""
+def set_side_stream(flag, min_items=None):
+    """Enable / disable the weight-gradient side stream (default on; env CTCN_SIDE_STREAM=0 disables).  min_items: smallest
+    T*B*H of a recurrent layer whose weight GEMMs go to the side stream (default 2^21; smaller layers stay inline)."""
     _side["enabled"] = bool(flag)
+    if min_items is not None:
+        _side["min_items"] = int(min_items)
 
 
 def _side_stream(dev):
@@ -322,14 +325,17 @@ class _RNNLayer(torch.autograd.Function):
         # XCDs a persistent recurrence of this shape leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
         nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
         allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
-        side = into_flat and _side["enabled"] and allow != 0 and T > 1
-        if dx is None:
-            side = False         # bottom layer: no recurrence follows; its weight GEMMs run inline on the main stream, which
-                                 # would otherwise idle while the side stream finishes the layer above
+        # small layers stay inline: below ~2 M (frame, row, unit) items the weight GEMMs are launch-bound and the XCD-filtered
+        # launches of the side stream (thousands of workgroups that exit at once) only disturb the main stream (cfg1: 2.27 ms
+        # per step inline, 2.8-4.5 ms with the side stream)
+        side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items"]
         null = ctypes.c_void_p(None)
         key = (dev.type, dev.index)
         if ctx.counted:
             _side["live"][key] = max(0, _side["live"].get(key, 0) - 1)
+        if dx is None or _side["live"].get(key, 0) == 0:
+            side = False         # bottom recurrent layer: no recurrence follows; its weight GEMMs run inline on the main stream
+                                 # (whole device), which would otherwise idle while the side stream finishes the layer above
         # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right
         # before that launch, behind its own small preparatory kernels, and the side stream waits for it
         above, ev = _side["deferred"].pop(key, None), None
@@ -368,10 +374,7 @@ class _RNNLayer(torch.autograd.Function):
                         t.record_stream(st)         # the caching allocator must not recycle them under the side stream
                 _side["pending"][key] = st
 
-            if _side["live"].get(key, 0) > 0:
-                _side["deferred"][key] = weights_on_side_stream    # issued when the recurrence of the layer below is launched
-            else:
-                weights_on_side_stream()                           # no recurrence follows: overlap with whatever does
+            _side["deferred"][key] = weights_on_side_stream        # issued when the recurrence of the layer below is launched
             # one join per layer is harmless and keeps the path safe if an earlier backward pass died before its callback ran
             torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if into_flat:
