@@ -105,7 +105,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        for var, opt in (("CTCN_RNN_PERSISTENT", b"rnn_persistent"), ("CTCN_HANDOFF", b"handoff"), ("CTCN_GEMM_BIG_TILES", b"gemm_big_tiles"), ("CTCN_BWD_SCATTER", b"bwd_scatter"), ("CTCN_HANDOFF_TAGS", b"handoff_tags")):
+        for var, opt in (("CTCN_RNN_PERSISTENT", b"rnn_persistent"), ("CTCN_HANDOFF", b"handoff"), ("CTCN_GEMM_BIG_TILES", b"gemm_big_tiles"), ("CTCN_BWD_SCATTER", b"bwd_scatter"), ("CTCN_HANDOFF_TAGS", b"handoff_tags"), ("CTCN_SIDE_SPLIT_WGS", b"side_split_wgs")):
             env = os.environ.get(var)
             if env is not None:
                 l.ctcn_set_option(opt, int(env))

@@ -20,6 +20,7 @@ int ctcn_opt_handoff(void);
 int ctcn_opt_poll_depth(void);
 int ctcn_opt_bwd_scatter(void);
 int ctcn_opt_handoff_tags(void);
+int ctcn_opt_side_split_wgs(void);
 int ctcn_opt_gemm_big_tiles(void);
 int ctcn_opt_recurrence_only(void);   // measurement aid: ctcn_rnn_fwd/bwd skip their GEMMs (results are NOT valid)
 

@@ -29,6 +29,7 @@ static int g_opt_poll_depth = 2;
 static int g_opt_recurrence_only = 0;
 static int g_opt_bwd_scatter = 1;
 static int g_opt_handoff_tags = 1;
+static int g_opt_side_split_wgs = 8;
 static int g_opt_gemm_big_tiles = 0;   // 256x128 / 128x256 plane-GEMM tiles: measured 7 % slower than 128x128 x 2 per CU
 static int *g_status_dev = nullptr;
 
@@ -39,6 +40,7 @@ extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "rnn_recurrence_only")) { g_opt_recurrence_only = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "bwd_scatter")) { g_opt_bwd_scatter = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "handoff_tags")) { g_opt_handoff_tags = value ? 1 : 0; return CTCN_OK; }
+  if (name && !strcmp(name, "side_split_wgs")) { g_opt_side_split_wgs = value < 1 ? 1 : (value > 16 ? 16 : value); return CTCN_OK; }
   if (name && !strcmp(name, "gemm_big_tiles")) { g_opt_gemm_big_tiles = value ? 1 : 0; return CTCN_OK; }
   ctcn_set_error("ctcn_set_option: unknown option %s", name ? name : "(null)");
   return CTCN_EINVAL;
@@ -50,6 +52,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "rnn_recurrence_only")) return g_opt_recurrence_only;
   if (name && !strcmp(name, "bwd_scatter")) return g_opt_bwd_scatter;
   if (name && !strcmp(name, "handoff_tags")) return g_opt_handoff_tags;
+  if (name && !strcmp(name, "side_split_wgs")) return g_opt_side_split_wgs;
   if (name && !strcmp(name, "gemm_big_tiles")) return g_opt_gemm_big_tiles;
   return -1;
 }
@@ -61,4 +64,5 @@ int ctcn_opt_poll_depth(void) { return g_opt_poll_depth; }
 int ctcn_opt_recurrence_only(void) { return g_opt_recurrence_only; }
 int ctcn_opt_bwd_scatter(void) { return g_opt_bwd_scatter; }
 int ctcn_opt_handoff_tags(void) { return g_opt_handoff_tags; }
+int ctcn_opt_side_split_wgs(void) { return g_opt_side_split_wgs; }
 int ctcn_opt_gemm_big_tiles(void) { return g_opt_gemm_big_tiles; }

@@ -681,7 +681,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
           hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min((size_t)8192, ceil_div_z(total, 256))), dim3(256), 0, st, src, ld, rows, K, Kp, hi, lo);
         } else {                    // src[k*ld + row] -> transpose
           if (xcd_allow)
-            hipLaunchKernelGGL(split_transpose_queue_kernel, dim3(8 * ctcn_device_cus()), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, ceil_div(rows, 64),
+            hipLaunchKernelGGL(split_transpose_queue_kernel, dim3(ctcn_opt_side_split_wgs() * ctcn_device_cus()), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, ceil_div(rows, 64),
                                ceil_div(Kp, 64), xcd_allow, queue + (++nq), shift);
           else
             hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, shift);

@@ -47,6 +47,8 @@ int ctcn_device_xcds(void);
  * "handoff_tags" = 1 (default): the scatter formulation hands its partial tiles over WITHOUT flags: every float carries a
  * step tag in its mantissa LSB (cleared again by the consumer: partial sums lose 1 ulp) and the consumer polls the block itself,
  * which removes the producer's store drain and the consumer's flag round trip from the per-step chain; 0: drain + one flag per block.
+ * "side_split_wgs" = 8 (default): workgroups per CU launched by the XCD-filtered operand-split kernels of the weight-gradient
+ * side stream (1..16; measured at cfg2: 1 -> 20.2, 2 -> 18.0, 4 -> 17.0, 8..16 -> 16.8 ms per step: the side work is nearly critical).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */
