@@ -75,8 +75,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // round-to-nearest-even f32 -> bf16 (bits)
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }

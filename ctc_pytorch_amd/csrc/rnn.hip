@@ -483,6 +483,23 @@ __device__ __forceinline__ void st_slab(const __amdgpu_buffer_rsrc_t &rs, unsign
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, off, slab_off, 0);
 }
 
+// The same store, invisible to hipcc's s_waitcnt bookkeeping.  gfx9 counts loads and stores in ONE counter (vmcnt), loads
+// return in order among themselves but stores do not, so as soon as a wave has a load AND a store pending hipcc waits with
+// vmcnt(0) for any loaded register -- which, for an item wave, turns "loaded two steps ahead" into "loaded one step ahead".
+// With the stores hidden it sees loads only and emits the counted wait (vmcnt(7): the seven younger loads may stay in
+// flight).  That wait is still sufficient: completions >= pending - 7, of which at most all stores, and the loads among
+// them are the oldest ones.  Dword stores only (no store-data hazard), the "memory" clobber keeps the order.
+__device__ __forceinline__ void st_slab_untracked(const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned slab_off, float v) {
+  asm volatile("buffer_store_dword %0, %1, %2, %3 offen" ::"v"(v), "v"(off), "s"(rs), "s"(slab_off) : "memory");
+}
+
+// ... and the matching load: issued by hand INTO `dst` and waited for by hand (`s_waitcnt vmcnt(7)` + the registers as
+// "+v" operands right before their first use), because with loads of two steps in flight across the back-edge of the
+// step loop hipcc falls back to vmcnt(0) for the older set even when it sees nothing but loads.
+__device__ __forceinline__ void ld_slab_untracked(float &dst, const __amdgpu_buffer_rsrc_t &rs, unsigned off, unsigned slab_off) {
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(dst) : "v"(off), "s"(rs), "s"(slab_off) : "memory");
+}
+
 // Role of a workgroup in a persistent launch.  Device-scope mode: grid (slices, dirs, batch tiles).  XCD-local mode:
 // a 1-D grid of nx * (wpx + spare) workgroups.  The hardware deals workgroups round-robin over the XCDs (starting
 // wherever the previous dispatch stopped), so every XCD receives >= wpx of them; each workgroup reads the XCD it
@@ -1166,7 +1183,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 // 8*(q & 1) .. +7; precision 0: k = gate * 16 + unit, consumed 4 at a time by v_mfma_f32_16x16x4_f32.
 // grid as rnn_bwd_persist; NTW = ceil(nsl / 12) tiles (and source blocks) per exchange wave.
 // ================================================================================================
-template <int NTW, int PREC, bool TAGGED>
+// CELL: the cell type as a compile-time constant (the gate math is then branch-free: with the run-time `p.cell` the item path
+// carried ~20 scalar branches and as many phi copies per step)
+template <int NTW, int PREC, bool TAGGED, int CELL>
 __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   constexpr int NW = 16;
   const RnnArgs &p = pa.a;
@@ -1175,7 +1194,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  constexpr int G = CELL == CTCN_CELL_LSTM ? 4 : (CELL == CTCN_CELL_GRU ? 3 : 1);
+  const int H = p.H, D = p.D, B = p.B, T = p.T;
   __shared__ int s_ticket;
   const PersistRole role = persist_role(pa, D, &s_ticket);
   if (!role.active) return;
@@ -1240,7 +1260,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   const unsigned vg0 = (unsigned)(((bcl * D + d) * K + jcl) * 4);
   const unsigned vg1 = vg0 + (unsigned)(min(1, G - 1) * H * 4), vg2 = vg0 + (unsigned)(min(2, G - 1) * H * 4), vg3 = vg0 + (unsigned)(min(3, G - 1) * H * 4);
   const unsigned vh = (unsigned)(((bcl * D + d) * H + jcl) * 4);
-  const bool is_lstm = p.cell == CTCN_CELL_LSTM, is_tanh = p.cell == CTCN_CELL_TANH;
+  constexpr bool is_lstm = CELL == CTCN_CELL_LSTM, is_tanh = CELL == CTCN_CELL_TANH;
   const __amdgpu_buffer_rsrc_t rg = whole_rsrc(p.gates, (size_t)T * slab_g), rdy = whole_rsrc(p.dy, (size_t)T * slab_h);
   const __amdgpu_buffer_rsrc_t r0 = whole_rsrc(is_tanh ? p.y : p.aux, (size_t)T * slab_h), r1 = whole_rsrc(is_lstm ? p.aux : p.y, (size_t)T * slab_h);
   const __amdgpu_buffer_rsrc_t ra = whole_rsrc(p.aux, (size_t)T * slab_h);
@@ -1250,8 +1270,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     constexpr int ps = decltype(PSC)::value;
     const int uc = min(u, T - 1), tu = d == 0 ? T - 1 - uc : uc, tu1 = uc + 1 < T ? tu + tdir : tu;
     const unsigned og = (unsigned)tu * sg_b, oh = (unsigned)tu * sh_b;
-    sv[ps][0] = ld_slab(rg, vg0, og); sv[ps][1] = ld_slab(rg, vg1, og); sv[ps][2] = ld_slab(rg, vg2, og); sv[ps][3] = ld_slab(rg, vg3, og);
-    dyv[ps] = ld_slab(rdy, vh, oh); e0[ps] = ld_slab(r0, vh, oh); e1[ps] = ld_slab(r1, vh, (unsigned)tu1 * sh_b);
+    ld_slab_untracked(sv[ps][0], rg, vg0, og); ld_slab_untracked(sv[ps][1], rg, vg1, og); ld_slab_untracked(sv[ps][2], rg, vg2, og);
+    ld_slab_untracked(sv[ps][3], rg, vg3, og);
+    ld_slab_untracked(dyv[ps], rdy, vh, oh); ld_slab_untracked(e0[ps], r0, vh, oh); ld_slab_untracked(e1[ps], r1, vh, (unsigned)tu1 * sh_b);
   };
   if (item) {
     load_set(0, std::integral_constant<int, 0>{});
@@ -1260,7 +1281,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   __syncthreads();
 
 #ifdef CTCN_PERSIST_STATS
-  long long zt[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64();
+  long long zt[6] = {0, 0, 0, 0, 0, 0}, zi[4] = {0, 0, 0, 0}, zt0 = clock64();
 #endif
   auto step = [&](const int s, auto PSC) {
     constexpr int ps = decltype(PSC)::value;
@@ -1332,13 +1353,20 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         for (int w = 0; w < NGW; ++w) rec += rp[w * RT_T];
       }
     }
+#ifdef CTCN_PERSIST_STATS
+    if (rec == 12345.678f) zi[3] += 1;         // consume the sum before the stamp
+    const long long z_i0 = clock64();
+#endif
 
     float out[4] = {0.f, 0.f, 0.f, 0.f};      // d(pre-activation) the next step multiplies by W_hh, per gate block
     float dan = 0.f;
+    // the seven reserve values of this step have landed once at most the seven loads of the NEXT step's set (issued one step
+    // later, in order behind them) are still in flight; stores, which vmcnt counts too, can only make this wait longer
+    asm volatile("s_waitcnt vmcnt(7)" : "+v"(sv[ps][0]), "+v"(sv[ps][1]), "+v"(sv[ps][2]), "+v"(sv[ps][3]), "+v"(dyv[ps]), "+v"(e0[ps]), "+v"(e1[ps])::"memory");
     if (item) {
       float dh = dyv[ps] + rec;
       const float e1u = (s + 1 < T && !is_tanh) ? e1[ps] : 0.0f;   // c / h of a step before the sequence start is 0
-      if (p.cell == CTCN_CELL_LSTM) {
+      if constexpr (CELL == CTCN_CELL_LSTM) {
         const float i_ = sv[ps][0], f_ = sv[ps][1], g_ = sv[ps][2], o_ = sv[ps][3];
         const float tc = act_tanh(e0[ps]);
         const float do_ = dh * tc;
@@ -1348,7 +1376,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         out[2] = dc * i_ * (1.0f - g_ * g_);
         out[3] = do_ * o_ * (1.0f - o_);
         state = dc * f_;
-      } else if (p.cell == CTCN_CELL_GRU) {
+      } else if constexpr (CELL == CTCN_CELL_GRU) {
         dh += state;
         const float r_ = sv[ps][0], z_ = sv[ps][1], n_ = sv[ps][2], hn = e0[ps], hp = e1u;
         const float dn = dh * (1.0f - z_);
@@ -1378,10 +1406,15 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
           }
       }
     }
+#ifdef CTCN_PERSIST_STATS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long z_i1 = clock64();
+#endif
     if (s + 1 < T) {
       lds_barrier();
 #ifdef CTCN_PERSIST_STATS
       z_m = clock64();
+      zi[0] += z_i0 - z_g; zi[1] += z_i1 - z_i0; zi[2] += z_m - z_i1;
 #endif
       const int par = s & 1;
       if (wave >= 4) {
@@ -1450,13 +1483,13 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     {
       const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
       if (item) {
-        if (is_lstm) {
-          st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, out[2]); st_slab(rg, vg3, og, out[3]);
-        } else if (p.cell == CTCN_CELL_GRU) {
-          st_slab(rg, vg0, og, out[0]); st_slab(rg, vg1, og, out[1]); st_slab(rg, vg2, og, dan);
-          st_slab(ra, vh, oh, out[2]);
+        if constexpr (is_lstm) {
+          st_slab_untracked(rg, vg0, og, out[0]); st_slab_untracked(rg, vg1, og, out[1]); st_slab_untracked(rg, vg2, og, out[2]); st_slab_untracked(rg, vg3, og, out[3]);
+        } else if constexpr (CELL == CTCN_CELL_GRU) {
+          st_slab_untracked(rg, vg0, og, out[0]); st_slab_untracked(rg, vg1, og, out[1]); st_slab_untracked(rg, vg2, og, dan);
+          st_slab_untracked(ra, vh, oh, out[2]);
         } else {
-          st_slab(rg, vg0, og, out[0]);
+          st_slab_untracked(rg, vg0, og, out[0]);
         }
         load_set(s + 2, PSC);                                 // this set is free again: refill it for step s + 2
       }
@@ -1474,23 +1507,33 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     long long *o = pa.stats + (tid == 0 ? 0 : 8);
     for (int i = 0; i < 6; ++i) o[i] = zt[i];
     o[6] = clock64() - zt0;
+    if (tid == 0) for (int i = 0; i < 3; ++i) pa.stats[16 + i] = zi[i];
   }
 #endif
   const bool bad = pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   if (bad && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
 }
 
-template <int PREC, bool TAGGED>
+template <bool TAGGED, int CELL>
+bool launch_bwd_scatter_c(int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  switch (ntw) {      // precision 1 only: the host never picks the scatter formulation for the f32 matmul
+    case 1: return launch_resident(rnn_bwd_scatter<1, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
+    case 2: return launch_resident(rnn_bwd_scatter<2, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
+    default: return false;
+  }
+}
+template <bool TAGGED>
 bool launch_bwd_scatter_p(int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
-  switch (ntw) {
-    case 1: return launch_resident(rnn_bwd_scatter<1, PREC, TAGGED>, grid, 1024, 0, st, a, wpx);
-    case 2: return launch_resident(rnn_bwd_scatter<2, PREC, TAGGED>, grid, 1024, 0, st, a, wpx);
+  switch (a.a.cell) {
+    case CTCN_CELL_LSTM: return launch_bwd_scatter_c<TAGGED, CTCN_CELL_LSTM>(ntw, grid, st, a, wpx);
+    case CTCN_CELL_GRU: return launch_bwd_scatter_c<TAGGED, CTCN_CELL_GRU>(ntw, grid, st, a, wpx);
+    case CTCN_CELL_TANH: return launch_bwd_scatter_c<TAGGED, CTCN_CELL_TANH>(ntw, grid, st, a, wpx);
     default: return false;
   }
 }
 bool launch_bwd_scatter(int prec, int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
-  if (a.tagmode) return prec ? launch_bwd_scatter_p<1, true>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<0, true>(ntw, grid, st, a, wpx);
-  return prec ? launch_bwd_scatter_p<1, false>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<0, false>(ntw, grid, st, a, wpx);
+  if (!prec) return false;
+  return a.tagmode ? launch_bwd_scatter_p<true>(ntw, grid, st, a, wpx) : launch_bwd_scatter_p<false>(ntw, grid, st, a, wpx);
 }
 
 template <int PREC>

@@ -194,7 +194,7 @@ int main() {
       printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
              (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
     }
-    for (int lp = 0; lp < 2; ++lp) {
+    for (int lp = 0; lp < 3; ++lp) {
       const int local = 1, prec = 1, pd = 2, scatter = lp;
       if (nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
@@ -205,7 +205,9 @@ int main() {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st)); CK(hipMemsetAsync(hx, 0, hx_bytes, st));
         hipEventRecord(e0, st);
-        if (scatter) hipLaunchKernelGGL((rnn_bwd_scatter<2, 1>), gp, dim3(1024), 0, st, pa);
+        pa.tagmode = scatter == 2;
+        if (scatter == 2) hipLaunchKernelGGL((rnn_bwd_scatter<2, 1, true, 0>), gp, dim3(1024), 0, st, pa);
+        else if (scatter) hipLaunchKernelGGL((rnn_bwd_scatter<2, 1, false, 0>), gp, dim3(1024), 0, st, pa);
         else hipLaunchKernelGGL((rnn_bwd_persist<5, 1>), gp, dim3(1024), 0, st, pa);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
       }
@@ -213,11 +215,13 @@ int main() {
       int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost));
       CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
       for (int wv = 0; wv < 2; ++wv)
-        printf("  bwd %s per step (cycles), slice 3, %s: %s %.0f | %.0f | %.0f | %.0f | %.0f | %.0f | total %.0f\n", scatter ? "SCATTER" : "gather",
-               wv ? "wave 15 (poller)" : "wave 0 (items)", scatter ? "poll+barrier | gather+park+barrier | item sum+math+stage+barrier | lds+mfma+scatter issue | drain+barrier | flag+reserve:" : "phases:",
+        printf("  bwd %s per step (cycles), slice 3, %s: %s %.0f | %.0f | %.0f | %.0f | %.0f | %.0f | total %.0f\n", scatter == 2 ? "SCATTER tagged" : scatter ? "SCATTER flags" : "gather",
+               wv ? "wave 15 (exchange)" : "wave 0 (items)", scatter ? "gather+park+barrier | - | item sum+math+stage+barrier | lds+mfma+scatter issue | drain+flags | reserve traffic:" : "phases:",
                (double)h[wv * 8 + 0] / T, (double)h[wv * 8 + 1] / T, (double)h[wv * 8 + 2] / T, (double)h[wv * 8 + 3] / T,
                (double)h[wv * 8 + 4] / T, (double)h[wv * 8 + 5] / T, (double)h[wv * 8 + 6] / T);
-      printf("bwd PERSISTENT %s   %8.2f us/step   (status %d)\n", scatter ? "scatter" : "gather", ms * 1e3 / T, hs);
+      if (scatter) printf("    item wave, inside 'item sum+math+stage+barrier': partial sum (12 LDS reads) %.0f | gate math + stage writes %.0f | barrier wait %.0f\n",
+                          (double)h[16] / T, (double)h[17] / T, (double)h[18] / T);
+      printf("bwd PERSISTENT %s   %8.2f us/step   (status %d)\n", scatter == 2 ? "scatter tagged" : scatter ? "scatter flags" : "gather", ms * 1e3 / T, hs);
     }
   }
   // graph replay of the forward loop: is the host the limiter?
