@@ -533,29 +533,34 @@ __device__ __forceinline__ void park_tile(float *red, int slot, int lane, const 
 }
 __device__ __forceinline__ int parked_at(int row, int col) { return (row >> 2) * RT_Q + col * 4 + (row & 3); }
 
-template <int NT, int KQ4, int PREC>
+// CELL >= 0: the cell type as a compile-time constant (branch-free gate math; instantiated for the LSTM at precision 1);
+// CELL = -1: read from the arguments
+template <int NT, int KQ4, int PREC, int CELL>
 __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   constexpr int NW = 4;
   const RnnArgs &p = pa.a;
   __shared__ __attribute__((aligned(16))) float red[NW * NT * RT_T];
   __shared__ __attribute__((aligned(16))) float hpub[16][16];   // h_t of this workgroup's units: f32 [row][unit], or (precision 1) two bf16 planes [hi|lo][row][unit]
   __shared__ int s_abort;
+  __shared__ int s_pub;                     // step whose h block the communication wave has handed over (release of the reserve traffic)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int H = p.H, G = p.G, D = p.D, B = p.B, T = p.T;
+  const int cell = CELL >= 0 ? CELL : pa.a.cell;
+  const int G = CELL == CTCN_CELL_LSTM ? 4 : (CELL == CTCN_CELL_GRU ? 3 : (CELL == CTCN_CELL_TANH ? 1 : p.G));
+  const int H = p.H, D = p.D, B = p.B, T = p.T;
   __shared__ int s_ticket;
   const PersistRole role = persist_role(pa, D, &s_ticket);
   if (!role.active) return;
   const int d = role.d, bt = role.bt, nbt = pa.nbt, nsl = pa.nsl, slice = role.slice, local = pa.local;
   const int b0 = bt * 16;
   const int Bc = min(16, B - b0);
-  const bool tanh_cell = p.cell == CTCN_CELL_TANH;
+  const bool tanh_cell = cell == CTCN_CELL_TANH;
   const int HSU = pa.hsu;                                  // hidden units owned by this workgroup (<= 4*NT; 16 for tanh)
   const int j0 = slice * HSU;
   const float *W = d == 0 ? p.w0 : p.w1;
   const int kb = wave * 16 * KQ4 + q * 4;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  if (tid == 0) s_abort = 0;
+  if (tid == 0) { s_abort = 0; s_pub = 0; }
 
   // W_hh slice of this lane, resident for the whole sequence: tile nt covers units j0+4nt..+3 (x 4 gates)
   constexpr int KB = (KQ4 + 1) / 2;                       // precision 1: 32-k blocks per wave (4 * KB * 32 >= H)
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       for (int w = 0; w < NW; ++w)
 #pragma unroll
         for (int g = 0; g < 4; ++g) o[g] += rp[w * NT * RT_T + g * 16];          // +4 columns = +16 floats
-      if (p.cell == CTCN_CELL_LSTM) {
+      if (cell == CTCN_CELL_LSTM) {
         const float i_ = act_sigmoid(o[0] + pre[0]);
         const float f_ = act_sigmoid(o[1] + pre[1]);
         const float g_ = act_tanh(o[2] + pre[2]);
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
         hval = o_ * act_tanh(c);
         state = c;
         sv0 = i_; sv1 = f_; sv2 = g_; sv3 = o_; sv4 = c;
-      } else if (p.cell == CTCN_CELL_GRU) {
+      } else if (cell == CTCN_CELL_GRU) {
         const float hn = o[2];
         const float r_ = act_sigmoid(o[0] + pre[0]);
         const float z_ = act_sigmoid(o[1] + pre[1]);
@@ -793,16 +798,24 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #endif
       if (lane == 0) st_u1(rf, (flg_el[par] + (unsigned)slice) * 4, (unsigned)(s + 1), local);
     }
+    // The item waves' reserve stores (6 scattered dword stores per item) must not enter this CU's memory pipeline ahead of
+    // the 16-B hand-off stores: queued behind them the "drain" above took 1 100-1 400 cycles instead of 300.  They are held
+    // back (an LDS word, polled) until the communication wave has raised its flag.
+    if (wave == cw) {
+      if (lane == 0) __hip_atomic_store(&s_pub, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (item) {
+      while (__hip_atomic_load(&s_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != s + 1) __builtin_amdgcn_s_sleep(1);
+    }
     // off the critical path (item waves): the reserve (gates, c / hn) and y leave after the hand-off, and the next
     // step's pre-activations are requested a whole step before the gate math needs them
     {
       const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
       const unsigned on = (unsigned)(s + 1 < T ? (d == 0 ? t + 1 : t - 1) : t) * sg_b;      // past the end: re-read t (unused)
       if (item) {
-        if (p.cell == CTCN_CELL_LSTM) {
+        if (cell == CTCN_CELL_LSTM) {
           st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2); st_slab(rg, vg3, og, sv3);
           st_slab(ra, vh, oh, sv4);
-        } else if (p.cell == CTCN_CELL_GRU) {
+        } else if (cell == CTCN_CELL_GRU) {
           st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2);
           st_slab(ra, vh, oh, sv4);
         }
@@ -850,31 +863,32 @@ bool launch_resident(Kern kern, dim3 grid, int threads, size_t lds, hipStream_t 
   return true;
 }
 
-template <int NT, int PREC>
+template <int NT, int PREC, int CELL>
 bool launch_fwd_persist_nt(int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (kq4) {
-    case 1: return launch_resident(rnn_fwd_persist<NT, 1, PREC>, grid, 256, lds, st, a, wpx);
-    case 2: return launch_resident(rnn_fwd_persist<NT, 2, PREC>, grid, 256, lds, st, a, wpx);
-    case 3: return launch_resident(rnn_fwd_persist<NT, 3, PREC>, grid, 256, lds, st, a, wpx);
-    case 4: return launch_resident(rnn_fwd_persist<NT, 4, PREC>, grid, 256, lds, st, a, wpx);
-    case 5: return launch_resident(rnn_fwd_persist<NT, 5, PREC>, grid, 256, lds, st, a, wpx);
-    case 6: return launch_resident(rnn_fwd_persist<NT, 6, PREC>, grid, 256, lds, st, a, wpx);
-    case 8: return launch_resident(rnn_fwd_persist<NT, 8, PREC>, grid, 256, lds, st, a, wpx);
+    case 1: return launch_resident(rnn_fwd_persist<NT, 1, PREC, CELL>, grid, 256, lds, st, a, wpx);
+    case 2: return launch_resident(rnn_fwd_persist<NT, 2, PREC, CELL>, grid, 256, lds, st, a, wpx);
+    case 3: return launch_resident(rnn_fwd_persist<NT, 3, PREC, CELL>, grid, 256, lds, st, a, wpx);
+    case 4: return launch_resident(rnn_fwd_persist<NT, 4, PREC, CELL>, grid, 256, lds, st, a, wpx);
+    case 5: return launch_resident(rnn_fwd_persist<NT, 5, PREC, CELL>, grid, 256, lds, st, a, wpx);
+    case 6: return launch_resident(rnn_fwd_persist<NT, 6, PREC, CELL>, grid, 256, lds, st, a, wpx);
+    case 8: return launch_resident(rnn_fwd_persist<NT, 8, PREC, CELL>, grid, 256, lds, st, a, wpx);
     default: return false;
   }
 }
-template <int PREC>
+template <int PREC, int CELL>
 bool launch_fwd_persist_p(int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (nt) {
-    case 1: return launch_fwd_persist_nt<1, PREC>(kq4, grid, lds, st, a, wpx);
-    case 2: return launch_fwd_persist_nt<2, PREC>(kq4, grid, lds, st, a, wpx);
-    case 3: return launch_fwd_persist_nt<3, PREC>(kq4, grid, lds, st, a, wpx);
-    case 4: return launch_fwd_persist_nt<4, PREC>(kq4, grid, lds, st, a, wpx);
+    case 1: return launch_fwd_persist_nt<1, PREC, CELL>(kq4, grid, lds, st, a, wpx);
+    case 2: return launch_fwd_persist_nt<2, PREC, CELL>(kq4, grid, lds, st, a, wpx);
+    case 3: return launch_fwd_persist_nt<3, PREC, CELL>(kq4, grid, lds, st, a, wpx);
+    case 4: return launch_fwd_persist_nt<4, PREC, CELL>(kq4, grid, lds, st, a, wpx);
     default: return false;
   }
 }
 bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
-  return prec ? launch_fwd_persist_p<1>(nt, kq4, grid, lds, st, a, wpx) : launch_fwd_persist_p<0>(nt, kq4, grid, lds, st, a, wpx);
+  if (prec && a.a.cell == CTCN_CELL_LSTM) return launch_fwd_persist_p<1, CTCN_CELL_LSTM>(nt, kq4, grid, lds, st, a, wpx);
+  return prec ? launch_fwd_persist_p<1, -1>(nt, kq4, grid, lds, st, a, wpx) : launch_fwd_persist_p<0, -1>(nt, kq4, grid, lds, st, a, wpx);
 }
 
 // ================================================================================================
