@@ -121,12 +121,12 @@ def gemm_roofline(dev, c):
                 peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
 
 
-def recurrence_traffic(workload):
-    """HBM bytes per launch of the backward recurrent kernel from the committed rocprofv3 PMC passes (cfg2 only)."""
+def recurrence_traffic(workload, kernel="rnn_bwd_scatter"):
+    """HBM bytes per launch of a recurrent kernel from the committed rocprofv3 PMC passes (cfg2 only)."""
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
         for k, v in pm.items():
-            if workload == "cfg2" and k.startswith("rnn_bwd_scatter"):
+            if workload == "cfg2" and k.startswith(kernel):
                 return v["hbm_bytes"]
     except Exception:
         pass
@@ -251,15 +251,20 @@ def run_train(args):
         "per_gpu_frames_per_s": value / world,
     }
     try:
-        # dominant kernel by GPU time (profiles/): the persistent backward recurrence.  It is a chain of T dependent
+        # dominant kernels by GPU time (profiles/): the persistent recurrences.  Each is a chain of T dependent
         # [B x H] x [H x 4H] products, so its ceiling is the MFMA peak of the arithmetic it uses -- which B = 32 rows and an
         # 800-step dependence chain cannot approach: the per-timestep cost is two in-XCD L2 hand-offs, not flops.
         rec = recurrence_probe(dev, c)
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 3.0
-        tf = rec["algorithmic_flops_per_launch"] / (rec["kernel_bwd_us"] * 1e-6) / 1e12
-        res["roofline"] = dict(kernel="rnn_bwd_scatter (backward recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (c["rnn"], c["T"]),
-                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=recurrence_traffic(args.workload),
-                               us_per_launch=rec["kernel_bwd_us"], us_per_dependent_step=rec["bwd_us_per_timestep"],
+        # the roofline object describes the DOMINANT kernel: whichever recurrence (forward / backward) is the longer launch
+        fwd_dom = rec["kernel_fwd_us"] >= rec["kernel_bwd_us"]
+        kname, kus, kstep = (("rnn_fwd_persist", rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
+                             ("rnn_bwd_scatter", rec["kernel_bwd_us"], rec["bwd_us_per_timestep"]))
+        tf = rec["algorithmic_flops_per_launch"] / (kus * 1e-6) / 1e12
+        res["roofline"] = dict(kernel="%s (%s recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (
+                                   kname, "forward" if fwd_dom else "backward", c["rnn"], c["T"]),
+                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=recurrence_traffic(args.workload, kname),
+                               us_per_launch=kus, us_per_dependent_step=kstep,
                                algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],
                                peak_note=("f32 MFMA 157.3 TFLOP/s" if args.precision == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
                                + "; latency-bound: see DESIGN.md section 5 for the per-step critical path")

@@ -158,7 +158,7 @@ int main() {
     CK(hipMalloc(&hx, hx_bytes)); CK(hipMalloc(&flags, fl_bytes)); CK(hipMalloc(&status, 4)); CK(hipMalloc(&stats, sizeof(long long) * (16 + 64 * 3))); CK(hipMemset(stats, 0, sizeof(long long) * (16 + 64 * 3)));
     const int nx = ctcn_device_xcds();
     printf("device XCDs (even deal verified): %d\n", nx);
-    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{1, 8, 2, 1, 2}, {1, 12, 3, 1, 2}, {1, 16, 4, 1, 2}};
+    struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{1, 8, 2, 1, 2}, {1, 4, 1, 1, 2}, {1, 16, 4, 1, 2}};
     for (auto &c : cfgs) {
       if (c.local && nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
@@ -174,6 +174,7 @@ int main() {
         if (c.nt == 2 && !c.prec) hipLaunchKernelGGL((rnn_fwd_persist<2, 5, 0, 0>), gp, dim3(256), lds, st, pa);
         else if (c.nt == 3 && !c.prec) hipLaunchKernelGGL((rnn_fwd_persist<3, 5, 0, 0>), gp, dim3(256), lds, st, pa);
         else if (c.nt == 2) hipLaunchKernelGGL((rnn_fwd_persist<2, 5, 1, 0>), gp, dim3(256), lds, st, pa);
+        else if (c.nt == 1) hipLaunchKernelGGL((rnn_fwd_persist<1, 5, 1, 0>), gp, dim3(256), lds, st, pa);
         else if (c.nt == 3) hipLaunchKernelGGL((rnn_fwd_persist<3, 5, 1, 0>), gp, dim3(256), lds, st, pa);
         else hipLaunchKernelGGL((rnn_fwd_persist<4, 5, 1, 0>), gp, dim3(256), lds, st, pa);
         hipEventRecord(e1, st); hipEventSynchronize(e1);
