@@ -365,6 +365,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 // the same with the bwd_scatter protocol (tag in the LSB of every dword, one chunk polled, the other five fetched together
 // and validated): 2.20 vs 2.03 -- here the polling waves are the item waves, whose polls return behind their own reserve
 // stores / pre-activation loads (in-order vm queue), and six chunks cost six tag reductions per step |
+// slices of 10 units (32 workgroups per group, one per CU, 4-byte publish pieces): 2.37 -- the flag wait (~2 100 cycles) is not
+// the doubled-up CUs, it is the poll round trip itself; slices of 4: 2.55; 1 / 3 / 4 polls in flight: 2.08 / 2.09 / 2.15 |
 // 5 waves per workgroup (16 units = 4 item waves + a communication wave of its own, 20 workgroups per group, one per CU, no
 // stragglers): flag wait 2100 -> 1500 cycles but tile loads and publish longer, 2.05 us either way.
 // grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
