@@ -213,6 +213,8 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
   ctc_lattice_body<DIR, NS, true>(smem, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax);
 }
 
+// (Measured and dropped: one wave per (utterance, pass) with the lattice in registers -- lane l holding states 2l and 2l + 1,
+// neighbour states through ds_bpermute, no LDS, no barrier -- is bit-identical but SLOWER at cfg2: 230 us against 193 us.)
 // alpha (blockIdx.y = 0) and beta (blockIdx.y = 1) of every utterance in one launch: the two passes are independent chains of
 // T dependent steps, so running them side by side halves the latency of the loss (2B workgroups instead of B twice).
 template <int NS>
