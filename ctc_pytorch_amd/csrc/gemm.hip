@@ -394,7 +394,40 @@ __global__ void split_rows_kernel(const float *__restrict__ src, int ld, int R, 
 __device__ __forceinline__ void split_transpose_tile(float (*t)[65], int bx, int by, const float *__restrict__ src, int ld, int R, int C, int Rp,
                                                      unsigned short *__restrict__ hi, unsigned short *__restrict__ lo, int shift) {
   const int r0 = by * 64, c0 = bx * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  // fast path (every large operand): 16-B global loads along the columns, 16-B plane stores along the rows (8 bf16 of one
+  // output row per lane: a wave writes eight 128-B runs), LDS image padded to 65 floats so that both the row-wise scalar
+  // writes and the column-wise reads are conflict-free.  8 global instructions per thread instead of 48.
+  const bool vec = c0 + 64 <= C && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0;
+  if (vec) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j, i = idx >> 4, c4 = idx & 15;
+      const int r = r0 + i - shift;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r >= 0 && r < R && r0 + i < R) v = *reinterpret_cast<const float4 *>(src + (size_t)r * ld + c0 + 4 * c4);
+      t[i][4 * c4 + 0] = v.x; t[i][4 * c4 + 1] = v.y; t[i][4 * c4 + 2] = v.z; t[i][4 * c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = tid + 256 * j, c = g >> 3, ro = g & 7;
+      unsigned hw[4], lw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short h0, l0, h1, l1;
+        split_bf16(t[ro * 8 + 2 * e][c], h0, l0);
+        split_bf16(t[ro * 8 + 2 * e + 1][c], h1, l1);
+        hw[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lw[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+      const size_t o = (size_t)(c0 + c) * Rp + r0 + ro * 8;
+      *reinterpret_cast<uint4 *>(hi + o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      *reinterpret_cast<uint4 *>(lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+    return;
+  }
+  const int tx = tid & 63, ty = tid >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i - shift, c = c0 + tx;
     t[i][tx] = (r >= 0 && r < R && r0 + i < R && c < C) ? src[(size_t)r * ld + c] : 0.0f;
