@@ -108,8 +108,8 @@ def gemm_roofline(dev, c):
     traffic = None     # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected inside bench.py)
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        key = "gemm_f32_kernel<NT> %dx%dx%d" % (M, N, K)
-        if prec == 0 and key in pm:
+        key = ("gemm_f32_kernel<NT> %dx%dx%d" if prec == 0 else "gemm_planes_nt_kernel %dx%dx%d") % (M, N, K)
+        if key in pm:
             traffic = pm[key]["hbm_bytes"]
     except Exception:
         pass
