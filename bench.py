@@ -115,7 +115,7 @@ def gemm_roofline(dev, c):
         pass
     # bf16x3 issues 3 bf16 MFMAs per algorithmic product: its ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s
     peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0 / 3.0
-    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_bf16x3_kernel<NT>") + " %dx%dx%d" % (M, N, K), bound="mfma",
+    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_planes_nt_kernel<2,2> + its two operand-split passes,") + " %dx%dx%d" % (M, N, K), bound="mfma",
                 achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic, us_per_launch=ms * 1e3,
                 algorithmic_flops_per_launch=flops,
                 peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
