@@ -474,6 +474,9 @@ __device__ __forceinline__ int pswz(int row, int kc) { return row * 128 + ((kc ^
 // MFMA tiles: per 16-k step a wave reads 2*(TI + TJ) fragments from LDS for 3*TI*TJ MFMAs, so the LDS traffic per MFMA
 // falls from 0.67 fragments (TI = TJ = 2) to 0.5 (2 x 4 / 4 x 2) -- the 128x128 kernel is LDS-bound, not MFMA-bound.
 // sm = dynamic LDS: [Ah | Al] (64*TI rows x 128 B each) then [Bh | Bl] (64*TJ rows x 128 B each).
+// Measured and dropped: 32-k stages (32 KB of LDS, 156 VGPRs: three workgroups per CU instead of two) -- bit-identical, 1-4 %
+// slower (dx 25 600 x 640 x 2 560: 436 vs 418 us with its split passes), so occupancy is not what holds the 128x128 tile at
+// ~36 % of the MFMA rate; PMC (profiles/r01_pmc_gemm_probe_v10.txt): the A planes cross the fabric 2.3 x per XCD.
 template <int TI, int TJ>
 __device__ __forceinline__ void plane_tile(unsigned char *sm, int bid, int split, int M, int N, int Kp,
                                            const unsigned short *__restrict__ Ah, const unsigned short *__restrict__ Al,
