@@ -228,7 +228,7 @@ def run_train(args):
     dt = time.perf_counter() - t0
     _ops.check_health()                # a hand-off timeout in a persistent kernel poisons the step: never report such a run
     dt = parallel.max_over_ranks(dt, dev)
-    last_loss = float(losses[-1]) * world if losses else float("nan")
+    last_loss = float(losses[-1].detach()) * world if losses else float("nan")
     if rank != 0:
         return
     frames = c["B"] * c["T"] * world * args.steps
