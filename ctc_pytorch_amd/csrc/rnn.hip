@@ -1666,7 +1666,11 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   bool proj_done = ctcn_opt_recurrence_only();
   if (!proj_done && dirs == 2) {
     const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
-    if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
+    if (w_ih1 == w_ih0 + (size_t)GH * I) {      // already one (2*GH, I) matrix (optim.FlatAdam places them so): no stacking copies
+      int rc = ctcn_gemm(0, 1, T * B, 2 * GH, I, x, I, w_ih0, I, gates, 2 * GH, 0.0f, precision, ws, ws_bytes, stream);
+      if (rc) return rc;
+      proj_done = true;
+    } else if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
       float *wcat = (float *)ws;
       CTCN_HIP(hipMemcpyAsync(wcat, w_ih0, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, st));
       CTCN_HIP(hipMemcpyAsync(wcat + (size_t)GH * I, w_ih1, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1772,7 +1776,11 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   bool dx_done = false;
   if (dx && dirs == 2) {
     const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
-    if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
+    if (w_ih1 == w_ih0 + (size_t)GH * I) {      // the two W_ih are already stacked in memory
+      int rc = ctcn_gemm_on_xcds(0, 0, TB, I, 2 * GH, gates, 2 * GH, w_ih0, I, dx, I, 0.0f, precision, ws, ws_bytes, stream, xcd_allow);
+      if (rc) return rc;
+      dx_done = true;
+    } else if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
       float *wcat = (float *)ws;
       CTCN_HIP(hipMemcpyAsync(wcat, w_ih0, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
       CTCN_HIP(hipMemcpyAsync(wcat + (size_t)GH * I, w_ih1, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -20,13 +20,24 @@ class FlatAdam:
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.model = model
-        params = [p for p in model.parameters() if p.requires_grad]
-        if not params:
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
             raise ValueError("no parameters")
+        # Placement order in the flat buffers: model order, except that the input-projection weights of the two directions of a
+        # recurrent layer sit next to each other (weight_ih_l0, weight_ih_l0_reverse, then the two weight_hh): ctcn_rnn_fwd /
+        # ctcn_rnn_bwd then see [W_ih_fwd ; W_ih_rev] as ONE (2*G*H, I) matrix and run the input projection / dx as a single
+        # product without stacking copies.  `self.params` keeps the model's own order.
+        rank = {"weight_ih_l0": 0, "weight_ih_l0_reverse": 1, "weight_hh_l0": 2, "weight_hh_l0_reverse": 3}
+        first = {}
+        for i, (n, _) in enumerate(named):
+            first.setdefault(n.rsplit(".", 1)[0], i)
+        placed = sorted(range(len(named)), key=lambda i: (first[named[i][0].rsplit(".", 1)[0]], rank.get(named[i][0].rsplit(".", 1)[-1], 4), i))
+        self.layout = [named[i][0] for i in placed]
+        params = [named[i][1] for i in placed]
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam: move the model to the ROCm device first (no CPU path)")
-        self.params = params
+        self.params = [p for _, p in named]
         sizes = [p.numel() for p in params]
         total = sum(sizes)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -43,7 +54,7 @@ class FlatAdam:
                 p.grad = g
                 off += n
         self.step_count = 0
-        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=params)]
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.params)]
 
     def zero_grad(self, set_to_none=False):
         ops.join_side_stream()            # no-op unless weight gradients are still in flight on the side stream
@@ -58,10 +69,12 @@ class FlatAdam:
 
     def state_dict(self):
         g = self.param_groups[0]
-        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone(),
+        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone(), "layout": list(self.layout),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"}]}
 
     def load_state_dict(self, sd):
+        if "layout" in sd and list(sd["layout"]) != list(self.layout):
+            raise ValueError("FlatAdam.load_state_dict: the moment buffers were saved with a different parameter placement")
         self.step_count = sd["step"]
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
