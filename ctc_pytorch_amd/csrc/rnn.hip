@@ -540,6 +540,9 @@ __device__ __forceinline__ int parked_at(int row, int col) { return (row >> 2) *
 template <int NT, int KQ4, int PREC, int CELL>
 __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   constexpr int NW = 4;
+  // parked partials, in 16-B slots: tile stride 72, unit stride 18 (16 rows + 2): 72 = 8 and 18 = 2 (mod 16) spread the 16 lanes
+  // of a ds_read_b128 group (2 rows x 4 units x 2 tiles of an item wave) over all 16 slots of the 256-B bank window
+  constexpr int PK_T = 72, PK_Q = 18;
   const RnnArgs &p = pa.a;
   __shared__ __attribute__((aligned(16))) float red[NW * NT * RT_T];
   __shared__ __attribute__((aligned(16))) float hpub[16][16];   // h_t of this workgroup's units: f32 [row][unit], or (precision 1) two bf16 planes [hi|lo][row][unit]
@@ -570,7 +573,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   bf16x8_t whi[NT][KB], wlo[NT][KB];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int gate = tanh_cell ? 0 : (r >> 2), jj = tanh_cell ? r : (nt * 4 + (r & 3));
+    // W_hh is the FIRST MFMA operand here (C = W h^T): its fragment row r is output column "unit r >> 2, gate r & 3" of
+    // tile nt, so that a lane's four C registers (rows 4q .. 4q+3 of C) are the FOUR GATES of unit q for batch row lane & 15
+    const int gate = tanh_cell ? 0 : (r & 3), jj = tanh_cell ? r : (nt * 4 + (r >> 2));
     const bool bvalid = gate < G && jj < HSU && (j0 + jj) < H;
     const float *brow = bvalid ? W + (size_t)(gate * H + j0 + jj) * H : W;
     if constexpr (PREC == 0) {
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #ifdef CTCN_PERSIST_STATS
   long long st_poll = 0, st_fill = 0, st_mm = 0, st_red = 0, st_epi = 0, st_t0 = clock64();
   long long st_e1 = 0, st_e2 = 0, st_e3 = 0, st_e4 = 0;   // gate math (to hpub barrier) | publish stores issued | drained | flag + reserve issue
+  long long st_i0 = 0, st_i1 = 0, st_i2 = 0;             // item wave: partial sums | gate math + split + hpub writes
 #endif
 
   for (int s = 0; s < T; ++s) {
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
           for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[si][c], bv[nt][si][c], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[nt][si][c], av[si][c], acc[nt], 0, 0, 0);
       } else {
         u32x4 ah[KB], al[KB];                     // plain vectors: a union here made hipcc wait after every second load
 #pragma unroll
@@ -692,9 +698,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
           const bf16x8_t ahv = __builtin_bit_cast(bf16x8_t, ah[i]), alv = __builtin_bit_cast(bf16x8_t, al[i]);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alv, whi[nt][i], acc[nt], 0, 0, 0);   // small terms first
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, wlo[nt][i], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahv, whi[nt][i], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[nt][i], alv, acc[nt], 0, 0, 0);   // small terms first
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[nt][i], ahv, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[nt][i], ahv, acc[nt], 0, 0, 0);
           }
         }
       }
@@ -703,7 +709,8 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     const long long c_b = clock64();
 #endif
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) park_tile(red, wave * NT + nt, lane, acc[nt]);
+    for (int nt = 0; nt < NT; ++nt)      // park [wave][tile][unit q][row]: one 16-B slot = the four gates (tanh cell: four units) of a row
+      *reinterpret_cast<f32x4 *>(red + (((wave * NT + nt) * PK_T + q * PK_Q + r) << 2)) = acc[nt];
     lds_barrier();
 #ifdef CTCN_PERSIST_STATS
     const long long c_c = clock64();
@@ -711,14 +718,28 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
 #endif
 
     float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f, sv3 = 0.f, sv4 = 0.f, hval = 0.f;     // values this item stores after the hand-off
+#ifdef CTCN_PERSIST_STATS
+    long long c_i0 = c_c;
+#endif
     if (item) {
       // recurrent pre-activations of this item: gate g sits in column g*4 + ojl of tile ont (tanh cell: column jl)
       float o[4] = {0.f, 0.f, 0.f, 0.f};
-      const float *rp = red + ont * RT_T + parked_at(bl, tanh_cell ? jl : ojl);
+      if (tanh_cell) {                                                           // unit jl = register jl & 3 of slot (jl >> 2, row)
+        const float *rp = red + (((jl >> 2) * PK_Q + bl) << 2) + (jl & 3);
 #pragma unroll
-      for (int w = 0; w < NW; ++w)
+        for (int w = 0; w < NW; ++w) o[0] += rp[(w * NT * PK_T) << 2];
+      } else {                                                                   // one 16-B read per wave: the item's four gates
+        const float *rp = red + ((ont * PK_T + ojl * PK_Q + bl) << 2);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) o[g] += rp[w * NT * RT_T + g * 16];          // +4 columns = +16 floats
+        for (int w = 0; w < NW; ++w) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + ((w * NT * PK_T) << 2));
+          o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+        }
+      }
+#ifdef CTCN_PERSIST_STATS
+      if (o[0] + o[1] + o[2] + o[3] == 12345.678f) st_i2 += 1;                  // consume the sums before the stamp
+      c_i0 = clock64();
+#endif
       if (cell == CTCN_CELL_LSTM) {
         const float i_ = act_sigmoid(o[0] + pre[0]);
         const float f_ = act_sigmoid(o[1] + pre[1]);
@@ -749,7 +770,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
       }
     }
 #ifdef CTCN_PERSIST_STATS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const long long c_d0 = clock64();
+    st_i0 += c_i0 - c_c; st_i1 += c_d0 - c_i0;
 #endif
     lds_barrier();
 #ifdef CTCN_PERSIST_STATS
@@ -837,6 +860,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     pa.stats[0] = st_poll; pa.stats[1] = st_fill; pa.stats[2] = st_mm; pa.stats[3] = st_red; pa.stats[4] = st_epi; pa.stats[5] = clock64() - st_t0;
     pa.stats[6] = st_e1; pa.stats[7] = st_e2; pa.stats[8] = st_e3; pa.stats[9] = st_e4;
   }
+  if (pa.stats && slice == 7 && d == 0 && bt == 0 && tid == 0) { pa.stats[10] = st_i0; pa.stats[11] = st_i1; pa.stats[12] = st_i2; }
   if (pa.stats && d == 0 && bt == 0 && tid == cw * 64 && slice < 64) {      // per-slice poll / rest split + the CU it ran on
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
