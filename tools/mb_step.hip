@@ -194,7 +194,7 @@ int main() {
       }
       printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
              (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
-      printf("    item wave 0: partial sums (16 LDS reads) %.0f | gate math + split + hpub writes %.0f\n", (double)h[10] / T, (double)h[11] / T);
+      printf("    item wave 0: partial sums (4 x 16-B LDS reads) %.0f | gate math + split + hpub writes %.0f\n", (double)h[10] / T, (double)h[11] / T);
     }
     for (int lp = 0; lp < 3; ++lp) {
       const int local = 1, prec = 1, pd = 2, scatter = lp;
