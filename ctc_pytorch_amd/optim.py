@@ -14,6 +14,16 @@ import torch
 from . import ops
 
 
+def placement_order(names):
+    """Indices of `names` (model.named_parameters() order) in flat-buffer placement order: unchanged, except that inside each
+    module the recurrent weights come as weight_ih_l0, weight_ih_l0_reverse, weight_hh_l0, weight_hh_l0_reverse."""
+    rank = {"weight_ih_l0": 0, "weight_ih_l0_reverse": 1, "weight_hh_l0": 2, "weight_hh_l0_reverse": 3}
+    first = {}
+    for i, n in enumerate(names):
+        first.setdefault(n.rsplit(".", 1)[0], i)
+    return sorted(range(len(names)), key=lambda i: (first[names[i].rsplit(".", 1)[0]], rank.get(names[i].rsplit(".", 1)[-1], 4), i))
+
+
 class FlatAdam:
     """Adam over the flattened parameters of `model`; same public surface as torch.optim.Optimizer where the
     reference touches it: zero_grad(), step(), state_dict(), load_state_dict(), param_groups[i]['lr']."""
@@ -27,11 +37,7 @@ class FlatAdam:
         # recurrent layer sit next to each other (weight_ih_l0, weight_ih_l0_reverse, then the two weight_hh): ctcn_rnn_fwd /
         # ctcn_rnn_bwd then see [W_ih_fwd ; W_ih_rev] as ONE (2*G*H, I) matrix and run the input projection / dx as a single
         # product without stacking copies.  `self.params` keeps the model's own order.
-        rank = {"weight_ih_l0": 0, "weight_ih_l0_reverse": 1, "weight_hh_l0": 2, "weight_hh_l0_reverse": 3}
-        first = {}
-        for i, (n, _) in enumerate(named):
-            first.setdefault(n.rsplit(".", 1)[0], i)
-        placed = sorted(range(len(named)), key=lambda i: (first[named[i][0].rsplit(".", 1)[0]], rank.get(named[i][0].rsplit(".", 1)[-1], 4), i))
+        placed = placement_order([n for n, _ in named])
         self.layout = [named[i][0] for i in placed]
         params = [named[i][1] for i in placed]
         dev = params[0].device

@@ -237,3 +237,24 @@ def test_data_parallel_plumbing_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_flat_adam_placement_puts_the_two_input_projections_side_by_side():
+    """optim.placement_order: model order, except weight_ih of both directions adjacent (ctcn_rnn_fwd / bwd then take
+    [W_ih_fwd ; W_ih_rev] as one matrix); every index exactly once; modules keep their relative order."""
+    from ctc_pytorch_amd.optim import placement_order
+    names = ["conv.0.conv.weight", "conv.0.conv.bias", "conv.0.batch_norm.weight", "conv.0.batch_norm.bias",
+             "rnns.0.rnn.weight_ih_l0", "rnns.0.rnn.weight_hh_l0", "rnns.0.rnn.weight_ih_l0_reverse", "rnns.0.rnn.weight_hh_l0_reverse",
+             "rnns.1.batch_norm.weight", "rnns.1.batch_norm.bias",
+             "rnns.1.rnn.weight_ih_l0", "rnns.1.rnn.weight_hh_l0", "rnns.1.rnn.weight_ih_l0_reverse", "rnns.1.rnn.weight_hh_l0_reverse",
+             "fc.0.weight", "fc.0.bias", "fc.1.weight"]
+    order = placement_order(names)
+    assert sorted(order) == list(range(len(names)))
+    placed = [names[i] for i in order]
+    for l in (0, 1):
+        i = placed.index("rnns.%d.rnn.weight_ih_l0" % l)
+        assert placed[i:i + 4] == ["rnns.%d.rnn.%s" % (l, k) for k in ("weight_ih_l0", "weight_ih_l0_reverse", "weight_hh_l0", "weight_hh_l0_reverse")]
+    rest = [n for n in placed if ".rnn." not in n]
+    assert rest == [n for n in names if ".rnn." not in n]
+    uni = ["rnns.0.rnn.weight_ih_l0", "rnns.0.rnn.weight_hh_l0", "fc.weight"]                # unidirectional: nothing moves
+    assert placement_order(uni) == [0, 1, 2]
