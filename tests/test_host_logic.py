@@ -258,3 +258,19 @@ def test_flat_adam_placement_puts_the_two_input_projections_side_by_side():
     assert rest == [n for n in names if ".rnn." not in n]
     uni = ["rnns.0.rnn.weight_ih_l0", "rnns.0.rnn.weight_hh_l0", "fc.weight"]                # unidirectional: nothing moves
     assert placement_order(uni) == [0, 1, 2]
+
+
+def test_hand_waited_reserve_loads_are_not_touched_before_their_wait():
+    """rnn_bwd_scatter issues its reserve loads as inline asm and waits for them by hand (`s_waitcnt vmcnt(7)`), which hipcc
+    cannot see: tools/check_untracked_loads.py compiles rnn.hip to assembly (no GPU needed) and fails if any instruction
+    reads or overwrites such a destination register between the load and the wait."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_untracked_loads.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("findings 0") >= 6
