@@ -14,9 +14,18 @@ from . import _lib
 CELL = {"lstm": 0, "gru": 1, "tanh": 2}
 GATES = {0: 4, 1: 3, 2: 1}
 
-# process-wide numeric mode of the MFMA GEMMs: 0 = exact f32 MFMA, 1 = bf16x3 split-operand MFMA (f32-class accuracy).
+# process-wide numeric mode of the MFMA GEMMs: 0 = exact f32 MFMA, 1 = bf16x3 split-operand MFMA (f32-class accuracy, the
+# default: it is the mode every headline number is measured in).  Environment CTCN_PRECISION=0|1 picks the start value.
 # A plain module global on purpose: autograd runs backward() on its own worker threads.
-_precision = [0]
+def _precision_from_env():
+    v = os.environ.get("CTCN_PRECISION", "1").strip()
+    if v not in ("0", "1"):
+        raise ValueError("CTCN_PRECISION must be 0 (exact f32 MFMA) or 1 (bf16x3 split-operand MFMA), got %r" % v)
+    return int(v)
+
+
+DEFAULT_PRECISION = _precision_from_env()
+_precision = [DEFAULT_PRECISION]
 
 
 def set_precision(p):

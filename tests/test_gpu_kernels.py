@@ -30,6 +30,36 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _f32_strict_unless_stated():
+    """Every test starts in precision 0 (exact f32 MFMA: the f32-strict gates of SURVEY 8a); tests that take a `prec`
+    parameter switch to the bf16x3 mode themselves.  The library default (precision 1, ops.DEFAULT_PRECISION) is
+    restored afterwards."""
+    from ctc_pytorch_amd import ops
+    ops.set_precision(0)
+    yield
+    ops.set_precision(ops.DEFAULT_PRECISION)
+
+
+# SURVEY 8a gates of the bf16-operand mode (precision 1 = bf16x3 split operands, ~2^-16 per product): activations / log-probs
+# max-abs <= 1e-3, loss rel <= 1e-3, gradients and parameters after 3 Adam steps rel-L2 <= 1e-3, arg-max identical.
+def gates(prec, strict_act, strict_grad, strict_loss):
+    return (strict_act, strict_grad, strict_loss) if prec == 0 else (1e-3, 1e-3, 1e-3)
+
+
+def argmax_report(lp, want, what):
+    """arg-max must be identical; when it is not, say how close the flipped frames' top-2 margins are."""
+    from ctc_pytorch_amd import ops
+    got = ops.argmax_last(lp).cpu().numpy()
+    want = np.asarray(want).astype(np.int32)
+    if np.array_equal(got, want):
+        return
+    v = lp.detach().cpu().numpy()
+    bad = np.argwhere(got != want)
+    top2 = np.sort(v[tuple(bad.T)], axis=-1)[:, -2:]
+    raise AssertionError("%s: %d arg-max flips; top-2 margins of the flipped frames: %s" % (what, len(bad), (top2[:, 1] - top2[:, 0])[:8]))
+
+
 def gpu(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
@@ -349,8 +379,11 @@ def test_sync_batchnorm_two_shards_equal_full_batch(dev, rows, C, inner, relu):
     assert maxabs(y2, y) < 1e-6 and maxabs(x2.grad, xg.grad) < 1e-6 and rel_l2(g2.grad, gg.grad) < 1e-6
 
 
-def test_conv_front_golden(dev):
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv_front_golden(dev, prec):
+    """(the direct convolution and BatchNorm are f32 in both modes: the same f32-strict gates hold at precision 1)"""
     from ctc_pytorch_amd import ops
+    ops.set_precision(prec)
     m, z = _load_conv_model(dev)
     m.train()
     x = gpu(z["x"], dev).requires_grad_(True)
@@ -373,8 +406,11 @@ def test_conv_front_golden(dev):
     assert maxabs(ce, z["conv_out_eval"]) < 2e-5
 
 
-def test_fc_logsoftmax_golden(dev):
+@pytest.mark.parametrize("prec", [0, 1])
+def test_fc_logsoftmax_golden(dev, prec):
     from ctc_pytorch_amd import ops
+    ops.set_precision(prec)
+    tol_act, tol_grad, _ = gates(prec, 1e-5, 1e-4, 0)
     z = load("fc_lsm")
     x = gpu(z["x"], dev).requires_grad_(True)
     g, b = gpu(z["w.0.weight"], dev).requires_grad_(True), gpu(z["w.0.bias"], dev).requires_grad_(True)
@@ -383,13 +419,16 @@ def test_fc_logsoftmax_golden(dev):
     T, B, V = z["lp"].shape
     y = ops.batch_norm(x, g, b, torch.zeros(C, device=dev), torch.ones(C, device=dev), x.shape[0], C, 1, True)
     logits = ops.linear(y, W)
-    assert maxabs(logits, z["logits"]) < 1e-5
+    assert maxabs(logits, z["logits"]) < tol_act
     lp = ops.log_softmax(logits.view(T, B, V))
-    assert maxabs(lp, z["lp"]) < 1e-5
-    assert np.array_equal(ops.argmax_last(lp).cpu().numpy(), z["argmax"].astype(np.int32))
+    assert maxabs(lp, z["lp"]) < tol_act
+    argmax_report(lp, z["argmax"], "fc_lsm")
     lp.backward(gpu(z["dlp"], dev))
-    assert maxabs(x.grad, z["dx"]) < 2e-5
-    assert maxabs(W.grad, z["g.1.weight"]) < 1e-4 and maxabs(g.grad, z["g.0.weight"]) < 1e-4
+    if prec == 0:
+        assert maxabs(x.grad, z["dx"]) < 2e-5
+        assert maxabs(W.grad, z["g.1.weight"]) < 1e-4 and maxabs(g.grad, z["g.0.weight"]) < 1e-4
+    else:
+        assert rel_l2(x.grad, z["dx"]) < tol_grad and rel_l2(W.grad, z["g.1.weight"]) < tol_grad and rel_l2(g.grad, z["g.0.weight"]) < tol_grad
 
 
 def test_ctc_golden(dev):
@@ -518,6 +557,36 @@ def test_dropout_statistics_and_mask_reuse(dev):
     assert ops.dropout(x, 0.25, False) is x and ops.dropout(x, 0.0, True) is x
 
 
+@pytest.mark.parametrize("p", [0.1, 0.5])
+@pytest.mark.parametrize("n,offset", [(800 * 32 * 640, 0), (100003, 12345), (7, 3), (1 << 20, (1 << 33) + 5)])
+def test_dropout_bit_exact_vs_philox_oracle(dev, p, n, offset):
+    """R6: ctcn_dropout(x, p, seed, offset) == x * m / (1 - p) with m drawn by the host restatement of Philox4x32-10
+    (oracle/philox.py, pinned to the Random123 known-answer vectors), bit for bit: odd sizes (scalar tail), offsets beyond
+    2^32 (the high counter word), a misaligned view (scalar path), and the backward pass regenerating the same mask."""
+    from ctc_pytorch_amd import _lib
+    from oracle import philox
+    L = _lib.lib()
+    seed = 0x9E3779B97F4A7C15 ^ n
+    rs = np.random.RandomState(n % 9973)
+    xh = rs.standard_normal(n + 1).astype(np.float32)
+    for shift in (0, 1):                                    # shift 1: 4-byte aligned only -> the kernel's scalar path
+        x = torch.from_numpy(xh).to(dev)[shift:shift + n]
+        y = torch.empty(n + 1, device=dev)[shift:shift + n]
+        _lib.check(L.ctcn_dropout(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), n, p, seed, offset, _lib.stream_ptr()), "dropout")
+        want = philox.dropout(xh[shift:shift + n], p, seed, offset)
+        got = y.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got != want).sum())
+    # through autograd: forward and backward draw the same mask from the (seed, offset) the wrapper recorded
+    from ctc_pytorch_amd import ops
+    xg = torch.from_numpy(xh[:n]).to(dev).requires_grad_(True)
+    yg = ops.dropout(xg, p, True)
+    gy = torch.from_numpy(rs.standard_normal(n).astype(np.float32)).to(dev)
+    yg.backward(gy)
+    pp, sd, off = yg.grad_fn.rng
+    assert np.array_equal(yg.detach().cpu().numpy(), philox.dropout(xh[:n], pp, sd, off))
+    assert np.array_equal(xg.grad.cpu().numpy(), philox.dropout(gy.cpu().numpy(), pp, sd, off))
+
+
 def test_adam_vs_oracle(dev):
     from ctc_pytorch_amd import ops
     rs = np.random.RandomState(4)
@@ -601,11 +670,17 @@ def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
     assert torch.equal(grads[True], grads[False])
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16"])
 @pytest.mark.parametrize("flat", [True, False])
-def test_model_three_steps_golden(dev, tag, flat):
+def test_model_three_steps_golden(dev, tag, flat, prec):
+    """Whole-model fixtures captured from the reference (oracle/gen_golden.py): `visualize` activations, log-probs, arg-max,
+    all parameter gradients, 3 Adam steps, eval forward -- at both matmul precisions.  precision 0: the f32-strict gates;
+    precision 1 (the library default, the mode bench.py measures): SURVEY 8a's bf16-mode gates."""
     from ctc_pytorch_amd import nn, ops
     from ctc_pytorch_amd.optim import FlatAdam
+    ops.set_precision(prec)
+    tol_act, tol_grad, tol_loss = gates(prec, 5e-5, 2e-4, 2e-5)
     m, z = _build_model(tag, dev)
     m.train()
     x, tg, tl = gpu(z["x"], dev), gpu(z["targets"], dev), gpu(z["tgt_len"], dev)
@@ -618,10 +693,10 @@ def test_model_three_steps_golden(dev, tag, flat):
         in_len = torch.from_numpy(R.frames_from_fraction(z["frac"], lp.size(0)))
         if step == 0:
             assert np.array_equal(in_len.numpy(), z["in_len"])
-            assert maxabs(lp, z["lp"]) < 5e-5
-            assert np.array_equal(ops.argmax_last(lp).cpu().numpy(), z["argmax"].astype(np.int32))
+            assert maxabs(lp, z["lp"]) < tol_act
+            argmax_report(lp, z["argmax"], tag)
             if "rnn_in" in z.files:
-                assert maxabs(vis[1], z["conv_out"]) < 5e-5 and maxabs(vis[2], z["rnn_in"]) < 5e-5
+                assert maxabs(vis[1], z["conv_out"]) < tol_act and maxabs(vis[2], z["rnn_in"]) < tol_act
         loss = loss_fn(lp, tg, in_len.to(dev), tl) / B
         opt.zero_grad()
         loss.backward()
@@ -632,10 +707,10 @@ def test_model_three_steps_golden(dev, tag, flat):
                     # float32 rounding noise (reference ~1e-6), so only its magnitude is checked
                     assert float(p.grad.abs().max()) < 1e-4, k
                     continue
-                assert rel_l2(p.grad, z["g." + k]) < 2e-4 or maxabs(p.grad, z["g." + k]) < 1e-6, k
+                assert rel_l2(p.grad, z["g." + k]) < tol_grad or maxabs(p.grad, z["g." + k]) < 1e-6, k
         opt.step()
         losses.append(float(loss))
-    assert np.allclose(losses, z["losses"], rtol=2e-5), (losses, z["losses"])
+    assert np.allclose(losses, z["losses"], rtol=tol_loss), (losses, z["losses"])
     for k, v in m.state_dict().items():
         want = z["after." + k]
         if "num_batches" in k:
@@ -648,20 +723,29 @@ def test_model_three_steps_golden(dev, tag, flat):
             # Adam turns a gradient into lr*sign-like steps, so an entry whose gradient is smaller than the float32
             # rounding noise of its tensor (measured: |g| ~ 2e-5 against ~5e-5 of noise in rnns.1.rnn.weight_hh_l0 of the
             # CNN model, both sides; tools/dbg_cnn.py shows every per-step gradient within 4e-5 rel-L2 of torch) can move
-            # by +-lr per step in either implementation.  Gate: (almost) all entries within 5e-5, none beyond 3 steps * lr.
+            # by +-lr per step in either implementation.  Gate: (almost) all entries within 5e-5, none beyond 3 steps * lr;
+            # precision 1 additionally: rel-L2 of the whole tensor within the bf16-mode gate.
             dv = (v.detach().cpu().double() - torch.from_numpy(np.asarray(want)).double()).abs()
             assert float(dv.max()) < 3.5e-3, k
-            assert float((dv > 5e-5).double().mean()) < 0.01, (k, float(dv.max()))
+            if prec == 0:
+                assert float((dv > 5e-5).double().mean()) < 0.01, (k, float(dv.max()))
+            else:
+                assert rel_l2(v, want) < tol_grad or float(dv.max()) < 1e-5, (k, rel_l2(v, want))
     m.eval()
     with torch.no_grad():
         lpe = m(x)
-    assert maxabs(lpe, z["lp_eval_after"]) < 2e-4
-    assert np.array_equal(ops.argmax_last(lpe).cpu().numpy(), z["argmax_eval_after"].astype(np.int32))
+    assert maxabs(lpe, z["lp_eval_after"]) < (2e-4 if prec == 0 else tol_act)
+    argmax_report(lpe, z["argmax_eval_after"], tag + " (eval, after 3 steps)")
 
 
-def test_run_epoch_trajectory_golden(dev):
-    from ctc_pytorch_amd import nn
+@pytest.mark.parametrize("prec", [0, 1])
+def test_run_epoch_trajectory_golden(dev, prec):
+    """cfg1 (2x128 BiLSTM, B=8, T=300, full size): the reference's printed 3-step loss trajectory, (acc, avg loss) returns of a
+    train epoch and of an eval epoch -- error counts identical, losses to 1e-4 (f32-strict) / 1e-3 (bf16 mode)."""
+    from ctc_pytorch_amd import nn, ops
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    ops.set_precision(prec)
+    rt = 1e-4 if prec == 0 else 1e-3
     from ctc_pytorch_amd.optim import FlatAdam
     from ctc_pytorch_amd.steps.train_ctc import run_epoch
     z = load("run_epoch_cfg1")
@@ -678,31 +762,74 @@ def test_run_epoch_trajectory_golden(dev):
     acc, avg = run_epoch(1, m, [batch, batch, batch], nn.CTCLoss(reduction="sum"), dev, optimizer=opt, print_every=1,
                          is_training=True, log=lines.append)
     step_losses = [float(l.split("cur_loss = ")[1].split(",")[0]) for l in lines if "cur_loss" in l]
-    assert np.allclose(step_losses, z["printed_step_losses"], rtol=1e-4), (step_losses, z["printed_step_losses"])
-    assert abs(avg - float(z["train_avg_loss"])) / float(z["train_avg_loss"]) < 1e-4
+    assert np.allclose(step_losses, z["printed_step_losses"], rtol=rt), (step_losses, z["printed_step_losses"])
+    assert abs(avg - float(z["train_avg_loss"])) / float(z["train_avg_loss"]) < rt
     assert abs(acc - float(z["train_acc"])) < 1e-9
     acc_e, avg_e = run_epoch(1, m, [batch], nn.CTCLoss(reduction="sum"), dev, optimizer=None, is_training=False, log=lines.append)
-    assert abs(avg_e - float(z["eval_avg_loss"])) / float(z["eval_avg_loss"]) < 2e-4
+    assert abs(avg_e - float(z["eval_avg_loss"])) / float(z["eval_avg_loss"]) < (2e-4 if prec == 0 else rt)
     assert abs(acc_e - float(z["eval_acc"])) < 1e-9
 
 
-def test_cfg2_bf16x3_mode_within_tolerance(dev):
-    """precision=1 (bf16x3 split-operand MFMA for the time-parallel GEMMs) at the full cfg2 shape: loss within 1e-4
-    and gradient norms within 2e-3 of the reference (north-star gate: 1e-3 on loss / activations)."""
-    from ctc_pytorch_amd import ops
-    ops.set_precision(1)
-    try:
-        test_large_shape_checksums(dev, "cfg2")
-    finally:
-        ops.set_precision(0)
-
-
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
-def test_large_shape_checksums(dev, name):
-    """BASELINE.json full-size configs: loss / log-prob checksums / per-parameter gradient norms captured from the
-    reference (cfg4 at B=8 per rank, as one DP shard)."""
+def _full_size_model(name, dev):
     from ctc_pytorch_amd import nn
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    shapes = json.load(open(os.path.join(G, "large_checksums.json")))
+    c = dict(B=8, T=300, V=62, H=128, L=2, rnn="LSTM", cnn=False) if name == "cfg1" else shapes[name]["shape"]
+    lab = (60, 100) if name == "cfg4" else ((10, 35) if name == "cfg1" else (30, 60))
+    b = synth.make_batch(seed=1, B=c["B"], T=c["T"], F=40, V=c["V"], lab_lo=lab[0], lab_hi=lab[1])
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(nn, c["rnn"]),
+          "bidirectional": True, "batch_norm": True}
+    if c["cnn"]:
+        cp = {"batch_norm": True, "activate_function": nn.ReLU,
+              "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
+        m = CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=0.0)
+    else:
+        m = CTC_Model(rnn_param=rp, num_class=c["V"], drop_out=0.0)
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=91)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    return m.to(dev).train(), b, c
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4"])
+def test_full_size_bf16x3_against_f32_vectors(dev, name):
+    """The benchmarked arithmetic (precision 1) against the exact-f32 HIP path (precision 0, itself held to the reference's
+    checksums below and to the small fixtures) at the FULL BASELINE shapes, vector by vector -- what norms cannot show:
+    log-probs max-abs <= 1e-3, loss rel <= 1e-3, every parameter gradient rel-L2 <= 1e-3 (SURVEY 8a bf16-mode gates);
+    arg-max identical except on frames whose f32 top-2 margin is below 1e-4 (near-ties; count and margins reported)."""
+    from ctc_pytorch_amd import nn, ops
+    runs = {}
+    for prec in (0, 1):
+        ops.set_precision(prec)
+        m, b, c = _full_size_model(name, dev)
+        lp = m(gpu(b["x"], dev))
+        in_len = torch.from_numpy(R.frames_from_fraction(b["frac"], lp.size(0))).to(dev)
+        loss = nn.CTCLoss(reduction="sum")(lp, gpu(b["targets"], dev), in_len, gpu(b["tgt_len"], dev)) / c["B"]
+        loss.backward()
+        torch.cuda.synchronize()
+        ops.check_health()
+        runs[prec] = (lp.detach(), float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, ops.argmax_last(lp))
+    lp0, l0, g0, a0 = runs[0]
+    lp1, l1, g1, a1 = runs[1]
+    assert maxabs(lp1, lp0) < 1e-3, maxabs(lp1, lp0)
+    assert abs(l1 - l0) / abs(l0) < 1e-3
+    worst = max((rel_l2(g1[k], g0[k]), k) for k in g0 if not k.endswith("conv.bias"))
+    assert worst[0] < 1e-3, worst
+    flips = (a0 != a1)
+    if bool(flips.any()):
+        top2 = torch.topk(lp0[flips], 2, dim=-1).values
+        margin = (top2[:, 0] - top2[:, 1])
+        assert float(margin.max()) < 1e-4, (int(flips.sum()), float(margin.max()))
+        assert int(flips.sum()) <= max(4, a0.numel() // 1000), int(flips.sum())
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
+def test_large_shape_checksums(dev, name, prec):
+    """BASELINE.json full-size configs at both matmul precisions: loss / log-prob checksums / per-parameter gradient norms
+    captured from the reference (cfg4 at B=8 per rank, as one DP shard); gradient norms within 1e-3."""
+    from ctc_pytorch_amd import nn, ops
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    ops.set_precision(prec)
     want = json.load(open(os.path.join(G, "large_checksums.json")))[name]
     c = want["shape"]
     lab = (60, 100) if name == "cfg4" else (30, 60)
@@ -730,7 +857,7 @@ def test_large_shape_checksums(dev, name):
         if k.endswith("conv.bias"):        # zero in exact arithmetic (bias -> BatchNorm): rounding noise on both sides
             assert gn < 0.05
             continue
-        assert abs(gn - want["grad_norm"][k]) <= 2e-3 * want["grad_norm"][k] + 1e-6, (k, gn, want["grad_norm"][k])
+        assert abs(gn - want["grad_norm"][k]) <= 1e-3 * want["grad_norm"][k] + 1e-6, (k, gn, want["grad_norm"][k])
 
 
 # ---------------------------------------------------------------------------------------------------------

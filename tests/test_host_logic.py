@@ -57,6 +57,23 @@ def test_product_has_no_cpu_fallback():
                 assert "oracle" not in src.replace("oracle/", "").replace("the oracle", ""), (dirpath, f)
 
 
+def test_default_precision_is_the_benchmarked_mode():
+    """README / DESIGN / bench.py call bf16x3 (precision 1) the default: the library must agree, and CTCN_PRECISION must be
+    honoured by the package itself (not only by bench.py), so that steps/train_ctc.main and the unmodified reference drivers
+    train in the mode the headline number is measured in."""
+    from ctc_pytorch_amd import ops
+    if "CTCN_PRECISION" not in os.environ:
+        assert ops.DEFAULT_PRECISION == 1 and ops.get_precision() == 1
+    code = "from ctc_pytorch_amd import ops; print(ops.get_precision(), ops.DEFAULT_PRECISION)"
+    for env_val, want in (("0", "0 0"), ("1", "1 1")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CTCN_PRECISION=env_val), cwd=ROOT, capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.split("\n")[0].strip() == want, (out.stdout, out.stderr[-500:])
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CTCN_PRECISION="7"), cwd=ROOT, capture_output=True, text=True)
+    assert bad.returncode != 0 and "CTCN_PRECISION" in bad.stderr
+    with pytest.raises(ValueError):
+        ops.set_precision(2)
+
+
 def test_state_dict_surface_matches_reference_keys():
     from ctc_pytorch_amd import nn
     from ctc_pytorch_amd.models.model_ctc import CTC_Model

@@ -187,3 +187,20 @@ def test_beam_error_paths():
     probs[0, 2, 7] = 0.0                                    # math.log(0)
     with pytest.raises(ValueError):
         beam_ref.decode_strings(probs, [5], tab, 0.1, 5, i2c)
+
+
+def test_philox_restatement_matches_random123_known_answers():
+    """oracle/philox.py (the generator behind ctcn_dropout) against the published Random123 philox4x32-10 vectors, and the
+    statistics / determinism of the dropout mapping built on it (reference call sites model_ctc.py:34,67)."""
+    from oracle import philox
+    for ctr, key, want in philox.KAT:
+        got = philox.philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    x = np.ones(100003, dtype=np.float32)
+    y = philox.dropout(x, 0.25, seed=0x123456789ABCDEF, offset=7)
+    assert abs(float((y != 0).mean()) - 0.75) < 5e-3
+    assert np.all(y[y != 0] == np.float32(1.0) / (np.float32(1.0) - np.float32(0.25)))
+    assert np.array_equal(y, philox.dropout(x, 0.25, seed=0x123456789ABCDEF, offset=7))
+    # element i of a call with offset o uses block o + i // 4: a call shifted by one block sees the stream shifted by 4 elements
+    w0, w1 = philox.dropout_words(64, 5, 10), philox.dropout_words(64, 5, 11)
+    assert np.array_equal(w0[4:], w1[:-4]) and not np.array_equal(w0, w1)
