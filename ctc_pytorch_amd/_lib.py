@@ -78,16 +78,33 @@ def sources():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> ctc_pytorch_amd/libctcn.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> ctc_pytorch_amd/libctcn.so (cross-compiles without a GPU).  One object per source
+    under csrc/_obj/ (compiled in parallel, only when the source or a header is newer), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(_CSRC, "*.h")) + [os.path.join(os.path.dirname(_HERE), "include", "ctcn.h")]
-    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
-        return SO_PATH
+    hdrs = glob.glob(os.path.join(_CSRC, "*.h")) + [os.path.join(os.path.dirname(_HERE), "include", "ctcn.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objdir = os.path.join(_CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(run, jobs))
+    if jobs or not os.path.exists(SO_PATH) or any(os.path.getmtime(SO_PATH) < os.path.getmtime(o) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", SO_PATH] + objs)
     return SO_PATH
 
 

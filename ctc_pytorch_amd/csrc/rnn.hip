@@ -1664,6 +1664,20 @@ void launch_bwd(int kq4, dim3 grid, hipStream_t st, const RnnArgs &a) {
 
 int gates_of(int cell) { return cell == CTCN_CELL_LSTM ? 4 : (cell == CTCN_CELL_GRU ? 3 : 1); }
 
+// One line on stderr (per distinct reason, per process) when a layer that asked for the persistent recurrence runs one launch
+// per timestep instead: that path is 4x slower and nothing else would tell the user.  CTCN_QUIET=1 silences it.
+void log_fallback(const char *which, int T, int B, int H, int dirs, const char *reason) {
+  static unsigned seen = 0;
+  unsigned h = 5381;
+  for (const char *c = which; *c; ++c) h = h * 33 + (unsigned char)*c;
+  for (const char *c = reason; *c; ++c) h = h * 33 + (unsigned char)*c;
+  const unsigned bit = 1u << (h & 31);
+  if ((seen & bit) || getenv("CTCN_QUIET")) return;
+  seen |= bit;
+  fprintf(stderr, "libctcn: %s T=%d B=%d H=%d dirs=%d: persistent recurrence not used (%s) -> one launch per timestep (about 4x slower)\n",
+          which, T, B, H, dirs, reason);
+}
+
 }  // namespace
 
 extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
@@ -1741,6 +1755,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       }
       cands[nc++] = {0, H % 8 == 0 ? 8 : 4};
     }
+    const char *why = kq > 8 ? "hidden size above 512" : "no candidate geometry is co-resident on this device";
     for (int ci = 0; ci < nc && kq <= 8; ++ci) {
       const int mode = cands[ci].mode, HSU = cands[ci].hsu;
       const int nx = mode ? nxd : 1;
@@ -1751,7 +1766,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       const int prec = precision == 1 && HSU % 4 == 0 && H % 8 == 0 ? 1 : 0;       // bf16x3 recurrent matmul
       const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(H, 32) * 512 : ceil_div(H, 16) * 256) * sizeof(float), 256);
       const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
-      if (!ws || ws_bytes < hx_bytes + fl_bytes + 512) break;
+      if (!ws || ws_bytes < hx_bytes + fl_bytes + 512) { why = "workspace too small for the hand-off tiles"; break; }
       PersistArgs pa;
       pa.a = a;
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
@@ -1771,6 +1786,9 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
         return CTCN_OK;
       }
     }
+    log_fallback("ctcn_rnn_fwd", T, B, H, dirs, why);
+  } else if (ctcn_opt_rnn_persistent() && T > 1) {
+    log_fallback("ctcn_rnn_fwd", T, B, H, dirs, "a reserve tensor of 4 GB or more");
   }
   const int kq4 = pick_kq4(H, 4, MT, 20);
   for (int s = 0; s < T; ++s) {
@@ -1940,6 +1958,9 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     }
   }
   record_prelaunch(st);          // no-op if a persistent launch already consumed the event
+  if (!done && ctcn_opt_rnn_persistent() && T > 1)
+    log_fallback("ctcn_rnn_bwd", T, B, H, dirs, !fits32 ? "a reserve tensor of 4 GB or more"
+                                                     : (ceil_div(GH, 256) > 8 ? "gate width G*H above 2048" : "not co-resident / workspace too small"));
   if (!done) {
     const int kq4 = pick_kq4(GH, 16, 1, 5);
     for (int s = 0; s < T; ++s) {

@@ -291,3 +291,64 @@ def test_hand_waited_reserve_loads_are_not_touched_before_their_wait():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_untracked_loads.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.count("findings 0") >= 6
+
+
+REF = "/root/reference/timit"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the build container")
+def test_reference_drivers_resolve_to_the_hip_classes():
+    """The drop-in boundary as a regression test: execute the TEXT of the reference's
+    steps/train_ctc.py and steps/test_ctc.py (everything above their __main__ guards: imports, supported_rnn /
+    supported_activate tables, argparse set-up, function definitions) with ctc_pytorch_amd/ first on sys.path, and check
+    that every name the drivers use resolves to the HIP-backed class.  Runs in a subprocess: the drivers import top-level
+    packages called `models`, `utils`, `steps`."""
+    code = r"""
+import os, sys, types
+sys.path.insert(0, os.path.join(%r, "ctc_pytorch_amd"))
+os.chdir(%r)                                      # the drivers do sys.path.append('./'); it must not find the reference tree
+import ctc_pytorch_amd.nn as hnn
+from ctc_pytorch_amd.models import model_ctc as hmodel
+from ctc_pytorch_amd.utils import ctcDecoder as hdec, data_loader as hdl
+def same_def(f, g):            # the drivers import the package files under their top-level names: same source, second module object
+    return os.path.samefile(f.__code__.co_filename, g.__code__.co_filename) and f.__code__.co_firstlineno == g.__code__.co_firstlineno
+for drv in ("train_ctc.py", "test_ctc.py"):
+    ns = {"__name__": "reference_driver", "__file__": drv}
+    exec(compile(open(os.path.join(%r, "steps", drv)).read(), drv, "exec"), ns)
+    assert ns["nn"] is hmodel.nn is hnn, (drv, ns["nn"])
+    assert ns["CTC_Model"].__module__.endswith("models.model_ctc") and same_def(ns["CTC_Model"].forward, hmodel.CTC_Model.forward)
+    assert ns["nn"].CTCLoss is hnn.CTCLoss and ns["nn"].LSTM is hnn.LSTM
+    assert ns["Vocab"].__module__.endswith("utils.data_loader") and same_def(ns["SpeechDataLoader"].__init__, hdl.SpeechDataLoader.__init__)
+    if drv == "train_ctc.py":
+        assert ns["supported_rnn"] == {"nn.LSTM": hnn.LSTM, "nn.GRU": hnn.GRU, "nn.RNN": hnn.RNN}
+        assert ns["supported_activate"]["relu"] is hnn.ReLU
+        assert callable(ns["run_epoch"]) and callable(ns["main"])
+        loss_fn = ns["nn"].CTCLoss(reduction="sum")                      # train_ctc.py:144
+        assert type(loss_fn) is hnn.CTCLoss
+        m = ns["CTC_Model"](rnn_param={"rnn_input_size": 40, "rnn_hidden_size": 8, "rnn_layers": 2, "rnn_type": ns["supported_rnn"]["nn.LSTM"],
+                                       "bidirectional": True, "batch_norm": True}, num_class=10, drop_out=0.1)
+        assert type(m.rnns[0].rnn) is hnn.LSTM and type(m.rnns[1].batch_norm) is hnn.BatchNorm1d and type(m.fc[1]) is hnn.Linear
+    else:
+        assert same_def(ns["GreedyDecoder"].decode, hdec.GreedyDecoder.decode) and same_def(ns["BeamDecoder"].decode, hdec.BeamDecoder.decode)
+        assert ns["Config"].__module__.endswith("steps.train_ctc") and callable(ns["test"])
+print("BOUNDARY_OK")
+""" % (ROOT, ROOT, REF)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0 and "BOUNDARY_OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_decode_driver_picks_the_decoder_from_the_yaml_keys(tmp_path):
+    """steps/test_ctc.make_decoder: decode_type / beam_width / lm_alpha / lm_path as the reference's test() reads them
+    (test_ctc.py:47-51,64-67)."""
+    from ctc_pytorch_amd.steps import test_ctc as TE
+    from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder, GreedyDecoder
+    i2c = synth.int2char(62)
+
+    class O:
+        decode_type, beam_width, lm_alpha, lm_path = "Greedy", 7, 0.25, os.path.join(G, "lm_phone_bg.arpa")
+    assert type(TE.make_decoder(O, i2c)) is GreedyDecoder
+    O.decode_type = "Beam"
+    d = TE.make_decoder(O, i2c)
+    assert type(d) is BeamDecoder and d._decoder.beamWidth == 7 and d._decoder.lm_alpha == 0.25
+    with pytest.raises(RuntimeError, match="use_gpu"):
+        TE.main({"use_gpu": False})
