@@ -102,6 +102,11 @@ __device__ __forceinline__ void ctc_lattice_body(float *smem, const float *__res
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Smax = 2 * Lmax + 1;
   const int Tb = (int)in_len[b], L = (int)tgt_len[b];
+  // lengths a caller must not pass (torch.nn.CTCLoss raises): nothing of the lattice is defined -- NaN loss, NaN gradient rows
+  if (in_len[b] < 0 || in_len[b] > T || tgt_len[b] < 0 || tgt_len[b] > Lmax) {
+    if (DIR > 0 && tid == 0) nll[b] = __uint_as_float(0x7fc00000u);
+    return;
+  }
   const int S = 2 * L + 1;
   float *buf0 = smem, *buf1 = smem + Smax;
   int *ext = reinterpret_cast<int *>(smem + 2 * Smax);
@@ -253,6 +258,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__
   const int t = (int)(pair / B), b = (int)(pair - (size_t)t * B);
   const int Tb = (int)in_len[b], L = (int)tgt_len[b];
   float *g = grad + pair * V;
+  if (in_len[b] < 0 || in_len[b] > T || tgt_len[b] < 0 || tgt_len[b] > Lmax) {          // see ctc_lattice_body
+    for (int c = lane; c < V; c += 64) g[c] = __uint_as_float(0x7fc00000u);
+    return;
+  }
   if (t >= Tb) {
     for (int c = lane; c < V; c += 64) g[c] = 0.0f;
     return;
@@ -316,7 +325,7 @@ __global__ void edit_distance_kernel(const int32_t *__restrict__ a, const int32_
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= B) return;
   int *row = rows + (size_t)threadIdx.x * ldrow;
-  const int la = a_len[u], lb = (int)b_len[u];
+  const int la = min(max(a_len[u], 0), lda), lb = (int)min(max(b_len[u], (int64_t)0), (int64_t)min(ldrow - 2, ldb));   // never beyond the row / the buffers
   const int32_t *pa = a + (size_t)u * lda;
   const int64_t *pb = bl + (size_t)u * ldb;
   for (int j = 0; j <= lb; ++j) row[j] = j;

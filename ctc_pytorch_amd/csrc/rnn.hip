@@ -867,7 +867,11 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
     pa.stats[16 + slice * 3] = st_poll; pa.stats[17 + slice * 3] = st_fill + st_mm + st_red + st_epi; pa.stats[18 + slice * 3] = hw;
   }
 #endif
-  if (s_abort && item) p.y[((size_t)(d == 0 ? T - 1 : 0) * B + b) * D * H + d * H + j] = __uint_as_float(0x7fc00000u);   // poison
+  // a hand-off timed out: nothing this launch produced can be trusted.  Every (row, unit) item poisons its WHOLE output
+  // column with NaN (all T frames -- a single poisoned frame can sit in the padding of every shorter utterance and be masked
+  // out of the CTC loss), so the loss of this step is NaN for every model configuration, besides the sticky status word.
+  if (s_abort && item)
+    for (int tt = 0; tt < T; ++tt) st_slab(ry, vh, (unsigned)tt * sh_b, __uint_as_float(0x7fc00000u));
 }
 
 // Launch a persistent kernel only if every working workgroup is co-resident (occupancy query x CU count, with one
@@ -1197,7 +1201,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
     o[0] = bt_poll; o[1] = bt_mm; o[2] = bt_red; o[3] = bt_math; o[4] = bt_copy; o[5] = bt_tail; o[6] = clock64() - bt_t0;
   }
 #endif
-  if (s_abort && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
+  if (s_abort && item)       // poison d(pre-activation) of every frame: dx and both weight gradients of the layer become NaN
+    for (int tt = 0; tt < T; ++tt) st_slab(rg, vg0, (unsigned)tt * sg_b, __uint_as_float(0x7fc00000u));
 }
 
 // ================================================================================================
@@ -1551,7 +1556,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   }
 #endif
   const bool bad = pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  if (bad && item) p.gates[(((size_t)(d == 0 ? 0 : T - 1) * B + b) * D + d) * (size_t)K + j] = __uint_as_float(0x7fc00000u);   // poison
+  if (bad && item)           // poison d(pre-activation) of every frame: dx and both weight gradients of the layer become NaN
+    for (int tt = 0; tt < T; ++tt) st_slab(rg, vg0, (unsigned)tt * sg_b, __uint_as_float(0x7fc00000u));
 }
 
 template <bool TAGGED, int CELL>

@@ -657,6 +657,14 @@ class _CTCLoss(torch.autograd.Function):
             raise NotImplementedError("ctc_pytorch_amd.CTCLoss: concatenated 1-D targets are not used by the reference "
                                       "(train_ctc.py:47 passes (B,Lmax)); pass padded 2-D targets")
         targets = targets.contiguous()
+        # torch.nn.CTCLoss raises on lengths outside the tensors; lengths still on the host are checked here for free, lengths
+        # already on the device are checked by the kernels (NaN loss and NaN gradient rows for the offending utterance)
+        for name, t, hi in (("input_lengths", in_len, T), ("target_lengths", tgt_len, targets.shape[1])):
+            if not t.is_cuda and t.numel() and (int(t.min()) < 0 or int(t.max()) > hi):
+                raise ValueError("ctc_pytorch_amd.CTCLoss: %s must lie in [0, %d], got min %d max %d" % (name, hi, int(t.min()), int(t.max())))
+        if in_len.numel() != B or tgt_len.numel() != B or targets.shape[0] != B:
+            raise ValueError("ctc_pytorch_amd.CTCLoss: batch size mismatch (log_probs %d, targets %d, input_lengths %d, target_lengths %d)"
+                             % (B, targets.shape[0], in_len.numel(), tgt_len.numel()))
         in_len = in_len.to(device=dev, dtype=torch.int64).contiguous()
         tgt_len = tgt_len.to(device=dev, dtype=torch.int64).contiguous()
         Lmax = targets.shape[1]
@@ -729,7 +737,9 @@ def edit_distance(ids, ids_len, targets, tgt_len):
     targets = targets.to(device=dev, dtype=torch.int64).contiguous()
     tgt_len = tgt_len.to(device=dev, dtype=torch.int64).contiguous()
     B = ids.shape[0]
-    ldb = targets.shape[1] if targets.dim() == 2 else 0
+    if targets.dim() != 2 or targets.shape[0] != B or tgt_len.numel() != B or ids_len.numel() != B:
+        raise ValueError("ctc_pytorch_amd.edit_distance: expected ids (B,T), ids_len (B), targets (B,Lmax), tgt_len (B)")
+    ldb = targets.shape[1]
     out = torch.empty(B, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().ctcn_edit_distance(_ptr(ids), _ptr(ids_len), _ptr(targets), _ptr(tgt_len), _ptr(out), B, ids.shape[1], ldb,
                                              max(ldb, 1), _lib.stream_ptr()), "edit_distance")

@@ -73,16 +73,59 @@ class FlatAdam:
         ops.adam_step(self.flat, self.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                       self.step_count)
 
+    # ---- checkpoint surface: the torch.optim.Adam layout, so that 'optim_dict' of a package written by either side loads in
+    # the other (train_ctc.py:198,223,246 snapshot / roll back / save optimizer.state_dict()) ---------------------------------
+    def _slices(self):
+        """(index in model.parameters() order, offset, numel, shape) of every parameter inside the flat buffers."""
+        order = {id(p): i for i, p in enumerate(self.params)}
+        by_name = dict((n, p) for n, p in self.model.named_parameters() if p.requires_grad)
+        out, off = [], 0
+        for name in self.layout:
+            p = by_name[name]
+            out.append((order[id(p)], off, p.numel(), tuple(p.shape)))
+            off += p.numel()
+        return out
+
     def state_dict(self):
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.Adam writes it
+        (parameter i = i-th of model.parameters()); the moments are per-parameter copies of the flat buffers."""
         g = self.param_groups[0]
-        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone(), "layout": list(self.layout),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"}]}
+        template = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"],
+                                    weight_decay=g["weight_decay"]).state_dict()["param_groups"][0]      # key set of this torch version
+        group = dict(template, params=list(range(len(self.params))))
+        state = {}
+        if self.step_count > 0:
+            for i, off, n, shape in self._slices():
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": self.v[off:off + n].view(shape).clone()}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        if "layout" in sd and list(sd["layout"]) != list(self.layout):
-            raise ValueError("FlatAdam.load_state_dict: the moment buffers were saved with a different parameter placement")
-        self.step_count = sd["step"]
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
+        if "state" not in sd and "m" in sd:            # round-1 packages: flat moment buffers
+            if "layout" in sd and list(sd["layout"]) != list(self.layout):
+                raise ValueError("FlatAdam.load_state_dict: the moment buffers were saved with a different parameter placement")
+            self.step_count = int(sd["step"])
+            self.m.copy_(sd["m"])
+            self.v.copy_(sd["v"])
+        else:
+            groups = sd["param_groups"]
+            if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+                raise ValueError("FlatAdam.load_state_dict: expected one parameter group over %d parameters" % len(self.params))
+            state, steps = sd["state"], set()
+            self.m.zero_()
+            self.v.zero_()
+            for i, off, n, shape in self._slices():
+                st = state.get(i, state.get(str(i)))
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != shape:
+                    raise ValueError("FlatAdam.load_state_dict: parameter %d has shape %s, the checkpoint %s" % (i, shape, tuple(st["exp_avg"].shape)))
+                self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError("FlatAdam.load_state_dict: per-parameter step counts differ (%s); one fused step serves all" % sorted(steps))
+            self.step_count = steps.pop() if steps else 0
         for k, v in sd["param_groups"][0].items():
-            self.param_groups[0][k] = v
+            if k in ("lr", "betas", "eps", "weight_decay"):
+                self.param_groups[0][k] = v

@@ -20,8 +20,8 @@ def init_from_env(backend=None):
     if (world > 1 or _FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:      # CTCN_DIST_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL refuses two ranks per device)
+            backend = os.environ.get("CTCN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -58,13 +58,63 @@ def allreduce_grads(flat_grad):
     return flat_grad
 
 
+# Utterances of the current minibatch: (global, in this rank's shard).  Every shard is padded to the GLOBAL T_max, so a
+# BatchNorm layer's global element count is local_count * B_global / B_local -- known on the host without a collective
+# (and without a device sync), also when the shards are uneven.  None: equal shards (count = local_count * world).
+_batch = {"global": None, "local": None}
+
+
+def set_batch_split(global_b=None, local_b=None):
+    """Tell the synchronised BatchNorm how the current minibatch is split (run_epoch calls it per step)."""
+    _batch["global"], _batch["local"] = global_b, local_b
+
+
 def _sync_bn_reduce(sums, local_count):
-    """All-reduce of the (C, 2) float64 per-channel BatchNorm sums; returns the global element count per channel.
-    Every rank holds the same padded shard shape (global T_max, equal utterances per rank), so the count is
-    local_count * world_size and needs no second collective."""
+    """All-reduce of the (C, 2) float64 per-channel BatchNorm sums; returns the global element count per channel."""
     if _collectives_on():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    if _batch["global"] is not None and _batch["local"]:
+        q, r = divmod(int(local_count) * int(_batch["global"]), int(_batch["local"]))
+        if r != 0:
+            raise RuntimeError("sync BatchNorm: %d elements per channel is not a multiple of the %d local utterances" % (local_count, _batch["local"]))
+        return float(q)
     return float(local_count) * world_size()
+
+
+class ShardedBatches(object):
+    """Data-parallel view of a loader of GLOBAL minibatches: every rank iterates the same loader (same seed, same
+    shuffle), and takes the contiguous shard [lo, hi) = shard_range(B_global, rank, world) of each collated batch.  The
+    collate (utils/data_loader.create_input, reference data_loader.py:119-140) has already padded the batch to the GLOBAL
+    T_max / L_max and expressed the lengths as fractions of the global T_max, so slicing rows keeps both: N-GPU math equals
+    single-process math on the same global batch (with sync BatchNorm).  Yields (inputs, input_sizes, targets, target_sizes,
+    utt_list, B_global).  A global batch with fewer utterances than ranks is dropped on every rank (logged once)."""
+
+    def __init__(self, loader, rank, world, log=print):
+        self.loader, self.rank, self.world, self.log = loader, rank, world, log
+        self._warned = False
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for inputs, input_sizes, targets, target_sizes, utt_list in self.loader:
+            n = int(inputs.shape[0])
+            if n < self.world:
+                if not self._warned and self.rank == 0:
+                    self.log("ShardedBatches: dropping a minibatch of %d utterances (< %d ranks)" % (n, self.world))
+                self._warned = True
+                continue
+            lo, hi = shard_range(n, self.rank, self.world)
+            yield inputs[lo:hi], input_sizes[lo:hi], targets[lo:hi], target_sizes[lo:hi], utt_list[lo:hi], n
+
+
+def allreduce_stats(t):
+    """SUM over ranks of a small statistics tensor (loss / error / token counts of a step), in place."""
+    if _collectives_on():
+        if dist.get_backend() == "nccl" and not t.is_cuda:
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
 
 
 def enable_sync_bn(flag=True):

@@ -49,7 +49,11 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
     cur_loss = 0.0
     n_batches = 0
     for i, data in enumerate(data_iter):
-        inputs, input_sizes, targets, target_sizes, utt_list = data
+        inputs, input_sizes, targets, target_sizes, utt_list = data[:5]
+        # data parallel (parallel.ShardedBatches): a 6th entry carries the utterance count of the GLOBAL minibatch; the loss
+        # is sum_shard nll / B_global, so that the SUM all-reduce of the gradients yields the single-process gradient
+        step_global = data[5] if len(data) > 5 else global_batch
+        parallel.set_batch_split(step_global, int(inputs.shape[0]) if step_global else None)
         inputs = inputs.to(device, non_blocking=True)
         targets_d = targets.to(device, non_blocking=True)
         target_sizes_d = target_sizes.to(device, non_blocking=True)
@@ -58,7 +62,7 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
             out_len, batch_size, _ = out.size()
             in_len = torch.from_numpy(frames_from_fraction(input_sizes, out_len)).to(device)
             loss = loss_fn(out, targets_d, in_len, target_sizes_d)
-            loss = loss / (global_batch or batch_size)
+            loss = loss / (step_global or batch_size)
         # greedy error count on the pre-update model, all on device
         idx = ops.argmax_last(out)                                        # (T,B) int32
         ids, ids_len = ops.greedy_collapse(idx, in_len, blank=0)
@@ -71,7 +75,10 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
             optimizer.step()
         # one D2H per step: loss, error count, token count and the sticky hand-off status word of the persistent kernels
         health = _lib.status_word(inputs.device).reshape(1).double() if inputs.is_cuda else torch.zeros(1, dtype=torch.float64)
-        stats = torch.cat([torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]), health]).cpu()
+        stats = torch.cat([torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]), health])
+        if step_global:
+            stats = parallel.allreduce_stats(stats)          # global loss / error / token counts (and any rank's bad health)
+        stats = stats.cpu()
         if int(stats[3]) != 0:
             raise RuntimeError("ctc_pytorch_amd: a persistent recurrent kernel gave up waiting for a hand-off (status %d); "
                                "results of this step are poisoned -- set CTCN_RNN_PERSISTENT=0 to run one launch per timestep" % int(stats[3]))
@@ -85,6 +92,7 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
             log("Epoch = %d, step = %d, cur_loss = %.4f, total_loss = %.4f, total_wer = %.4f" % (
                 epoch_id, i + 1, cur_loss / print_every, total_loss / (i + 1), total_errs / total_tokens))
             cur_loss = 0.0
+    parallel.set_batch_split(None, None)
     average_loss = total_loss / max(n_batches, 1)
     log("Epoch %d %s done, total_loss: %.4f, total_wer: %.4f" % (epoch_id, "Train" if is_training else "Valid", average_loss,
                                                                 total_errs / max(total_tokens, 1)))
@@ -178,6 +186,14 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
                                         batch_size=opts.batch_size, shuffle=opts.shuffle_train, num_workers=opts.num_workers)
         dev_loader = SpeechDataLoader(SpeechDataset(vocab, opts.valid_scp_path, opts.valid_lab_path, opts),
                                       batch_size=opts.batch_size, shuffle=False, num_workers=opts.num_workers)
+    if world > 1:
+        # data parallel: `batch_size` stays the GLOBAL minibatch (the optimisation trajectory of the 1-GPU run); every rank
+        # walks the same loader (same seed / shuffle) and keeps its contiguous shard of each batch, padded to the global T_max
+        train_loader = parallel.ShardedBatches(train_loader, rank, world, log=log)
+        dev_loader = parallel.ShardedBatches(dev_loader, rank, world, log=log)
+        parallel.enable_sync_bn(bool(getattr(opts, "sync_bn", False)))
+    if rank != 0:
+        log = lambda *_a, **_k: None                      # one log stream: every rank holds the same all-reduced statistics
     if device.type == "cuda":
         from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher
         train_loader, dev_loader = DevicePrefetcher(train_loader, device), DevicePrefetcher(dev_loader, device)   # async double-buffered H2D

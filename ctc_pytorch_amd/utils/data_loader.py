@@ -181,12 +181,12 @@ class DevicePrefetcher(object):
         return len(self.loader)
 
     def _stage(self, batch, stream):
-        inputs, input_sizes, targets, target_sizes, utt_list = batch
+        inputs, input_sizes, targets, target_sizes, utt_list = batch[:5]
         with torch.cuda.stream(stream):
             dev = [t.pin_memory().to(self.device, non_blocking=True) for t in (inputs, targets, target_sizes)]
             ready = torch.cuda.Event()
             ready.record(stream)
-        return (dev[0], input_sizes, dev[1], dev[2], utt_list), ready
+        return (dev[0], input_sizes, dev[1], dev[2], utt_list) + tuple(batch[5:]), ready   # (+ the global batch size of a DP shard)
 
     def __iter__(self):
         if self.device.type != "cuda":

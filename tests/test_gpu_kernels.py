@@ -602,6 +602,72 @@ def test_adam_vs_oracle(dev):
     assert maxabs(pt, pr) < 2e-6
 
 
+def test_flat_adam_state_dict_is_the_torch_adam_layout(dev):
+    """'optim_dict' of a package must load on either side.  FlatAdam.state_dict() -> torch.optim.Adam.load_state_dict
+    and back; after the hand-over both optimisers take the same next step."""
+    import copy
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import CTC_Model
+    from ctc_pytorch_amd.optim import FlatAdam
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 16, "rnn_layers": 2, "rnn_type": nn.LSTM, "bidirectional": True, "batch_norm": True}
+    torch.manual_seed(3)
+    m1 = CTC_Model(rnn_param=rp, num_class=12, drop_out=0.0).to(dev)
+    m2 = copy.deepcopy(m1)
+    fa = FlatAdam(m1, lr=2e-3, weight_decay=5e-4)
+    ta = torch.optim.Adam(m2.parameters(), lr=2e-3, weight_decay=5e-4)
+    assert fa.state_dict()["state"] == {} and fa.state_dict()["param_groups"][0]["params"] == list(range(len(list(m2.parameters()))))
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    def fake_grads(model):
+        gs = [torch.randn(p.shape, generator=gen) for p in model.parameters()]
+        return gs
+    for step in range(3):
+        gs = fake_grads(m1)
+        fa.zero_grad()
+        for p, g in zip(m1.parameters(), gs):
+            p.grad.copy_(g.to(dev))
+        for p, g in zip(m2.parameters(), gs):
+            p.grad = g.to(dev)
+        fa.step()
+        ta.step()
+        if step == 0:                                   # hand the moments over in both directions after the first step
+            sd_f, sd_t = copy.deepcopy(fa.state_dict()), copy.deepcopy(ta.state_dict())
+            assert set(sd_f["param_groups"][0]) == set(sd_t["param_groups"][0]) and set(sd_f["state"]) == set(sd_t["state"])
+            ta.load_state_dict(sd_f)
+            fa.load_state_dict(sd_t)
+            assert fa.step_count == 1
+    for (k, a), b in zip(m1.named_parameters(), m2.parameters()):
+        assert maxabs(a, b) < 2e-6, k
+    legacy = {"step": 3, "m": fa.m.clone(), "v": fa.v.clone(), "layout": list(fa.layout), "param_groups": [{"lr": 1e-4}]}
+    fa.load_state_dict(legacy)                          # round-1 packages still load
+    assert fa.param_groups[0]["lr"] == 1e-4 and fa.step_count == 3
+
+
+def test_ctc_rejects_lengths_outside_the_tensors(dev):
+    """torch.nn.CTCLoss raises on input_lengths > T / target_lengths > Lmax / negative lengths.  Host-resident
+    lengths raise here too; device-resident ones make the kernels return NaN for that utterance (loss and gradient rows)
+    without touching memory outside the tensors; the edit-distance kernel clamps."""
+    from ctc_pytorch_amd import nn, ops
+    T, B, V, Lmax = 20, 3, 8, 5
+    rs = np.random.RandomState(0)
+    lp = ops.log_softmax(torch.from_numpy(rs.standard_normal((T, B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+    tg = torch.from_numpy(rs.randint(1, V, size=(B, Lmax)).astype(np.int64))
+    ok_in, ok_tl = torch.tensor([20, 15, 9]), torch.tensor([5, 3, 2])
+    loss_fn = nn.CTCLoss(reduction="sum")
+    for bad_in, bad_tl in ((torch.tensor([21, 15, 9]), ok_tl), (ok_in, torch.tensor([6, 3, 2])), (torch.tensor([20, -1, 9]), ok_tl)):
+        with pytest.raises(ValueError):
+            loss_fn(lp, tg, bad_in, bad_tl)
+    nll = nn.CTCLoss(reduction="none")(lp.detach(), tg.to(dev), torch.tensor([21, 15, 9]).to(dev), torch.tensor([5, 7, 2]).to(dev)).cpu().numpy()
+    assert np.isnan(nll[0]) and np.isnan(nll[1]) and np.isfinite(nll[2])
+    loss = loss_fn(lp, tg.to(dev), torch.tensor([20, 15, 40]).to(dev), ok_tl.to(dev))
+    loss.backward()
+    g = lp.grad.cpu().numpy()
+    assert np.isnan(float(loss)) and np.isnan(g[:, 2]).all() and np.isfinite(g[:, :2]).all()
+    ids = torch.from_numpy(rs.randint(1, V, size=(B, T)).astype(np.int32)).to(dev)
+    d = ops.edit_distance(ids, torch.tensor([4, 50, -3], dtype=torch.int32, device=dev), tg.to(dev), torch.tensor([5, 99, 2]).to(dev)).cpu().numpy()
+    assert d[0] >= 1 and 0 <= d[1] <= T                     # lengths clamped to the buffers: finite, no fault
+    assert d[2] == 2
+
+
 # ---------------------------------------------------------------------------------------------------------
 # whole model
 # ---------------------------------------------------------------------------------------------------------
@@ -1023,3 +1089,65 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["config"]["sync_bn"] is True
     assert res["value"] > 0 and np.isfinite(res["final_loss"])
+
+
+def _spawn_ranks(args, world, port, extra_env=None, timeout=600):
+    """`world` ranks on the ONE GPU of the box (LOCAL_RANK 0 for all; gloo carries the collectives, RCCL refuses two ranks per
+    device).  The persistent recurrences need their whole grid co-resident, which two processes sharing the chip cannot promise
+    each other: these runs use the one-launch-per-timestep kernels (same arithmetic, same summation order)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), LOCAL_RANK="0", CTCN_DIST_BACKEND="gloo",
+               CTCN_RNN_PERSISTENT="0", CTCN_PRECISION="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1", CTCN_QUIET="1")
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py")] + args, env=dict(env, RANK=str(r)), cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+
+
+def test_data_parallel_two_ranks_equal_single_process(dev, tmp_path):
+    """SURVEY 8a last gate / 8e: one global minibatch of 7 ragged utterances, (a) single process, (b) two ranks holding
+    shards of 4 + 3 utterances padded to the GLOBAL T_max, loss = sum_shard nll / B_global, synchronised BatchNorm (1d over
+    (T*B) rows, and 2d in the CNN variant) and one SUM all-reduce of the flat gradient: loss <= 1e-5 rel, gradient equal up
+    to summation order, per-shard log-probs and BatchNorm running statistics equal."""
+    out = str(tmp_path / "equiv.json")
+    _spawn_ranks(["equiv", out], 2, 29631)
+    res = json.load(open(out))
+    for kind in ("rnn", "cnn"):
+        r = res[kind]
+        assert r["loss_rel"] < 1e-5, r
+        assert r["grad_rel_l2"] < 2e-6 and r["grad_norm"] > 0, r
+        assert r["lp_shard_maxabs"] < 2e-5 and r["running_stats_maxabs"] < 1e-6, r
+
+
+def test_train_driver_data_parallel_matches_single_process(dev, tmp_path):
+    """steps/train_ctc.main under WORLD_SIZE=2 (global minibatches sharded by parallel.ShardedBatches, global padding,
+    global_batch scaling, sync BatchNorm, all-reduced statistics, rank-0 checkpoint) follows the 1-process run of the same
+    YAML: same per-epoch train / dev losses and dev accuracy, same final parameters on both ranks."""
+    from ctc_pytorch_amd.utils.data_loader import write_kaldi_ark
+    rs = np.random.RandomState(11)
+    phones = ["p%d" % i for i in range(8)]
+    proto = rs.standard_normal((len(phones), 40)).astype(np.float32) * 2.0
+    mats, labs = {}, {}
+    for u in range(21):                                   # 21 utterances, batch 8: the last global batch has 5 (shards 3 + 2)
+        seq = [int(k) for k in rs.randint(0, len(phones), size=int(rs.randint(4, 8)))]
+        frames = [proto[k] + 0.3 * rs.standard_normal(40) for k in seq for _ in range(int(rs.randint(5, 9)))]
+        mats["utt%02d" % u] = np.asarray(frames, dtype=np.float32)
+        labs["utt%02d" % u] = " ".join(phones[k] for k in seq)
+    d = str(tmp_path)
+    write_kaldi_ark(d + "/feats.ark", d + "/feats.scp", mats)
+    open(d + "/text", "w").write("".join("%s %s\n" % kv for kv in labs.items()))
+    open(d + "/vocab", "w").write("".join("%d %s\n" % (i, ph) for i, ph in enumerate(phones)))
+    _spawn_ranks(["main", d, d + "/w1"], 1, 29633)
+    _spawn_ranks(["main", d, d + "/w2"], 2, 29635)
+    one = json.load(open(d + "/w1.rank0"))
+    two = [json.load(open(d + "/w2.rank%d" % r)) for r in range(2)]
+    assert one["ckpt"] and two[0]["ckpt"] and not two[1]["ckpt"]              # rank 0 writes the package
+    assert two[0]["hist"] == two[1]["hist"] and two[0]["param_sum"] == two[1]["param_sum"]
+    for key in ("loss", "dev_loss"):
+        assert np.allclose(two[0]["hist"][key], one["hist"][key], rtol=2e-4), (key, two[0]["hist"][key], one["hist"][key])
+    assert np.allclose(two[0]["hist"]["dev_acc"], one["hist"]["dev_acc"], atol=0.02)
+    assert abs(two[0]["param_norm"] - one["param_norm"]) / one["param_norm"] < 1e-4
+    assert two[1]["lines"] == 0 and two[0]["lines"] > 0                       # one log stream

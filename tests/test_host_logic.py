@@ -235,6 +235,28 @@ assert parallel.max_over_ranks(1.5 + rank, torch.device("cpu")) == 2.5
 # synchronised BatchNorm: the per-channel fp64 sums of the two shards are added, the count doubles
 sums = torch.full((6, 2), float(rank + 1), dtype=torch.float64)
 assert parallel._sync_bn_reduce(sums, 100) == 200.0 and torch.equal(sums, torch.full((6, 2), 3.0, dtype=torch.float64))
+# uneven shards (7 utterances over 2 ranks, padded to the same global T_max): the global count comes from the batch split
+parallel.set_batch_split(7, hi - lo)
+assert parallel._sync_bn_reduce(torch.zeros((6, 2), dtype=torch.float64), 50 * (hi - lo)) == 350.0
+parallel.set_batch_split(None, None)
+# ShardedBatches: the same global batches on every rank, contiguous shards, global padding and fractions kept, short batch dropped
+from ctc_pytorch_amd.utils.data_loader import create_input
+import numpy as np
+rs = np.random.RandomState(3)
+items = [(torch.from_numpy(rs.standard_normal((int(rs.randint(20, 60)), 40)).astype(np.float32)),
+          torch.from_numpy(rs.randint(1, 30, size=int(rs.randint(3, 9))).astype(np.int64)), "utt%%d" %% i) for i in range(8)]
+batches = [create_input(items[0:5]), create_input(items[5:8]), create_input(items[7:8])]
+logged = []
+got = list(parallel.ShardedBatches(batches, rank, world, log=logged.append))
+assert len(got) == 2 and (len(logged) == 1) == (rank == 0)
+for g, w in zip(got, batches):
+    n = w[0].shape[0]
+    a, b = parallel.shard_range(n, rank, world)
+    assert g[5] == n and g[0].shape[1] == w[0].shape[1] and g[2].shape[1] == w[2].shape[1]       # global T_max / L_max
+    assert torch.equal(g[0], w[0][a:b]) and torch.equal(g[1], w[1][a:b]) and torch.equal(g[2], w[2][a:b]) and torch.equal(g[3], w[3][a:b])
+    assert g[4] == w[4][a:b]
+st = parallel.allreduce_stats(torch.tensor([1.0 + rank, 10.0], dtype=torch.float64))
+assert torch.equal(st, torch.tensor([3.0, 20.0], dtype=torch.float64))
 from ctc_pytorch_amd import ops
 parallel.enable_sync_bn(True)
 assert ops._sync_bn["reduce"] is parallel._sync_bn_reduce
