@@ -101,7 +101,7 @@ def main_mode(corpus, out_path):
                 batch_norm=True, add_cnn=False, layers=2, channel="[(1,32),(32,32)]", kernel_size="[(3,3),(3,3)]", stride="[(1,2),(2,2)]",
                 padding="[(1,1),(1,1)]", pooling="None", activation_function="relu", drop_out=0.0, init_lr=1e-2, weight_decay=0.0,
                 end_adjust_acc=2.0, lr_decay=0.5, num_epoches=3, verbose_step=100, seed=1, sync_bn=True,
-                checkpoint_dir=d + "/ckpt_w%s" % os.environ.get("WORLD_SIZE", "1"), exp_name="toy")
+                checkpoint_dir=d + "/ckpt_w%s_r%d" % (os.environ.get("WORLD_SIZE", "1"), rank), exp_name="toy")   # per rank: only rank 0 may write
     ops.set_precision(0)
     lines = []
     model, hist = TR.main(conf, log=lines.append)

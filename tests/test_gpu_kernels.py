@@ -830,10 +830,28 @@ def test_run_epoch_trajectory_golden(dev, prec):
     step_losses = [float(l.split("cur_loss = ")[1].split(",")[0]) for l in lines if "cur_loss" in l]
     assert np.allclose(step_losses, z["printed_step_losses"], rtol=rt), (step_losses, z["printed_step_losses"])
     assert abs(avg - float(z["train_avg_loss"])) / float(z["train_avg_loss"]) < rt
-    assert abs(acc - float(z["train_acc"])) < 1e-9
+    # error counts: identical in f32.  In the bf16 mode an untrained model (near-uniform posteriors) has frames whose two best
+    # classes are closer than the 1e-5 the modes differ by; SURVEY 8a: report the margin.  Gate: at most 3 greedy errors of the
+    # ~1 000 scored tokens differ, and (below) every arg-max flip of the initial model is a near-tie (f32 top-2 margin < 1e-4).
+    tokens = float(np.sum(z["tgt_len"]))
+    slack = 1e-9 if prec == 0 else 3.0 / (3 * tokens)
+    assert abs(acc - float(z["train_acc"])) < slack, (acc, float(z["train_acc"]))
     acc_e, avg_e = run_epoch(1, m, [batch], nn.CTCLoss(reduction="sum"), dev, optimizer=None, is_training=False, log=lines.append)
     assert abs(avg_e - float(z["eval_avg_loss"])) / float(z["eval_avg_loss"]) < (2e-4 if prec == 0 else rt)
-    assert abs(acc_e - float(z["eval_acc"])) < 1e-9
+    assert abs(acc_e - float(z["eval_acc"])) < (1e-9 if prec == 0 else 3.0 / tokens), (acc_e, float(z["eval_acc"]))
+    if prec == 1:
+        lps = {}
+        for pr in (0, 1):
+            ops.set_precision(pr)
+            m0 = CTC_Model(rnn_param=rp, num_class=62, drop_out=0.0)
+            m0.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+            with torch.no_grad():
+                lps[pr] = m0.to(dev).train()(batch[0].to(dev))
+        a0, a1 = ops.argmax_last(lps[0]), ops.argmax_last(lps[1])
+        flips = a0 != a1
+        if bool(flips.any()):
+            top2 = torch.topk(lps[0][flips], 2, dim=-1).values
+            assert float((top2[:, 0] - top2[:, 1]).max()) < 1e-4, (int(flips.sum()), float((top2[:, 0] - top2[:, 1]).max()))
 
 
 def _full_size_model(name, dev):
