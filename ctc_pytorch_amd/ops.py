@@ -746,9 +746,9 @@ def edit_distance(ids, ids_len, targets, tgt_len):
     return out
 
 
-def beam_decode(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):
-    """x (T,B,V) float32 device tensor (log-probs, or probabilities if input_is_prob); returns CPU
-    (ids list-of-lists, scores (B,) float64, status (B,) int32).  Synchronises (host result)."""
+def beam_decode_device(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):
+    """Enqueue the prefix beam search (ctcn_beam_decode) on the current stream; returns DEVICE tensors
+    (out_ids (B,T) int32, out_len (B) int32, score (B) float64, status (B) int32) without synchronising."""
     _need_gpu(x_tbv)
     x = _f32c(x_tbv.detach())
     T, B, V = x.shape
@@ -767,6 +767,14 @@ def beam_decode(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob
     _lib.check(L.ctcn_beam_decode(_ptr(x), int(bool(input_is_prob)), _ptr(lens_t), _ptr(lm), float(alpha), int(beam_width), int(blank),
                                   _ptr(out_ids), _ptr(out_len), _ptr(score), _ptr(status), T, B, V, _ptr(ws), ws.numel(),
                                   _lib.stream_ptr()), "beam_decode")
+    return out_ids, out_len, score, status
+
+
+def beam_decode(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):
+    """x (T,B,V) float32 device tensor (log-probs, or probabilities if input_is_prob); returns CPU
+    (ids list-of-lists, scores (B,) float64, status (B,) int32).  Synchronises (host result)."""
+    out_ids, out_len, score, status = beam_decode_device(x_tbv, lens, lm_table, alpha, beam_width, blank, input_is_prob)
+    B = out_ids.shape[0]
     ids_c, len_c = out_ids.cpu().numpy(), out_len.cpu().numpy()
     return [list(map(int, ids_c[b, : len_c[b]])) for b in range(B)], score.cpu().numpy(), status.cpu().numpy()
 

@@ -1100,7 +1100,7 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     env = dict(os.environ, CTCN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
-           "--sync-bn", "--no-cpu-baseline"]
+           "--sync-bn", "--no-cpu-baseline", "--no-decode"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
