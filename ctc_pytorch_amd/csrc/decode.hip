@@ -252,6 +252,499 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
   }
 }
 
+
+// =====================================================================================================================
+// Fast path (W <= 64, W*V <= 4096, V <= 256): the same search, restructured around the per-frame latency chain.
+// The generic kernel above spends ~39 us per processed frame (cfg5): W block-wide arg-max rounds (two __syncthreads + a
+// serial 4-way compare each), the double-precision log of the frame, LM gathers from global memory, trie CAS round trips
+// to L2 (~1.9 us each), and -- everywhere -- chains of dependent LDS reads (~100 cycles per hop).  Here:
+//   * beam_prep_kernel (fully parallel, one wave per (frame, utterance) row) takes everything that does not depend on the
+//     beam state out of the chain: ln p as double for every class, p(blank), the "some p is not > 0" flag;
+//   * the workgroup compacts its list of processed frames once (the skip rule 1 - p_blank < 0.1 needs no beam state), keeps
+//     alpha * LM (31.7 KB at V = 62) in LDS, and every thread prefetches the next frame's ln p of ITS candidate classes;
+//   * the beam lives in the registers of wave 0 (lane = beam slot); cross-slot reads are v_readlane / ds_bpermute, not LDS
+//     round trips; the per-slot values the candidate scoring needs are mirrored into a 24-byte LDS record;
+//   * top-W: candidate c lives in registers of wave c % 4, lane (c / 4) / NPT (so that lane order == candidate order inside a
+//     wave).  Each wave extracts ITS best candidates with wave-local rounds: the doubles are mapped to order-preserving
+//     64-bit keys and reduced as two 32-bit DPP max-reductions (high word, then low word among the lanes that hold the
+//     high maximum) -- exact, no barrier, no LDS; the first lane holding the maximum wins (== lowest candidate index on
+//     ties).  The four sorted lists are merged by rank counting (a few parallel compares per lane + a quad reduction).  A wave
+//     extracts ceil(W/4) + 4 candidates at first and continues only while its last extracted candidate still ranks inside
+//     the top W of the union (if it does not, the rest of its candidates cannot either: exact);
+//   * trie: a 16K-slot open-addressing table IN LDS (node id = slot + 1, entry = {parent id + 1 : 15 | symbol : 17}), one
+//     ds_cmpst per probe; only when it fills beyond 3/4 do new labellings go to the global-memory table of the generic kernel
+//     (64-bit entries {parent : 24 | symbol : 16 | id : 24}).
+// Every score is computed by the same expressions on the same operands as in beam_kernel: bit-identical results.
+// =====================================================================================================================
+constexpr int FAST_WMAX = 64;
+
+struct FastArgs {
+  const double *lgd; const float *pb; const unsigned char *zf;
+  const int32_t *lens; const double *lm; double alpha; int W, blank;
+  int32_t *out_ids, *out_len; double *out_score; int32_t *status; int T, B, V;
+  unsigned long long *ht; int *node_par; int *node_sym; int ht_size, max_nodes;
+  int trie_slots;       // LDS trie slots (power of two)
+#ifdef CTCN_BEAM_STATS
+  long long *stats;     // development instrumentation (tools/mb_beam.py): cycles per phase of workgroup 0
+#endif
+};
+#ifdef CTCN_BEAM_STATS
+#define BSTAMP(i) do { const long long now_ = clock64(); zst[i] += now_ - zlast; zlast = now_; } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256) void beam_prep_kernel(const float *__restrict__ x, int input_is_prob, double *__restrict__ lgd,
+                                                        float *__restrict__ pb, unsigned char *__restrict__ zf, size_t rows, int V, int blank) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *xr = x + row * V;
+  bool bad = false;
+  for (int k = lane; k < V; k += 64) {
+    const float p = input_is_prob ? xr[k] : expf(xr[k]);
+    if (!(p > 0.0f)) bad = true;
+    lgd[row * V + k] = log((double)p);                 // math.log of the float32 value widened to double
+    if (k == blank) pb[row] = p;
+  }
+  const bool any_bad = __any(bad);
+  if (lane == 0) zf[row] = any_bad ? 1 : 0;
+}
+
+// order-preserving map double -> uint64 (total order of the IEEE values; -0.0 / NaN do not occur among the scores)
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+  return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax_step(unsigned v) {
+  const unsigned s = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return max(v, s);
+}
+// max over the 64 lanes on the DPP network: row_shr 1/2/4/8 leave each row's maximum in its lane 15, row_bcast15 / row_bcast31
+// carry it across the rows; lane 63 holds the result (max is idempotent: lanes without a source keep their own value)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  v = dpp_umax_step<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_umax_step<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_umax_step<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_umax_step<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_umax_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v = dpp_umax_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umin_step(unsigned v) {
+  const unsigned s = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return min(v, s);
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+  v = dpp_umin_step<0x111, 0xf>(v);
+  v = dpp_umin_step<0x112, 0xf>(v);
+  v = dpp_umin_step<0x114, 0xf>(v);
+  v = dpp_umin_step<0x118, 0xf>(v);
+  v = dpp_umin_step<0x142, 0xa>(v);
+  v = dpp_umin_step<0x143, 0xc>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int lane_gather(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ double lane_gather(double v, int src_lane) {
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v)));
+}
+
+struct __attribute__((aligned(16))) Survivor { unsigned long long k; int idx; int pad; };
+constexpr int SURV_MAX = 256;
+
+constexpr int FAST_NTH = 1024, FAST_NWV = FAST_NTH / 64;      // 16 waves: the parallel phases are instruction-issue bound (~10 cycles per
+                                                               // dependent instruction and wave), so more waves per SIMD is what shortens them
+template <int NPT, bool LM_LDS>
+__global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
+  constexpr int NTH = FAST_NTH, NWV = FAST_NWV;
+  // dynamic LDS: [alpha*LM (V+1)^2 doubles] | cand[W*V] doubles | lg[V] doubles | mslot[W*V] ints | flist[T] ints | trie[slots] uints
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  __shared__ Survivor surv[SURV_MAX];                                 // candidates above the pruning bound (order-preserving key, index)
+  __shared__ double red_v[NWV];
+  __shared__ int red_i[NWV + 1];
+  __shared__ unsigned gmax[64];                                        // per 16-lane row: largest candidate key (high word)
+  __shared__ double bm_pB[FAST_WMAX], bm_pT[FAST_WMAX], selv[FAST_WMAX];
+  __shared__ int bm_c1[FAST_WMAX], sel[FAST_WMAX];
+  __shared__ int f_node[FAST_WMAX], f_len[FAST_WMAX], f_last[FAST_WMAX];   // final beam (dumped once, after the last frame)
+  __shared__ double f_pT[FAST_WMAX];
+  __shared__ int woff[NWV];
+  __shared__ int s_cnt;
+  __shared__ unsigned s_theta;
+  __shared__ int s_nfl, s_gnodes, s_lnodes;      // processed frames | 0 while the LDS trie takes inserts, else 1 + global nodes | LDS trie nodes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, V = a.V, W = a.W, B = a.B, T = a.T, blank = a.blank;
+  const int V1 = V + 1;
+  double *lmA = reinterpret_cast<double *>(fsm);
+  double *cand = lmA + (LM_LDS ? V1 * V1 : 0);
+  double *lg = cand + W * V;
+  int *mslot = reinterpret_cast<int *>(lg + V);
+  int *flist = mslot + W * V;
+  unsigned *trie = reinterpret_cast<unsigned *>(flist + T);
+  const int TS = a.trie_slots;
+  const unsigned tmask = (unsigned)TS - 1u;
+  unsigned long long *ht = a.ht + (size_t)b * a.ht_size;
+  int *npar = a.node_par + (size_t)b * a.max_nodes;
+  int *nsym = a.node_sym + (size_t)b * a.max_nodes;
+  const unsigned htmask = (unsigned)a.ht_size - 1u;
+  constexpr int TMASK = (1 << 29) - 1;
+
+  if (LM_LDS)
+    for (int i = tid; i < V1 * V1; i += NTH) lmA[i] = a.lm[i] * a.alpha;        // the same product the generic kernel forms per use
+  for (int i = tid; i < W * V; i += NTH) mslot[i] = -1;
+  for (int i = tid; i < TS; i += NTH) trie[i] = 0u;
+  const int nframes = min(max(a.lens[b], 0), T);
+  if (tid == 0) {
+    bm_c1[0] = V; bm_pB[0] = 0.0; bm_pT[0] = 0.0;                                // the empty labelling: prBlank = prTotal = 0 (BeamSearch.py:83-87)
+    s_nfl = 0; s_gnodes = 0; s_lnodes = 0;
+  }
+  __syncthreads();
+  // frames the search processes, in order (BeamSearch.py:93-94: skip when 1 - p_blank < 0.1, a float32 compare), each with its
+  // "p_blank of the previous frame < 0.9" bit (:63) and its "log(0)" bit
+  for (int t0 = 0; t0 < nframes; t0 += NTH) {
+    const int t = t0 + tid;
+    bool keep = false;
+    int word = 0;
+    if (t < nframes) {
+      const float pbl = a.pb[(size_t)t * B + b];
+      keep = !((1.0f - pbl) < 0.1f);
+      const bool rep = t > 0 && a.pb[(size_t)(t - 1) * B + b] < 0.9f;
+      word = t | (rep ? 1 << 30 : 0) | (a.zf[(size_t)t * B + b] ? 1 << 29 : 0);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) woff[wave] = __popcll(mask);
+    __syncthreads();
+    int base = s_nfl;
+    for (int w = 0; w < wave; ++w) base += woff[w];
+    if (keep) flist[base + __popcll(mask & ((1ull << lane) - 1ull))] = word;
+    __syncthreads();
+    if (tid == 0) { int add = 0; for (int w = 0; w < NWV; ++w) add += woff[w]; s_nfl += add; }
+    __syncthreads();
+  }
+  const int nfl = s_nfl;
+
+  // static candidate slots of this thread: c = ((37 * tid) mod NTH) + i * NTH -> (beam ci, class ck; ck < 0: the stay slot).  Any
+  // bijection works (the selection below ranks by explicit (score, index)); the odd multiplier spreads neighbouring candidates --
+  // the classes of one beam -- over different 16-lane rows, which keeps the pruning bound of the selection tight.
+  int cc[NPT], ci[NPT], ck[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int c = ((37 * tid) & (NTH - 1)) + i * NTH;
+    cc[i] = c;
+    ci[i] = c < W * V ? c / V : FAST_WMAX;                        // beyond the table: never valid (nb <= W <= FAST_WMAX)
+    const int kk = c - (c / V) * V;
+    ck[i] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
+  }
+  // ln p row of the next frame, one frame ahead (threads < V; handed to everybody through LDS)
+  double nlg = 0.0;
+  auto fetch_lg = [&](int fword) {
+    if (tid < V) nlg = a.lgd[((size_t)(fword & TMASK) * B + b) * V + tid];
+  };
+  if (nfl > 0) fetch_lg(flist[0]);
+  if (tid < V) lg[tid] = nlg;
+
+  // the beam: lane r of wave 0 holds slot r
+  int z_node = 0, z_len = 0, z_last = -1, z_par = -1;              // node ids: 0 = the empty labelling, s + 1 = LDS trie slot s,
+  double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;                 // TS + 1 + g = entry g of the global table
+  int nb = 1, status = 0;
+  __syncthreads();
+#ifdef CTCN_BEAM_STATS
+  long long zst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zlast = clock64(), zrounds = 0, ziters = 0;
+  const long long zt0 = zlast;
+#endif
+
+  for (int j = 0; j < nfl; ++j) {
+    const int fw = flist[j];
+    if (fw & (1 << 29)) { status = 2; break; }                     // math.log(0) in the reference: ValueError
+    const bool rep_ok = (fw >> 30) & 1;
+    if (j + 1 < nfl) fetch_lg(flist[j + 1]);
+    // P1: extension scores (calcExtPr), candidate slot c = i*V + 1 + kk'.  Two LDS hops: the slot's context class, then
+    // LM / prBlank / prTotal -- every read of a hop is issued before the first use (clamped addresses, selects afterwards)
+    {
+      int c1[NPT];
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[min(ci[i], FAST_WMAX - 1)];
+      double lmv[NPT], pbv[NPT], ptv[NPT], lk[NPT];
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        const int bi = min(ci[i], FAST_WMAX - 1), k = max(ck[i], 0);
+        const int c1c = min(max(c1[i], 0), V);
+        lmv[i] = LM_LDS ? lmA[c1c * V1 + k] : a.lm[(size_t)c1c * V1 + k] * a.alpha;
+        lk[i] = lg[k];
+        pbv[i] = bm_pB[bi];
+        ptv[i] = bm_pT[bi];
+      }
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        if (ci[i] < nb && ck[i] >= 0) {
+          const double base = (c1[i] == ck[i] && rep_ok) ? pbv[i] : ptv[i];     // c1 == k <=> non-empty labelling ending in k
+          cand[cc[i]] = lk[i] + lmv[i] + base;
+        }
+      }
+    }
+    BSTAMP(0);
+    lds_barrier();
+    BSTAMP(1);
+    // P2 (wave 0): parent slot of every slot + stay entries, merged with the matching extension in the reference's visiting order
+    double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;
+    if (wave == 0) {
+      const int ip = lane;
+      const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
+      int mi = -1;
+      for (int i2 = 0; i2 < nb; ++i2) {
+        const int n2 = __builtin_amdgcn_readlane(z_node, i2);
+        if (z_len > 0 && n2 == z_par) mi = i2;
+      }
+      const int kkl = (z_last < blank) ? z_last + 1 : z_last;
+      const int ce = max(mi, 0) * V + max(kkl, 0);
+      const double pr = cand[min(ce, W * V - 1)];                  // the extension that equals this labelling (if mi >= 0)
+      BSTAMP(6);
+      if (ip < nb) {
+        double s_nb = LOG_ZERO;
+        if (z_len > 0) s_nb = z_pNB + lgl;                         // BeamSearch.py:102-103
+        const double s_b = z_pT + lgb;                             // :106
+        Fields e{LOG_ZERO, LOG_ZERO, LOG_ZERO};
+        if (mi >= 0) {
+          if (mi < ip) { apply_ext(e, pr); apply_stay(e, s_nb, s_b); cand[ce] = e.t; cand[ip * V] = -INFINITY; mslot[ce] = (j << 8) | ip; }
+          else         { apply_stay(e, s_nb, s_b); apply_ext(e, pr); cand[ip * V] = e.t; cand[ce] = -INFINITY; }
+        } else {
+          apply_stay(e, s_nb, s_b);
+          cand[ip * V] = e.t;
+        }
+        e_nb = e.nb; e_b = e.b; e_t = e.t;
+      }
+      BSTAMP(7);
+      if (lane == 0) { s_theta = 0u; s_cnt = 0; }
+    }
+    lds_barrier();
+    BSTAMP(2);
+    // P3: BHat = top-W by (prTotal desc, candidate index asc), without sorting.
+    //  1. splitter: every 16-lane row reduces the largest key (high word) of its ~16 * NPT candidates on the DPP network; the W-th
+    //     largest of the 64 row maxima is a lower bound of the W-th best candidate (W distinct candidates reach it): exact pruning;
+    //  2. the survivors (typically W + a few) are compacted into LDS and ranked by counting, all threads sharing the compares.
+    unsigned long long key[NPT];
+    bool val[NPT];
+    unsigned mhi = 0u;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const double v = cand[min(cc[i], W * V - 1)];
+      key[i] = f64_key(v);
+      val[i] = ci[i] < nb && v != -INFINITY;
+      mhi = max(mhi, val[i] ? (unsigned)(key[i] >> 32) : 0u);
+    }
+    mhi = dpp_umax_step<0x111, 0xf>(mhi);
+    mhi = dpp_umax_step<0x112, 0xf>(mhi);
+    mhi = dpp_umax_step<0x114, 0xf>(mhi);
+    mhi = dpp_umax_step<0x118, 0xf>(mhi);
+    if ((lane & 15) == 15) gmax[tid >> 4] = mhi;
+    BSTAMP(8);
+    lds_barrier();
+    {
+      // rank of row maximum e among the 64 (ties broken by the row number: a strict order); 16 threads per row maximum
+      const int e = tid >> 4, part = tid & 15;
+      const unsigned mine = gmax[e];
+      int cnt = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = part * 4 + u;
+        const unsigned o = gmax[q];
+        cnt += (o > mine || (o == mine && q < e)) ? 1 : 0;
+      }
+      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);    // row_half_mirror
+      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
+      if (part == 0 && cnt == W - 1) s_theta = mine;                        // (no such row when fewer than W rows hold a candidate: 0)
+    }
+    lds_barrier();
+    {
+      const unsigned theta = s_theta;
+      bool keep[NPT];
+      int wtot = 0, pos[NPT];
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        keep[i] = val[i] && (unsigned)(key[i] >> 32) >= theta;
+        const unsigned long long bal = __ballot(keep[i]);
+        pos[i] = wtot + __popcll(bal & ((1ull << lane) - 1ull));
+        wtot += __popcll(bal);
+      }
+      int wbase = 0;
+      if (lane == 0 && wtot > 0) wbase = atomicAdd(&s_cnt, wtot);
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+      for (int i = 0; i < NPT; ++i)
+        if (keep[i] && wbase + pos[i] < SURV_MAX) { surv[wbase + pos[i]].k = key[i]; surv[wbase + pos[i]].idx = cc[i]; }
+    }
+    BSTAMP(3);
+    lds_barrier();
+    const int S = s_cnt;
+    int total = S;
+    if (S <= SURV_MAX) {
+      // rank counting: P threads per survivor, thread part p compares it with survivors p, p + P, ...; DPP butterfly sum
+      const int P = S <= 64 ? 16 : (S <= 128 ? 8 : 4);
+      const int e = tid / P, part = tid - e * P;
+      const Survivor me = surv[min(e, SURV_MAX - 1)];
+      int cnt = 0;
+      for (int q0 = part; q0 < S; q0 += 4 * P) {
+        Survivor oe[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) oe[u] = surv[min(q0 + u * P, SURV_MAX - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          cnt += (q0 + u * P < S && (oe[u].k > me.k || (oe[u].k == me.k && oe[u].idx < me.idx))) ? 1 : 0;
+      }
+      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
+      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);                  // quad_perm [2,3,0,1]
+      if (P >= 8) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
+      if (P >= 16) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
+      if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
+    } else {
+      // more than SURV_MAX candidates above the bound (never seen on the synthetic regimes): W block-wide arg-max rounds over the
+      // candidate table, exactly as the generic kernel does
+      const int ncand = nb * V;
+      int got = 0;
+      for (int r = 0; r < W; ++r) {
+        double bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = tid; c < ncand; c += NTH) {
+          const double v = cand[c];
+          if (v != -INFINITY && cand_better(v, c, bv, bi)) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const double ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (oi != 0x7fffffff && (bi == 0x7fffffff || cand_better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        lds_barrier();
+        if (tid == 0) {
+          double v = red_v[0]; int ix = red_i[0];
+          for (int w = 1; w < NWV; ++w)
+            if (red_i[w] != 0x7fffffff && (ix == 0x7fffffff || cand_better(red_v[w], red_i[w], v, ix))) { v = red_v[w]; ix = red_i[w]; }
+          red_i[NWV] = ix;
+          if (ix != 0x7fffffff) { sel[r] = ix; selv[r] = v; cand[ix] = -INFINITY; }
+        }
+        lds_barrier();
+        if (red_i[NWV] == 0x7fffffff) break;
+        ++got;
+      }
+      total = got;
+    }
+    lds_barrier();
+    const int m = min(W, total);
+    BSTAMP(4);
+    // P4 (wave 0): materialise the new beam in lane order of the ranks
+    if (wave == 0) {
+      const int rr = min(lane, FAST_WMAX - 1);
+      const int c = sel[rr];
+      const double sv = selv[rr];
+      const bool act = lane < m;
+      const int i = act ? (int)(((float)c + 0.5f) * (1.0f / (float)V)) : 0;       // c / V (exact for c < 2^20)
+      const int kk = c - i * V;
+      const int k = (kk - 1 < blank) ? kk - 1 : kk;
+      const int ms = mslot[act ? c : 0];
+      const bool merged = act && kk != 0 && (ms >> 8) == j && ms >= 0;            // this slot holds the merged entry of slot ms & 255
+      const bool fresh = act && kk != 0 && !merged;
+      const int src = merged ? (ms & 255) : i;
+      const int g_node = lane_gather(z_node, src), g_len = lane_gather(z_len, src), g_last = lane_gather(z_last, src), g_par = lane_gather(z_par, src);
+      const double g_nb = lane_gather(e_nb, src), g_b = lane_gather(e_b, src), g_t = lane_gather(e_t, src);
+      int n_node = g_node, n_len = g_len, n_last = g_last, n_par = g_par;
+      double n_pNB = g_nb, n_pB = g_b, n_pT = g_t;
+      if (fresh) {
+        n_len = g_len + 1; n_last = k; n_par = g_node; n_pNB = sv; n_pB = LOG_ZERO; n_pT = sv;
+        // trie child (g_node, k): LDS table first; the global table only once the LDS table is 3/4 full
+        const int parent = g_node;
+        int id = -1;
+        bool lds_ok = parent <= TS;                                 // a child of a global node was created after the overflow
+        if (lds_ok) {
+          const unsigned entry = ((unsigned)(parent + 1) << 17) | (unsigned)k;
+          unsigned h = (unsigned)mix64(((unsigned long long)(unsigned)parent << 20) | (unsigned)k) & tmask;
+          const bool may_insert = s_gnodes == 0;
+          for (int probe = 0; probe < TS; ++probe) {
+            unsigned prev = may_insert ? atomicCAS(&trie[h], 0u, entry) : trie[h];
+            if (prev == entry) { id = (int)h + 1; break; }
+            if (prev == 0u) { if (may_insert) id = (int)h + 1; break; }
+            h = (h + 1) & tmask;
+          }
+        }
+        if (id < 0) {                                               // global table: {parent : 24 | symbol : 16 | id : 24}
+          const unsigned long long key40 = ((unsigned long long)(unsigned)parent << 16) | (unsigned)k;
+          unsigned h = (unsigned)mix64(key40) & htmask;
+          int gid = -1;
+          for (int probe = 0; probe <= (int)htmask; ++probe) {
+            const unsigned long long seen = __hip_atomic_load(&ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen != HT_EMPTY) {
+              if ((seen >> 24) == key40) { id = TS + 1 + (int)(seen & 0xFFFFFFull); break; }
+              h = (h + 1) & htmask;
+              continue;
+            }
+            if (gid < 0) gid = atomicAdd(&s_gnodes, 1) - 1;         // s_gnodes = 1 + number of global nodes once overflowed
+            const unsigned long long prev = atomicCAS(&ht[h], HT_EMPTY, (key40 << 24) | (unsigned long long)(unsigned)gid);
+            if (prev == HT_EMPTY) { id = TS + 1 + gid; if (gid < a.max_nodes) { npar[gid] = parent; nsym[gid] = k; } break; }
+            if ((prev >> 24) == key40) { id = TS + 1 + (int)(prev & 0xFFFFFFull); break; }   // (cannot happen: keys of a frame are distinct)
+            h = (h + 1) & htmask;
+          }
+        }
+        n_node = id;
+      }
+      // LDS trie occupancy: count this frame's fresh lanes; past 3/4 the table is closed for inserts
+      {
+        const unsigned long long fm = __ballot(fresh && n_node <= TS);
+        if (lane == 0 && s_gnodes == 0) {
+          s_lnodes += __popcll(fm);
+          if (s_lnodes * 4 > TS * 3) s_gnodes = 1;
+        }
+      }
+      z_node = n_node; z_len = n_len; z_last = n_last; z_par = n_par; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
+      if (act) { bm_c1[lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
+    }
+    if (tid < V) lg[tid] = nlg;                                    // the next frame's ln p row (lg is not read after P2)
+    lds_barrier();
+    BSTAMP(5);
+    nb = m;
+  }
+#ifdef CTCN_BEAM_STATS
+  if (a.stats && b == 0 && (tid == 0 || tid == 64)) {
+    long long *o = a.stats + (tid == 0 ? 0 : 16);
+    for (int i = 0; i < 12; ++i) o[i] = zst[i];
+    o[12] = zrounds; o[13] = ziters; o[14] = nfl; o[15] = clock64() - zt0;
+  }
+#endif
+  if (wave == 0) { f_node[lane] = z_node; f_len[lane] = z_len; f_last[lane] = z_last; f_pT[lane] = z_pT; }
+  __syncthreads();
+  // final LM step, length normalisation and best labelling (BeamSearch.py:130-151)
+  if (status == 0 && tid == 0) {
+    int st = 0;
+    for (int r = 0; r < nb; ++r) if (f_len[r] == 0) st = 1;          // classes[y[-1]] on () -> IndexError
+    if (s_gnodes > a.max_nodes) st = 3;
+    int best = -1; double bestv = 0.0;
+    if (st == 0) {
+      for (int r = 0; r < nb; ++r) {
+        const double pr = f_pT[r] + a.lm[(size_t)f_last[r] * V1 + V] * a.alpha;
+        const double tot = log_add_prob(LOG_ZERO, pr);
+        const int ln = f_len[r];
+        const double nv = tot * (1.0 / (ln ? ln : 1));
+        if (best < 0 || nv > bestv) { best = r; bestv = nv; }
+      }
+      const int ln = f_len[best];
+      a.out_len[b] = ln; a.out_score[b] = bestv;
+      int n = f_node[best];
+      for (int i = ln - 1; i >= 0; --i) {
+        if (n <= TS) { const unsigned e = trie[n - 1]; a.out_ids[(size_t)b * T + i] = (int)(e & 0x1FFFFu); n = (int)(e >> 17) - 1; }
+        else { const int gq = n - TS - 1; a.out_ids[(size_t)b * T + i] = nsym[gq]; n = npar[gq]; }
+      }
+    } else { a.out_len[b] = 0; a.out_score[b] = 0.0; }
+    a.status[b] = st;
+  } else if (tid == 0) {
+    a.out_len[b] = 0; a.out_score[b] = 0.0; a.status[b] = status;
+  }
+}
+
 struct BeamLayout { size_t keys, ids, npar, nsym, cand, total; int ht_size, max_nodes; };
 BeamLayout beam_layout(int T, int B, int V, int W) {
   BeamLayout l;
@@ -269,11 +762,58 @@ BeamLayout beam_layout(int T, int B, int V, int W) {
   return l;
 }
 
+// fast path: [hash table | node parents | node symbols | ln p (T,B,V) double | p_blank (T,B) | log(0) flags (T,B)]
+struct FastLayout { size_t ht, npar, nsym, lgd, pb, zf, total; int ht_size, max_nodes, npt, trie_slots; bool ok, lm_lds; size_t lds; };
+FastLayout fast_layout(int T, int B, int V, int W) {
+  FastLayout l = {};
+  l.max_nodes = W * T + 2;
+  int ht = 1024;
+  while (ht < 2 * l.max_nodes) ht <<= 1;
+  l.ht_size = ht;
+  size_t off = 0;
+  l.ht = off;   off += align_up((size_t)B * ht * sizeof(unsigned long long), 256);
+  l.npar = off; off += align_up((size_t)B * l.max_nodes * sizeof(int), 256);
+  l.nsym = off; off += align_up((size_t)B * l.max_nodes * sizeof(int), 256);
+  l.lgd = off;  off += align_up((size_t)T * B * V * sizeof(double), 256);
+  l.pb = off;   off += align_up((size_t)T * B * sizeof(float), 256);
+  l.zf = off;   off += align_up((size_t)T * B, 256);
+  l.total = off;
+  l.npt = ceil_div(W * V, FAST_NTH);                     // candidate slots per thread (1..4)
+  if (l.npt > 4) l.npt = 0;
+  const size_t core = ((size_t)W * V + V) * sizeof(double) + ((size_t)W * V + T) * sizeof(int);   // cand, lg | mslot, flist
+  const size_t lm = (size_t)(V + 1) * (V + 1) * sizeof(double);
+  const size_t budget = 144 * 1024;                     // of the CU's 160 KB (the kernel also has ~8 KB of static LDS)
+  // LDS trie: as many slots as fit, at most 16 K (node ids of the LDS table must fit 14 bits); then the LM if it still fits
+  l.trie_slots = 16384;
+  while (l.trie_slots > 1024 && core + (size_t)l.trie_slots * 4 + (lm <= 40 * 1024 ? lm : 0) > budget) l.trie_slots >>= 1;
+  l.lm_lds = core + (size_t)l.trie_slots * 4 + lm <= budget;
+  l.lds = core + (size_t)l.trie_slots * 4 + (l.lm_lds ? lm : 0);
+  l.ok = W <= FAST_WMAX && l.npt > 0 && V <= 256 && l.max_nodes < (1 << 24) && T < (1 << 22) && l.lds <= budget;
+  return l;
+}
+
+#ifdef CTCN_BEAM_STATS
+long long *g_beam_stats_dev = nullptr;
+#endif
+template <int NPT>
+int launch_fast(const FastLayout &l, const FastArgs &a, hipStream_t st) {
+  if (l.lm_lds) {
+    auto kern = beam_fast_kernel<NPT, true>;
+    CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(FAST_NTH), l.lds, st, a);
+  } else {
+    auto kern = beam_fast_kernel<NPT, false>;
+    CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(FAST_NTH), l.lds, st, a);
+  }
+  return CTCN_OK;
+}
+
 }  // namespace
 
 extern "C" size_t ctcn_beam_ws_bytes(int T, int B, int V, int W) {
   if (T <= 0 || B <= 0 || V <= 0 || W <= 0) return 0;
-  return beam_layout(T, B, V, W).total;
+  return std::max(beam_layout(T, B, V, W).total, fast_layout(T, B, V, W).total);
 }
 
 extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha, int W,
@@ -282,10 +822,42 @@ extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t
   CTCN_REQUIRE(x && lens && lm && out_ids && out_len && out_score && status && ws, "ctcn_beam_decode: null pointer");
   CTCN_REQUIRE(T > 0 && B > 0 && V > 1 && blank >= 0 && blank < V, "ctcn_beam_decode: bad dims");
   if (W < 1 || W > BEAM_WMAX) { ctcn_set_error("ctcn_beam_decode: beam width %d outside [1,%d]", W, BEAM_WMAX); return CTCN_EUNSUPPORTED; }
-  const BeamLayout l = beam_layout(T, B, V, W);
-  if (ws_bytes < l.total) { ctcn_set_error("ctcn_beam_decode: workspace too small (%zu < %zu)", ws_bytes, l.total); return CTCN_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   char *base = (char *)ws;
+  const FastLayout fl = fast_layout(T, B, V, W);
+  if (fl.ok && ctcn_get_option("beam_fast") != 0) {
+    if (ws_bytes < fl.total) { ctcn_set_error("ctcn_beam_decode: workspace too small (%zu < %zu)", ws_bytes, fl.total); return CTCN_EWORKSPACE; }
+    CTCN_HIP(hipMemsetAsync(base + fl.ht, 0xFF, (size_t)B * fl.ht_size * sizeof(unsigned long long), st));
+    FastArgs a;
+    a.lgd = (const double *)(base + fl.lgd); a.pb = (const float *)(base + fl.pb); a.zf = (const unsigned char *)(base + fl.zf);
+    a.lens = lens; a.lm = lm; a.alpha = alpha; a.W = W; a.blank = blank;
+    a.out_ids = out_ids; a.out_len = out_len; a.out_score = out_score; a.status = status; a.T = T; a.B = B; a.V = V;
+    a.ht = (unsigned long long *)(base + fl.ht); a.node_par = (int *)(base + fl.npar); a.node_sym = (int *)(base + fl.nsym);
+    a.ht_size = fl.ht_size; a.max_nodes = fl.max_nodes; a.trie_slots = fl.trie_slots;
+#ifdef CTCN_BEAM_STATS
+    static long long *g_stats = nullptr;
+    if (!g_stats) { CTCN_HIP(hipMalloc(&g_stats, 64 * sizeof(long long))); }
+    CTCN_HIP(hipMemsetAsync(g_stats, 0, 64 * sizeof(long long), st));
+    a.stats = g_stats;
+    g_beam_stats_dev = g_stats;
+#endif
+    const size_t rows = (size_t)T * B;
+    hipLaunchKernelGGL(beam_prep_kernel, dim3((unsigned)ceil_div_z(rows, 4)), dim3(256), 0, st, x, input_is_prob, (double *)(base + fl.lgd),
+                       (float *)(base + fl.pb), (unsigned char *)(base + fl.zf), rows, V, blank);
+    CTCN_LAUNCH_CHECK();
+    int rc;
+    switch (fl.npt) {
+      case 1: rc = launch_fast<1>(fl, a, st); break;
+      case 2: rc = launch_fast<2>(fl, a, st); break;
+      case 3: rc = launch_fast<3>(fl, a, st); break;
+      default: rc = launch_fast<4>(fl, a, st); break;
+    }
+    if (rc) return rc;
+    CTCN_LAUNCH_CHECK();
+    return CTCN_OK;
+  }
+  const BeamLayout l = beam_layout(T, B, V, W);
+  if (ws_bytes < l.total) { ctcn_set_error("ctcn_beam_decode: workspace too small (%zu < %zu)", ws_bytes, l.total); return CTCN_EWORKSPACE; }
   CTCN_HIP(hipMemsetAsync(base + l.keys, 0xFF, (size_t)B * l.ht_size * sizeof(unsigned long long), st));
   BeamArgs a;
   a.x = x; a.input_is_prob = input_is_prob; a.lens = lens; a.lm = lm; a.alpha = alpha; a.W = W; a.blank = blank;
@@ -300,3 +872,11 @@ extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
+
+#ifdef CTCN_BEAM_STATS
+extern "C" int ctcn_beam_stats(long long *host_out) {       // tools/mb_beam.py only
+  if (!g_beam_stats_dev) return CTCN_EINVAL;
+  CTCN_HIP(hipMemcpy(host_out, g_beam_stats_dev, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CTCN_OK;
+}
+#endif

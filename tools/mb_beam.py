@@ -1,0 +1,65 @@
+"""Per-phase cycle budget of beam_fast_kernel (development aid): builds decode.hip with -DCTCN_BEAM_STATS into
+tools/libctcn_beamstats.so, decodes the cfg5 batch and prints the cycles workgroup 0 spent per phase and frame.
+    python tools/mb_beam.py build     (no GPU needed)        python tools/mb_beam.py run [peaky|flat]"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SO = os.path.join(ROOT, "tools", "libctcn_beamstats.so")
+CS = os.path.join(ROOT, "ctc_pytorch_amd", "csrc")
+
+
+def build():
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCTCN_BEAM_STATS", "-o", SO,
+                           os.path.join(CS, "decode.hip"), os.path.join(CS, "core.hip")])
+
+
+def run(regime):
+    import numpy as np
+    import torch
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    from oracle import synth
+    L = ctypes.CDLL(SO)
+    V, T, B, W = 62, 800, 128, 20
+    i2c = synth.int2char(V)
+    tab = LanguageModel(os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    lp = synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)
+    lens = np.random.RandomState(2).randint(400, 801, size=B).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(lp).to(dev)
+    lens_t = torch.from_numpy(lens).to(dev)
+    lm = torch.from_numpy(np.asarray(tab, dtype=np.float64)).to(dev)
+    L.ctcn_beam_ws_bytes.restype = ctypes.c_size_t
+    nb = L.ctcn_beam_ws_bytes(T, B, V, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out_ids = torch.zeros((B, T), dtype=torch.int32, device=dev)
+    out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    score = torch.zeros(B, dtype=torch.float64, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.ctcn_beam_decode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    for _ in range(2):
+        rc = L.ctcn_beam_decode(P(x), 0, P(lens_t), P(lm), 0.1, W, 0, P(out_ids), P(out_len), P(score), P(status), T, B, V, P(ws), nb, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+    st = (ctypes.c_longlong * 64)()
+    assert L.ctcn_beam_stats(st) == 0
+    names = ["P1 cand scores", "barrier after P1", "P2 tail: barrier", "P3 barrier + splitter rank + barrier + prune/compact", "P3 barrier + rank count + barrier", "P4 materialise + barrier",
+             "barrier + P2 mfrom", "P2 stay/merge math", "P3 candidate load + row max"]
+    for base, who in ((0, "wave 0"), (16, "wave 1")):
+        nfl = max(st[base + 14], 1)
+        print("%s  %s: frames %d, total %.0f cycles/frame, rounds/frame %.2f, merge iterations/frame %.2f" % (regime, who, nfl, st[base + 15] / nfl, st[base + 12] / nfl, st[base + 13] / nfl))
+        for i, n in enumerate(names):
+            print("    %-36s %8.0f cycles/frame" % (n, st[base + i] / nfl))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(sys.argv[2] if len(sys.argv) > 2 else "flat")
