@@ -623,6 +623,142 @@ __global__ __launch_bounds__(256) void gemm_planes_nt_queue_kernel(int M, int N,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 / 256 x 128 plane tiles for the activation-sized products (M = T*B rows).
+// The 128 x 128 tile above moves 64 KB of planes through a CU per 64-k slab for 3 x 128 x 128 x 64 MACs: at the MFMA rate that
+// is ~42 B/clk per CU out of an L2 that delivers ~56, so the kernel is L2-bandwidth bound at ~36 % of the MFMA rate (and the A
+// planes cross the fabric 2.3 x per XCD).  A 256 x 256 tile halves the bytes per MAC (21 B/clk), a 256 x 128 tile takes 31.
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 (or 128 x 32) outputs = 4 x WNT MFMA tiles of 32 x 32: 128 / 64
+//     accumulator VGPRs; per 16-k step 8 + 4 (or 8 + 2) ds_read_b128 feed 24 (12) v_mfma_f32_32x32x16_bf16;
+//   * 32-k stages, two LDS buffers (2 x 64 KB / 2 x 48 KB): the next stage is copied global -> LDS by the DMA path
+//     (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) while the current one is multiplied; ONE barrier per stage;
+//   * LDS image: rows of 64 B (4 chunks of 16 B = 8 bf16), chunk' = chunk ^ ((row >> 2) & 3): the 16 lanes of every ds_read_b128
+//     group hit 16 distinct bank slots.  The DMA writes LDS lane-linearly, so the swizzle is applied to the SOURCE address;
+//   * same products, same k order inside a 16-k step and across steps as the 128 x 128 tile: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool v_is_magic(float v) { return v == 1.2345678e33f; }   // (debug switch of tools/gemm_bench.py: keeps the accumulators live)
+__device__ __forceinline__ int qswz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int WNT>      // 32-column MFMA tiles per wave: 2 -> 256 x 256 workgroup tile, 1 -> 256 x 128
+__global__ __launch_bounds__(512) void gemm_planes_nt256_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                                const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                                const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
+                                                                int tiles_m, int tiles_n, int dbg) {
+  constexpr int TBM = 256, TBN = 128 * WNT;
+  constexpr int A_BYTES = TBM * 64, B_BYTES = TBN * 64;              // one plane of one stage
+  constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;                   // Ah | Al | Bh | Bl
+  constexpr int IA = TBM * 4 / 512, IB = TBN * 4 / 512;              // DMA instructions per thread and plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {   // XCD-aware remap: blocks b, b + 8, ... share an XCD / L2; give each XCD a contiguous band of tiles (N fastest: shared A panel)
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x16 acc[4][WNT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // DMA source offsets (elements) of this lane: LDS position p = (inst * 8 + wave) * 64 + lane -> row p >> 2, swizzled chunk p & 3
+  unsigned offA[IA], offB[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane, row = p >> 2, chunk = (p & 3) ^ ((row >> 2) & 3);
+    offA[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)Kp + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane, row = p >> 2, chunk = (p & 3) ^ ((row >> 2) & 3);
+    offB[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)Kp + chunk * 8;
+  }
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  auto issue = [&](int k0, int buf) {
+    unsigned char *sb = qsm + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int dst = (i * 8 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ah + offA[i] + k0), (lptr_t)(sb + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Al + offA[i] + k0), (lptr_t)(sb + A_BYTES + dst), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int dst = (i * 8 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bh + offB[i] + k0), (lptr_t)(sb + 2 * A_BYTES + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bl + offB[i] + k0), (lptr_t)(sb + 2 * A_BYTES + B_BYTES + dst), 16, 0, 0);
+    }
+  };
+  const int nst = Kp / 32;
+  const int ml = lane & 31, g = lane >> 5;
+  issue(0, 0);
+  for (int s = 0; s < nst; ++s) {
+    __syncthreads();                       // stage s has landed (the DMA is waited for here), everybody is done with stage s - 1
+    if (s + 1 < nst && !(dbg & 2)) issue((s + 1) * 32, (s + 1) & 1);
+    const unsigned char *sb = qsm + (s & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cq = ks * 2 + g;
+      bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = qswz(wm * 128 + i * 32 + ml, cq);
+        ah[i] = *reinterpret_cast<const bf16x8_t *>(sb + o);
+        al[i] = *reinterpret_cast<const bf16x8_t *>(sb + A_BYTES + o);
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int o = qswz(wn * 32 * WNT + j * 32 + ml, cq);
+        bh[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + o);
+        bl[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + B_BYTES + o);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + wn * 32 * WNT + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N && (!(dbg & 1) || v_is_magic(acc[i][j][e]))) {
+          float v = acc[i][j][e];
+          float *p = C + (size_t)row * ldc + col;
+          if (beta != 0.0f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+template <int WNT>
+static int launch_planes256(hipStream_t st, int M, int N, int Kp, const unsigned short *ah, const unsigned short *al, const unsigned short *bh,
+                            const unsigned short *bl, float *C, int ldc, float beta) {
+  const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
+  const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
+  auto kern = gemm_planes_nt256_kernel<WNT>;
+  CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, tiles_m, tiles_n, ctcn_get_option("gemm_dbg"));
+  return CTCN_OK;
+}
+
 // launch one of the three tile shapes (dynamic LDS = 2 planes x (BM + BN) rows x 128 B)
 template <int TI, int TJ>
 static int launch_planes(bool queued, int nt, int psplits, hipStream_t st, int M, int N, int Kp, const unsigned short *ah, const unsigned short *al,
@@ -746,6 +882,18 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
         if (ctcn_opt_gemm_big_tiles() && (ok42 || ok24)) {
           if (ok24 && (!ok42 || t24 <= t42)) { shape = 2; ptm = m24; ptn = n24; }
           else { shape = 1; ptm = m42; ptn = n42; }
+        }
+      }
+      // activation-sized products (M = T*B): the 256-row tiles, when they give the device at least ~0.75 workgroups per CU
+      if (!xcd_allow && ctcn_get_option("gemm_tile256") != 0 && M >= 1024 && N >= 96) {
+        const int wnt = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
+        const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128 * wnt);
+        if (t256 * 4 >= (long)ctcn_device_cus() * 3) {
+          const int lrc256 = wnt == 2 ? launch_planes256<2>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta)
+                                      : launch_planes256<1>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta);
+          if (lrc256) return lrc256;
+          CTCN_LAUNCH_CHECK();
+          return CTCN_OK;
         }
       }
       const int pnt = ptm * ptn;

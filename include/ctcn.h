@@ -51,6 +51,8 @@ int ctcn_device_xcds(void);
  * side stream (1..16; measured at cfg2: 1 -> 20.2, 2 -> 18.0, 4 -> 17.0, 8..16 -> 16.8 ms per step: the side work is nearly critical).
  * "beam_fast" = 1 (default): ctcn_beam_decode uses the restructured search (wave-local top-W extraction, LM in LDS, ln p precomputed
  * by a parallel pre-pass) whenever W <= 64, W*V <= 4096 and V <= 256; 0: always the generic kernel (same results, ~15x slower).
+ * "gemm_tile256" = 1 (default): the bf16x3 GEMM multiplies activation-sized products (M >= 1024 rows, enough tiles to fill the
+ * device) with 256 x 256 / 256 x 128 workgroup tiles staged by global_load_lds; 0: always the 128 x 128 tile (same results).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */

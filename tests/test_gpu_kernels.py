@@ -138,6 +138,33 @@ def test_gemm_bf16x3_big_tiles_equal_small_tiles(dev, M, N, K, ta, tb):
     assert float((outs[1][rows].double() - ref).abs().max()) < 2e-4 * (K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,beta", [(25600, 1280, 640, 0, 1, 0.0), (25600, 640, 2560, 0, 0, 0.0), (16390, 1030, 200, 0, 1, 1.0),
+                                                  (8192, 2560, 136, 0, 1, 0.0), (12800, 96, 320, 0, 0, 1.0), (76800, 1536, 1024, 0, 1, 0.0)])
+def test_gemm_bf16x3_tile256_equals_tile128(dev, M, N, K, ta, tb, beta):
+    """precision 1: the 256 x 256 / 256 x 128 workgroup tiles (global_load_lds staging, `gemm_tile256`, the default for
+    activation-sized products) accumulate every output element over k in the same order with the same operands as the
+    128 x 128 tiling: bit-identical results (ragged M / N / K edges and beta = 1 included), within bf16x3 accuracy of float64."""
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(M % 1000 + K)
+    A = torch.from_numpy(rs.standard_normal((K, M) if ta else (M, K)).astype(np.float32)).to(dev)
+    B = torch.from_numpy(rs.standard_normal((N, K) if tb else (K, N)).astype(np.float32)).to(dev)
+    C0 = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(dev)
+    outs = []
+    ops.set_precision(1)
+    try:
+        for t256 in (0, 1):
+            ops.set_option("gemm_tile256", t256)
+            C = C0.clone()
+            ops.gemm(ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C, N, beta=beta)
+            outs.append(C)
+    finally:
+        ops.set_option("gemm_tile256", 1)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+    rows = torch.arange(0, M, max(1, M // 64), device=dev)
+    ref = (A.t() if ta else A)[rows].double() @ (B.t() if tb else B).double() + beta * C0[rows].double()
+    assert float((outs[1][rows].double() - ref).abs().max()) < 2e-4 * (K ** 0.5)
+
+
 @pytest.mark.parametrize("kind", ["lstm", "gru", "rnn"])
 def test_rnn_layer_golden(dev, kind):
     from ctc_pytorch_amd import ops
