@@ -197,6 +197,7 @@ def run_train(args):
     from oracle import synth                      # synthetic inputs only (no arithmetic)
     rank, world, local = parallel.init_from_env()
     parallel.enable_sync_bn(bool(getattr(args, "sync_bn", False)))
+    parallel.enable_overlap(True)       # per-layer gradient slices are all-reduced behind their weight GEMMs (no-op without collectives)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     torch.cuda.set_device(local)
@@ -217,6 +218,7 @@ def run_train(args):
     global_b = c["B"] * world
     in_len = None
     losses = []
+    overlapped = [0]
 
     def step():
         nonlocal in_len
@@ -226,6 +228,8 @@ def run_train(args):
         loss = loss_fn(out, tg, in_len, tl) / global_b
         opt.zero_grad()
         loss.backward()
+        _ops.join_side_stream()
+        overlapped[0] = len(parallel._overlap["done"])         # gradient slices already all-reduced behind their weight GEMMs
         parallel.allreduce_grads(opt.grad)
         opt.step()
         return loss
@@ -262,7 +266,7 @@ def run_train(args):
             args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], ", 2-layer CNN front-end" if c["cnn"] else ""),
             "global_batch": global_b, "seq_len": c["T"], "parallelism": "dp%d" % world, "full_length_utterances": True,
             "sync_bn": bool(getattr(args, "sync_bn", False))},
-        "final_loss": last_loss,
+        "final_loss": last_loss, "overlapped_allreduce_slices_last_step": overlapped[0],
         "model_tflops_per_s": train_flops_per_step * world / (dt / args.steps) / 1e12,
         "per_gpu_frames_per_s": value / world,
     }

@@ -68,6 +68,10 @@ _SIGS = {
     "ctcn_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, P]),
     "ctcn_greedy_collapse": (I, [P, Z, Z, P, P, P, I, I, I, P]),
     "ctcn_edit_distance": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_comm_unique_id": (I, [P]),
+    "ctcn_comm_init": (I, [P, I, I, ctypes.POINTER(ctypes.c_void_p)]),
+    "ctcn_comm_allreduce_sum_f32": (I, [P, P, Z, P]),
+    "ctcn_comm_destroy": (I, [P]),
     "ctcn_beam_ws_bytes": (Z, [I, I, I, I]),
     "ctcn_beam_decode": (I, [P, I, P, P, D, I, I, P, P, P, P, I, I, I, P, Z, P]),
 }

@@ -94,6 +94,16 @@ def _ws(t, tag="main"):
 # straight away it competes with the critical-path kernels that sit between two recurrences (the input-gradient GEMMs, the
 # BatchNorm / dropout backward), which measured 1.5-10x their stand-alone time in that window; behind the deferral they
 # have the chip to themselves and the side work overlaps with nothing but the recurrence, on the XCDs it leaves idle.
+# Data parallel overlap: `_grad_ready["hook"]` (parallel.enable_overlap) is called on the side stream right after the weight-gradient
+# GEMMs of a recurrent layer were enqueued there, with the flat-buffer views they accumulate into: the all-reduce of that slice
+# then runs next to the rest of the backward pass instead of after it.
+_grad_ready = {"hook": None}
+
+
+def set_grad_ready_hook(fn):
+    _grad_ready["hook"] = fn
+
+
 _side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": 1 << 21}
 
 
@@ -378,6 +388,8 @@ class _RNNLayer(torch.autograd.Function):
                     _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0),
                                                       _ptr(d_hh0), _ptr(d_ih1), _ptr(d_hh1), 1.0, prec, allow, wp2, wn2,
                                                       st.cuda_stream), "rnn_bwd_weights")
+                    if _grad_ready["hook"] is not None:          # this layer's weight gradients are final once `st` gets here
+                        _grad_ready["hook"]([t for t in (d_ih0, d_hh0, d_ih1, d_hh1) if t is not None])
                 for t in (x, y, gates, aux):
                     if t is not None:
                         t.record_stream(st)         # the caching allocator must not recycle them under the side stream

@@ -48,13 +48,115 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class CtcnComm(object):
+    """The RCCL communicator behind the C ABI (ctcn_comm_*): what a host without torch.distributed would bind.  Selected for the
+    gradient all-reduce with CTCN_COMM=1; the 128-byte unique id travels over the torch.distributed process group (any backend)."""
+
+    def __init__(self, rank, world):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        L = _lib.lib()
+        blob = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (ctypes.c_char * 128)()
+            _lib.check(L.ctcn_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "comm_unique_id")
+            blob = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        if world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            blob = blob.to(dev)
+            dist.broadcast(blob, src=0)
+            blob = blob.cpu()
+        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(blob.numpy().tobytes()))
+        self.handle = ctypes.c_void_p()
+        _lib.check(L.ctcn_comm_init(ctypes.cast(raw, ctypes.c_void_p), rank, world, ctypes.byref(self.handle)), "comm_init")
+
+    def all_reduce_sum_(self, t):
+        """in place, float32, enqueued on the current stream"""
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("CtcnComm.all_reduce_sum_: contiguous float32 device tensor expected")
+        self._lib.check(self._lib.lib().ctcn_comm_allreduce_sum_f32(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(), self._lib.stream_ptr()),
+                        "comm_allreduce_sum_f32")
+        return t
+
+    def destroy(self):
+        if self.handle:
+            self._lib.check(self._lib.lib().ctcn_comm_destroy(self.handle), "comm_destroy")
+            self.handle = None
+
+
+_ctcn_comm = {"comm": None}
+
+
+def _comm():
+    """The C-ABI communicator when CTCN_COMM=1 (created on first use), else None (torch.distributed carries the collective)."""
+    if os.environ.get("CTCN_COMM", "0") != "1":
+        return None
+    if _ctcn_comm["comm"] is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        _ctcn_comm["comm"] = CtcnComm(rank, world_size())
+    return _ctcn_comm["comm"]
+
+
+# ---- overlap of the gradient all-reduce with the backward pass -------------------------------------------------------------
+# optim.FlatAdam lays the four weight matrices of a recurrent layer out adjacently, and ops.py produces their gradients on the
+# weight-gradient side stream while the recurrence of the layer below runs.  With the overlap enabled the all-reduce of such a slice
+# (9.8 MB per 4x320 layer) is issued right behind those GEMMs -- on RCCL's own stream -- and the step-end call only waits for
+# them and reduces what is left (BatchNorm / fc / bottom-layer gradients).  One backward pass per optimiser step is assumed
+# (gradient accumulation over several backward passes would reduce a slice twice): opt in with enable_overlap().
+_overlap = {"works": [], "done": [], "events": []}
+
+
+def enable_overlap(flag=True):
+    from . import ops
+    ops.set_grad_ready_hook(_slice_ready if flag else None)
+    _overlap["works"], _overlap["done"], _overlap["events"] = [], [], []
+
+
+def _slice_ready(tensors):
+    if not _collectives_on() or not tensors:
+        return
+    ts = sorted(tensors, key=lambda t: t.data_ptr())
+    lo, n = ts[0].data_ptr(), sum(t.numel() for t in ts)
+    if any(not t.is_contiguous() or t.dtype != torch.float32 for t in ts) or ts[-1].data_ptr() + ts[-1].numel() * 4 - lo != n * 4:
+        return                                   # not one contiguous slice of the flat buffer: left to the step-end all-reduce
+    view = torch.as_strided(ts[0], (n,), (1,))
+    c = _comm()
+    if c is not None:                            # C-ABI communicator: in stream order on the side stream itself
+        c.all_reduce_sum_(view)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(view.device))
+        _overlap["events"].append(ev)
+    else:
+        _overlap["works"].append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+    _overlap["done"].append((lo, lo + n * 4))
+
+
 def allreduce_grads(flat_grad):
-    """SUM all-reduce of the flat gradient buffer (loss is already divided by the GLOBAL batch size)."""
+    """SUM all-reduce of the flat gradient buffer (loss is already divided by the GLOBAL batch size); with enable_overlap() the
+    slices reduced during the backward pass are only waited for and the remainder is reduced here."""
     if flat_grad.is_cuda:
         from . import ops
         ops.join_side_stream()            # weight gradients issued on the side stream must have landed
-    if _collectives_on():
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    if not _collectives_on():
+        return flat_grad
+    c = _comm() if flat_grad.is_cuda else None
+    reduce = (lambda t: c.all_reduce_sum_(t)) if c is not None else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    done = sorted(_overlap["done"])
+    for w in _overlap["works"]:
+        w.wait()                          # the current stream waits for the collective
+    for ev in _overlap["events"]:
+        torch.cuda.current_stream(flat_grad.device).wait_event(ev)
+    _overlap["works"], _overlap["done"], _overlap["events"] = [], [], []
+    if not done:
+        reduce(flat_grad)
+        return flat_grad
+    base, end = flat_grad.data_ptr(), flat_grad.data_ptr() + flat_grad.numel() * 4
+    cur = base
+    for lo, hi in done + [(end, end)]:
+        if lo > cur:
+            reduce(flat_grad[(cur - base) // 4:(lo - base) // 4])
+        cur = max(cur, hi)
     return flat_grad
 
 

@@ -192,6 +192,7 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
         train_loader = parallel.ShardedBatches(train_loader, rank, world, log=log)
         dev_loader = parallel.ShardedBatches(dev_loader, rank, world, log=log)
         parallel.enable_sync_bn(bool(getattr(opts, "sync_bn", False)))
+        parallel.enable_overlap(True)                     # run_epoch does one backward pass per optimiser step
     if rank != 0:
         log = lambda *_a, **_k: None                      # one log stream: every rank holds the same all-reduced statistics
     if device.type == "cuda":

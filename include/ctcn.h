@@ -206,6 +206,18 @@ int ctcn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float
                    float eps, float weight_decay, int step, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Data-parallel exchange step: SUM all-reduce of the flat float32 gradient buffer (or a slice of it) over RCCL / xGMI,
+ * one communicator per rank.  The reference is single-device (train_ctc.py:63-65 loss.backward(); optimizer.step()); utterance-
+ * sharded data parallelism inserts this one collective between the two calls.  librccl.so is opened at run time.
+ *   rank 0 calls ctcn_comm_unique_id (128 bytes) and hands the blob to the other ranks by any host channel; every rank then
+ *   calls ctcn_comm_init (collective: blocks until all `world` ranks arrived).  The communicator is the only object the library
+ *   owns; ctcn_comm_allreduce_sum_f32 is enqueued on `stream` (in place) and returns without synchronising. */
+int ctcn_comm_unique_id(void *id128);
+int ctcn_comm_init(const void *id128, int rank, int world, void **comm);
+int ctcn_comm_allreduce_sum_f32(void *comm, float *buf, size_t n, void *stream);
+int ctcn_comm_destroy(void *comm);
+
+/* ---------------------------------------------------------------------------------------------------
  * Greedy decode: collapse of arg-max paths (drop blank, drop frame-to-frame repeats, first lens[b]
  * frames); replaces GreedyDecoder.decode / CTC_Model.compute_wer inner loops
  * (ctcDecoder.py:152-166,80-92; model_ctc.py:190-199).  idx int32, element (t,b) at idx[t*stride_t+b*stride_b]

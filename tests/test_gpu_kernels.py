@@ -1117,16 +1117,19 @@ def test_beam_error_paths(dev):
         BeamDecoder(i2c, beam_width=5)                      # lm_path=None: open(None), as the reference
 
 
-def test_bench_under_torchrun_with_rccl_collectives(dev):
+@pytest.mark.parametrize("workload,comm", [("cfg1", "0"), ("cfg2", "0"), ("cfg2", "1")])
+def test_bench_under_torchrun_with_rccl_collectives(dev, workload, comm):
     """The driver's N>1 launch line, with one rank: torch.distributed.run -> process group on the nccl (= RCCL) backend ->
     parameter broadcast, flat-gradient all-reduce ordered behind the side stream, sync-BN all-reduces, max-over-ranks.
-    CTCN_FORCE_COLLECTIVES=1 makes the single rank issue every collective (parallel.py)."""
+    CTCN_FORCE_COLLECTIVES=1 makes the single rank issue every collective (parallel.py).  cfg2: the layers are large enough for
+    the weight-gradient side stream, so the per-layer slices are all-reduced DURING the backward pass (parallel.enable_overlap);
+    comm = 1: through the C-ABI communicator (ctcn_comm_init / ctcn_comm_allreduce_sum_f32) instead of torch.distributed."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CTCN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    env = dict(os.environ, CTCN_FORCE_COLLECTIVES="1", CTCN_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", workload,
            "--sync-bn", "--no-cpu-baseline", "--no-decode"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -1134,6 +1137,8 @@ def test_bench_under_torchrun_with_rccl_collectives(dev):
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["config"]["sync_bn"] is True
     assert res["value"] > 0 and np.isfinite(res["final_loss"])
+    if workload == "cfg2":
+        assert res["overlapped_allreduce_slices_last_step"] >= 2, res.get("overlapped_allreduce_slices_last_step")
 
 
 def _spawn_ranks(args, world, port, extra_env=None, timeout=600):

@@ -257,7 +257,22 @@ for g, w in zip(got, batches):
     assert g[4] == w[4][a:b]
 st = parallel.allreduce_stats(torch.tensor([1.0 + rank, 10.0], dtype=torch.float64))
 assert torch.equal(st, torch.tensor([3.0, 20.0], dtype=torch.float64))
+# overlapped gradient all-reduce: two slices are reduced "during the backward pass", the step-end call reduces the rest -- every
+# element of the flat buffer exactly once
+parallel.enable_overlap(True)
 from ctc_pytorch_amd import ops
+assert ops._grad_ready["hook"] is parallel._slice_ready
+flat = torch.arange(100, dtype=torch.float32) * (rank + 1)
+parallel._slice_ready([flat[10:20].view(2, 5), flat[20:30].view(5, 2)])          # adjacent views = one contiguous slice
+parallel._slice_ready([flat[60:70], flat[80:90]])                                  # not contiguous: left to the end
+parallel._slice_ready([flat[95:100]])
+assert len(parallel._overlap["works"]) == 2
+parallel.allreduce_grads(flat)
+assert torch.equal(flat, torch.arange(100, dtype=torch.float32) * 3) and parallel._overlap["works"] == [] and parallel._overlap["done"] == []
+parallel.allreduce_grads(flat)                                                      # nothing pending: one plain all-reduce
+assert torch.equal(flat, torch.arange(100, dtype=torch.float32) * 6)
+parallel.enable_overlap(False)
+assert ops._grad_ready["hook"] is None
 parallel.enable_sync_bn(True)
 assert ops._sync_bn["reduce"] is parallel._sync_bn_reduce
 parallel.enable_sync_bn(False)
