@@ -38,8 +38,27 @@ class _RecurrentMixin:
             raise NotImplementedError("initial state is always zero on the reference path (model_ctc.py:33)")
         self._check()
         w1 = (self.weight_ih_l0_reverse, self.weight_hh_l0_reverse) if self.bidirectional else (None, None)
-        y = ops.rnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, w1[0], w1[1], self._cell, self.training)
-        return y, None
+        H = self.hidden_size
+        if H % 4 == 0:
+            y = ops.rnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, w1[0], w1[1], self._cell, self.training)
+            return y, None
+        # The kernels move rows of W_hh / h in 16-byte pieces (H % 4 == 0).  Any other hidden size (nn.LSTM takes every H,
+        # model_ctc.py:24-25) runs as the next multiple of 4 with all-zero weights for the extra units: their pre-activations are 0,
+        # so c = h = 0 for every cell type at every step and the real units never see them; the padding / slicing around the
+        # kernels is plain tensor plumbing (autograd routes the gradients of the real rows back through it).
+        Hp, G = H + (4 - H % 4), {"lstm": 4, "gru": 3, "tanh": 1}[self._cell]
+
+        def pad(w_ih, w_hh):
+            wi = _tnn.functional.pad(w_ih.view(G, H, -1), (0, 0, 0, Hp - H)).reshape(G * Hp, -1)
+            wh = _tnn.functional.pad(w_hh.view(G, H, H), (0, Hp - H, 0, Hp - H)).reshape(G * Hp, Hp)
+            return wi.contiguous(), wh.contiguous()
+
+        p0 = pad(self.weight_ih_l0, self.weight_hh_l0)
+        p1 = pad(*w1) if self.bidirectional else (None, None)
+        yp = ops.rnn_layer(x, p0[0], p0[1], p1[0], p1[1], self._cell, self.training)
+        T, B, _ = yp.shape
+        D = 2 if self.bidirectional else 1
+        return ops.contiguous(yp.view(T, B, D, Hp)[..., :H]).view(T, B, D * H), None       # drop the padded units (strided gather kernel)
 
     def flatten_parameters(self):
         return None

@@ -271,11 +271,39 @@ def test_rnn_persistent_equals_per_step_launches(dev, kind, T, B, I, H, bi):
         assert rel_l2(g1, g0) < 2e-6
 
 
-def test_rnn_rejects_bad_hidden(dev):
+def test_rnn_c_abi_rejects_unaligned_hidden(dev):
+    """The C ABI states its contract (H % 4 == 0: rows move in 16-byte pieces) and says so instead of misbehaving."""
     from ctc_pytorch_amd import ops
     x = torch.zeros(3, 2, 5, device=dev)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="multiple of 4"):
         ops.rnn_layer(x, torch.zeros(4 * 6, 5, device=dev), torch.zeros(4 * 6, 6, device=dev), None, None, "lstm")
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("kind,H,bi", [("LSTM", 6, True), ("GRU", 10, True), ("RNN", 7, False), ("LSTM", 321, True)])
+def test_rnn_module_any_hidden_size(dev, kind, H, bi, prec):
+    """nn.LSTM / GRU / RNN of the reference take every hidden size (model_ctc.py:24-25); sizes that are not multiples of 4 run
+    zero-padded to the next multiple: outputs and all gradients equal the torch CPU layer."""
+    from ctc_pytorch_amd import nn, ops
+    ops.set_precision(prec)
+    T, B, I = (9, 5, 12) if H < 100 else (40, 32, 40)
+    torch.manual_seed(H)
+    ref = getattr(tnn, kind)(I, H, bidirectional=bi, bias=False)
+    m = getattr(nn, kind)(I, H, bidirectional=bi, bias=False)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev)
+    x, dy = torch.randn(T, B, I), torch.randn(T, B, (2 if bi else 1) * H)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    yr.backward(dy)
+    xg = x.to(dev).requires_grad_(True)
+    y, _ = m(xg)
+    assert tuple(y.shape) == tuple(yr.shape) and maxabs(y, yr) < (2e-5 if prec == 0 else 1e-4)
+    y.backward(dy.to(dev))
+    tol = 1e-4 if prec == 0 else 5e-4
+    assert rel_l2(xg.grad, xr.grad) < tol
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_l2(p.grad, q.grad) < tol, n
 
 
 def test_batchnorm_golden(dev):
