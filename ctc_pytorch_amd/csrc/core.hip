@@ -33,6 +33,7 @@ static int g_opt_side_split_wgs = 8;
 static int g_opt_gemm_big_tiles = 0;   // 256x128 / 128x256 plane-GEMM tiles: measured 7 % slower than 128x128 x 2 per CU
 static int g_opt_gemm_tile256 = 1;      // 1: 256-row plane-GEMM tiles (global_load_lds staging) for activation-sized products
 static int g_opt_gemm_dbg = 0;          // development: bit 0 = 256-tile GEMM skips its stores, bit 1 = skips its DMA loads (results invalid)
+static int g_opt_gemm_a_inline = 1;     // 1: 256-row tiles split a row-major float32 A operand while staging it (no plane pass over A)
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 64, W*V <= 4096); 0: the generic kernel always
 static int *g_status_dev = nullptr;
 
@@ -46,6 +47,7 @@ extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "side_split_wgs")) { g_opt_side_split_wgs = value < 1 ? 1 : (value > 16 ? 16 : value); return CTCN_OK; }
   if (name && !strcmp(name, "gemm_big_tiles")) { g_opt_gemm_big_tiles = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "beam_fast")) { g_opt_beam_fast = value ? 1 : 0; return CTCN_OK; }
+  if (name && !strcmp(name, "gemm_a_inline")) { g_opt_gemm_a_inline = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_dbg")) { g_opt_gemm_dbg = value; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_tile256")) { g_opt_gemm_tile256 = value ? 1 : 0; return CTCN_OK; }
   ctcn_set_error("ctcn_set_option: unknown option %s", name ? name : "(null)");
@@ -61,6 +63,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "side_split_wgs")) return g_opt_side_split_wgs;
   if (name && !strcmp(name, "gemm_big_tiles")) return g_opt_gemm_big_tiles;
   if (name && !strcmp(name, "beam_fast")) return g_opt_beam_fast;
+  if (name && !strcmp(name, "gemm_a_inline")) return g_opt_gemm_a_inline;
   if (name && !strcmp(name, "gemm_dbg")) return g_opt_gemm_dbg;
   if (name && !strcmp(name, "gemm_tile256")) return g_opt_gemm_tile256;
   return -1;

@@ -748,6 +748,152 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_kernel(int M, int N, in
     }
 }
 
+// The same tile with the A operand taken straight from the float32 matrix (row-major, k contiguous) and split into hi / lo bf16
+// while it is staged: no plane pass over A (for da = 25 600 x 2 560 that pass moves 524 MB, 91 us -- a third of the product's
+// own time).  Per stage a thread loads its 16 floats (64 B of one row) a stage ahead into registers, and after the stage's
+// MFMAs converts them (the same split_bf16 as the plane pass: identical planes, bit-identical results) and writes four 16-B
+// chunks into the other LDS buffer; the conversion is VALU work next to the other wave's MFMAs.  B (the weights) still comes
+// pre-split through the DMA path.
+template <int WNT>
+__global__ __launch_bounds__(512) void gemm_planes_nt256_af32_kernel(int M, int N, int K, int Kp, const float *__restrict__ A, int lda,
+                                                                     const unsigned short *__restrict__ Bh, const unsigned short *__restrict__ Bl,
+                                                                     float *__restrict__ C, int ldc, float beta, int tiles_m, int tiles_n) {
+  constexpr int TBM = 256, TBN = 128 * WNT;
+  constexpr int A_BYTES = TBM * 64, B_BYTES = TBN * 64;
+  constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+  constexpr int IB = TBN * 4 / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x16 acc[4][WNT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  unsigned offB[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane, row = p >> 2, chunk = (p & 3) ^ ((row >> 2) & 3);
+    offB[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)Kp + chunk * 8;
+  }
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  auto issue_b = [&](int k0, int buf) {
+    unsigned char *sb = qsm + buf * STAGE + 2 * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int dst = (i * 8 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bh + offB[i] + k0), (lptr_t)(sb + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bl + offB[i] + k0), (lptr_t)(sb + B_BYTES + dst), 16, 0, 0);
+    }
+  };
+  // A staging of this thread: row tid >> 1 of the tile, 16 consecutive k (two 16-B bf16 chunks per plane)
+  const int arow = tid >> 1, akh = (tid & 1) * 16;
+  const float *aptr = A + (size_t)min(m0 + arow, M - 1) * lda + akh;
+  f32x4 av[4];
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + akh + 4 * q;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(aptr + min(k0 + 4 * q, max(K - akh - 4, 0)));
+      av[q] = k + 3 < K ? v : (f32x4){k < K ? v[0] : 0.f, k + 1 < K ? v[1] : 0.f, k + 2 < K ? v[2] : 0.f, 0.f};
+    }
+  };
+  auto store_a = [&](int buf) {
+    unsigned char *sb = qsm + buf * STAGE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned hw[4], lw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short h0, l0, h1, l1;
+        split_bf16(av[2 * h + (e >> 1)][(e & 1) * 2], h0, l0);
+        split_bf16(av[2 * h + (e >> 1)][(e & 1) * 2 + 1], h1, l1);
+        hw[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lw[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+      const int o = qswz(arow, (tid & 1) * 2 + h);
+      *reinterpret_cast<u32x4 *>(sb + o) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
+      *reinterpret_cast<u32x4 *>(sb + A_BYTES + o) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+    }
+  };
+  const int nst = Kp / 32;
+  const int ml = lane & 31, g = lane >> 5;
+  load_a(0);
+  issue_b(0, 0);
+  store_a(0);
+  for (int s = 0; s < nst; ++s) {
+    __syncthreads();                       // stage s is in LDS (A written by the waves, B landed), everybody is done with stage s - 1
+    if (s + 1 < nst) { load_a((s + 1) * 32); issue_b((s + 1) * 32, (s + 1) & 1); }
+    const unsigned char *sb = qsm + (s & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cq = ks * 2 + g;
+      bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = qswz(wm * 128 + i * 32 + ml, cq);
+        ah[i] = *reinterpret_cast<const bf16x8_t *>(sb + o);
+        al[i] = *reinterpret_cast<const bf16x8_t *>(sb + A_BYTES + o);
+      }
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int o = qswz(wn * 32 * WNT + j * 32 + ml, cq);
+        bh[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + o);
+        bl[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + B_BYTES + o);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < nst) store_a((s + 1) & 1);  // (the other buffer: last read in stage s - 1, released by the barrier above)
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + wn * 32 * WNT + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][e];
+          float *p = C + (size_t)row * ldc + col;
+          if (beta != 0.0f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+template <int WNT>
+static int launch_planes256_af32(hipStream_t st, int M, int N, int K, int Kp, const float *A, int lda, const unsigned short *bh, const unsigned short *bl,
+                                 float *C, int ldc, float beta) {
+  const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
+  const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
+  auto kern = gemm_planes_nt256_af32_kernel<WNT>;
+  CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta, tiles_m, tiles_n);
+  return CTCN_OK;
+}
+
 template <int WNT>
 static int launch_planes256(hipStream_t st, int M, int N, int Kp, const unsigned short *ah, const unsigned short *al, const unsigned short *bh,
                             const unsigned short *bl, float *C, int ldc, float beta) {
@@ -862,6 +1008,27 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       const bool same_a = g_last_a.armed && g_last_a.valid && g_last_a.A == A && g_last_a.lda == lda && g_last_a.M == M && g_last_a.K == K &&
                           g_last_a.transA == transA && g_last_a.ws == ws && g_last_a.st == st;
       g_last_a.armed = false;
+      // activation-sized products (M = T*B): the 256-row tiles, when they give the device at least ~0.75 workgroups per CU; a
+      // row-major A (k contiguous) is then split while it is staged, without a plane pass of its own
+      const int wnt256 = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
+      const bool use256 = !xcd_allow && ctcn_get_option("gemm_tile256") != 0 && M >= 1024 && N >= 96 &&
+                          (long)ceil_div(M, 256) * ceil_div(N, 128 * wnt256) * 4 >= (long)ctcn_device_cus() * 3;
+      // (every N-tile converts its A rows again: measured faster than the plane pass up to 5 N-tiles -- 25 600 x 1 280 x 640: 160 vs
+      // 170 us, 25 600 x 640 x 2 560: 336 vs 363 us -- and slower beyond -- 25 600 x 2 560 x 640: 310 vs 271 us)
+      const bool a_inline = use256 && !same_a && !transA && ctcn_get_option("gemm_a_inline") != 0 && K >= 32 && K % 4 == 0 && lda % 4 == 0 &&
+                            ((uintptr_t)A & 15) == 0 && ceil_div(N, 128 * wnt256) <= 5;
+      if (a_inline) {
+        g_last_a.valid = false;                     // no A planes in the workspace after this call
+        const int bshift0 = g_b_shift;
+        g_b_shift = 0;
+        split(B, ldb, transB == 0, N, bh, bl, bshift0);
+        CTCN_LAUNCH_CHECK();
+        const int lrc = wnt256 == 2 ? launch_planes256_af32<2>(st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta)
+                                    : launch_planes256_af32<1>(st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta);
+        if (lrc) return lrc;
+        CTCN_LAUNCH_CHECK();
+        return CTCN_OK;
+      }
       if (!same_a) split(A, lda, transA != 0, M, ah, al, 0);
       g_last_a.A = A; g_last_a.lda = lda; g_last_a.M = M; g_last_a.K = K; g_last_a.transA = transA; g_last_a.ws = ws; g_last_a.st = st;
       g_last_a.valid = true;
@@ -884,17 +1051,12 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
           else { shape = 1; ptm = m42; ptn = n42; }
         }
       }
-      // activation-sized products (M = T*B): the 256-row tiles, when they give the device at least ~0.75 workgroups per CU
-      if (!xcd_allow && ctcn_get_option("gemm_tile256") != 0 && M >= 1024 && N >= 96) {
-        const int wnt = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
-        const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128 * wnt);
-        if (t256 * 4 >= (long)ctcn_device_cus() * 3) {
-          const int lrc256 = wnt == 2 ? launch_planes256<2>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta)
-                                      : launch_planes256<1>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta);
-          if (lrc256) return lrc256;
-          CTCN_LAUNCH_CHECK();
-          return CTCN_OK;
-        }
+      if (use256) {
+        const int lrc256 = wnt256 == 2 ? launch_planes256<2>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta)
+                                       : launch_planes256<1>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta);
+        if (lrc256) return lrc256;
+        CTCN_LAUNCH_CHECK();
+        return CTCN_OK;
       }
       const int pnt = ptm * ptn;
       int psplits = 1;

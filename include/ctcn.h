@@ -53,6 +53,8 @@ int ctcn_device_xcds(void);
  * by a parallel pre-pass) whenever W <= 64, W*V <= 4096 and V <= 256; 0: always the generic kernel (same results, ~15x slower).
  * "gemm_tile256" = 1 (default): the bf16x3 GEMM multiplies activation-sized products (M >= 1024 rows, enough tiles to fill the
  * device) with 256 x 256 / 256 x 128 workgroup tiles staged by global_load_lds; 0: always the 128 x 128 tile (same results).
+ * "gemm_a_inline" = 1 (default): those tiles take a row-major float32 A operand as it is and split it into bf16 planes while staging
+ * it (no separate plane pass over A; same planes, same results); 0: A is pre-split like B.
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */

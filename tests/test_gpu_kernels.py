@@ -152,14 +152,16 @@ def test_gemm_bf16x3_tile256_equals_tile128(dev, M, N, K, ta, tb, beta):
     outs = []
     ops.set_precision(1)
     try:
-        for t256 in (0, 1):
+        for t256, inline in ((0, 0), (1, 0), (1, 1)):
             ops.set_option("gemm_tile256", t256)
+            ops.set_option("gemm_a_inline", inline)        # A split into planes while it is staged (row-major A only)
             C = C0.clone()
             ops.gemm(ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C, N, beta=beta)
             outs.append(C)
     finally:
         ops.set_option("gemm_tile256", 1)
-    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+        ops.set_option("gemm_a_inline", 1)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     rows = torch.arange(0, M, max(1, M // 64), device=dev)
     ref = (A.t() if ta else A)[rows].double() @ (B.t() if tb else B).double() + beta * C0[rows].double()
     assert float((outs[1][rows].double() - ref).abs().max()) < 2e-4 * (K ** 0.5)
