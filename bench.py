@@ -121,32 +121,31 @@ def gemm_roofline(dev, c):
     flops = 2.0 * M * N * K
     tf = flops / (ms * 1e-3) / 1e12
     prec = ops.get_precision()
-    traffic = None     # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected inside bench.py)
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        key = ("gemm_f32_kernel<NT> %dx%dx%d" if prec == 0 else "gemm_planes_nt_kernel %dx%dx%d") % (M, N, K)
-        if key in pm:
-            traffic = pm[key]["hbm_bytes"]
-    except Exception:
-        pass
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (25 600 x 1 280 x 640 probe shape)
+    traffic = pmc_traffic("gemm_planes_nt256") if (prec == 1 and (M, N, K) == (25600, 1280, 640)) else None
     # bf16x3 issues 3 bf16 MFMAs per algorithmic product: its ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s
     peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0 / 3.0
-    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_planes_nt_kernel<2,2> + its two operand-split passes,") + " %dx%dx%d" % (M, N, K), bound="mfma",
+    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_planes_nt256 (256-row tiles) + its operand-split pass(es),") + " %dx%dx%d" % (M, N, K), bound="mfma",
                 achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic, us_per_launch=ms * 1e3,
                 algorithmic_flops_per_launch=flops,
                 peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
 
 
-def recurrence_traffic(workload, kernel="rnn_bwd_scatter"):
-    """HBM bytes per launch of a recurrent kernel from the committed rocprofv3 PMC passes (cfg2 only)."""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json, collected
+    by tools/run_profiles_r2.sh: counters cannot be read from inside bench.py).  None when the kernel is not in the table."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
         for k, v in pm.items():
-            if workload == "cfg2" and k.startswith(kernel):
+            if isinstance(v, dict) and ("[" + kernel) in k:
                 return v["hbm_bytes"]
     except Exception:
         pass
     return None
+
+
+def recurrence_traffic(workload, kernel="rnn_bwd_scatter"):
+    return pmc_traffic(kernel) if workload == "cfg2" else None
 
 
 def recurrence_probe(dev, c):
@@ -345,10 +344,11 @@ def decode_leg(dev, steps=5):
         r["cpu_baseline"] = {"value": nref / cdt, "unit": "utt/s", "cores": 1, "kind": "port",
                              "sample": "%d utterances of the same batch through oracle/beam_ref.c (C restatement of BeamSearch.py, 1 core, %.2f s)" % (nref, cdt)}
         r["strings_match_oracle"] = bool([list(map(int, s)) for s in want] == ids[:nref]) and bool((st == 0).all())
-        r["roofline"] = dict(kernel="beam_kernel (one launch per 128-utterance batch; latency / fp64-ALU bound -- the HBM floor is reported, "
+        r["roofline"] = dict(kernel="beam_prep_kernel + beam_fast_kernel (one launch each per 128-utterance batch; latency / fp64-ALU bound -- the HBM floor is reported, "
                                     "utt/s against the CPU is the figure of merit, SURVEY 8d)", bound="hbm",
                              achieved=lp.nbytes / (kernel_us * 1e-6) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                             frac=lp.nbytes / (kernel_us * 1e-6) / 1e9 / PEAK_HBM_GBS, traffic=None,
+                             frac=lp.nbytes / (kernel_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                             traffic=(pmc_traffic("beam_fast_kernel") or 0) + (pmc_traffic("beam_prep_kernel") or 0) or None if regime == "peaky" else None,
                              algorithmic_bytes_per_launch=int(lp.nbytes), us_per_launch=kernel_us)
         out["regimes"][regime] = r
     out["value"] = out["regimes"]["peaky"]["value"]

@@ -130,6 +130,9 @@ def lib():
             env = os.environ.get(var)
             if env is not None:
                 l.ctcn_set_option(opt, int(env))
+        for var, val in os.environ.items():            # CTCN_OPT_<NAME>=<int>: any ctcn_set_option name (A/B measurements)
+            if var.startswith("CTCN_OPT_"):
+                check(l.ctcn_set_option(var[len("CTCN_OPT_"):].lower().encode(), int(val)), "set_option(%s)" % var)
     return _lib
 
 

@@ -24,3 +24,15 @@ for _ in range(3):
     yr = ops.rnn_layer(xr, wr[0], wr[1], wr[2], wr[3], "lstm")
     yr.backward(torch.ones_like(yr))
 torch.cuda.synchronize()
+# cfg5 beam decode (peaky regime), two launches: beam_prep_kernel + beam_fast_kernel
+import numpy as np
+from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+from oracle import synth
+Vb, Tb, Bb, Wb = 62, 800, 128, 20
+i2c = synth.int2char(Vb)
+tab = LanguageModel(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lm_phone_bg.arpa")).table([i2c[i] for i in range(Vb)])
+lp = torch.from_numpy(synth.make_logprobs(seed=7, T=Tb, B=Bb, V=Vb, regime="peaky")).to(dev)
+lens = list(np.random.RandomState(2).randint(400, 801, size=Bb))
+for _ in range(2):
+    ops.beam_decode(lp, lens, tab, 0.1, Wb)
+torch.cuda.synchronize()
