@@ -373,6 +373,8 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   __shared__ int f_node[FAST_WMAX], f_len[FAST_WMAX], f_last[FAST_WMAX];   // final beam (dumped once, after the last frame)
   __shared__ double f_pT[FAST_WMAX];
   __shared__ int woff[NWV];
+  __shared__ double stayv[FAST_WMAX], homev[FAST_WMAX];
+  __shared__ int ns[FAST_WMAX];
   __shared__ int s_cnt;
   __shared__ unsigned s_theta;
   __shared__ int s_nfl, s_gnodes, s_lnodes;      // processed frames | 0 while the LDS trie takes inserts, else 1 + global nodes | LDS trie nodes
@@ -428,15 +430,17 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   }
   const int nfl = s_nfl;
 
-  // static candidate slots of this thread: c = ((37 * tid) mod NTH) + i * NTH -> (beam ci, class ck; ck < 0: the stay slot).  Any
-  // bijection works (the selection below ranks by explicit (score, index)); the odd multiplier spreads neighbouring candidates --
-  // the classes of one beam -- over different 16-lane rows, which keeps the pruning bound of the selection tight.
+  // Wave 0 owns the beam (lane = slot) and the serial work; waves 1..15 (960 threads) own the candidates: slot i of thread u = tid - 64
+  // is c = ((37 * u) mod 960) + 960 * i -> (beam ci, class ck; ck < 0: the stay slot).  Any bijection works (the selection ranks
+  // by explicit (score, index)); the multiplier spreads neighbouring candidates -- the classes of one beam -- over different
+  // 16-lane rows, which keeps the pruning bound of the selection tight.
+  constexpr int NCT = NTH - 64;
   int cc[NPT], ci[NPT], ck[NPT];
 #pragma unroll
   for (int i = 0; i < NPT; ++i) {
-    const int c = ((37 * tid) & (NTH - 1)) + i * NTH;
-    cc[i] = c;
-    ci[i] = c < W * V ? c / V : FAST_WMAX;                        // beyond the table: never valid (nb <= W <= FAST_WMAX)
+    const int c = wave == 0 ? W * V : ((37 * (tid - 64)) % NCT) + i * NCT;
+    cc[i] = min(c, W * V - 1);
+    ci[i] = c < W * V ? c / V : FAST_WMAX;                        // beyond the table / wave 0: never valid (nb <= W <= FAST_WMAX)
     const int kk = c - (c / V) * V;
     ck[i] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
   }
@@ -447,10 +451,13 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   };
   if (nfl > 0) fetch_lg(flist[0]);
   if (tid < V) lg[tid] = nlg;
+  if (nfl > 1) fetch_lg(flist[1]);
 
-  // the beam: lane r of wave 0 holds slot r
-  int z_node = 0, z_len = 0, z_last = -1, z_par = -1;              // node ids: 0 = the empty labelling, s + 1 = LDS trie slot s,
-  double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;                 // TS + 1 + g = entry g of the global table
+  // the beam: lane r of wave 0 holds slot r.  node ids: 0 = the empty labelling, s + 1 = LDS trie slot s, TS + 1 + g = entry g of the
+  // global table.  z_mf = the slot that holds this slot's parent labelling (-1: none) -- its extension by z_last IS this labelling
+  int z_node = 0, z_len = 0, z_last = -1, z_par = -1, z_mf = -1;
+  double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;
+  double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;          // this frame's stay / merged entry of the slot (BeamSearch.py:99-113)
   int nb = 1, status = 0;
   __syncthreads();
 #ifdef CTCN_BEAM_STATS
@@ -458,81 +465,106 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   const long long zt0 = zlast;
 #endif
 
+  // ---- scoring of frame jf, two parties side by side -------------------------------------------------------------------------
+  // waves 1..15: extension scores (calcExtPr) into cand[]: two LDS hops (the slot's context class, then LM / prBlank / prTotal),
+  // every read of a hop issued before the first use (clamped addresses, selects afterwards)
+  auto score_extensions = [&](bool rep_ok) {
+    int c1[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[min(ci[i], FAST_WMAX - 1)];
+    double lmv[NPT], pbv[NPT], ptv[NPT], lk[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int bi = min(ci[i], FAST_WMAX - 1), k = max(ck[i], 0);
+      const int c1c = min(max(c1[i], 0), V);
+      lmv[i] = LM_LDS ? lmA[c1c * V1 + k] : a.lm[(size_t)c1c * V1 + k] * a.alpha;
+      lk[i] = lg[k];
+      pbv[i] = bm_pB[bi];
+      ptv[i] = bm_pT[bi];
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      if (ci[i] < nb && ck[i] >= 0) {
+        const double base = (c1[i] == ck[i] && rep_ok) ? pbv[i] : ptv[i];     // c1 == k <=> non-empty labelling ending in k
+        cand[cc[i]] = lk[i] + lmv[i] + base;
+      }
+    }
+  };
+  // wave 0: stay entries of every slot, merged with the extension of the parent slot that equals the labelling (same expression,
+  // same operands as score_extensions writes for that candidate).  Results: e_nb / e_b / e_t in the slot's lane; for the selection:
+  // stayv[ip] = value of the stay candidate (or -inf when the entry lives in the extension's place), homev[ip] = e_t, and
+  // mslot[extension candidate] = {frame tag, 1: holds slot ip's merged entry | 0: removed (merged into the stay candidate), ip}
+  auto stay_and_merge = [&](bool rep_ok, int jf) {
+    const int ip = lane;
+    const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
+    const int mi = ip < nb ? z_mf : -1;
+    const int src = max(mi, 0);
+    const int p_len = lane_gather(z_len, src), p_last = lane_gather(z_last, src);
+    const double p_pB = lane_gather(z_pB, src), p_pT = lane_gather(z_pT, src);
+    const int c1 = p_len > 0 ? p_last : V, k = max(z_last, 0);
+    const double lmv = LM_LDS ? lmA[c1 * V1 + k] : a.lm[(size_t)c1 * V1 + k] * a.alpha;
+    const double base = (c1 == k && rep_ok) ? p_pB : p_pT;
+    const double pr = lgl + lmv + base;                           // == cand[mi * V + kk(z_last)]
+    double s_nb = LOG_ZERO;
+    if (z_len > 0) s_nb = z_pNB + lgl;                            // BeamSearch.py:102-103
+    const double s_b = z_pT + lgb;                                // :106
+    const bool ext_first = mi >= 0 && mi < ip;                    // the reference meets the extension before the stay entry
+    BSTAMP(6);
+    double r_nb, r_t;
+    if (nb <= 32) {
+      // lanes 0..31: tot = log_add(s_b, s_nb) of slot lane; lanes 32..63: e.nb of slot lane - 32 when merged -- side by side
+      const int q = lane & 31;
+      const double q_snb = lane_gather(s_nb, q), q_pr = lane_gather(pr, q);
+      const int q_mi = lane_gather(mi, q);
+      const bool q_first = q_mi >= 0 && q_mi < q;
+      double x = lane < 32 ? s_b : (q_first ? q_pr : q_snb), y = lane < 32 ? s_nb : (q_first ? q_snb : q_pr);
+      const bool need = lane < 32 ? true : q_mi >= 0;
+      const double r1 = need ? log_add_prob(x, y) : LOG_ZERO;
+      const double a_nb = lane_gather(r1, (lane & 31) + 32);
+      const double tot = r1;                                       // (lanes < 32)
+      r_nb = mi >= 0 ? a_nb : s_nb;
+      r_t = mi >= 0 ? (ext_first ? log_add_prob(pr, tot) : log_add_prob(tot, pr)) : tot;
+    } else {
+      const double tot = log_add_prob(s_b, s_nb);
+      r_nb = mi >= 0 ? (ext_first ? log_add_prob(pr, s_nb) : log_add_prob(s_nb, pr)) : s_nb;
+      r_t = mi >= 0 ? (ext_first ? log_add_prob(pr, tot) : log_add_prob(tot, pr)) : tot;
+    }
+    BSTAMP(7);
+    if (ip < nb) {
+      e_nb = r_nb; e_b = s_b; e_t = r_t;
+      homev[ip] = r_t;
+      stayv[ip] = ext_first ? -INFINITY : r_t;
+      if (mi >= 0) {
+        const int kkl = (z_last < blank) ? z_last + 1 : z_last;
+        mslot[mi * V + kkl] = (jf << 8) | (ext_first ? 128 : 0) | ip;
+      }
+    }
+    if (lane == 0) { s_theta = 0u; s_cnt = 0; }
+  };
+
+  if (nfl > 0 && !(flist[0] & (1 << 29))) {
+    const bool rep0 = (flist[0] >> 30) & 1;
+    if (wave == 0) stay_and_merge(rep0, 0); else score_extensions(rep0);
+  }
+  lds_barrier();
+
   for (int j = 0; j < nfl; ++j) {
     const int fw = flist[j];
     if (fw & (1 << 29)) { status = 2; break; }                     // math.log(0) in the reference: ValueError
-    const bool rep_ok = (fw >> 30) & 1;
-    if (j + 1 < nfl) fetch_lg(flist[j + 1]);
-    // P1: extension scores (calcExtPr), candidate slot c = i*V + 1 + kk'.  Two LDS hops: the slot's context class, then
-    // LM / prBlank / prTotal -- every read of a hop is issued before the first use (clamped addresses, selects afterwards)
-    {
-      int c1[NPT];
-#pragma unroll
-      for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[min(ci[i], FAST_WMAX - 1)];
-      double lmv[NPT], pbv[NPT], ptv[NPT], lk[NPT];
-#pragma unroll
-      for (int i = 0; i < NPT; ++i) {
-        const int bi = min(ci[i], FAST_WMAX - 1), k = max(ck[i], 0);
-        const int c1c = min(max(c1[i], 0), V);
-        lmv[i] = LM_LDS ? lmA[c1c * V1 + k] : a.lm[(size_t)c1c * V1 + k] * a.alpha;
-        lk[i] = lg[k];
-        pbv[i] = bm_pB[bi];
-        ptv[i] = bm_pT[bi];
-      }
-#pragma unroll
-      for (int i = 0; i < NPT; ++i) {
-        if (ci[i] < nb && ck[i] >= 0) {
-          const double base = (c1[i] == ck[i] && rep_ok) ? pbv[i] : ptv[i];     // c1 == k <=> non-empty labelling ending in k
-          cand[cc[i]] = lk[i] + lmv[i] + base;
-        }
-      }
-    }
     BSTAMP(0);
-    lds_barrier();
-    BSTAMP(1);
-    // P2 (wave 0): parent slot of every slot + stay entries, merged with the matching extension in the reference's visiting order
-    double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;
-    if (wave == 0) {
-      const int ip = lane;
-      const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
-      int mi = -1;
-      for (int i2 = 0; i2 < nb; ++i2) {
-        const int n2 = __builtin_amdgcn_readlane(z_node, i2);
-        if (z_len > 0 && n2 == z_par) mi = i2;
-      }
-      const int kkl = (z_last < blank) ? z_last + 1 : z_last;
-      const int ce = max(mi, 0) * V + max(kkl, 0);
-      const double pr = cand[min(ce, W * V - 1)];                  // the extension that equals this labelling (if mi >= 0)
-      BSTAMP(6);
-      if (ip < nb) {
-        double s_nb = LOG_ZERO;
-        if (z_len > 0) s_nb = z_pNB + lgl;                         // BeamSearch.py:102-103
-        const double s_b = z_pT + lgb;                             // :106
-        Fields e{LOG_ZERO, LOG_ZERO, LOG_ZERO};
-        if (mi >= 0) {
-          if (mi < ip) { apply_ext(e, pr); apply_stay(e, s_nb, s_b); cand[ce] = e.t; cand[ip * V] = -INFINITY; mslot[ce] = (j << 8) | ip; }
-          else         { apply_stay(e, s_nb, s_b); apply_ext(e, pr); cand[ip * V] = e.t; cand[ce] = -INFINITY; }
-        } else {
-          apply_stay(e, s_nb, s_b);
-          cand[ip * V] = e.t;
-        }
-        e_nb = e.nb; e_b = e.b; e_t = e.t;
-      }
-      BSTAMP(7);
-      if (lane == 0) { s_theta = 0u; s_cnt = 0; }
-    }
-    lds_barrier();
-    BSTAMP(2);
     // P3: BHat = top-W by (prTotal desc, candidate index asc), without sorting.
     //  1. splitter: every 16-lane row reduces the largest key (high word) of its ~16 * NPT candidates on the DPP network; the W-th
-    //     largest of the 64 row maxima is a lower bound of the W-th best candidate (W distinct candidates reach it): exact pruning;
+    //     largest of the 60 row maxima is a lower bound of the W-th best candidate (W distinct candidates reach it): exact pruning;
     //  2. the survivors (typically W + a few) are compacted into LDS and ranked by counting, all threads sharing the compares.
     unsigned long long key[NPT];
     bool val[NPT];
     unsigned mhi = 0u;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const double v = cand[min(cc[i], W * V - 1)];
+      const int bi = min(ci[i], FAST_WMAX - 1);
+      double v = ck[i] < 0 ? stayv[bi] : cand[cc[i]];
+      const int ms = mslot[cc[i]];
+      if (ck[i] >= 0 && ms >= 0 && (ms >> 8) == j) v = (ms & 128) ? homev[ms & 63] : -INFINITY;
       key[i] = f64_key(v);
       val[i] = ci[i] < nb && v != -INFINITY;
       mhi = max(mhi, val[i] ? (unsigned)(key[i] >> 32) : 0u);
@@ -578,7 +610,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       wbase = __builtin_amdgcn_readfirstlane(wbase);
 #pragma unroll
       for (int i = 0; i < NPT; ++i)
-        if (keep[i] && wbase + pos[i] < SURV_MAX) { surv[wbase + pos[i]].k = key[i]; surv[wbase + pos[i]].idx = cc[i]; }
+        if (keep[i] && wbase + pos[i] < SURV_MAX) { surv[wbase + pos[i]].k = key[i]; surv[wbase + pos[i]].idx = ci[i] * V + (ck[i] < 0 ? 0 : (ck[i] < blank ? ck[i] + 1 : ck[i])); }
     }
     BSTAMP(3);
     lds_barrier();
@@ -605,7 +637,12 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
     } else {
       // more than SURV_MAX candidates above the bound (never seen on the synthetic regimes): W block-wide arg-max rounds over the
-      // candidate table, exactly as the generic kernel does
+      // candidate table (patched first so that it holds this frame's stay / merged entries), exactly as the generic kernel does
+      if (wave == 0 && lane < nb) {
+        cand[lane * V] = stayv[lane];
+        if (z_mf >= 0) { const int kkl = (z_last < blank) ? z_last + 1 : z_last; cand[z_mf * V + kkl] = (z_mf < lane) ? homev[lane] : -INFINITY; }
+      }
+      lds_barrier();
       const int ncand = nb * V;
       int got = 0;
       for (int r = 0; r < W; ++r) {
@@ -638,32 +675,50 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     lds_barrier();
     const int m = min(W, total);
     BSTAMP(4);
-    // P4 (wave 0): materialise the new beam in lane order of the ranks
+    // P4a (wave 0): the new beam in rank order -- everything the next frame's extension scores need (context class, prBlank, prTotal)
+    bool fresh = false, act = false;
+    int n_node = 0, n_len = 0, n_last = -1, n_par = -1, n_mf = -1, g_mf = -1, src = 0, sym = 0;
+    double n_pNB = LOG_ZERO, n_pB = LOG_ZERO, n_pT = LOG_ZERO;
     if (wave == 0) {
       const int rr = min(lane, FAST_WMAX - 1);
       const int c = sel[rr];
       const double sv = selv[rr];
-      const bool act = lane < m;
+      act = lane < m;
       const int i = act ? (int)(((float)c + 0.5f) * (1.0f / (float)V)) : 0;       // c / V (exact for c < 2^20)
       const int kk = c - i * V;
-      const int k = (kk - 1 < blank) ? kk - 1 : kk;
+      sym = (kk - 1 < blank) ? kk - 1 : kk;
       const int ms = mslot[act ? c : 0];
-      const bool merged = act && kk != 0 && (ms >> 8) == j && ms >= 0;            // this slot holds the merged entry of slot ms & 255
-      const bool fresh = act && kk != 0 && !merged;
-      const int src = merged ? (ms & 255) : i;
+      const bool merged = act && kk != 0 && ms >= 0 && (ms >> 8) == j && (ms & 128);   // this candidate holds the merged entry of slot ms & 63
+      fresh = act && kk != 0 && !merged;
+      src = merged ? (ms & 63) : i;
+      ns[lane] = -1;
       const int g_node = lane_gather(z_node, src), g_len = lane_gather(z_len, src), g_last = lane_gather(z_last, src), g_par = lane_gather(z_par, src);
+      g_mf = lane_gather(z_mf, src);
       const double g_nb = lane_gather(e_nb, src), g_b = lane_gather(e_b, src), g_t = lane_gather(e_t, src);
-      int n_node = g_node, n_len = g_len, n_last = g_last, n_par = g_par;
-      double n_pNB = g_nb, n_pB = g_b, n_pT = g_t;
+      n_node = g_node; n_len = g_len; n_last = g_last; n_par = g_par;
+      n_pNB = g_nb; n_pB = g_b; n_pT = g_t;
+      if (fresh) { n_len = g_len + 1; n_last = sym; n_par = g_node; n_pNB = sv; n_pB = LOG_ZERO; n_pT = sv; }
+      if (act) { bm_c1[lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
+      if (act && !fresh) ns[src] = lane;                           // where the old slot's labelling went
+    }
+    if (tid < V) lg[tid] = nlg;                                    // the next frame's ln p row (lg is not read during the selection)
+    if (j + 2 < nfl) fetch_lg(flist[j + 2]);
+    lds_barrier();
+    BSTAMP(5);
+    const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
+    const bool rep_next = (flist[min(j + 1, nfl - 1)] >> 30) & 1;
+    const int nb_old = nb;
+    nb = m;
+    if (wave == 0) {
+      // P4b: trie node of every fresh labelling, parent slots of the new beam; then the stay / merge entries of the NEXT frame,
+      // while waves 1..15 score its extensions
       if (fresh) {
-        n_len = g_len + 1; n_last = k; n_par = g_node; n_pNB = sv; n_pB = LOG_ZERO; n_pT = sv;
-        // trie child (g_node, k): LDS table first; the global table only once the LDS table is 3/4 full
-        const int parent = g_node;
+        const int parent = n_par;
         int id = -1;
-        bool lds_ok = parent <= TS;                                 // a child of a global node was created after the overflow
+        const bool lds_ok = parent <= TS;                           // a child of a global node was created after the overflow
         if (lds_ok) {
-          const unsigned entry = ((unsigned)(parent + 1) << 17) | (unsigned)k;
-          unsigned h = (unsigned)mix64(((unsigned long long)(unsigned)parent << 20) | (unsigned)k) & tmask;
+          const unsigned entry = ((unsigned)(parent + 1) << 17) | (unsigned)sym;
+          unsigned h = (unsigned)mix64(((unsigned long long)(unsigned)parent << 20) | (unsigned)sym) & tmask;
           const bool may_insert = s_gnodes == 0;
           for (int probe = 0; probe < TS; ++probe) {
             unsigned prev = may_insert ? atomicCAS(&trie[h], 0u, entry) : trie[h];
@@ -673,7 +728,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
           }
         }
         if (id < 0) {                                               // global table: {parent : 24 | symbol : 16 | id : 24}
-          const unsigned long long key40 = ((unsigned long long)(unsigned)parent << 16) | (unsigned)k;
+          const unsigned long long key40 = ((unsigned long long)(unsigned)parent << 16) | (unsigned)sym;
           unsigned h = (unsigned)mix64(key40) & htmask;
           int gid = -1;
           for (int probe = 0; probe <= (int)htmask; ++probe) {
@@ -685,28 +740,44 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
             }
             if (gid < 0) gid = atomicAdd(&s_gnodes, 1) - 1;         // s_gnodes = 1 + number of global nodes once overflowed
             const unsigned long long prev = atomicCAS(&ht[h], HT_EMPTY, (key40 << 24) | (unsigned long long)(unsigned)gid);
-            if (prev == HT_EMPTY) { id = TS + 1 + gid; if (gid < a.max_nodes) { npar[gid] = parent; nsym[gid] = k; } break; }
+            if (prev == HT_EMPTY) { id = TS + 1 + gid; if (gid < a.max_nodes) { npar[gid] = parent; nsym[gid] = sym; } break; }
             if ((prev >> 24) == key40) { id = TS + 1 + (int)(prev & 0xFFFFFFull); break; }   // (cannot happen: keys of a frame are distinct)
             h = (h + 1) & htmask;
           }
         }
         n_node = id;
       }
-      // LDS trie occupancy: count this frame's fresh lanes; past 3/4 the table is closed for inserts
-      {
+      {   // LDS trie occupancy: count this frame's fresh lanes; past 3/4 the table is closed for inserts
         const unsigned long long fm = __ballot(fresh && n_node <= TS);
         if (lane == 0 && s_gnodes == 0) {
           s_lnodes += __popcll(fm);
           if (s_lnodes * 4 > TS * 3) s_gnodes = 1;
         }
       }
-      z_node = n_node; z_len = n_len; z_last = n_last; z_par = n_par; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
-      if (act) { bm_c1[lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
+      // parent slot of every new slot: a fresh labelling's parent is the old slot it extends; a copy's parent is the old slot's
+      // parent, wherever that went -- or, when the parent was NOT in the old beam, possibly a labelling created just now
+      {
+        const int pm = fresh ? src : g_mf;
+        n_mf = (act && pm >= 0 && n_len > 0) ? ns[pm] : -1;
+        const bool scan = act && !fresh && n_len > 0 && g_mf < 0;
+        unsigned long long fmask = __ballot(fresh);
+        if (__any(scan)) {
+          while (fmask) {
+            const int fl = __ffsll((long long)fmask) - 1;
+            fmask &= fmask - 1;
+            const int fid = __builtin_amdgcn_readlane(n_node, fl);
+            if (scan && fid == n_par) n_mf = fl;
+          }
+        }
+      }
+      z_node = n_node; z_len = n_len; z_last = n_last; z_par = n_par; z_mf = n_mf; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
+      if (more) stay_and_merge(rep_next, j + 1);
+    } else if (more) {
+      score_extensions(rep_next);
     }
-    if (tid < V) lg[tid] = nlg;                                    // the next frame's ln p row (lg is not read after P2)
+    (void)nb_old;
     lds_barrier();
-    BSTAMP(5);
-    nb = m;
+    BSTAMP(2);
   }
 #ifdef CTCN_BEAM_STATS
   if (a.stats && b == 0 && (tid == 0 || tid == 64)) {
@@ -778,7 +849,7 @@ FastLayout fast_layout(int T, int B, int V, int W) {
   l.pb = off;   off += align_up((size_t)T * B * sizeof(float), 256);
   l.zf = off;   off += align_up((size_t)T * B, 256);
   l.total = off;
-  l.npt = ceil_div(W * V, FAST_NTH);                     // candidate slots per thread (1..4)
+  l.npt = ceil_div(W * V, FAST_NTH - 64);                // candidate slots per thread of waves 1..15 (1..4)
   if (l.npt > 4) l.npt = 0;
   const size_t core = ((size_t)W * V + V) * sizeof(double) + ((size_t)W * V + T) * sizeof(int);   // cand, lg | mslot, flist
   const size_t lm = (size_t)(V + 1) * (V + 1) * sizeof(double);
@@ -788,7 +859,7 @@ FastLayout fast_layout(int T, int B, int V, int W) {
   while (l.trie_slots > 1024 && core + (size_t)l.trie_slots * 4 + (lm <= 40 * 1024 ? lm : 0) > budget) l.trie_slots >>= 1;
   l.lm_lds = core + (size_t)l.trie_slots * 4 + lm <= budget;
   l.lds = core + (size_t)l.trie_slots * 4 + (l.lm_lds ? lm : 0);
-  l.ok = W <= FAST_WMAX && l.npt > 0 && V <= 256 && l.max_nodes < (1 << 24) && T < (1 << 22) && l.lds <= budget;
+  l.ok = W <= 60 && l.npt > 0 && V <= 256 && l.max_nodes < (1 << 24) && T < (1 << 22) && l.lds <= budget;
   return l;
 }
 

@@ -49,8 +49,8 @@ def run(regime):
         torch.cuda.synchronize()
     st = (ctypes.c_longlong * 64)()
     assert L.ctcn_beam_stats(st) == 0
-    names = ["P1 cand scores", "barrier after P1", "P2 tail: barrier", "P3 barrier + splitter rank + barrier + prune/compact", "P3 barrier + rank count + barrier", "P4 materialise + barrier",
-             "barrier + P2 mfrom", "P2 stay/merge math", "P3 candidate load + row max"]
+    names = ["(loop top)", "-", "B1..B2: trie + parents + next frame's stay/merge (wave 0) | next frame's extension scores (waves 1-15)", "splitter rank + prune/compact", "barrier + rank count + barrier",
+             "P4a new beam + barrier B1", "stay/merge: gathers + pr", "stay/merge: log-adds", "candidate load + row max"]
     for base, who in ((0, "wave 0"), (16, "wave 1")):
         nfl = max(st[base + 14], 1)
         print("%s  %s: frames %d, total %.0f cycles/frame, rounds/frame %.2f, merge iterations/frame %.2f" % (regime, who, nfl, st[base + 15] / nfl, st[base + 12] / nfl, st[base + 13] / nfl))
