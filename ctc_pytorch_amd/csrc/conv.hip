@@ -1,17 +1,17 @@
-// conv.hip -- direct Conv2d (bias, NCHW) forward / data-gradient / weight-gradient for the CNN front-end (gfx950).
+// conv.hip -- Conv2d (bias, NCHW) forward / data-gradient / weight-gradient for the CNN front-end (gfx950).
 //
 // replaces: nn.Conv2d in LayerCNN (reference timit/models/model_ctc.py:46,61; geometry from
 // timit/conf/ctc_config.yaml:33-37: 3x3, 1->32 stride (1,2), 32->32 stride (2,2), pad (1,1)) and its backward.
-// Arithmetic: SURVEY Appendix A.5.  The front-end is ~0.2 % of the FLOPs of the training step
-// (92 KFLOP/frame against 50 MFLOP/frame), so these kernels are written for coalesced HBM traffic and
-// LDS-resident weights rather than for MFMA:
-//   fwd : one lane per output position (b,t',f'), 16 output channels per pass in registers; the whole
-//         filter bank (<= 60 KiB) sits in LDS and is read by broadcast; lanes are adjacent in f' so input
-//         reads and output writes are coalesced rows.
-//   dgrad: same shape, gather form over the (co, tap) pairs that hit an output position.
-//   wgrad: positions are tiled 16 at a time into LDS (input patch + dy vector), every thread owns a fixed
-//         set of filter taps and accumulates over the workgroup's chunk of positions; per-chunk partials
-//         are reduced in a fixed order by a second pass (deterministic, no atomics).
+// Arithmetic: SURVEY Appendix A.5.  Two families of kernels:
+//   * MFMA implicit GEMMs (the default, second half of this file): raw source window of a 128-position tile in LDS, filter
+//     matrix in LDS, v_mfma_f32_16x16x4_f32; dgrad as one dense stride-1 product per stride class; wgrad as a contraction over
+//     positions with per-chunk partials reduced in a fixed order (deterministic, no atomics).
+//   * direct kernels (first half; option "conv_mfma" = 0, and the fallback for shapes the tile planner rejects):
+//     fwd : one lane per output position (b,t',f'), 16 output channels per pass in registers; the whole
+//           filter bank (<= 60 KiB) sits in LDS and is read by broadcast; lanes are adjacent in f'.
+//     dgrad: same shape, gather form over the (co, tap) pairs that hit an output position.
+//     wgrad: positions are tiled 16 at a time into LDS (input patch + dy vector), every thread owns a fixed
+//           set of filter taps and accumulates over the workgroup's chunk of positions.
 #include <algorithm>
 
 #include "common.h"
@@ -172,15 +172,240 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
   if (tid < g.Co) out[Wn + tid] = bacc;
 }
 
-__global__ void conv_wgrad_reduce_kernel(const float *__restrict__ part, int chunks, int Wn, int Co, float *__restrict__ dw,
-                                         float *__restrict__ dbias, float beta_acc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Wn + Co) return;
+// ================================================================================================
+// MFMA implicit-GEMM kernels (the default; the direct kernels above remain for filter banks whose LDS images do not fit).
+//   forward : y[pos, co]  = sum_{ci,tap} x[src(pos, tap), ci] * w[co, ci, tap]          pos = (b, t', f')
+//   dgrad   : dx[pos, ci] = sum_{co,tap} dy[src(pos, tap), co] * w[co, ci, tap]         pos = (b, t, f), one launch per stride class
+//             (a, b) = ((t + ph) mod sh, (f + pw) mod sw): inside a class only the taps ki = a (mod sh), kj = b (mod sw) reach an
+//             output position and they do so at unit stride, so the class is a dense stride-1 convolution with ~KK / (sh*sw) taps
+//   wgrad   : dw[co, (ci,tap)] = sum_pos dy[pos, co] * x[src(pos, tap), ci]              contraction over positions, per-chunk partials
+// A workgroup owns a tile of R x C positions (R*C <= 128) of one image.  It stages the RAW source window of the tile -- Cs channels
+// x RH rows x RW columns, zero-filled outside the image -- in LDS with row-contiguous loads (no im2col copy: every source element is
+// read from HBM/L2 once per tile and the 9x tap reuse happens in LDS), and each of its 8 waves multiplies 16 positions by all
+// output channels with v_mfma_f32_16x16x4_f32, reading the A operand at raw[koff[k] + posoff[position]].  The arithmetic is exact
+// float32 (fma chain in ascending k): both matmul "precisions" of the library give the same convolution.  Outputs go through an
+// LDS transpose so that stores are rows of consecutive positions per channel.
+// ================================================================================================
+constexpr int TP = 128;                 // positions per tile (8 waves x 16)
+constexpr int CONV_THREADS = 512;
+constexpr int MAX_TAPS = 25;
+
+struct ConvTile {
+  int Cs, Hs, Ws;                       // source tensor: channels, rows, columns
+  int N, Hd, Wd;                        // destination tensor
+  int Hc, Wc;                           // positions of this class per image
+  int a, b, osh, osw;                   // destination coordinates of class position (hc, wc): (a + hc*osh, b + wc*osw)
+  int ssh, ssw, dh0, dw0;               // source coordinates of tap (dh, dw) at (hc, wc): (hc*ssh + dh0 + dh, wc*ssw + dw0 + dw)
+  int R, C, RH, RW;                     // tile = R x C positions; raw window = RH x RW per channel
+  int ntap, K, K4;                      // taps of the class, K = Cs*ntap, K4 = K rounded up to the MFMA k-step
+  int wsn, wsc;                         // weight address: w[n*wsn + c*wsc + tap index]
+  int tiles_h, tiles_w, ntiles;
+  int tap[MAX_TAPS];                    // (dh << 16) | (dw << 8) | (ki*kw + kj), dh / dw relative to (dh0, dw0)
+};
+
+__host__ __device__ inline int conv_ws_stride(int nt) { return nt == 1 ? 16 : (nt <= 3 ? 48 : 80); }   // k-rows of an MFMA step in disjoint banks
+
+__device__ __forceinline__ void conv_fill_koff(int *koff, const ConvTile &m) {
+  for (int k = threadIdx.x; k < m.K4; k += CONV_THREADS) {
+    int v = 0;
+    if (k < m.K) {
+      const int c = k / m.ntap, t = m.tap[k - c * m.ntap];
+      v = (c * m.RH + (t >> 16)) * m.RW + ((t >> 8) & 255);
+    }
+    koff[k] = v;
+  }
+}
+
+// raw[c][rh][rw] = src[b, c, h0 + rh, w0 + rw] (0 outside the tensor); a group of RWP lanes walks one row.  Loads are issued
+// eight rows at a time from clamped (always valid) addresses and masked afterwards, so that eight HBM/L2 latencies overlap.
+__device__ __forceinline__ void conv_load_raw(float *raw, const float *__restrict__ src, const ConvTile &m, int b, int h0, int w0, int rwp_log) {
+  constexpr int U = 8;
+  const int tid = threadIdx.x, rw = tid & ((1 << rwp_log) - 1), grp = tid >> rwp_log, ngrp = CONV_THREADS >> rwp_log;
+  if (rw >= m.RW) return;
+  const int rows = m.Cs * m.RH, ws = w0 + rw;
+  const bool col_ok = ws >= 0 && ws < m.Ws;
+  const int wsc = min(max(ws, 0), m.Ws - 1);
+  const float *base = src + (size_t)b * m.Cs * m.Hs * m.Ws + wsc;
+  int c = grp / m.RH, rh = grp - c * m.RH;
+  const int dc = ngrp / m.RH, drh = ngrp - dc * m.RH;
+  for (int row0 = grp; row0 < rows; row0 += ngrp * U) {
+    float v[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int hs = h0 + rh, cc = min(c, m.Cs - 1), hc = min(max(hs, 0), m.Hs - 1);
+      ok[u] = col_ok && hs >= 0 && hs < m.Hs && row0 + u * ngrp < rows;
+      v[u] = base[((size_t)cc * m.Hs + hc) * m.Ws];
+      c += dc; rh += drh;
+      if (rh >= m.RH) { rh -= m.RH; ++c; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (row0 + u * ngrp < rows) raw[(row0 + u * ngrp) * m.RW + rw] = ok[u] ? v[u] : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void conv_tile_origin(const ConvTile &m, int tile, int &b, int &hc0, int &wc0) {
+  const int per_img = m.tiles_h * m.tiles_w;
+  b = tile / per_img;
+  const int rem = tile - b * per_img, th = rem / m.tiles_w;
+  hc0 = th * m.R;
+  wc0 = (rem - th * m.tiles_w) * m.C;
+}
+
+template <int NT>
+__global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(const float *__restrict__ src, const float *__restrict__ w, const float *__restrict__ bias,
+                                                                 float *__restrict__ out, ConvTile m, int rwp_log, int region_floats) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];   // region[max(raw, transpose)] | wmat[K4][WS] | koff[K4]
+  constexpr int N16 = 16 * NT, OS = TP + 1;
+  const int WS = conv_ws_stride(NT);
+  float *raw = csm, *wmat = csm + region_floats;
+  int *koff = reinterpret_cast<int *>(wmat + (size_t)m.K4 * WS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  conv_fill_koff(koff, m);
+  for (int i = tid; i < m.K4 * N16; i += CONV_THREADS) {
+    const int k = i / N16, n = i - k * N16;
+    float v = 0.0f;
+    if (k < m.K && n < m.N) { const int c = k / m.ntap; v = w[(size_t)n * m.wsn + (size_t)c * m.wsc + (m.tap[k - c * m.ntap] & 255)]; }
+    wmat[k * WS + n] = v;
+  }
+  const int r = lane & 15, q = lane >> 4;
+  const int p = wave * 16 + r, ptr_ = p / m.C, ptc = p - ptr_ * m.C;
+  const int posoff = ptr_ < m.R ? ptr_ * m.ssh * m.RW + ptc * m.ssw : 0;
+  const int RC = m.R * m.C;
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < m.ntiles; tile += gridDim.x) {
+    int b, hc0, wc0;
+    conv_tile_origin(m, tile, b, hc0, wc0);
+    if (m.K > 0) conv_load_raw(raw, src, m, b, hc0 * m.ssh + m.dh0, wc0 * m.ssw + m.dw0, rwp_log);
+    __syncthreads();
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < m.K4; k0 += 4) {
+      const int kk = k0 + q;
+      float av = raw[koff[kk] + posoff];
+      av = kk < m.K ? av : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wmat[kk * WS + nt * 16 + r], acc[nt], 0, 0, 0);
+    }
+    __syncthreads();
+    // C layout: column r (= channel within the 16-tile), rows 4q .. 4q+3 (= positions of this wave's 16) -> ot[n][p]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) raw[(nt * 16 + r) * OS + wave * 16 + 4 * q + e] = acc[nt][e];
+    __syncthreads();
+    for (int i = tid; i < m.N * RC; i += CONV_THREADS) {
+      const int n = i / RC, pp = i - n * RC, tr = pp / m.C, tc = pp - tr * m.C;
+      const int hc = hc0 + tr, wc = wc0 + tc;
+      if (hc < m.Hc && wc < m.Wc)
+        out[(((size_t)b * m.N + n) * m.Hd + m.a + hc * m.osh) * m.Wd + m.b + wc * m.osw] = raw[n * OS + pp] + (bias ? bias[n] : 0.0f);
+    }
+    __syncthreads();
+  }
+}
+
+// wgrad: per chunk of tiles, part[co][k] = sum_pos dy[pos][co] * x[src(pos, k)], and the bias partial as the extra column k = K
+// (a patch value of 1).  A = dyT[pos][co] (LDS, zero for positions outside the image), B = raw[koff[k] + posoff[pos]]; wave v owns the
+// 16-wide k tiles v, v + 8, ... (JR of them) for all NTC channel tiles.
+template <int NTC, int JR>
+__global__ __launch_bounds__(CONV_THREADS) void conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part,
+                                                                       ConvTile m, int Co, int rwp_log, int raw_floats, int tiles_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];   // raw | dyT[TP][16*NTC + 1] | koff[K4] | posoff[TP]
+  constexpr int C16 = 16 * NTC, DS = C16 + 1;
+  float *raw = csm, *dyT = csm + raw_floats;
+  int *koff = reinterpret_cast<int *>(dyT + (size_t)TP * DS);
+  int *posoff = koff + m.K4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int K = m.K, Wn = Co * K;
+  conv_fill_koff(koff, m);
+  if (tid < TP) {
+    const int tr = tid / m.C, tc = tid - tr * m.C;
+    posoff[tid] = tr < m.R ? tr * m.ssh * m.RW + tc * m.ssw : 0;
+  }
+  __syncthreads();
+  int kbase[JR];
+  bool kone[JR];
+  f32x4 acc[JR][NTC];
+#pragma unroll
+  for (int j = 0; j < JR; ++j) {
+    const int k = (wave + 8 * j) * 16 + r;
+    kbase[j] = k < K ? koff[k] : 0;
+    kone[j] = k == K;
+#pragma unroll
+    for (int ct = 0; ct < NTC; ++ct) acc[j][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int nkt = (K + 1 + 15) / 16;                         // k tiles in use (with the bias column)
+  const int t_begin = blockIdx.x * tiles_per_chunk, t_end = min(m.ntiles, t_begin + tiles_per_chunk);
+  const int dp = tid & (TP - 1), dq = tid >> 7;              // dy staging role: position dp, channels dq, dq + 4, ...
+  const int dtr = dp / m.C, dtc = dp - dtr * m.C;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int b, hc0, wc0;
+    conv_tile_origin(m, tile, b, hc0, wc0);
+    conv_load_raw(raw, x, m, b, hc0 * m.ssh + m.dh0, wc0 * m.ssw + m.dw0, rwp_log);
+    {
+      const int hc = hc0 + dtr, wc = wc0 + dtc;
+      const bool pv = dtr < m.R && hc < m.Hc && wc < m.Wc;
+      const size_t base = ((size_t)b * Co * m.Hc + min(hc, m.Hc - 1)) * m.Wc + min(wc, m.Wc - 1);
+      float v[C16 / 4];
+#pragma unroll
+      for (int u = 0; u < C16 / 4; ++u) v[u] = dy[base + (size_t)min(dq + 4 * u, Co - 1) * m.Hc * m.Wc];
+#pragma unroll
+      for (int u = 0; u < C16 / 4; ++u) dyT[dp * DS + dq + 4 * u] = (pv && dq + 4 * u < Co) ? v[u] : 0.0f;
+    }
+    __syncthreads();
+    if (wave < nkt) {
+      for (int s = 0; s < TP; s += 4) {
+        const int po = posoff[s + q];
+        float av[NTC];
+#pragma unroll
+        for (int ct = 0; ct < NTC; ++ct) av[ct] = dyT[(s + q) * DS + ct * 16 + r];
+#pragma unroll
+        for (int j = 0; j < JR; ++j) {
+          if (wave + 8 * j < nkt) {
+            float bv = raw[kbase[j] + po];
+            bv = kone[j] ? 1.0f : bv;
+#pragma unroll
+            for (int ct = 0; ct < NTC; ++ct) acc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct], bv, acc[j][ct], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float *outp = part + (size_t)blockIdx.x * (Wn + Co);
+#pragma unroll
+  for (int j = 0; j < JR; ++j) {
+    const int k = (wave + 8 * j) * 16 + r;                   // C layout: column r = k, rows 4q + e = co
+#pragma unroll
+    for (int ct = 0; ct < NTC; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = ct * 16 + 4 * q + e;
+        if (co < Co && k < K) outp[(size_t)co * K + k] = acc[j][ct][e];
+        else if (co < Co && k == K) outp[Wn + co] = acc[j][ct][e];
+      }
+  }
+}
+
+// fixed-order reduction of the per-chunk partials: 64 elements x 16 chunk groups per workgroup, doubles, LDS tree
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float *__restrict__ part, int chunks, int Wn, int Co, float *__restrict__ dw,
+                                                                 float *__restrict__ dbias, float beta_acc) {
+  __shared__ double red[16][65];
+  const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e, n = Wn + Co;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)part[(size_t)c * (Wn + Co) + i];
-  float *dst = i < Wn ? dw + i : (dbias ? dbias + (i - Wn) : nullptr);
-  if (!dst) return;
-  *dst = (float)s + (beta_acc != 0.0f ? beta_acc * *dst : 0.0f);
+  if (i < n)
+    for (int c = cg; c < chunks; c += 16) s += (double)part[(size_t)c * n + i];
+  red[cg][e] = s;
+  __syncthreads();
+  if (cg == 0 && i < n) {
+    for (int c = 1; c < 16; ++c) s += red[c][e];
+    float *dst = i < Wn ? dw + i : (dbias ? dbias + (i - Wn) : nullptr);
+    if (dst) *dst = (float)s + (beta_acc != 0.0f ? beta_acc * *dst : 0.0f);
+  }
 }
 
 int make_geom(ConvGeom &g, int B, int Ci, int Hi, int Wi, int Co, int kh, int kw, int sh, int sw, int ph, int pw) {
@@ -193,6 +418,132 @@ int make_geom(ConvGeom &g, int B, int Ci, int Hi, int Wi, int Co, int kh, int kw
   if (Co * Ci * kh * kw > 256 * WPT) return -2;
   return 0;
 }
+
+// ---- MFMA path: tile plans ---------------------------------------------------------------------------------------------------------
+constexpr size_t CONV_LDS_MAX = 158 * 1024;
+inline int round4(int k) { return (k + 3) & ~3; }
+inline int log2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct ConvPlan { ConvTile m; int rwp_log; int region_floats; size_t lds; bool ok; };
+
+// mode 0: forward / wgrad position space (output positions, all taps);  mode 1: dgrad class `cls` = a*sw + b
+// extra_floats(m): LDS floats next to the raw window (filter matrix, tables) as a function of the finished map
+template <class Extra>
+ConvPlan plan_tiles(const ConvGeom &g, int mode, int cls, int region_min_floats, Extra extra_floats) {
+  ConvPlan P{};
+  ConvTile &m = P.m;
+  P.ok = false;
+  if (g.kh * g.kw > MAX_TAPS || g.kh > 255 || g.kw > 255) return P;
+  int dh[MAX_TAPS], dw[MAX_TAPS], ki[MAX_TAPS], kj[MAX_TAPS], nki = 0, nkj = 0;
+  if (mode == 0) {
+    m.Cs = g.Ci; m.Hs = g.Hi; m.Ws = g.Wi; m.N = g.Co; m.Hd = g.Ho; m.Wd = g.Wo; m.Hc = g.Ho; m.Wc = g.Wo;
+    m.a = m.b = 0; m.osh = m.osw = 1; m.ssh = g.sh; m.ssw = g.sw;
+    for (int i = 0; i < g.kh; ++i) { ki[nki] = i; dh[nki++] = i - g.ph; }
+    for (int j = 0; j < g.kw; ++j) { kj[nkj] = j; dw[nkj++] = j - g.pw; }
+    m.wsn = g.Ci * g.kh * g.kw; m.wsc = g.kh * g.kw;
+  } else {
+    m.Cs = g.Co; m.Hs = g.Ho; m.Ws = g.Wo; m.N = g.Ci; m.Hd = g.Hi; m.Wd = g.Wi;
+    // class (ra, rb) = ((t + ph) mod sh, (f + pw) mod sw); its first position is a = (ra - ph) mod sh
+    const int ra = cls / g.sw, rb = cls % g.sw;
+    m.a = ((ra - g.ph) % g.sh + g.sh) % g.sh; m.b = ((rb - g.pw) % g.sw + g.sw) % g.sw;
+    m.osh = g.sh; m.osw = g.sw; m.ssh = m.ssw = 1;
+    m.Hc = m.a < g.Hi ? (g.Hi - m.a + g.sh - 1) / g.sh : 0;
+    m.Wc = m.b < g.Wi ? (g.Wi - m.b + g.sw - 1) / g.sw : 0;
+    for (int i = 0; i < g.kh; ++i) if ((m.a + g.ph - i) % g.sh == 0) { ki[nki] = i; dh[nki++] = (m.a + g.ph - i) / g.sh; }
+    for (int j = 0; j < g.kw; ++j) if ((m.b + g.pw - j) % g.sw == 0) { kj[nkj] = j; dw[nkj++] = (m.b + g.pw - j) / g.sw; }
+    m.wsn = g.kh * g.kw; m.wsc = g.Ci * g.kh * g.kw;
+  }
+  int dhs = 1, dws = 1;
+  m.dh0 = m.dw0 = 0;
+  if (nki && nkj) {
+    m.dh0 = *std::min_element(dh, dh + nki); m.dw0 = *std::min_element(dw, dw + nkj);
+    dhs = *std::max_element(dh, dh + nki) - m.dh0 + 1; dws = *std::max_element(dw, dw + nkj) - m.dw0 + 1;
+  }
+  m.ntap = nki * nkj;
+  for (int i = 0; i < nki; ++i)
+    for (int j = 0; j < nkj; ++j) m.tap[i * nkj + j] = ((dh[i] - m.dh0) << 16) | ((dw[j] - m.dw0) << 8) | (ki[i] * g.kw + kj[j]);
+  if (dhs > 255 || dws > 255) return P;
+  m.K = m.Cs * m.ntap; m.K4 = round4(m.K);
+  if (m.Hc <= 0 || m.Wc <= 0) { m.ntiles = 0; P.ok = true; return P; }
+  m.C = std::min(m.Wc, TP);
+  for (m.R = std::max(1, std::min(TP / m.C, m.Hc)); m.R >= 1; --m.R) {
+    m.RH = (m.R - 1) * m.ssh + dhs; m.RW = (m.C - 1) * m.ssw + dws;
+    if (m.RW > CONV_THREADS) return P;
+    P.region_floats = std::max(region_min_floats, m.K > 0 ? m.Cs * m.RH * m.RW : 0);
+    P.lds = ((size_t)P.region_floats + extra_floats(m)) * sizeof(float);
+    if (P.lds <= CONV_LDS_MAX) break;
+  }
+  if (m.R < 1) return P;
+  P.rwp_log = log2_ceil(m.RW);
+  m.tiles_h = ceil_div(m.Hc, m.R); m.tiles_w = ceil_div(m.Wc, m.C);
+  const size_t nt = (size_t)g.B * m.tiles_h * m.tiles_w;
+  if (nt >= ((size_t)1 << 30)) return P;
+  m.ntiles = (int)nt;
+  P.ok = true;
+  return P;
+}
+
+ConvPlan plan_gemm(const ConvGeom &g, int mode, int cls) {
+  const int N = mode == 0 ? g.Co : g.Ci, NT = ceil_div(N, 16);
+  if (N > 64 || ctcn_get_option("conv_mfma") == 0) { ConvPlan P{}; P.ok = false; return P; }
+  return plan_tiles(g, mode, cls, 16 * NT * (TP + 1), [NT](const ConvTile &m) { return (size_t)m.K4 * (conv_ws_stride(NT) + 1); });
+}
+
+constexpr int WGRAD_JR_MAX = 8;
+ConvPlan plan_wgrad(const ConvGeom &g) {
+  const int NTC = ceil_div(g.Co, 16);
+  ConvPlan P{};
+  P.ok = false;
+  if (g.Co > 64 || ctcn_get_option("conv_mfma") == 0) return P;
+  P = plan_tiles(g, 0, 0, 0, [NTC](const ConvTile &m) { return (size_t)TP * (16 * NTC + 1) + round4(m.K + 1) + TP; });
+  if (P.ok) {
+    P.m.K4 = round4(P.m.K + 1);                       // + the bias column
+    if (ceil_div(ceil_div(P.m.K + 1, 16), 8) > WGRAD_JR_MAX) P.ok = false;
+  }
+  return P;
+}
+
+template <int NT>
+int launch_gemm_nt(const float *src, const float *w, const float *bias, float *out, const ConvPlan &P, hipStream_t st) {
+  auto kern = conv_mfma_kernel<NT>;
+  CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds));
+  const int blocks = std::min(P.m.ntiles, 2 * std::max(ctcn_device_cus(), 64));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(CONV_THREADS), P.lds, st, src, w, bias, out, P.m, P.rwp_log, P.region_floats);
+  return CTCN_OK;
+}
+int launch_gemm(const float *src, const float *w, const float *bias, float *out, const ConvPlan &P, hipStream_t st) {
+  if (P.m.ntiles == 0) return CTCN_OK;
+  switch (ceil_div(P.m.N, 16)) {
+    case 1: return launch_gemm_nt<1>(src, w, bias, out, P, st);
+    case 2: return launch_gemm_nt<2>(src, w, bias, out, P, st);
+    case 3: return launch_gemm_nt<3>(src, w, bias, out, P, st);
+    default: return launch_gemm_nt<4>(src, w, bias, out, P, st);
+  }
+}
+
+template <int NTC, int JR>
+int launch_wgrad_t(const float *x, const float *dy, float *part, const ConvPlan &P, int Co, int nch, int tpc, hipStream_t st) {
+  auto kern = conv_wgrad_mfma_kernel<NTC, JR>;
+  CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds));
+  hipLaunchKernelGGL(kern, dim3(nch), dim3(CONV_THREADS), P.lds, st, x, dy, part, P.m, Co, P.rwp_log, P.region_floats, tpc);
+  return CTCN_OK;
+}
+template <int NTC>
+int launch_wgrad_ntc(const float *x, const float *dy, float *part, const ConvPlan &P, int Co, int nch, int tpc, hipStream_t st) {
+  const int jr = ceil_div(ceil_div(P.m.K + 1, 16), 8);
+  if (jr <= 1) return launch_wgrad_t<NTC, 1>(x, dy, part, P, Co, nch, tpc, st);
+  if (jr <= 3) return launch_wgrad_t<NTC, 3>(x, dy, part, P, Co, nch, tpc, st);
+  return launch_wgrad_t<NTC, WGRAD_JR_MAX>(x, dy, part, P, Co, nch, tpc, st);
+}
+int launch_wgrad(const float *x, const float *dy, float *part, const ConvPlan &P, int Co, int nch, int tpc, hipStream_t st) {
+  switch (ceil_div(Co, 16)) {
+    case 1: return launch_wgrad_ntc<1>(x, dy, part, P, Co, nch, tpc, st);
+    case 2: return launch_wgrad_ntc<2>(x, dy, part, P, Co, nch, tpc, st);
+    case 3: return launch_wgrad_ntc<3>(x, dy, part, P, Co, nch, tpc, st);
+    default: return launch_wgrad_ntc<4>(x, dy, part, P, Co, nch, tpc, st);
+  }
+}
+
 int wgrad_chunks(const ConvGeom &g) {
   const size_t npos = (size_t)g.B * g.Ho * g.Wo;
   return (int)std::max((size_t)1, std::min((size_t)512, ceil_div_z(npos, 64)));
@@ -202,7 +553,7 @@ int wgrad_chunks(const ConvGeom &g) {
 
 extern "C" size_t ctcn_conv2d_ws_bytes(int B, int Ci, int Hi, int Wi, int Co, int kh, int kw, int sh, int sw, int ph, int pw) {
   ConvGeom g;
-  if (make_geom(g, B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw)) return 0;
+  if (make_geom(g, B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw) == -1) return 0;
   return (size_t)wgrad_chunks(g) * (Co * Ci * kh * kw + Co) * sizeof(float);
 }
 
@@ -211,7 +562,14 @@ extern "C" int ctcn_conv2d_fwd(const float *x, const float *w, const float *bias
   ConvGeom g;
   const int rc = make_geom(g, B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw);
   CTCN_REQUIRE(rc != -1 && x && w && y, "ctcn_conv2d_fwd: bad args");
-  if (rc == -2) { ctcn_set_error("ctcn_conv2d_fwd: filter bank %dx%dx%dx%d too large for the LDS-resident kernel", Co, Ci, kh, kw); return CTCN_EUNSUPPORTED; }
+  const ConvPlan P = plan_gemm(g, 0, 0);
+  if (P.ok) {
+    const int lrc = launch_gemm(x, w, bias, y, P, (hipStream_t)stream);
+    if (lrc) return lrc;
+    CTCN_LAUNCH_CHECK();
+    return CTCN_OK;
+  }
+  if (rc == -2) { ctcn_set_error("ctcn_conv2d_fwd: filter bank %dx%dx%dx%d too large for the LDS-resident kernels", Co, Ci, kh, kw); return CTCN_EUNSUPPORTED; }
   const size_t npos = (size_t)B * g.Ho * g.Wo;
   const int blocks = (int)std::min((size_t)2048, ceil_div_z(npos, 256));
   const size_t sm = (size_t)Co * Ci * kh * kw * sizeof(float);
@@ -226,10 +584,22 @@ extern "C" int ctcn_conv2d_bwd(const float *x, const float *w, const float *dy, 
   ConvGeom g;
   const int rc = make_geom(g, B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw);
   CTCN_REQUIRE(rc != -1 && x && w && dy && dw && ws, "ctcn_conv2d_bwd: bad args");
-  if (rc == -2) { ctcn_set_error("ctcn_conv2d_bwd: filter bank too large for the LDS-resident kernel"); return CTCN_EUNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const int Wn = Co * Ci * kh * kw;
-  if (dx) {
+  // dgrad: one dense stride-1 product per stride class
+  const int ncls = sh * sw;
+  bool dgrad_mfma = dx != nullptr && ncls <= 16;
+  ConvPlan DP[16];
+  for (int c = 0; dgrad_mfma && c < ncls; ++c) { DP[c] = plan_gemm(g, 1, c); dgrad_mfma = DP[c].ok; }
+  const ConvPlan WP = plan_wgrad(g);
+  if (rc == -2 && !(WP.ok && (dgrad_mfma || !dx))) { ctcn_set_error("ctcn_conv2d_bwd: filter bank too large for the LDS-resident kernels"); return CTCN_EUNSUPPORTED; }
+  if (dx && dgrad_mfma) {
+    for (int c = 0; c < ncls; ++c) {
+      const int lrc = launch_gemm(dy, w, nullptr, dx, DP[c], st);
+      if (lrc) return lrc;
+      CTCN_LAUNCH_CHECK();
+    }
+  } else if (dx) {
     const size_t npos = (size_t)B * Hi * Wi;
     const int blocks = (int)std::min((size_t)2048, ceil_div_z(npos, 256));
     hipLaunchKernelGGL(conv_dgrad_kernel, dim3(blocks), dim3(256), (size_t)Wn * sizeof(float), st, dy, w, dx, g);
@@ -237,13 +607,21 @@ extern "C" int ctcn_conv2d_bwd(const float *x, const float *w, const float *dy, 
   }
   const int chunks = wgrad_chunks(g);
   if (ws_bytes < (size_t)chunks * (Wn + Co) * sizeof(float)) { ctcn_set_error("ctcn_conv2d_bwd: workspace too small"); return CTCN_EWORKSPACE; }
-  const size_t npos = (size_t)B * g.Ho * g.Wo;
-  const int ppc = (int)ceil_div_z(npos, chunks);
-  const int nch = (int)ceil_div_z(npos, ppc);
-  const size_t sm = (size_t)WG_P * (Ci * kh * kw + Co) * sizeof(float);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nch), dim3(256), sm, st, x, dy, (float *)ws, g, ppc);
+  int nch;
+  if (WP.ok) {
+    const int tpc = ceil_div(WP.m.ntiles, std::min(WP.m.ntiles, chunks));
+    nch = ceil_div(WP.m.ntiles, tpc);
+    const int lrc = launch_wgrad(x, dy, (float *)ws, WP, Co, nch, tpc, st);
+    if (lrc) return lrc;
+  } else {
+    const size_t npos = (size_t)B * g.Ho * g.Wo;
+    const int ppc = (int)ceil_div_z(npos, chunks);
+    nch = (int)ceil_div_z(npos, ppc);
+    const size_t sm = (size_t)WG_P * (Ci * kh * kw + Co) * sizeof(float);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nch), dim3(256), sm, st, x, dy, (float *)ws, g, ppc);
+  }
   CTCN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(Wn + Co, 256)), dim3(256), 0, st, (const float *)ws, nch, Wn, Co, dw, dbias, beta_acc);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(Wn + Co, 64)), dim3(1024), 0, st, (const float *)ws, nch, Wn, Co, dw, dbias, beta_acc);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }

@@ -55,6 +55,8 @@ int ctcn_device_xcds(void);
  * device) with 256 x 256 / 256 x 128 workgroup tiles staged by global_load_lds; 0: always the 128 x 128 tile (same results).
  * "gemm_a_inline" = 1 (default): those tiles take a row-major float32 A operand as it is and split it into bf16 planes while staging
  * it (no separate plane pass over A; same planes, same results); 0: A is pre-split like B.
+ * "conv_mfma" = 1 (default): ctcn_conv2d_fwd / _bwd run as implicit GEMMs on v_mfma_f32_16x16x4_f32 (im2col tile of 64 positions and
+ * the filter matrix staged in LDS; exact float32 in both matmul precisions); 0: the direct (lane-per-position) kernels.
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */
@@ -157,7 +159,8 @@ int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uin
 
 /* ---------------------------------------------------------------------------------------------------
  * Conv2d (bias) NCHW, direct; replaces nn.Conv2d in LayerCNN (model_ctc.py:46,61).
- * x (B,Ci,Hi,Wi) w (Co,Ci,kh,kw) y (B,Co,Ho,Wo), Ho=(Hi+2ph-kh)/sh+1.  Co,Ci <= 64, kh*kw <= 25. */
+ * x (B,Ci,Hi,Wi) w (Co,Ci,kh,kw) y (B,Co,Ho,Wo), Ho=(Hi+2ph-kh)/sh+1.  Co,Ci <= 64, kh*kw <= 25.
+ * Default: MFMA implicit GEMMs (option "conv_mfma"); the direct kernels serve filter banks whose LDS images do not fit. */
 size_t ctcn_conv2d_ws_bytes(int B, int Ci, int Hi, int Wi, int Co, int kh, int kw, int sh, int sw, int ph, int pw);
 int ctcn_conv2d_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Ci, int Hi, int Wi,
                     int Co, int kh, int kw, int sh, int sw, int ph, int pw, void *stream);

@@ -436,6 +436,49 @@ def test_sync_batchnorm_two_shards_equal_full_batch(dev, rows, C, inner, relu):
     assert maxabs(y2, y) < 1e-6 and maxabs(x2.grad, xg.grad) < 1e-6 and rel_l2(g2.grad, gg.grad) < 1e-6
 
 
+CONV_CASES = [  # B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw
+    (3, 1, 37, 40, 32, 3, 3, 1, 2, 1, 1),      # the reference's first layer shape (ctc_config.yaml)
+    (2, 32, 21, 20, 32, 3, 3, 2, 2, 1, 1),     # its second layer
+    (2, 3, 9, 11, 5, 3, 2, 1, 1, 0, 1),        # K = 18, Co = 5: ragged in both MFMA dimensions
+    (1, 7, 5, 6, 17, 1, 1, 1, 1, 0, 0),        # 1x1 taps, Co just over one 16-column tile
+    (2, 2, 4, 4, 64, 5, 5, 2, 3, 2, 2),        # taps wider than the image, widest filter bank
+    (1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0),         # a single output position
+    (5, 16, 13, 7, 48, 3, 3, 1, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_conv2d_vs_oracle(dev, case, mfma):
+    """ctcn_conv2d_fwd / _bwd (torch.nn.Conv2d of model/cnn.py:32-38 in the reference) against the float64 oracle
+    (oracle/np_ref.py conv2d_fwd / conv2d_bwd): the MFMA implicit-GEMM kernels (default) and the direct kernels
+    (option conv_mfma = 0) under the same float32 gate, on ragged shapes either side of the 16 / 4 / 64 tile edges."""
+    from ctc_pytorch_amd import _lib, ops
+    B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw = case
+    rs = np.random.RandomState(sum(case))
+    x = rs.standard_normal((B, Ci, Hi, Wi)).astype(np.float32)
+    w = (rs.standard_normal((Co, Ci, kh, kw)) / np.sqrt(Ci * kh * kw)).astype(np.float32)
+    b = rs.standard_normal(Co).astype(np.float32)
+    y_ref = R.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), (sh, sw), (ph, pw))
+    dy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref, dw_ref, db_ref = R.conv2d_bwd(x.astype(np.float64), w.astype(np.float64), (sh, sw), (ph, pw), dy.astype(np.float64))
+    _lib.lib().ctcn_set_option(b"conv_mfma", mfma)
+    try:
+        xt = torch.from_numpy(x).to(dev).requires_grad_()
+        wt = torch.from_numpy(w).to(dev).requires_grad_()
+        bt = torch.from_numpy(b).to(dev).requires_grad_()
+        y = ops.conv2d(xt, wt, bt, (sh, sw), (ph, pw))
+        y.backward(torch.from_numpy(dy).to(dev))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().ctcn_set_option(b"conv_mfma", 1)
+    scale = lambda a: max(1.0, float(np.abs(a).max()))
+    assert tuple(y.shape) == y_ref.shape
+    assert maxabs(y, y_ref) < 2e-6 * scale(y_ref) * np.sqrt(Ci * kh * kw)
+    assert maxabs(xt.grad, dx_ref) < 2e-6 * scale(dx_ref) * np.sqrt(Co * kh * kw)
+    assert rel_l2(wt.grad, dw_ref) < 2e-6 and rel_l2(bt.grad, db_ref) < 2e-6
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_conv_front_golden(dev, prec):
     """(the direct convolution and BatchNorm are f32 in both modes: the same f32-strict gates hold at precision 1)"""
