@@ -291,6 +291,17 @@ def run_train(args):
         res["roofline_gemm"] = gemm_roofline(dev, c)
     except Exception as e:      # keep the headline line even if a probe fails
         res["roofline"] = {"error": repr(e)}
+    try:        # host side of one step: time to ENQUEUE it (python + autograd + ~300 launches) with the device idle at the start
+        torch.cuda.synchronize()
+        th = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            step()
+            th.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        res["host_enqueue_ms_per_step"] = 1e3 * min(th)
+    except Exception as e:
+        res["host_enqueue_ms_per_step"] = repr(e)
     try:
         # the real training loop: steps/train_ctc.run_epoch over host batches staged by DevicePrefetcher -- on top
         # of the timed step above it runs the greedy error count (arg-max, collapse, edit distance) and ONE small D2H per step
@@ -299,17 +310,19 @@ def run_train(args):
         nloop = max(8, min(args.steps, 20))
         hb = (torch.from_numpy(batch["x"]), torch.ones(c["B"], dtype=torch.float32), torch.from_numpy(batch["targets"]),
               torch.from_numpy(batch["tgt_len"]), ["u%d" % i for i in range(c["B"])])
-        run_epoch(0, model, DevicePrefetcher([hb] * 3, dev), loss_fn, dev, optimizer=opt, print_every=10 ** 9, is_training=True,
+        pf = DevicePrefetcher([hb] * 3, dev)        # one prefetcher for the run, as in steps/train_ctc.main: its pinned slots persist
+        run_epoch(0, model, pf, loss_fn, dev, optimizer=opt, print_every=10 ** 9, is_training=True,
                   global_batch=global_b, log=lambda *_: None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_epoch(0, model, DevicePrefetcher([hb] * nloop, dev), loss_fn, dev, optimizer=opt, print_every=10 ** 9, is_training=True,
+        pf.loader = [hb] * nloop
+        run_epoch(0, model, pf, loss_fn, dev, optimizer=opt, print_every=10 ** 9, is_training=True,
                   global_batch=global_b, log=lambda *_: None)
         torch.cuda.synchronize()
         dte = (time.perf_counter() - t0) / nloop
         res["epoch_loop"] = {"ms_per_step": dte * 1e3, "frames_per_s": c["B"] * c["T"] * world / dte, "steps": nloop,
                              "note": "steps/train_ctc.run_epoch with DevicePrefetcher (pinned host batch -> async H2D each step), on-device greedy "
-                                     "error count and one 4-number D2H per step; not the headline `value`"}
+                                     "error count, step statistics read one step behind through pinned memory; not the headline `value`"}
     except Exception as e:
         res["epoch_loop"] = {"error": repr(e)}
     if world == 1 and not args.no_decode:

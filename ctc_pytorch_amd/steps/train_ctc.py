@@ -48,6 +48,32 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
     total_errs = 0
     cur_loss = 0.0
     n_batches = 0
+    # Step statistics travel one step behind the launches: the (loss, errors, tokens, health) vector of step i is copied into pinned
+    # host memory asynchronously and read while step i+1 is already queued, so the host never drains the device inside the loop
+    # (a blocking .cpu() per step left the GPU idle for the whole host-side enqueue of the next step: 39 vs 16 ms per cfg2 step).
+    on_gpu = torch.device(device).type == "cuda"
+    host_stats = [torch.empty(4, dtype=torch.float64).pin_memory() if on_gpu else torch.empty(4, dtype=torch.float64) for _ in range(2)]
+    acc = dict(total_loss=0.0, cur_loss=0.0, total_errs=0, total_tokens=0, n_batches=0)
+
+    def consume(pending):
+        buf, ready, step = pending
+        if ready is not None:
+            ready.synchronize()
+        if int(buf[3]) != 0:
+            raise RuntimeError("ctc_pytorch_amd: a persistent recurrent kernel gave up waiting for a hand-off (status %d); "
+                               "results of this step are poisoned -- set CTCN_RNN_PERSISTENT=0 to run one launch per timestep" % int(buf[3]))
+        lv = float(buf[0])
+        acc["cur_loss"] += lv
+        acc["total_loss"] += lv
+        acc["total_errs"] += int(buf[1])
+        acc["total_tokens"] += int(buf[2])
+        acc["n_batches"] = step + 1
+        if (step + 1) % print_every == 0 and is_training:
+            log("Epoch = %d, step = %d, cur_loss = %.4f, total_loss = %.4f, total_wer = %.4f" % (
+                epoch_id, step + 1, acc["cur_loss"] / print_every, acc["total_loss"] / (step + 1), acc["total_errs"] / acc["total_tokens"]))
+            acc["cur_loss"] = 0.0
+
+    pending = None
     for i, data in enumerate(data_iter):
         inputs, input_sizes, targets, target_sizes, utt_list = data[:5]
         # data parallel (parallel.ShardedBatches): a 6th entry carries the utterance count of the GLOBAL minibatch; the loss
@@ -60,7 +86,12 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
         with torch.set_grad_enabled(is_training):
             out = model(inputs)
             out_len, batch_size, _ = out.size()
-            in_len = torch.from_numpy(frames_from_fraction(input_sizes, out_len)).to(device)
+            if torch.is_tensor(input_sizes) and input_sizes.is_cuda:
+                # DevicePrefetcher staged the fractions: the float32 product and truncation of train_ctc.py:46 on the device
+                # (same IEEE multiply, same integers), no blocking pageable H2D in the middle of the step
+                in_len = (input_sizes.float() * float(out_len)).long()
+            else:
+                in_len = torch.from_numpy(frames_from_fraction(input_sizes, out_len)).to(device)
             loss = loss_fn(out, targets_d, in_len, target_sizes_d)
             loss = loss / (step_global or batch_size)
         # greedy error count on the pre-update model, all on device
@@ -73,25 +104,23 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
             if isinstance(optimizer, FlatAdam):
                 parallel.allreduce_grads(optimizer.grad)
             optimizer.step()
-        # one D2H per step: loss, error count, token count and the sticky hand-off status word of the persistent kernels
+        # loss, error count, token count and the sticky hand-off status word of the persistent kernels
         health = _lib.status_word(inputs.device).reshape(1).double() if inputs.is_cuda else torch.zeros(1, dtype=torch.float64)
         stats = torch.cat([torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]), health])
         if step_global:
             stats = parallel.allreduce_stats(stats)          # global loss / error / token counts (and any rank's bad health)
-        stats = stats.cpu()
-        if int(stats[3]) != 0:
-            raise RuntimeError("ctc_pytorch_amd: a persistent recurrent kernel gave up waiting for a hand-off (status %d); "
-                               "results of this step are poisoned -- set CTCN_RNN_PERSISTENT=0 to run one launch per timestep" % int(stats[3]))
-        lv = float(stats[0])
-        cur_loss += lv
-        total_loss += lv
-        total_errs += int(stats[1])
-        total_tokens += int(stats[2])
-        n_batches = i + 1
-        if (i + 1) % print_every == 0 and is_training:
-            log("Epoch = %d, step = %d, cur_loss = %.4f, total_loss = %.4f, total_wer = %.4f" % (
-                epoch_id, i + 1, cur_loss / print_every, total_loss / (i + 1), total_errs / total_tokens))
-            cur_loss = 0.0
+        buf = host_stats[i % 2]
+        buf.copy_(stats, non_blocking=True)
+        ready = None
+        if stats.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+        if pending is not None:
+            consume(pending)
+        pending = (buf, ready, i)
+    if pending is not None:
+        consume(pending)
+    total_loss, total_errs, total_tokens, n_batches = acc["total_loss"], acc["total_errs"], acc["total_tokens"], acc["n_batches"]
     parallel.set_batch_split(None, None)
     average_loss = total_loss / max(n_batches, 1)
     log("Epoch %d %s done, total_loss: %.4f, total_wer: %.4f" % (epoch_id, "Train" if is_training else "Valid", average_loss,
@@ -176,6 +205,10 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
         setattr(opts, k, v)
     rank, world, local = parallel.init_from_env()
     device = torch.device("cuda", local)
+    # The host side of a step is collation and a 4 MB staging copy: a torch CPU op that fans out to every core (128 OpenMP
+    # threads on the GPU box) between two steps stalls the launch thread for 8-10 ms (tools/epoch_probe.py).  CTCN_HOST_THREADS
+    # overrides; one process per GPU shares the host anyway.
+    torch.set_num_threads(max(1, int(os.environ.get("CTCN_HOST_THREADS", "4"))))
     torch.manual_seed(opts.seed)
     np.random.seed(opts.seed)
     if train_loader is None:

@@ -169,24 +169,47 @@ class DevicePrefetcher(object):
     """Double-buffered asynchronous host->device staging of the batches of a SpeechDataLoader.
 
     While step n computes, batch n+1 is copied from pinned host memory on a dedicated copy stream; the iterator yields
-    the loader's 5-tuple with `inputs`, `targets` and `target_sizes` already resident on the device (`input_sizes` stays
-    on the host: the length conversion of run_epoch is host arithmetic, train_ctc.py:46).  4.1 MB per cfg2 batch =
-    ~65 us of PCIe Gen5 time, hidden behind a 21 ms step."""
+    the loader's 5-tuple with `inputs`, `input_sizes` (the float32 length fractions), `targets` and `target_sizes` already
+    resident on the device; run_epoch does the length conversion of train_ctc.py:46 there (same float32 product and
+    truncation), so no pageable copy blocks the host in the middle of a step.  4.1 MB per cfg2 batch = ~65 us of PCIe Gen5
+    time, hidden behind a 16 ms step."""
 
     def __init__(self, loader, device):
         self.loader = loader
         self.device = torch.device(device)
+        # Two staging slots of persistent pinned host memory, grown on demand to the largest batch seen.  (A fresh
+        # tensor.pin_memory() per batch is a hipHostMalloc per step: it drains the device and cost 10-18 ms per cfg2 step.)
+        self._slots = [{"bufs": {}, "copied": None} for _ in range(2)]
+        self._turn = 0
 
     def __len__(self):
         return len(self.loader)
 
+    @staticmethod
+    def _pinned(slot, key, t):
+        buf = slot["bufs"].get(key)
+        if buf is None or buf.dtype != t.dtype or buf.numel() < t.numel():
+            buf = torch.empty(max(64, int(t.numel() * 1.25)), dtype=t.dtype, pin_memory=True)
+            slot["bufs"][key] = buf
+        view = buf[:t.numel()].view(t.shape)
+        # single-threaded memcpy on purpose: Tensor.copy_ fans a 4 MB copy out to every host core, and the OpenMP team spinning
+        # next to the HIP runtime's threads cost 8-10 ms per cfg2 step (tools/epoch_probe.py); one core copies 4 MB in 0.4 ms
+        np.copyto(view.numpy(), t.detach().numpy())
+        return view
+
     def _stage(self, batch, stream):
         inputs, input_sizes, targets, target_sizes, utt_list = batch[:5]
+        slot = self._slots[self._turn]
+        self._turn ^= 1
+        if slot["copied"] is not None:
+            slot["copied"].synchronize()         # the H2D copies that last read this slot (two batches ago: long done)
+        sizes = input_sizes if torch.is_tensor(input_sizes) else torch.as_tensor(np.asarray(input_sizes, dtype=np.float32))
         with torch.cuda.stream(stream):
-            dev = [t.pin_memory().to(self.device, non_blocking=True) for t in (inputs, targets, target_sizes)]
+            dev = [self._pinned(slot, k, t).to(self.device, non_blocking=True) for k, t in enumerate((inputs, sizes, targets, target_sizes))]
             ready = torch.cuda.Event()
             ready.record(stream)
-        return (dev[0], input_sizes, dev[1], dev[2], utt_list) + tuple(batch[5:]), ready   # (+ the global batch size of a DP shard)
+        slot["copied"] = ready
+        return (dev[0], dev[1], dev[2], dev[3], utt_list) + tuple(batch[5:]), ready   # (+ the global batch size of a DP shard)
 
     def __iter__(self):
         if self.device.type != "cuda":
@@ -205,6 +228,6 @@ class DevicePrefetcher(object):
                 staged = None
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ready)
-            for t in (batch[0], batch[2], batch[3]):
+            for t in batch[:4]:
                 t.record_stream(cur)
             yield batch

@@ -1048,7 +1048,8 @@ def test_large_shape_checksums(dev, name, prec):
 # decoders
 # ---------------------------------------------------------------------------------------------------------
 def test_device_prefetcher_yields_the_loader_batches(dev):
-    """async double-buffered H2D staging; same tensors, same order, targets / sizes on the device."""
+    """async double-buffered H2D staging; same tensors, same order, inputs / length fractions / targets / sizes on
+    the device; and the device-side length conversion of run_epoch gives the integers of the host expression."""
     from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher, create_input
     rs = np.random.RandomState(4)
     items = [(torch.from_numpy(rs.standard_normal((int(rs.randint(20, 60)), 40)).astype(np.float32)),
@@ -1057,9 +1058,11 @@ def test_device_prefetcher_yields_the_loader_batches(dev):
     got = list(DevicePrefetcher(batches, dev))
     assert len(got) == len(batches) == 3
     for g, w in zip(got, batches):
-        assert g[0].device.type == "cuda" and g[2].device.type == "cuda" and g[3].device.type == "cuda" and g[1].device.type == "cpu"
-        assert torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2].cpu(), w[2]) and torch.equal(g[3].cpu(), w[3])
+        assert all(g[k].device.type == "cuda" for k in range(4))
+        assert all(torch.equal(g[k].cpu(), w[k]) for k in range(4))
         assert g[4] == w[4]
+        for t_out in (7, 59, 800, 1601):
+            assert (g[1].float() * float(t_out)).long().cpu().tolist() == R.frames_from_fraction(w[1].numpy(), t_out).tolist()
     assert list(DevicePrefetcher([], dev)) == []
 
 
@@ -1108,6 +1111,35 @@ def test_end_to_end_train_checkpoint_decode(dev, tmp_path):
     assert 0.0 <= wer_g < 100.0 and np.isfinite(cer_g) and np.isfinite(cer_b) and np.isfinite(wer_b)
     # the greedy WER of the scoring script equals 1 - accuracy of the training-time on-device PER at the best epoch
     assert abs(wer_g / 100.0 - (1.0 - max(hist["dev_acc"]))) < 1e-6, (wer_g, hist["dev_acc"])
+
+
+@pytest.mark.parametrize("wave", [1, 0])
+@pytest.mark.parametrize("max_lab", [1, 9, 64, 65, 130, 257, 512, 600])
+def test_edit_distance_vs_oracle(dev, wave, max_lab):
+    """ctcn_edit_distance (the error count of run_epoch: editdistance.eval at model_ctc.py:200 / ctcDecoder.py:131-149 in the
+    reference) against the Levenshtein oracle, bit-exact: the wavefront kernel (anti-diagonals, 1/2/4/8 label columns per lane) and
+    the lane-per-utterance kernel, empty predictions and labels, label lengths either side of the 64-column chunk edges, a small
+    alphabet (many matches) and a large one."""
+    from ctc_pytorch_amd import _lib, ops
+    rs = np.random.RandomState(max_lab)
+    B, lda = 9, 150
+    a = rs.randint(1, 5 if max_lab % 2 else 40, size=(B, lda)).astype(np.int32)
+    la = rs.randint(0, lda + 1, size=B).astype(np.int32)
+    lb = rs.randint(0, max_lab + 1, size=B).astype(np.int64)
+    la[0], lb[0] = 0, max_lab          # empty prediction
+    la[1], lb[1] = lda, 0              # empty label
+    la[2], lb[2] = 0, 0
+    la[3], lb[3] = lda, max_lab
+    b = rs.randint(1, 5 if max_lab % 2 else 40, size=(B, max_lab)).astype(np.int64)
+    b[4, :min(max_lab, lda)] = a[4, :min(max_lab, lda)]            # a long common prefix
+    want = [R.edit_distance(a[u, :la[u]].tolist(), b[u, :lb[u]].tolist()) for u in range(B)]
+    _lib.lib().ctcn_set_option(b"edit_wave", wave)
+    try:
+        got = ops.edit_distance(torch.from_numpy(a).to(dev), torch.from_numpy(la).to(dev), torch.from_numpy(b).to(dev), torch.from_numpy(lb).to(dev))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().ctcn_set_option(b"edit_wave", 1)
+    assert got.cpu().tolist() == want
 
 
 def test_greedy_decoder_golden(dev):
