@@ -38,6 +38,8 @@ _SIGS = {
     "ctcn_copy_strided4": (I, [P, P, I, I, I, I, Z, Z, Z, Z, P]),
     "ctcn_relu_fwd": (I, [P, P, Z, P]),
     "ctcn_relu_bwd": (I, [P, P, P, Z, P]),
+    "ctcn_maxpool2d_fwd": (I, [P, P, P, Z, I, I, I, I, P]),
+    "ctcn_maxpool2d_bwd": (I, [P, P, P, Z, I, I, I, I, P]),
     "ctcn_rnn_scratch_bytes": (Z, [I, I, I, I]),
     "ctcn_rnn_fwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, Z, P]),
     "ctcn_rnn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P]),

@@ -1846,7 +1846,7 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
       rc = ctcn_gemm_on_xcds(0, 0, TB, I, GH, da, ldg, w_ih[d], I, dx, I, d == 0 ? 0.0f : 1.0f, precision, ws, ws_bytes, stream, xcd_allow);
       if (rc) return rc;
     }
-    if (!weights) continue;
+    if (!weights || !dw_ih[d]) continue;
     rc = ctcn_gemm_on_xcds(1, 0, GH, I, TB, da, ldg, x, I, dw_ih[d], I, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
     if (rc) return rc;
     // dW_hh = sum_t dgh_t^T h_prev(t);  h_prev(t) = y[t-1] (fwd) / y[t+1] (reverse), zero at the sequence start
@@ -1987,7 +1987,9 @@ extern "C" int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int di
                                     int precision, unsigned xcd_allow, void *ws, size_t ws_bytes, void *stream) {
   CTCN_REQUIRE(cell >= 0 && cell <= 2, "ctcn_rnn_bwd_weights: unknown cell %d", cell);
   CTCN_REQUIRE(T > 0 && B > 0 && I > 0 && H > 0 && (dirs == 1 || dirs == 2), "ctcn_rnn_bwd_weights: bad dims");
-  CTCN_REQUIRE(x && y && gates && dw_ih0 && dw_hh0 && (dirs == 1 || (dw_ih1 && dw_hh1)), "ctcn_rnn_bwd_weights: null pointer");
+  // a direction whose two gradient pointers are both NULL is skipped (the host runs the directions of the bottom layer on two streams)
+  CTCN_REQUIRE(x && y && gates && (dw_ih0 != nullptr) == (dw_hh0 != nullptr) && (dirs == 1 || (dw_ih1 != nullptr) == (dw_hh1 != nullptr)) &&
+                   (dw_ih0 || (dirs == 2 && dw_ih1)), "ctcn_rnn_bwd_weights: null pointer");
   CTCN_REQUIRE(cell != CTCN_CELL_GRU || aux, "ctcn_rnn_bwd_weights: aux (d of the GRU n-gate) required");
   if (ctcn_opt_recurrence_only()) return CTCN_OK;
   return rnn_bwd_gemms(cell, T, B, I, H, dirs, x, nullptr, nullptr, y, gates, aux, nullptr, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w,

@@ -190,8 +190,24 @@ class CTCLoss(_tnn.Module):
 
 
 class MaxPool2d(_tnn.Module):
+    """nn.MaxPool2d(pooling_size) of LayerCNN (model_ctc.py:52-53): stride = kernel, no padding, floor."""
+
+    def __init__(self, kernel_size, stride=None, padding=0, dilation=1, return_indices=False, ceil_mode=False):
+        super().__init__()
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        st = ks if stride is None else ((stride, stride) if isinstance(stride, int) else tuple(stride))
+        if st != ks or padding not in (0, (0, 0)) or dilation not in (1, (1, 1)) or return_indices or ceil_mode:
+            raise NotImplementedError("MaxPool2d(kernel_size) with its defaults only (model_ctc.py:53)")
+        self.kernel_size = ks
+
+    def forward(self, x):
+        return ops.max_pool2d(x, self.kernel_size)
+
+    def extra_repr(self):
+        return "kernel_size=%s" % (self.kernel_size,)
+
+
+class MaxPool1d(_tnn.Module):
     def __init__(self, *a, **k):
-        raise NotImplementedError("pooling is configured off on the reference path (ctc_config.yaml:38 `pooling: None`)")
-
-
-MaxPool1d = MaxPool2d
+        raise NotImplementedError("the Conv1d / MaxPool1d branch of LayerCNN cannot run in the reference either: CTC_Model.forward feeds "
+                                  "a 4-D tensor (model_ctc.py:148)")

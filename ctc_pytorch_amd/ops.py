@@ -352,9 +352,12 @@ class _RNNLayer(torch.autograd.Function):
         key = (dev.type, dev.index)
         if ctx.counted:
             _side["live"][key] = max(0, _side["live"].get(key, 0) - 1)
+        split_dirs = False
         if dx is None or _side["live"].get(key, 0) == 0:
-            side = False         # bottom recurrent layer: no recurrence follows; its weight GEMMs run inline on the main stream
-                                 # (whole device), which would otherwise idle while the side stream finishes the layer above
+            # bottom recurrent layer: no recurrence follows, so its weight GEMMs get the whole device -- one direction per stream
+            # (eight small dependent launches per direction that do not fill 256 CUs one at a time: 440 -> ~250 us at cfg2)
+            split_dirs = side and dirs == 2
+            side = False
         # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right
         # before that launch, behind its own small preparatory kernels, and the side stream waits for it
         above, ev = _side["deferred"].pop(key, None), None
@@ -364,8 +367,9 @@ class _RNNLayer(torch.autograd.Function):
         try:
             _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
                                       _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
-                                      null if side else _ptr(d_ih0), null if side else _ptr(d_hh0), null if side else _ptr(d_ih1),
-                                      null if side else _ptr(d_hh1), 1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
+                                      null if (side or split_dirs) else _ptr(d_ih0), null if (side or split_dirs) else _ptr(d_hh0),
+                                      null if (side or split_dirs) else _ptr(d_ih1), null if (side or split_dirs) else _ptr(d_hh1),
+                                      1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
                                       wp, wn, _lib.stream_ptr()), "rnn_bwd")
         except Exception:
             if above is not None:                       # keep the parked work for the join, drop the armed event
@@ -374,6 +378,22 @@ class _RNNLayer(torch.autograd.Function):
             raise
         if above is not None:
             above(ev)
+        if split_dirs:
+            st = _side_stream(dev)
+            prec = get_precision()
+            st.wait_stream(torch.cuda.current_stream(dev))          # (behind the layer above's weight GEMMs already queued there)
+            with torch.cuda.stream(st):
+                w2, wp2, wn2 = _ws(x, tag="side")
+                _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), null, null,
+                                                  _ptr(d_ih1), _ptr(d_hh1), 1.0, prec, 0, wp2, wn2, st.cuda_stream), "rnn_bwd_weights")
+            _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0), _ptr(d_hh0),
+                                              null, null, 1.0, prec, 0, wp, wn, _lib.stream_ptr()), "rnn_bwd_weights")
+            # (no gradient-ready hook: nothing is left to hide a collective behind; these slices go with the step-end all-reduce)
+            for t in (x, y, gates, aux):
+                if t is not None:
+                    t.record_stream(st)
+            _side["pending"][key] = st
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if side:
             st = _side_stream(dev)
             prec = get_precision()
@@ -612,6 +632,37 @@ class _Conv2d(torch.autograd.Function):
         if into_flat:
             dw = db = None
         return dx, dw, db, None, None
+
+
+class _MaxPool2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kh, kw):
+        _need_gpu(x)
+        x = _f32c(x)
+        if x.dim() != 4:
+            raise ValueError("ctc_pytorch_amd.max_pool2d: expected (B, C, H, W), got %s" % (tuple(x.shape),))
+        B, C, Hi, Wi = x.shape
+        y = torch.empty((B, C, Hi // kh, Wi // kw), dtype=torch.float32, device=x.device)
+        arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().ctcn_maxpool2d_fwd(_ptr(x), _ptr(y), _ptr(arg), B * C, Hi, Wi, kh, kw, _lib.stream_ptr()), "maxpool2d_fwd")
+        ctx.save_for_backward(arg)
+        ctx.geom = (B * C, Hi, Wi, kh, kw)
+        ctx.in_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (arg,) = ctx.saved_tensors
+        gy = _f32c(gy)
+        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=gy.device)
+        _lib.check(_lib.lib().ctcn_maxpool2d_bwd(_ptr(gy), _ptr(arg), _ptr(dx), *ctx.geom, _lib.stream_ptr()), "maxpool2d_bwd")
+        return dx, None, None
+
+
+def max_pool2d(x, kernel_size):
+    """nn.MaxPool2d(kernel_size)(x): stride = kernel, no padding, floor (model_ctc.py:52-53)."""
+    kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+    return _MaxPool2d.apply(x, int(kh), int(kw))
 
 
 def conv2d(x, w, b, stride, padding):

@@ -88,6 +88,11 @@ int ctcn_copy_strided4(const float *in, float *out, int d0, int d1, int d2, int 
 /* nn.ReLU when it is not fused into the BatchNorm apply pass (LayerCNN with batch_norm=False, model_ctc.py:64) */
 int ctcn_relu_fwd(const float *x, float *y, size_t n, void *stream);
 int ctcn_relu_bwd(const float *y, const float *dy, float *dx, size_t n, void *stream);
+/* nn.MaxPool2d(pooling_size) of LayerCNN (model_ctc.py:52-53,64-65): kernel = stride = (kh, kw), no padding, floor; x / dx are
+ * `planes` (= B*C) images of Hi x Wi, y / dy / arg of (Hi/kh) x (Wi/kw).  `arg` (one byte per output) keeps the winner's offset
+ * ki*kw + kj inside its window for the backward pass (first maximum wins, NaN replaces anything: torch's scan rule). kh*kw <= 256. */
+int ctcn_maxpool2d_fwd(const float *x, float *y, unsigned char *arg, size_t planes, int Hi, int Wi, int kh, int kw, void *stream);
+int ctcn_maxpool2d_bwd(const float *dy, const unsigned char *arg, float *dx, size_t planes, int Hi, int Wi, int kh, int kw, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Recurrent layer, bias-free, 1 layer, 1 or 2 directions, zero initial state, no packing/masking.

@@ -128,6 +128,7 @@ def gen_bn():
 # (1c) CNN front-end (LayerCNN x2 + layout shuffle, model_ctc.py:38-68,148-158)
 # ---------------------------------------------------------------------------------------------
 CNN_LAYERS = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
+POOL_LAYERS = [[(1, 8), (3, 3), (1, 2), (1, 1), (2, 1)], [(8, 8), (3, 3), (1, 2), (1, 1), (3, 1)]]
 
 
 def small_cnn_model(rnn_type=nn.LSTM, H=16, layers=1, V=12, act=nn.ReLU, drop=0.0):
@@ -298,6 +299,12 @@ def gen_models():
     b2 = synth.make_batch(seed=65, B=3, T=61, F=40, V=V, lab_lo=3, lab_hi=6)
     m = small_cnn_model(H=16, layers=2, V=V)
     print("cnn ", model_fixture("cnn_lstm2x16", m, b2, 66))
+    # (e) CNN with MaxPool2d over time (model_ctc.py:52-53; pooling widths of 1 keep the reference's rnn_input_size formula valid,
+    #     model_ctc.py:111): 121 frames -> 60 -> 20, odd sizes exercise the floor
+    b3 = synth.make_batch(seed=67, B=3, T=121, F=40, V=V, lab_lo=3, lab_hi=6)
+    cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": POOL_LAYERS}
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": 16, "rnn_layers": 2, "rnn_type": nn.LSTM, "bidirectional": True, "batch_norm": True}
+    print("pool", model_fixture("cnn_pool_lstm2x16", CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=V, drop_out=0.0), b3, 68))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -36,18 +36,22 @@ class _RnnBlock(tnn.Module):
 
 
 class _CnnBlock(tnn.Module):
-    def __init__(self, cin, cout, k, s, pad, batch_norm, p):
+    def __init__(self, cin, cout, k, s, pad, batch_norm, p, pool=None):
         super().__init__()
         self.conv = tnn.Conv2d(cin, cout, kernel_size=k, stride=s, padding=pad)
         self.batch_norm = tnn.BatchNorm2d(cout) if batch_norm else None
         self.activation = tnn.ReLU(inplace=True)
+        self.pooling = tnn.MaxPool2d(pool) if pool is not None else None        # model_ctc.py:52-53
         self.dropout = tnn.Dropout(p=p)
 
     def forward(self, x):
         x = self.conv(x)
         if self.batch_norm is not None:
             x = self.batch_norm(x)
-        return self.dropout(self.activation(x))
+        x = self.activation(x)
+        if self.pooling is not None:
+            x = self.pooling(x)
+        return self.dropout(x)
 
 
 class TorchCpuCTCModel(tnn.Module):
@@ -59,8 +63,7 @@ class TorchCpuCTCModel(tnn.Module):
             blocks = []
             cout = 1
             for n, ((cin, cout), k, s, pad, pool) in enumerate(cnn_param["layer"]):
-                assert pool is None
-                blocks.append((str(n), _CnnBlock(cin, cout, k, s, pad, cnn_param["batch_norm"], drop_out)))
+                blocks.append((str(n), _CnnBlock(cin, cout, k, s, pad, cnn_param["batch_norm"], drop_out, pool)))
                 feat = (feat + 2 * pad[1] - k[1]) // s[1] + 1
             self.conv = tnn.Sequential(OrderedDict(blocks))
             feat *= cout

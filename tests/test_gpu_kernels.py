@@ -479,6 +479,28 @@ def test_conv2d_vs_oracle(dev, case, mfma):
     assert rel_l2(wt.grad, dw_ref) < 2e-6 and rel_l2(bt.grad, db_ref) < 2e-6
 
 
+@pytest.mark.parametrize("shape,k", [((2, 3, 9, 8), (2, 2)), ((1, 2, 7, 5), (3, 1)), ((2, 1, 4, 6), (1, 3)), ((1, 1, 5, 5), (5, 5)),
+                                     ((3, 8, 121, 20), (2, 1)), ((1, 4, 16, 16), (16, 16))])
+def test_maxpool2d_vs_oracle(dev, shape, k):
+    """ctcn_maxpool2d_fwd / _bwd (nn.MaxPool2d(pooling_size) of LayerCNN, model_ctc.py:52-53) against oracle/np_ref.py (itself
+    pinned to torch's CPU op in tests/test_oracle_golden.py), bit-exact: values, the gradient routing on ties (first maximum: the
+    post-ReLU zeros of the reference path tie all the time), NaN inputs, rows / columns cut off by the floor."""
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(sum(shape) + k[0])
+    x = np.maximum(rs.standard_normal(shape), 0).astype(np.float32)          # ReLU output: many exact ties at 0
+    x.reshape(-1)[rs.randint(0, x.size, size=max(1, x.size // 40))] = np.nan
+    y_ref, arg = R.maxpool2d_fwd(x, *k)
+    dy = rs.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = R.maxpool2d_bwd(dy, arg, shape, *k)
+    xt = torch.from_numpy(x).to(dev).requires_grad_()
+    y = ops.max_pool2d(xt, k)
+    y.backward(torch.from_numpy(dy).to(dev))
+    assert np.array_equal(y.detach().cpu().numpy(), y_ref, equal_nan=True)
+    assert np.array_equal(xt.grad.cpu().numpy(), dx_ref)
+    with pytest.raises(RuntimeError):
+        ops.max_pool2d(xt, (shape[2] + 1, 1))                                  # window larger than the image
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_conv_front_golden(dev, prec):
     """(the direct convolution and BatchNorm are f32 in both modes: the same f32-strict gates hold at precision 1)"""
@@ -784,8 +806,10 @@ def _build_model(tag, dev):
         m = CTC_Model(rnn_param=dict(base, rnn_hidden_size=20, rnn_type=nn.RNN, bidirectional=False, batch_norm=False),
                       num_class=V, drop_out=0.0)
     else:
-        cnn_param = {"batch_norm": True, "activate_function": nn.ReLU,
-                     "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
+        layers = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
+        if tag == "cnn_pool_lstm2x16":           # MaxPool2d over time after each conv block (model_ctc.py:52-53)
+            layers = [[(1, 8), (3, 3), (1, 2), (1, 1), (2, 1)], [(8, 8), (3, 3), (1, 2), (1, 1), (3, 1)]]
+        cnn_param = {"batch_norm": True, "activate_function": nn.ReLU, "layer": layers}
         m = CTC_Model(add_cnn=True, cnn_param=cnn_param, rnn_param=dict(base, rnn_hidden_size=16, rnn_type=nn.LSTM),
                       num_class=V, drop_out=0.0)
     z = load("model_" + tag)
@@ -837,7 +861,7 @@ def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16"])
+@pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16", "cnn_pool_lstm2x16"])
 @pytest.mark.parametrize("flat", [True, False])
 def test_model_three_steps_golden(dev, tag, flat, prec):
     """Whole-model fixtures captured from the reference (oracle/gen_golden.py): `visualize` activations, log-probs, arg-max,

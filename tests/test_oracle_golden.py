@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import np_ref as R
 from oracle import beam_ref, synth
@@ -204,3 +205,23 @@ def test_philox_restatement_matches_random123_known_answers():
     # element i of a call with offset o uses block o + i // 4: a call shifted by one block sees the stream shifted by 4 elements
     w0, w1 = philox.dropout_words(64, 5, 10), philox.dropout_words(64, 5, 11)
     assert np.array_equal(w0[4:], w1[:-4]) and not np.array_equal(w0, w1)
+
+
+@pytest.mark.parametrize("shape,k", [((2, 3, 9, 8), (2, 2)), ((1, 2, 7, 5), (3, 1)), ((2, 1, 4, 6), (1, 3)), ((1, 1, 5, 5), (5, 5))])
+def test_maxpool_restatement_is_pinned_to_torch(shape, k):
+    """oracle/np_ref.py maxpool2d_fwd / _bwd against torch's CPU MaxPool2d (the arithmetic the reference's nn.MaxPool2d runs,
+    model_ctc.py:53): values, winner positions on ties and NaNs, and the routed gradient."""
+    rs = np.random.RandomState(3)
+    x = np.maximum(rs.standard_normal(shape), 0).astype(np.float32)
+    x.reshape(-1)[rs.randint(0, x.size, size=3)] = np.nan
+    y, arg = R.maxpool2d_fwd(x, *k)
+    xt = torch.from_numpy(x).requires_grad_()
+    yt, idx = torch.nn.functional.max_pool2d(xt, k, return_indices=True)
+    assert np.array_equal(y, yt.detach().numpy(), equal_nan=True)
+    Ho, Wo = shape[2] // k[0], shape[3] // k[1]
+    hh, ww = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing="ij")
+    flat = (hh * k[0] + arg // k[1]) * shape[3] + ww * k[1] + arg % k[1]
+    assert np.array_equal(flat, idx.numpy())
+    dy = rs.standard_normal(y.shape).astype(np.float32)
+    yt.backward(torch.from_numpy(dy))
+    assert np.array_equal(R.maxpool2d_bwd(dy, arg, shape, *k), xt.grad.numpy())
