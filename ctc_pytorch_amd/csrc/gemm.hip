@@ -17,6 +17,7 @@
 //   * XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, so the remap
 //     gives each XCD a contiguous band of M-tiles that share the same B panel in its private L2.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -699,36 +700,49 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_kernel(int M, int N, in
   };
   const int nst = Kp / 32;
   const int ml = lane & 31, g = lane >> 5;
+  // fragment loads of one 16-k half: 8 + 2*WNT ds_read_b128
+  auto load_frags = [&](const unsigned char *sb, int ks, bf16x8_t (&ah)[4], bf16x8_t (&al)[4], bf16x8_t (&bh)[WNT], bf16x8_t (&bl)[WNT]) {
+    const int cq = ks * 2 + g;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int o = qswz(wn * 32 * WNT + j * 32 + ml, cq);
+      bh[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + o);
+      bl[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + B_BYTES + o);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = qswz(wm * 128 + i * 32 + ml, cq);
+      ah[i] = *reinterpret_cast<const bf16x8_t *>(sb + o);
+      al[i] = *reinterpret_cast<const bf16x8_t *>(sb + A_BYTES + o);
+    }
+  };
+  auto multiply = [&](const bf16x8_t (&ah)[4], const bf16x8_t (&al)[4], const bf16x8_t (&bh)[WNT], const bf16x8_t (&bl)[WNT]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
   issue(0, 0);
   for (int s = 0; s < nst; ++s) {
     __syncthreads();                       // stage s has landed (the DMA is waited for here), everybody is done with stage s - 1
-    if (s + 1 < nst && !(dbg & 2)) issue((s + 1) * 32, (s + 1) & 1);
     const unsigned char *sb = qsm + (s & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int cq = ks * 2 + g;
-      bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int o = qswz(wm * 128 + i * 32 + ml, cq);
-        ah[i] = *reinterpret_cast<const bf16x8_t *>(sb + o);
-        al[i] = *reinterpret_cast<const bf16x8_t *>(sb + A_BYTES + o);
-      }
-#pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        const int o = qswz(wn * 32 * WNT + j * 32 + ml, cq);
-        bh[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + o);
-        bl[j] = *reinterpret_cast<const bf16x8_t *>(sb + 2 * A_BYTES + B_BYTES + o);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
+    // Both 16-k halves of the stage are requested from LDS up front (two register sets): the second half's reads return behind
+    // the first half's 24 MFMAs instead of behind an s_waitcnt in front of every second MFMA group (the compiler's own
+    // schedule waited nine times per stage with 2-4 reads in flight)
+    bf16x8_t ah0[4], al0[4], bh0[WNT], bl0[WNT], ah1[4], al1[4], bh1[WNT], bl1[WNT];
+    load_frags(sb, 0, ah0, al0, bh0, bl0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nst && !(dbg & 2)) issue((s + 1) * 32, (s + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(sb, 1, ah1, al1, bh1, bl1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(ah0, al0, bh0, bl0);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(ah1, al1, bh1, bl1);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -742,7 +756,194 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_kernel(int M, int N, in
           float v = acc[i][j][e];
           float *p = C + (size_t)row * ldc + col;
           if (beta != 0.0f) v += beta * *p;
-          *p = v;
+          if (dbg & 4) __builtin_nontemporal_store(v, p); else *p = v;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong schedule of the same tile (MI355X_MICROARCH.md "Two waves per SIMD"): the workgroup's two waves on a SIMD share that
+// SIMD's matrix pipe, so when all eight waves run the same phase (barrier -> LDS reads -> 48 MFMAs) the pipe idles through every
+// read / DMA-issue phase.  Here the wave halves (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; one of each per SIMD) run
+// half a 16-k step apart: while one half issues its 24 MFMAs the other fetches its next fragments from LDS and issues its share
+// of the next stage's DMA; an s_barrier separates the phases (4 per 32-k stage).  Per stage s:
+//     phase 4s     A: read fragments (s, k-half 0)                              B: multiply (s-1, 1)
+//     phase 4s+1   A: multiply (s, 0) + DMA share of stage s+1                  B: read (s, 0)
+//     phase 4s+2   A: read (s, 1), own DMA pieces landed                        B: multiply (s, 0) + DMA share of s+1
+//     phase 4s+3   A: multiply (s, 1)                                           B: read (s, 1), own DMA pieces landed
+// Buffer (s+1)&1 is rewritten from phase 4s+1 on: its last readers were phases 4s-2 (A) and 4s-1 (B); it is first read in 4s+4.
+// Same products in the same order per accumulator: bit-identical to the other plane tiles.
+// ------------------------------------------------------------------------------------------------
+// (sched_barrier: MFMAs are register-only instructions, a "memory" clobber alone lets the scheduler carry them across the barrier
+// into the other phase -- which is exactly what the phases exist to prevent)
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_barrier_vm() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int WNT>
+__global__ __launch_bounds__(512) void gemm_planes_nt256pp_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                                  const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                                  const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
+                                                                  int tiles_m, int tiles_n, int dbg) {
+  constexpr int TBM = 256, TBN = 128 * WNT;
+  constexpr int A_BYTES = TBM * 64, B_BYTES = TBN * 64;
+  constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+  constexpr int IA = TBM * 4 / 512, IB = TBN * 4 / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x16 acc[4][WNT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  unsigned offA[IA], offB[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane, row = p >> 2, chunk = (p & 3) ^ ((row >> 2) & 3);
+    offA[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)Kp + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane, row = p >> 2, chunk = (p & 3) ^ ((row >> 2) & 3);
+    offB[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)Kp + chunk * 8;
+  }
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  auto issue = [&](int k0, int buf) {
+    unsigned char *sb = qsm + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int dst = (i * 8 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ah + offA[i] + k0), (lptr_t)(sb + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Al + offA[i] + k0), (lptr_t)(sb + A_BYTES + dst), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int dst = (i * 8 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bh + offB[i] + k0), (lptr_t)(sb + 2 * A_BYTES + dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bl + offB[i] + k0), (lptr_t)(sb + 2 * A_BYTES + B_BYTES + dst), 16, 0, 0);
+    }
+  };
+  const int nst = Kp / 32;
+  const int ml = lane & 31, g = lane >> 5;
+  bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
+  // LDS byte offsets of this lane's fragments inside a stage, per 16-k half (loop-invariant)
+  int oa[2][4], ob[2][WNT];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oa[ks][i] = qswz(wm * 128 + i * 32 + ml, ks * 2 + g);
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) ob[ks][j] = 2 * A_BYTES + qswz(wn * 32 * WNT + j * 32 + ml, ks * 2 + g);
+  }
+  auto load_frags = [&](int stage, int ks) {
+    const unsigned char *sb = qsm + (stage & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      bh[j] = *reinterpret_cast<const bf16x8_t *>(sb + ob[ks][j]);
+      bl[j] = *reinterpret_cast<const bf16x8_t *>(sb + B_BYTES + ob[ks][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8_t *>(sb + oa[ks][i]);
+      al[i] = *reinterpret_cast<const bf16x8_t *>(sb + A_BYTES + oa[ks][i]);
+    }
+  };
+  // one DMA piece (1 KB) of this wave's share of a stage: n = 0 .. 2*IA + 2*IB - 1
+  auto issue_piece = [&](int n, int k0, int buf) {
+    unsigned char *sb = qsm + buf * STAGE;
+    if (n < 2 * IA) {
+      const int i = n >> 1, dst = (i * 8 + wave) * 1024;
+      if (n & 1) __builtin_amdgcn_global_load_lds((gptr_t)(Al + offA[i] + k0), (lptr_t)(sb + A_BYTES + dst), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(Ah + offA[i] + k0), (lptr_t)(sb + dst), 16, 0, 0);
+    } else {
+      const int m = n - 2 * IA, i = m >> 1, dst = (i * 8 + wave) * 1024;
+      if (m & 1) __builtin_amdgcn_global_load_lds((gptr_t)(Bl + offB[i] + k0), (lptr_t)(sb + 2 * A_BYTES + B_BYTES + dst), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(Bh + offB[i] + k0), (lptr_t)(sb + 2 * A_BYTES + dst), 16, 0, 0);
+    }
+  };
+  constexpr int NPIECE = 2 * IA + 2 * IB, NMM = 4 * WNT;
+  // 24 (12) MFMAs; with `dma` the wave's DMA pieces of the next stage are issued between them (an LDS-DMA instruction costs the
+  // issuing wave ~60 cycles among bare MFMAs and 100-185 inside a read phase: MI355X_MICROARCH.md), one piece per (i, j) tile
+  auto multiply = [&](auto dma, int k0, int buf) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          // term order per accumulator: al*bh, ah*bl, ah*bh (small terms first) -- as in the other plane tiles
+          if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          const int n = t * NMM + i * WNT + j;                 // running MFMA number; pieces after MFMAs 1, 3, 5, ...
+          if ((n & 1) && (n >> 1) < NPIECE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(dma)::value) issue_piece(n >> 1, k0, buf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+  };
+  // ONE instruction stream for both halves -- read (s,0) | multiply | read (s,1) | multiply, a barrier after each step -- which
+  // half B enters one barrier late: at every moment one half multiplies while the other reads
+  issue(0, 0);
+  pp_barrier_vm();                              // stage 0 landed
+  if (wm == 1) pp_barrier();
+  constexpr std::integral_constant<bool, true> with_dma{};
+  constexpr std::integral_constant<bool, false> no_dma{};
+  for (int s = 0; s + 1 < nst; ++s) {
+    load_frags(s, 0);
+    pp_barrier();
+    multiply(with_dma, (s + 1) * 32, (s + 1) & 1);          // + DMA share of stage s + 1 (buffer last read >= 2 steps ago by either half)
+    pp_barrier();
+    load_frags(s, 1);
+    if (dbg & 8) pp_barrier(); else pp_barrier_vm();        // own DMA pieces of stage s + 1 landed  (dbg 8: timing experiment, wrong results)
+    multiply(no_dma, 0, 0);
+    pp_barrier();
+  }
+  load_frags(nst - 1, 0);
+  pp_barrier();
+  multiply(no_dma, 0, 0);
+  pp_barrier();
+  load_frags(nst - 1, 1);
+  pp_barrier();
+  multiply(no_dma, 0, 0);
+  pp_barrier();
+  if (wm == 0) pp_barrier();                    // (half B's last multiply)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + wn * 32 * WNT + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N && (!(dbg & 1) || v_is_magic(acc[i][j][e]))) {
+          float v = acc[i][j][e];
+          float *p = C + (size_t)row * ldc + col;
+          if (beta != 0.0f) v += beta * *p;
+          if (dbg & 4) __builtin_nontemporal_store(v, p); else *p = v;
         }
       }
     }
@@ -899,7 +1100,7 @@ static int launch_planes256(hipStream_t st, int M, int N, int Kp, const unsigned
                             const unsigned short *bl, float *C, int ldc, float beta) {
   const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
   const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
-  auto kern = gemm_planes_nt256_kernel<WNT>;
+  auto kern = ctcn_get_option("gemm_pingpong") ? gemm_planes_nt256pp_kernel<WNT> : gemm_planes_nt256_kernel<WNT>;
   CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, tiles_m, tiles_n, ctcn_get_option("gemm_dbg"));
   return CTCN_OK;

@@ -57,6 +57,9 @@ int ctcn_device_xcds(void);
  * it (no separate plane pass over A; same planes, same results); 0: A is pre-split like B.
  * "conv_mfma" = 1 (default): ctcn_conv2d_fwd / _bwd run as implicit GEMMs on v_mfma_f32_16x16x4_f32 (im2col tile of 64 positions and
  * the filter matrix staged in LDS; exact float32 in both matmul precisions); 0: the direct (lane-per-position) kernels.
+ * "gemm_pingpong" = 1 (default): the 256-row bf16x3 plane tiles run the ping-pong schedule (the two waves of a SIMD half a
+ * 16-k step apart: one multiplies while the other reads its fragments; DMA pieces issued between MFMAs); 0: all waves in phase.
+ * Bit-identical results either way.
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
