@@ -36,6 +36,7 @@ static int g_opt_gemm_dbg = 0;          // development: bit 0 = 256-tile GEMM sk
 static int g_opt_gemm_a_inline = 1;     // 1: 256-row tiles split a row-major float32 A operand while staging it (no plane pass over A)
 static int g_opt_conv_mfma = 1;         // 1: Conv2d forward / dgrad / wgrad as MFMA implicit GEMMs; 0: the direct kernels
 static int g_opt_gemm_pingpong = 1;     // 1: 256-row plane tiles run the ping-pong schedule (wave halves half a k-step apart)
+static int g_opt_rnn_mixed_slices = 0;  // forward recurrence: one workgroup per CU with mixed 12- / 4-unit slices (experiment)
 static int g_opt_edit_wave = 1;         // 1: edit distance on one wavefront per utterance (anti-diagonals); 0: one lane per utterance
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 64, W*V <= 4096); 0: the generic kernel always
 static int *g_status_dev = nullptr;
@@ -52,6 +53,7 @@ extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "beam_fast")) { g_opt_beam_fast = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "conv_mfma")) { g_opt_conv_mfma = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "edit_wave")) { g_opt_edit_wave = value ? 1 : 0; return CTCN_OK; }
+  if (name && !strcmp(name, "rnn_mixed_slices")) { g_opt_rnn_mixed_slices = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_pingpong")) { g_opt_gemm_pingpong = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_a_inline")) { g_opt_gemm_a_inline = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_dbg")) { g_opt_gemm_dbg = value; return CTCN_OK; }
@@ -71,6 +73,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "beam_fast")) return g_opt_beam_fast;
   if (name && !strcmp(name, "conv_mfma")) return g_opt_conv_mfma;
   if (name && !strcmp(name, "edit_wave")) return g_opt_edit_wave;
+  if (name && !strcmp(name, "rnn_mixed_slices")) return g_opt_rnn_mixed_slices;
   if (name && !strcmp(name, "gemm_pingpong")) return g_opt_gemm_pingpong;
   if (name && !strcmp(name, "gemm_a_inline")) return g_opt_gemm_a_inline;
   if (name && !strcmp(name, "gemm_dbg")) return g_opt_gemm_dbg;

@@ -368,7 +368,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 // slices of 10 units (32 workgroups per group, one per CU, 4-byte publish pieces): 2.37 -- the flag wait (~2 100 cycles) is not
 // the doubled-up CUs, it is the poll round trip itself; slices of 4: 2.55; 1 / 3 / 4 polls in flight: 2.08 / 2.09 / 2.15 |
 // 5 waves per workgroup (16 units = 4 item waves + a communication wave of its own, 20 workgroups per group, one per CU, no
-// stragglers): flag wait 2100 -> 1500 cycles but tile loads and publish longer, 2.05 us either way.
+// stragglers): flag wait 2100 -> 1500 cycles but tile loads and publish longer, 2.05 us either way |
+// mixed slices (round 2, option "rnn_mixed_slices"): 24 x 12 + 8 x 4 units = one workgroup per CU of the XCD, no CU hosting two:
+// 2.05 vs 1.92 us -- again the one-per-CU geometry loses; two workgroups interleaving on a CU hide each other's latencies.
 // grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
 // workgroups co-resident (occupancy-checked on the host).
 // ================================================================================================
@@ -385,6 +387,7 @@ struct PersistArgs {
   int wpx;              // local mode: working workgroups per XCD
   unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)
   int hsu;              // forward: hidden units per workgroup (<= 4*NT)
+  int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
                         // gathering wave polls the block itself; 0 = stores drained, then a flag per block
@@ -560,8 +563,11 @@ __global__ __launch_bounds__(256) void rnn_fwd_persist(PersistArgs pa) {
   const int b0 = bt * 16;
   const int Bc = min(16, B - b0);
   const bool tanh_cell = cell == CTCN_CELL_TANH;
-  const int HSU = pa.hsu;                                  // hidden units owned by this workgroup (<= 4*NT; 16 for tanh)
-  const int j0 = slice * HSU;
+  // hidden units owned by this workgroup (<= 4*NT; 16 for tanh).  Mixed slices: one workgroup per CU of the XCD with a few light
+  // ones (e.g. H = 320 on 32 CUs: 24 x 12 + 8 x 4 units) instead of 40 equal slices of which 16 share 8 CUs and set the period
+  const bool small_slice = pa.nbig > 0 && slice >= pa.nbig;
+  const int HSU = small_slice ? pa.hsu_small : pa.hsu;
+  const int j0 = small_slice ? pa.nbig * pa.hsu + (slice - pa.nbig) * pa.hsu_small : slice * pa.hsu;
   const float *W = d == 0 ? p.w0 : p.w1;
   const int kb = wave * 16 * KQ4 + q * 4;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -1747,26 +1753,31 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
     // candidates in order of preference: XCD-local hand-off (each group's slices on one XCD, through its L2) with
     // 8 / 12 / 16 / 4 hidden units per workgroup -- fewer units = less matmul per step, but the group must stay
     // co-resident on one XCD -- then the device-scope hand-off.  The first one that is co-resident runs.
-    struct Cand { int mode, hsu; };
-    Cand cands[6];
+    struct Cand { int mode, hsu, nbig, hsu_small; };
+    Cand cands[8];
     int nc = 0;
     const int nxd = ctcn_opt_handoff() ? ctcn_device_xcds() : 1;
     if (cell == CTCN_CELL_TANH) {
-      if (nxd > 1) cands[nc++] = {1, 16};
-      cands[nc++] = {0, 16};
+      if (nxd > 1) cands[nc++] = {1, 16, 0, 0};
+      cands[nc++] = {0, 16, 0, 0};
     } else {
       if (nxd > 1) {
-        if (H % 8 == 0) cands[nc++] = {1, 8};
-        cands[nc++] = {1, 12}; cands[nc++] = {1, 16}; cands[nc++] = {1, 4};
+        // mixed slices: a 12-unit and b 4-unit workgroups, a + b = CUs of one XCD, 12 a + 4 b = H
+        const int cpx = ctcn_device_cus() / nxd, nbig = (H - 4 * cpx) / 8;
+        if (ctcn_get_option("rnn_mixed_slices") && H % 8 == 0 && (H - 4 * cpx) % 8 == 0 && nbig > 0 && nbig <= cpx && ceil_div(dirs * ceil_div(B, 16), nxd) == 1)
+          cands[nc++] = {1, 12, nbig, 4};
+        if (H % 8 == 0) cands[nc++] = {1, 8, 0, 0};
+        cands[nc++] = {1, 12, 0, 0}; cands[nc++] = {1, 16, 0, 0}; cands[nc++] = {1, 4, 0, 0};
       }
-      cands[nc++] = {0, H % 8 == 0 ? 8 : 4};
+      cands[nc++] = {0, H % 8 == 0 ? 8 : 4, 0, 0};
     }
     const char *why = kq > 8 ? "hidden size above 512" : "no candidate geometry is co-resident on this device";
     for (int ci = 0; ci < nc && kq <= 8; ++ci) {
       const int mode = cands[ci].mode, HSU = cands[ci].hsu;
       const int nx = mode ? nxd : 1;
       const int NT = cell == CTCN_CELL_TANH ? 1 : ceil_div(HSU, 4);
-      const int nsl = ceil_div(H, HSU);
+      const int nbig = cands[ci].nbig, hsu_small = cands[ci].hsu_small;
+      const int nsl = nbig ? nbig + (H - nbig * HSU) / hsu_small : ceil_div(H, HSU);
       const int wpx = ceil_div(groups, nx) * nsl;
       const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : dim3(nsl, dirs, nbt);
       const int prec = precision == 1 && HSU % 4 == 0 && H % 8 == 0 ? 1 : 0;       // bf16x3 recurrent matmul
@@ -1781,6 +1792,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
       pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
+      pa.nbig = nbig; pa.hsu_small = hsu_small;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
@@ -1944,7 +1956,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
       pa.spin_limit = 1 << 22;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
+      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;

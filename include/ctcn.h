@@ -60,6 +60,8 @@ int ctcn_device_xcds(void);
  * "gemm_pingpong" = 1 (default): the 256-row bf16x3 plane tiles run the ping-pong schedule (the two waves of a SIMD half a
  * 16-k step apart: one multiplies while the other reads its fragments; DMA pieces issued between MFMAs); 0: all waves in phase.
  * Bit-identical results either way.
+ * "rnn_mixed_slices" = 0 (default): 1 = forward persistent recurrence with one workgroup per CU of an XCD and mixed 12- / 4-unit
+ * slices (measured slower than 40 equal slices at H = 320; kept as an experiment switch).
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
