@@ -924,6 +924,7 @@ bool launch_fwd_persist_p(int nt, int kq4, dim3 grid, size_t lds, hipStream_t st
 }
 bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStream_t st, const PersistArgs &a, int wpx) {
   if (prec && a.a.cell == CTCN_CELL_LSTM) return launch_fwd_persist_p<1, CTCN_CELL_LSTM>(nt, kq4, grid, lds, st, a, wpx);
+  if (prec && a.a.cell == CTCN_CELL_GRU) return launch_fwd_persist_p<1, CTCN_CELL_GRU>(nt, kq4, grid, lds, st, a, wpx);
   return prec ? launch_fwd_persist_p<1, -1>(nt, kq4, grid, lds, st, a, wpx) : launch_fwd_persist_p<0, -1>(nt, kq4, grid, lds, st, a, wpx);
 }
 
