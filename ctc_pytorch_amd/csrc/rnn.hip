@@ -387,6 +387,7 @@ struct PersistArgs {
   int wpx;              // local mode: working workgroups per XCD
   unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)
   int hsu;              // forward: hidden units per workgroup (<= 4*NT)
+  int poll_delay;       // rnn_fwd_tagged: 64-cycle sleeps between the barrier and an exchange wave's first poll of a step
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
@@ -926,6 +927,259 @@ bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStr
   if (prec && a.a.cell == CTCN_CELL_LSTM) return launch_fwd_persist_p<1, CTCN_CELL_LSTM>(nt, kq4, grid, lds, st, a, wpx);
   if (prec && a.a.cell == CTCN_CELL_GRU) return launch_fwd_persist_p<1, CTCN_CELL_GRU>(nt, kq4, grid, lds, st, a, wpx);
   return prec ? launch_fwd_persist_p<1, -1>(nt, kq4, grid, lds, st, a, wpx) : launch_fwd_persist_p<0, -1>(nt, kq4, grid, lds, st, a, wpx);
+}
+
+// ================================================================================================
+// Persistent forward recurrence, TAGGED GATHER (round 2; precision 1, LSTM / GRU, H % 32 == 0, XCD-local placement).
+//
+// rnn_fwd_persist hands h_t over with data + flag: the publishing wave drains its stores, raises a flag, the consumers poll the
+// flags, pass a barrier and only then fetch the tile -- three L2 trips in series per timestep (store acknowledge, flag
+// store -> poll, operand load).  Here the structure of rnn_bwd_scatter is applied to the forward product:
+//   * a workgroup owns 16 hidden units (4 gates each) of one 16-row batch tile; 1024 threads.  Waves 0..3 hold the 256 (row, unit)
+//     items -- gate math, ALL reserve traffic, and the publish: each item stores ONE dword {bf16 hi | bf16 lo << 16} of its h_t
+//     straight into the group's tile, with the step tag in the LSB of lo (bit 16).  No drain, no flag;
+//   * waves 4..15 are exchange waves: wave 4 + g owns the 32-k blocks g, g + 12 of the contraction.  It re-reads its 2-KB block
+//     (two coalesced 1-KB loads in MFMA-B lane order) until all 8 dwords of every lane carry the tag of the step -- the polled
+//     registers ARE the operand: two v_perm per dword pair split them into the hi / lo fragments, 12 v_mfma_f32_16x16x32_bf16
+//     per block multiply them by the wave's resident W_hh fragments (4 tiles = 16 units x 4 gates, C = W h^T), the four partial
+//     tiles are parked in LDS;
+//   * ONE barrier per step (parked partials -> items).  The items' publish needs none: the exchange waves learn of it through L2.
+// A torn or stale block (any granularity down to a dword) is simply read again; the parity buffers start zeroed and the tag
+// alternates between the two uses of a buffer, as in rnn_bwd_scatter.  The tag costs the LSB of lo: h is carried to 2^-16
+// relative instead of 2^-17 (the saved y stays the exact float32 value).  Layout of the tile: [32-k block][half][octet q][row][4
+// dwords]: unit u of a block sits at octet u >> 3, half (u >> 2) & 1, dword u & 3, so each of a lane's two 16-B loads is one
+// fully coalesced 1-KB wave load.
+// Measured (tools/mb_step.hip, cfg2 layer, us per step; the flag kernel = 2.00 in the same run): THIS, one poll in flight, first poll
+// 8 x 64 cycles after the barrier: 1.60-1.65 (a poll round trip is ~600 cycles, 1.4 polls per step; no delay 1.66-1.74, >= 12 sleeps
+// 1.78-1.89) | two polls in flight 1.76 | sentinel spin (one dword per producing store instruction, then one full fetch) 1.86 | a flag
+// wave (item waves raise undrained words behind their publish, one idle wave polls them and releases the exchange waves through LDS,
+// tags stay the proof of arrival): 2.14-2.23 -- the words show up ~2 000 cycles after the publish although every block is then valid
+// on its first fetch | first poll timed from the workgroup's OWN publish (LDS counter) + 2..12 sleeps: every block valid on the first
+// fetch, but polls that coincide with the publishes of the whole XCD take 1 000-1 350 cycles instead of ~600: 1.71-1.93.
+// ================================================================================================
+template <int NBW, int CELL>
+__global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
+  constexpr int NGW = 12, NMT = 4;                           // exchange waves, MFMA tiles (4 units x 4 gates each) per workgroup
+  constexpr int PQ = 17;                                     // parked slots per (tile, unit) row: 16 batch rows + 1 (bank spread)
+  const RnnArgs &p = pa.a;
+  __shared__ __attribute__((aligned(16))) float red[NGW * NMT * 4 * PQ * 4];
+  __shared__ int s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  constexpr int G = CELL == CTCN_CELL_LSTM ? 4 : 3;
+  const int H = p.H, D = p.D, B = p.B, T = p.T;
+  const PersistRole role = persist_role(pa, D, &s_ticket);
+  if (!role.active) return;
+  const int d = role.d, bt = role.bt, nbt = pa.nbt, slice = role.slice;
+  const int b0 = bt * 16, j0 = slice * 16;
+  const int Bc = min(16, B - b0);
+  const float *W = d == 0 ? p.w0 : p.w1;
+  const int nblk = H >> 5;
+  const int gw = wave - 4;
+
+  // exchange waves: W_hh fragments (first MFMA operand) of this lane for its blocks: tile mt, row r = (unit mt*4 + (r >> 2), gate r & 3)
+  bf16x8_t whi[NBW][NMT], wlo[NBW][NMT];
+#pragma unroll
+  for (int bw = 0; bw < NBW; ++bw) {
+    // block of slot (wave, bw), rotated by the slice number: the workgroups of a group walk the tile in different orders
+    const int slot = gw + NGW * bw, blk = slot < nblk ? (slot + slice) % nblk : nblk;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+      const int gate = r & 3, jj = mt * 4 + (r >> 2);
+      const bool wv = wave >= 4 && blk < nblk && gate < G && (j0 + jj) < H;
+      load_w8(wv ? W + (size_t)(gate * H + j0 + jj) * H : nullptr, 32 * blk + 8 * q, H, whi[bw][mt], wlo[bw][mt]);
+    }
+  }
+  const size_t tile_b1 = (size_t)nblk * 2048;                                              // bytes per h tile
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_b1), 0x00020000);
+  const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_b1), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_b1)};
+
+  // item of this thread (waves 0..3): row bl, unit jl of the slice; c / h of the unit stay in a register
+  const int bl = (tid >> 4) & 15, jl = tid & 15, j = j0 + jl, b = b0 + bl;
+  const bool item = tid < 256 && bl < Bc && j < H;
+  float state = 0.0f;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  const long slab_g = (long)B * D * G * H, slab_h = (long)B * D * H;
+  const int bcl = min(b, B - 1), jcl = min(j, H - 1);
+  const unsigned vg0 = (unsigned)(((bcl * D + d) * (G * H) + jcl) * 4);
+  const unsigned vg1 = vg0 + (unsigned)(H * 4), vg2 = vg0 + (unsigned)(2 * H * 4), vg3 = vg0 + (unsigned)(min(3, G - 1) * H * 4);
+  const unsigned vh = (unsigned)(((bcl * D + d) * H + jcl) * 4);
+  const __amdgpu_buffer_rsrc_t rg = whole_rsrc(p.gates, (size_t)T * slab_g), ra = whole_rsrc(p.aux, (size_t)T * slab_h), ry = whole_rsrc(p.y, (size_t)T * slab_h);
+  const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);
+  // the item's dword in the published tile: block j >> 5, unit u = j & 31 -> [half (u>>2)&1][octet u>>3][row][dword u&3]
+  const unsigned pub_off = (unsigned)((j >> 5) * 2048 + (((((j >> 2) & 1) * 4 + ((j & 31) >> 3)) * 16 + bl) * 4 + (j & 3)) * 4);
+  if (item) {
+    const unsigned o = (unsigned)(d == 0 ? 0 : T - 1) * sg_b;
+    pre[0] = ld_slab(rg, vg0, o); pre[1] = ld_slab(rg, vg1, o); pre[2] = ld_slab(rg, vg2, o);
+    if (G == 4) pre[3] = ld_slab(rg, vg3, o);
+  }
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#ifdef CTCN_PERSIST_STATS
+  long long zx[4] = {0, 0, 0, 0}, zi[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64(), z_prev = zt0, zq = 0;
+#endif
+
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? s : T - 1 - s;
+#ifdef CTCN_PERSIST_STATS
+    const long long z_a = clock64();
+    long long z_p = z_a, z_m = z_a;
+#endif
+    if (wave >= 4) {
+      f32x4 acc[NMT];
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) acc[mt] = zero;
+      if (s > 0) {
+        const int par = (s - 1) & 1;
+        const unsigned tb = (((((unsigned)(s - 1)) >> 1) & 1u) ^ 1u) << 16;
+        // nothing can arrive before the items have done their sums and gate math and the stores have crossed L2: polls issued
+        // earlier only load the L2 channels the publishes are about to need
+        for (int i = 0; i < pa.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int bw = 0; bw < NBW; ++bw) {
+          const int slot = gw + NGW * bw, blk = slot < nblk ? (slot + slice) % nblk : nblk;
+          if (blk < nblk) {
+            const unsigned boff = tile_b[par] + (unsigned)(blk * 2048 + lane * 16);
+            u32x4 v0, v1;
+            auto valid = [&](const u32x4 &a0, const u32x4 &a1) {
+              const unsigned all1 = a0.x & a0.y & a0.z & a0.w & a1.x & a1.y & a1.z & a1.w;
+              const unsigned any1 = a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w;
+              const bool okl = ((all1 & 0x10000u) == tb) && ((any1 & 0x10000u) == tb);
+              return __builtin_amdgcn_ballot_w64(okl) == ~0ull;
+            };
+            for (int spins = 0;; ++spins) {
+#ifdef CTCN_PERSIST_STATS
+              const long long z_q0 = clock64();
+#endif
+              v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 16);
+              v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, boff + 1024, 0, 16);
+#ifdef CTCN_PERSIST_STATS
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+              zx[3] += clock64() - z_q0; zq += 1;
+#endif
+              if (valid(v0, v1)) break;
+              if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (pa.status) atomicCAS(pa.status, 0, 111);             // give up: the launch finishes with a poisoned output
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+#ifdef CTCN_PERSIST_STATS
+            z_p = clock64();
+#endif
+            // split the {hi | lo << 16} dwords into the two MFMA fragments (8 consecutive k per lane), tag bits cleared
+            Bf16Pack fh, fl;
+            fh.u = (u32x4){__builtin_amdgcn_perm(v0.y, v0.x, 0x05040100u), __builtin_amdgcn_perm(v0.w, v0.z, 0x05040100u),
+                           __builtin_amdgcn_perm(v1.y, v1.x, 0x05040100u), __builtin_amdgcn_perm(v1.w, v1.z, 0x05040100u)};
+            fl.u = (u32x4){__builtin_amdgcn_perm(v0.y, v0.x, 0x07060302u) & 0xFFFEFFFEu, __builtin_amdgcn_perm(v0.w, v0.z, 0x07060302u) & 0xFFFEFFFEu,
+                           __builtin_amdgcn_perm(v1.y, v1.x, 0x07060302u) & 0xFFFEFFFEu, __builtin_amdgcn_perm(v1.w, v1.z, 0x07060302u) & 0xFFFEFFFEu};
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[bw][mt], fl.v, acc[mt], 0, 0, 0);   // small terms first
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[bw][mt], fh.v, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[bw][mt], fh.v, acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // park: slot (wave, tile, unit q, row r) = the four gates of unit mt*4 + q for batch row r
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) *reinterpret_cast<f32x4 *>(red + ((((gw * NMT + mt) * 4 + q) * PQ + r) << 2)) = acc[mt];
+#ifdef CTCN_PERSIST_STATS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      z_m = clock64();
+#endif
+    }
+    lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+    const long long z_b = clock64();
+    if (wave >= 4) { zx[0] += z_p - z_a; zx[1] += z_m - z_p; zx[2] += z_b - z_m; }
+    long long z_i1 = z_b, z_i2 = z_b, z_i3 = z_b;
+#endif
+    if (wave < 4) {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      const float *rp = red + ((((jl >> 2) * 4 + (jl & 3)) * PQ + bl) << 2);
+#pragma unroll
+      for (int w = 0; w < NGW; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + ((w * NMT * 4 * PQ) << 2));
+        o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+      }
+#ifdef CTCN_PERSIST_STATS
+      if (o[0] + o[1] + o[2] + o[3] == 12345.678f) zi[5] += 1;
+      z_i1 = clock64();
+#endif
+      float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f, sv3 = 0.f, sv4 = 0.f, hval = 0.f;
+      if (item) {
+        if constexpr (CELL == CTCN_CELL_LSTM) {
+          const float i_ = act_sigmoid(o[0] + pre[0]);
+          const float f_ = act_sigmoid(o[1] + pre[1]);
+          const float g_ = act_tanh(o[2] + pre[2]);
+          const float o_ = act_sigmoid(o[3] + pre[3]);
+          const float c = f_ * state + i_ * g_;
+          hval = o_ * act_tanh(c);
+          state = c;
+          sv0 = i_; sv1 = f_; sv2 = g_; sv3 = o_; sv4 = c;
+        } else {
+          const float hn = o[2];
+          const float r_ = act_sigmoid(o[0] + pre[0]);
+          const float z_ = act_sigmoid(o[1] + pre[1]);
+          const float n_ = act_tanh(pre[2] + r_ * hn);
+          hval = (1.0f - z_) * n_ + z_ * state;
+          state = hval;
+          sv0 = r_; sv1 = z_; sv2 = n_; sv4 = hn;
+        }
+      }
+#ifdef CTCN_PERSIST_STATS
+      if (hval == 12345.678f) zi[5] += 1;
+      z_i2 = clock64();
+#endif
+      if (s + 1 < T) {             // publish (every lane of the item waves: rows / units nobody owns publish a tagged 0)
+        const unsigned hi = f2bf(hval);
+        const unsigned lo = f2bf(hval - __uint_as_float(hi << 16));
+        const unsigned tbit = ((((unsigned)s) >> 1) & 1u) ^ 1u;
+        const unsigned word = hi | (((lo & ~1u) | tbit) << 16);
+        __builtin_amdgcn_raw_buffer_store_b32(word, rs, tile_b[s & 1] + pub_off, 0, 0);   // write-back into this XCD's L2
+      }
+#ifdef CTCN_PERSIST_STATS
+      z_i3 = clock64();
+#endif
+      // reserve traffic, behind the publish in this wave's queue: saved activations, c / hn, y out; next step's pre-activations in
+      const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
+      const unsigned on = (unsigned)(s + 1 < T ? (d == 0 ? t + 1 : t - 1) : t) * sg_b;
+      if (item) {
+        st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2);
+        if constexpr (CELL == CTCN_CELL_LSTM) st_slab(rg, vg3, og, sv3);
+        st_slab(ra, vh, oh, sv4);
+        st_slab(ry, vh, oh, hval);
+        pre[0] = ld_slab(rg, vg0, on); pre[1] = ld_slab(rg, vg1, on); pre[2] = ld_slab(rg, vg2, on);
+        if constexpr (CELL == CTCN_CELL_LSTM) pre[3] = ld_slab(rg, vg3, on);
+      }
+#ifdef CTCN_PERSIST_STATS
+      { const long long z_e = clock64(); zi[0] += z_b - z_prev; zi[1] += z_i1 - z_b; zi[2] += z_i2 - z_i1; zi[3] += z_i3 - z_i2; zi[4] += z_e - z_i3; z_prev = z_e; }
+#endif
+    }
+  }
+#ifdef CTCN_PERSIST_STATS
+  if (pa.stats && slice == 3 && d == 0 && bt == 0 && tid == 4 * 64) { pa.stats[0] = zx[0]; pa.stats[1] = zx[1]; pa.stats[2] = zx[2]; pa.stats[3] = clock64() - zt0; pa.stats[4] = zx[3]; pa.stats[5] = zq; }
+  if (pa.stats && slice == 3 && d == 0 && bt == 0 && tid == 0) for (int i = 0; i < 5; ++i) pa.stats[8 + i] = zi[i];
+#endif
+  const bool bad = pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (bad && item)             // a hand-off timed out: poison the whole output column (see rnn_fwd_persist)
+    for (int tt = 0; tt < T; ++tt) st_slab(ry, vh, (unsigned)tt * sh_b, __uint_as_float(0x7fc00000u));
+}
+
+template <int CELL>
+bool launch_fwd_tagged_c(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  switch (nbw) {
+    case 1: return launch_resident(rnn_fwd_tagged<1, CELL>, grid, 1024, 0, st, a, wpx);
+    case 2: return launch_resident(rnn_fwd_tagged<2, CELL>, grid, 1024, 0, st, a, wpx);
+    default: return false;
+  }
+}
+bool launch_fwd_tagged(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  if (a.a.cell == CTCN_CELL_LSTM) return launch_fwd_tagged_c<CTCN_CELL_LSTM>(nbw, grid, st, a, wpx);
+  if (a.a.cell == CTCN_CELL_GRU) return launch_fwd_tagged_c<CTCN_CELL_GRU>(nbw, grid, st, a, wpx);
+  return false;
 }
 
 // ================================================================================================
@@ -1773,6 +2027,31 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       cands[nc++] = {0, H % 8 == 0 ? 8 : 4, 0, 0};
     }
     const char *why = kq > 8 ? "hidden size above 512" : "no candidate geometry is co-resident on this device";
+    // first choice: the tagged gather (rnn_fwd_tagged): 16-unit slices, 1024-thread workgroups, XCD-local, precision 1, LSTM / GRU
+    if (ctcn_get_option("rnn_fwd_tagged") && precision == 1 && cell != CTCN_CELL_TANH && H % 32 == 0 && H / 32 <= 24 && nxd > 1) {
+      const int nsl = H / 16, wpx = ceil_div(groups, nxd) * nsl;
+      const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (H / 32) * 2048, 256), fl_bytes = 512;
+      if (ws && ws_bytes >= hx_bytes + fl_bytes + 512) {
+        PersistArgs pa;
+        pa.a = a;
+        char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
+        pa.hx = (float *)tail;
+        pa.flags = (unsigned *)(tail + hx_bytes);
+        pa.status = ctcn_status_word();
+        pa.spin_limit = 1 << 22;
+        pa.local = 1; pa.nx = nxd; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
+        pa.poll_depth = 1; pa.tagmode = 1; pa.poll_delay = ctcn_get_option("tag_poll_delay");
+        pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
+#ifdef CTCN_PERSIST_STATS
+        pa.stats = nullptr;
+#endif
+        CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | role tickets
+        if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
+          CTCN_LAUNCH_CHECK();
+          return CTCN_OK;
+        }
+      }
+    }
     for (int ci = 0; ci < nc && kq <= 8; ++ci) {
       const int mode = cands[ci].mode, HSU = cands[ci].hsu;
       const int nx = mode ? nxd : 1;

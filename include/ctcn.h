@@ -60,6 +60,10 @@ int ctcn_device_xcds(void);
  * "gemm_pingpong" = 1 (default): the 256-row bf16x3 plane tiles run the ping-pong schedule (the two waves of a SIMD half a
  * 16-k step apart: one multiplies while the other reads its fragments; DMA pieces issued between MFMAs); 0: all waves in phase.
  * Bit-identical results either way.
+ * "rnn_fwd_tagged" = 1 (default): forward persistent recurrence as a tagged gather (rnn_fwd_tagged: no flags, no store drain; the
+ * h_t dwords carry the step tag and the gathering waves poll the data itself) where it applies -- precision 1, LSTM / GRU, H % 32 == 0,
+ * XCD-local placement; 0: the flag + data kernel (rnn_fwd_persist) everywhere.  "tag_poll_delay" = 8: 64-cycle sleeps between the
+ * step barrier and a gathering wave's first poll.
  * "rnn_mixed_slices" = 0 (default): 1 = forward persistent recurrence with one workgroup per CU of an XCD and mixed 12- / 4-unit
  * slices (measured slower than 40 equal slices at H = 320; kept as an experiment switch).
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);

@@ -162,7 +162,7 @@ int main() {
     for (auto &c : cfgs) {
       if (c.local && nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
-      pa.poll_depth = c.pd; pa.local = c.local; pa.nx = c.local ? nx : 1; pa.nbt = nbt; pa.hsu = c.hsu; pa.nsl = (H + c.hsu - 1) / c.hsu;
+      pa.nbig = 0; pa.hsu_small = 0; pa.poll_delay = 0; pa.poll_depth = c.pd; pa.local = c.local; pa.nx = c.local ? nx : 1; pa.nbt = nbt; pa.hsu = c.hsu; pa.nsl = (H + c.hsu - 1) / c.hsu;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
       dim3 gp = c.local ? dim3(pa.nx * (wpx + 4), 1, 1) : dim3(pa.nsl, D, nbt);
@@ -195,6 +195,27 @@ int main() {
       printf("    gate math+publish split: wait for gate math (hpub barrier) %.0f | convert + issue stores %.0f | drain %.0f | flag + tail %.0f\n",
              (double)h[6] / T, (double)h[7] / T, (double)h[8] / T, (double)h[9] / T);
       printf("    item wave 0: partial sums (4 x 16-B LDS reads) %.0f | gate math + split + hpub writes %.0f\n", (double)h[10] / T, (double)h[11] / T);
+    }
+    for (int pd : {0, 8}) {   // tagged-gather forward (round 2): 64-cycle sleeps before the first poll of a step
+      if (nx <= 1) break;
+      PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
+      pa.poll_depth = 1; pa.poll_delay = pd; pa.local = 1; pa.nx = nx; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.nsl = H / 16; pa.tagmode = 1;
+      const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
+      pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
+      dim3 gp = dim3(pa.nx * (wpx + 4), 1, 1);
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemsetAsync(flags, 0, fl_bytes, st)); CK(hipMemsetAsync(status, 0, 4, st)); CK(hipMemsetAsync(hx, 0, hx_bytes, st));
+        hipEventRecord(e0, st);
+        hipLaunchKernelGGL((rnn_fwd_tagged<1, 0>), gp, dim3(1024), 0, st, pa);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+      }
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      int hs = -1; CK(hipMemcpy(&hs, status, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
+      printf("fwd TAGGED GATHER poll delay=%d  %3d slices/group   %8.2f us/step   (status %d)\n", pd, pa.nsl, ms * 1e3 / T, hs);
+      printf("  per step (cycles), slice 3, exchange wave 4: poll until the block is valid %.0f | perm + 12 mfma + park %.0f | barrier wait %.0f | total %.0f   [%.2f full polls per step, %.0f cycles per poll round trip]\n",
+             (double)h[0] / T, (double)h[1] / T, (double)h[2] / T, (double)h[3] / T, (double)h[5] / T, (double)h[4] / (double)(h[5] ? h[5] : 1));
+      printf("  item wave 0: wait for the barrier %.0f | 12 partial reads + sums %.0f | gate math %.0f | split + publish issue %.0f | reserve issue %.0f\n",
+             (double)h[8] / T, (double)h[9] / T, (double)h[10] / T, (double)h[11] / T, (double)h[12] / T);
     }
     for (int lp = 0; lp < 3; ++lp) {
       const int local = 1, prec = 1, pd = 2, scatter = lp;
