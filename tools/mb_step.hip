@@ -218,10 +218,10 @@ int main() {
              (double)h[8] / T, (double)h[9] / T, (double)h[10] / T, (double)h[11] / T, (double)h[12] / T);
     }
     for (int lp = 0; lp < 3; ++lp) {
-      const int local = 1, prec = 1, pd = 2, scatter = lp;
+      const int local = 1, prec = 1, pd = 2, scatter = lp, bdelay = 0;
       if (nx <= 1) continue;
       PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
-      pa.poll_depth = pd; pa.local = local; pa.nx = nx; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
+      pa.poll_depth = pd; pa.poll_delay = bdelay; pa.nbig = 0; pa.hsu_small = 0; pa.local = local; pa.nx = nx; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
       dim3 gp = dim3(pa.nx * (wpx + 4), 1, 1);
@@ -244,7 +244,7 @@ int main() {
                (double)h[wv * 8 + 4] / T, (double)h[wv * 8 + 5] / T, (double)h[wv * 8 + 6] / T);
       if (scatter) printf("    item wave, inside 'item sum+math+stage+barrier': partial sum (12 LDS reads) %.0f | gate math + stage writes %.0f | barrier wait %.0f\n",
                           (double)h[16] / T, (double)h[17] / T, (double)h[18] / T);
-      printf("bwd PERSISTENT %s   %8.2f us/step   (status %d)\n", scatter == 2 ? "scatter tagged" : scatter ? "scatter flags" : "gather", ms * 1e3 / T, hs);
+      printf("bwd PERSISTENT %s delay %d  %8.2f us/step   (status %d)\n", scatter == 2 ? "scatter tagged" : scatter ? "scatter flags" : "gather", bdelay, ms * 1e3 / T, hs);
     }
   }
   // graph replay of the forward loop: is the host the limiter?
