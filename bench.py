@@ -277,7 +277,8 @@ def run_train(args):
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 3.0
         # the roofline object describes the DOMINANT kernel: whichever recurrence (forward / backward) is the longer launch
         fwd_dom = rec["kernel_fwd_us"] >= rec["kernel_bwd_us"]
-        kname, kus, kstep = (("rnn_fwd_persist", rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
+        fwd_name = "rnn_fwd_tagged" if (args.precision == 1 and c["rnn"] != "RNN" and c["H"] % 32 == 0 and _ops.get_option("rnn_fwd_tagged")) else "rnn_fwd_persist"
+        kname, kus, kstep = ((fwd_name, rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
                              ("rnn_bwd_scatter", rec["kernel_bwd_us"], rec["bwd_us_per_timestep"]))
         tf = rec["algorithmic_flops_per_launch"] / (kus * 1e-6) / 1e12
         res["roofline"] = dict(kernel="%s (%s recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (

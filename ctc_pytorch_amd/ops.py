@@ -71,6 +71,11 @@ def set_option(name, value):
     _lib.check(_lib.lib().ctcn_set_option(name.encode(), int(value)), "set_option")
 
 
+def get_option(name):
+    """Raw ctcn_get_option."""
+    return int(_lib.lib().ctcn_get_option(name.encode()))
+
+
 def check_health(device=None):
     """Synchronising check of the sticky status word written by persistent kernels on a hand-off timeout."""
     _lib.check_status(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
