@@ -956,6 +956,12 @@ bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStr
 // tags stay the proof of arrival): 2.14-2.23 -- the words show up ~2 000 cycles after the publish although every block is then valid
 // on its first fetch | first poll timed from the workgroup's OWN publish (LDS counter) + 2..12 sleeps: every block valid on the first
 // fetch, but polls that coincide with the publishes of the whole XCD take 1 000-1 350 cycles instead of ~600: 1.71-1.93.
+// The reserve traffic of the item waves is paced by accident: inside the wave-role branch hipcc keeps the (uniform) timestep offsets in
+// VGPRs and wraps each of the ten buffer instructions in a waterfall loop (~890 cycles of issue per step).  With scalar offsets
+// (readfirstlane) the ten instructions of 80 item waves per XCD reach L2 together with the publishes: 1.83; scalar offsets + an
+// explicit pause of 16-32 x 64 cycles before them: poll round trip 300-430 cycles instead of 600, but 1.64-1.69 overall (the step is
+// set by the slowest of the ten exchange waves, a ~1 000-cycle tail); the same + pre-activations fetched two steps ahead into
+// alternating register sets (as rnn_bwd_scatter does): 1.76-1.93.  Left as it is.
 // ================================================================================================
 template <int NBW, int CELL>
 __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
