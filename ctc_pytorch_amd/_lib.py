@@ -62,6 +62,7 @@ _SIGS = {
     "ctcn_log_softmax_bwd": (I, [P, P, P, I, I, P]),
     "ctcn_argmax": (I, [P, P, I, I, P]),
     "ctcn_set_prelaunch_event": (I, [P]),
+    "ctcn_set_fwd_overlap": (I, [P, P, P, Z, ctypes.c_uint]),
     "ctcn_ctc_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ctcn_ctc_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "ctcn_ctc_fwd_both": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),

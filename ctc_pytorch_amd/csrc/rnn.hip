@@ -388,6 +388,8 @@ struct PersistArgs {
   unsigned *tickets;    // local mode: nx zeroed counters (role tickets per XCD)
   int hsu;              // forward: hidden units per workgroup (<= 4*NT)
   int poll_delay;       // rnn_fwd_tagged: 64-cycle sleeps between the barrier and an exchange wave's first poll of a step
+  int chunk_T, nchunk;  // rnn_fwd_tagged, pipelined input projection: frames per time chunk (0 = all pre-activations are there at launch)
+  unsigned *chunk_ready; //   ... and the counter the side stream raises after each chunk PAIR (p covers chunks p and nchunk-1-p)
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
@@ -1020,6 +1022,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
     if (G == 4) pre[3] = ld_slab(rg, vg3, o);
   }
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  int have_chunks = 0;                                         // chunk pairs known to be complete (pair 0 is computed before the launch)
   __syncthreads();
 #ifdef CTCN_PERSIST_STATS
   long long zx[4] = {0, 0, 0, 0}, zi[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64(), z_prev = zt0, zq = 0;
@@ -1152,6 +1155,22 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       // reserve traffic, behind the publish in this wave's queue: saved activations, c / hn, y out; next step's pre-activations in
       const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
       const unsigned on = (unsigned)(s + 1 < T ? (d == 0 ? t + 1 : t - 1) : t) * sg_b;
+      if (pa.chunk_T > 0 && s + 1 < T) {
+        // pipelined input projection: the pre-activations of the time chunk the next step falls into are written by a GEMM on the
+        // side stream (other XCDs) while this kernel runs; chunk pair p is complete once the counter shows p
+        const int tn = d == 0 ? t + 1 : t - 1, c = tn / pa.chunk_T, need = min(c, pa.nchunk - 1 - c);
+        if (need > have_chunks) {
+          for (int spins = 0;; ++spins) {
+            have_chunks = (int)__hip_atomic_load(pa.chunk_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (have_chunks >= need) break;
+            if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              if (pa.status) atomicCAS(pa.status, 0, 112);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+      }
       if (item) {
         st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2);
         if constexpr (CELL == CTCN_CELL_LSTM) st_slab(rg, vg3, og, sv3);
@@ -1959,6 +1978,19 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
   return align_up((size_t)dirs * G * H * H * sizeof(float), 256) + align_up((size_t)B * dirs * H * sizeof(float), 256);
 }
 
+// One-shot request of the host for the NEXT ctcn_rnn_fwd on this thread: pipeline the input projection with the recurrence.  Only the
+// first pair of time chunks (the first frames of the forward direction, the last of the reverse one) is projected before the
+// recurrence is launched; the other pairs are projected on `side_stream`, restricted to the XCDs in `xcd_allow` (the ones the
+// persistent kernel leaves idle), behind `event` (recorded by the library right before the launch), each pair followed by a counter
+// update that the recurrence checks when it enters a new chunk.  `side_ws`: workspace of the side-stream GEMMs.
+struct FwdOverlap { void *stream, *event, *ws; size_t ws_bytes; unsigned xcd_allow; };
+static thread_local FwdOverlap g_fwd_overlap = {nullptr, nullptr, nullptr, 0, 0};
+extern "C" int ctcn_set_fwd_overlap(void *side_stream, void *event, void *side_ws, size_t side_ws_bytes, unsigned xcd_allow) {
+  g_fwd_overlap = FwdOverlap{side_stream, event, side_ws, side_ws_bytes, xcd_allow};
+  return CTCN_OK;
+}
+__global__ void set_counter_kernel(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
                             const float *w_hh0, const float *w_ih1, const float *w_hh1, float *y, float *gates,
                             float *aux, int precision, void *ws, size_t ws_bytes, void *stream) {
@@ -1976,6 +2008,31 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   // both directions project the same x and the gate reserve holds their pre-activations side by side (row = dirs*GH floats):
   // with the two W_ih stacked in the workspace one N = 2*GH product does the work of two (one pass over x, one launch)
   bool proj_done = ctcn_opt_recurrence_only();
+  const FwdOverlap ov = g_fwd_overlap;
+  g_fwd_overlap = FwdOverlap{nullptr, nullptr, nullptr, 0, 0};
+  // pipelined projection: needs the tagged-gather kernel (the only one that checks the chunk counter), both W_ih stacked, idle XCDs
+  constexpr int NCHUNK = 8;
+  const int chunk_T = ceil_div(T, NCHUNK);
+  const int nxd_p = ctcn_opt_handoff() ? ctcn_device_xcds() : 1;
+  const bool piped = !proj_done && ov.stream && ov.event && ov.ws && ov.xcd_allow != 0 && dirs == 2 && w_ih1 == w_ih0 + (size_t)GH * I &&
+                     ctcn_opt_rnn_persistent() && ctcn_get_option("rnn_fwd_tagged") && precision == 1 && cell != CTCN_CELL_TANH && H % 32 == 0 &&
+                     H / 32 <= 24 && nxd_p > 1 && T >= 4 * NCHUNK && chunk_T * (NCHUNK - 1) < T &&
+                     (size_t)T * B * dirs * GH * sizeof(float) < ((size_t)1 << 32) &&
+                     // the side GEMMs' workgroups that land on a recurrence XCD must be able to START there (to exit at once): the
+                     // 1024-thread workgroups of the recurrence leave no room on their own CUs, so some CUs of the XCD must stay free --
+                     // otherwise the GEMM cannot finish before the recurrence does, which is waiting for it (H = 512: 32 of 32 CUs)
+                     ceil_div(dirs * ceil_div(B, 16), nxd_p) * (H / 16) + 4 <= ctcn_device_cus() / nxd_p;
+  auto project_chunk = [&](int c, void *wsp, size_t wsb, void *strm, unsigned allow) -> int {
+    const int t0 = c * chunk_T, t1 = std::min(T, t0 + chunk_T);
+    return ctcn_gemm_on_xcds(0, 1, (t1 - t0) * B, 2 * GH, I, x + (size_t)t0 * B * I, I, w_ih0, I, gates + (size_t)t0 * B * 2 * GH, 2 * GH, 0.0f, precision,
+                             wsp, wsb, strm, allow);
+  };
+  if (piped) {
+    int rc = project_chunk(0, ws, ws_bytes, stream, 0);
+    if (!rc) rc = project_chunk(NCHUNK - 1, ws, ws_bytes, stream, 0);
+    if (rc) return rc;
+    proj_done = true;
+  }
   if (!proj_done && dirs == 2) {
     const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
     if (w_ih1 == w_ih0 + (size_t)GH * I) {      // already one (2*GH, I) matrix (optim.FlatAdam places them so): no stacking copies
@@ -2052,11 +2109,26 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
 #ifdef CTCN_PERSIST_STATS
         pa.stats = nullptr;
 #endif
-        CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | role tickets
+        pa.chunk_T = piped ? chunk_T : 0; pa.nchunk = NCHUNK; pa.chunk_ready = pa.flags;       // (first word of the flag area; tickets sit 256 B further)
+        CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | chunk counter | role tickets
+        if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();
+          if (piped) {          // the remaining chunk pairs, next to the recurrence on the XCDs it does not use
+            hipStream_t sd = (hipStream_t)ov.stream;
+            CTCN_HIP(hipStreamWaitEvent(sd, (hipEvent_t)ov.event, 0));
+            for (int pr = 1; pr < NCHUNK / 2; ++pr) {
+              int rc = project_chunk(pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
+              if (!rc) rc = project_chunk(NCHUNK - 1 - pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
+              if (rc) return rc;
+              hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, sd, pa.chunk_ready, (unsigned)pr);
+            }
+            CTCN_LAUNCH_CHECK();
+          }
           return CTCN_OK;
         }
+        if (piped)              // not co-resident after all: finish the projection here, then the other kernels take over
+          for (int c = 1; c < NCHUNK - 1; ++c) { const int rc = project_chunk(c, ws, ws_bytes, stream, 0); if (rc) return rc; }
       }
     }
     for (int ci = 0; ci < nc && kq <= 8; ++ci) {

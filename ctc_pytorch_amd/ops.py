@@ -109,7 +109,7 @@ def set_grad_ready_hook(fn):
     _grad_ready["hook"] = fn
 
 
-_side = {"enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": 1 << 21}
+_side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": 1 << 21}
 
 
 def set_side_stream(flag, min_items=None):
@@ -118,6 +118,12 @@ def set_side_stream(flag, min_items=None):
     _side["enabled"] = bool(flag)
     if min_items is not None:
         _side["min_items"] = int(min_items)
+
+
+def set_fwd_overlap(flag):
+    """Pipeline the input projection of a recurrent layer with its persistent forward recurrence (ctcn_set_fwd_overlap); default on
+    (environment: CTCN_FWD_OVERLAP=0 turns it off)."""
+    _side["fwd_overlap"] = bool(flag)
 
 
 def _side_stream(dev):
@@ -300,8 +306,30 @@ class _RNNLayer(torch.autograd.Function):
         gates = torch.empty((T, B, dirs, G * H), dtype=torch.float32, device=dev)
         aux = torch.empty((T, B, dirs, H), dtype=torch.float32, device=dev) if cell != 2 else None
         w, wp, wn = _ws(x)
-        _lib.check(_lib.lib().ctcn_rnn_fwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
-                                           _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
+        L = _lib.lib()
+        # pipelined input projection: only the first pair of time chunks is projected before the recurrence starts, the rest on the
+        # side stream, on the XCDs the persistent kernel leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
+        nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
+        allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
+        piped = _side["enabled"] and _side["fwd_overlap"] and allow != 0 and dirs == 2 and T * B * H >= _side["min_items"]
+        if piped:
+            st = _side_stream(dev)
+            ev = _prelaunch_event(dev)
+            w2, wp2, wn2 = _ws(x, tag="side")
+            _lib.check(L.ctcn_set_fwd_overlap(ctypes.c_void_p(st.cuda_stream), ctypes.c_void_p(ev.cuda_event), wp2, wn2, allow), "set_fwd_overlap")
+        try:
+            _lib.check(L.ctcn_rnn_fwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
+                                      _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
+        finally:
+            if piped:
+                L.ctcn_set_fwd_overlap(None, None, None, 0, 0)
+        if piped:
+            # by the time the recurrence ends the side stream's GEMMs have long finished (the kernel waited for their counter); the join
+            # only tells the allocator and the following kernels so
+            torch.cuda.current_stream(dev).wait_stream(st)
+            for t in (x, gates, ws[0], ws[2]):
+                if t is not None:
+                    t.record_stream(st)
         ctx.cell, ctx.dims, ctx.has_aux = cell, (T, B, I, H, dirs), aux is not None
         ctx.consumed = False
         # recurrent layers of this device whose backward is still to come (the deferral of the side work needs to know

@@ -125,6 +125,13 @@ int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x,
  * it launches the recurrence, behind its own preparatory memsets / transposes.  Work meant to run next to that recurrence
  * on another stream (ctcn_rnn_bwd_weights of the layer above) waits for this event.  NULL clears it. */
 int ctcn_set_prelaunch_event(void *event);
+/* One-shot request for the NEXT ctcn_rnn_fwd on this thread: pipeline the input projection with the persistent recurrence.  The
+ * library projects the first pair of time chunks on `stream` of ctcn_rnn_fwd, records `event` (hipEvent_t) right before the recurrence
+ * launch, and issues the remaining chunk GEMMs on `side_stream` behind that event, restricted to the XCDs of `xcd_allow` (bit x = XCD
+ * x; the ones the recurrence leaves idle), each pair followed by a counter update the recurrence checks when it enters a new chunk.
+ * `side_ws` / `side_ws_bytes`: workspace of the side-stream GEMMs.  Ignored (whole projection first, as without the call) when the
+ * tagged-gather recurrence does not apply.  The caller joins `side_stream` before it reuses x or the side workspace. */
+int ctcn_set_fwd_overlap(void *side_stream, void *event, void *side_ws, size_t side_ws_bytes, unsigned xcd_allow);
 /* ctcn_rnn_bwd with dw_ih0 == dw_hh0 == NULL runs the recurrence and dx only and leaves d(pre-activation) in gates
  * (and aux for the GRU n-gate); this call then produces the weight gradients from it: dW_ih = da^T x, dW_hh = da^T h_prev.
  * It has no consumer inside the backward pass, so the host side issues it on a second stream next to the NEXT layer's

@@ -818,6 +818,38 @@ def _build_model(tag, dev):
     return m.to(dev), z
 
 
+@pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 320, 32, 208), ("GRU", 256, 20, 419), ("LSTM", 128, 16, 1031)])
+def test_forward_projection_overlap_equals_inline(dev, rnn, H, B, T):
+    """Pipelined input projection (ctcn_set_fwd_overlap: only the first pair of time chunks is projected before the persistent
+    recurrence starts, the rest on the side stream behind a chunk counter) against the plain order: outputs, saved activations and
+    the gradients computed from them are bit-identical, five times in a row (a chunk read before its GEMM landed would show)."""
+    from ctc_pytorch_amd import nn, ops
+    ops.set_precision(1)
+    rs = np.random.RandomState(T)
+    layer = getattr(nn, rnn)(40, H, bidirectional=True, bias=False).to(dev)
+    x = torch.from_numpy(rs.standard_normal((T, B, 40)).astype(np.float32)).to(dev)
+    gy = torch.from_numpy(rs.standard_normal((T, B, 2 * H)).astype(np.float32)).to(dev)
+    outs = {}
+    try:
+        for mode in (False, True, True, True, True, True):
+            ops.set_fwd_overlap(mode)
+            xin = x.clone().requires_grad_()
+            for p_ in layer.parameters():
+                p_.grad = None
+            y, _ = layer(xin)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            ops.check_health()
+            got = [y.detach().clone(), xin.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()]
+            if mode not in outs:
+                outs[mode] = got
+            else:
+                assert all(torch.equal(a, b_) for a, b_ in zip(got, outs[mode]))
+    finally:
+        ops.set_fwd_overlap(True)
+    assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
+
+
 @pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 128, 8, 60), ("GRU", 192, 40, 25)])
 def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
