@@ -1978,6 +1978,12 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
   return align_up((size_t)dirs * G * H * H * sizeof(float), 256) + align_up((size_t)B * dirs * H * sizeof(float), 256);
 }
 
+// (The mirror image for the backward pass -- the dx GEMM of a time chunk on a second side stream as soon as both directions have passed
+// the chunk: d(pre-activation) written through to memory, per-chunk counters raised by the item waves, a one-wave wait kernel in
+// front of each chunk GEMM -- was built and measured in round 2: bit-identical, but 15.2 instead of 14.3 ms per cfg2 step.  The XCDs
+// the backward recurrence leaves idle are already full with the weight-gradient GEMMs of the layer above (6.9 ms of side-stream work
+// per step against 6.4 ms of recurrences): the chunk GEMMs finish 0.5 ms AFTER the recurrence and the write-through stores cost it
+// 0.13 ms per launch.  Not kept.)
 // One-shot request of the host for the NEXT ctcn_rnn_fwd on this thread: pipeline the input projection with the recurrence.  Only the
 // first pair of time chunks (the first frames of the forward direction, the last of the reverse one) is projected before the
 // recurrence is launched; the other pairs are projected on `side_stream`, restricted to the XCDs in `xcd_allow` (the ones the
@@ -2096,7 +2102,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       const int nsl = H / 16, wpx = ceil_div(groups, nxd) * nsl;
       const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (H / 32) * 2048, 256), fl_bytes = 512;
       if (ws && ws_bytes >= hx_bytes + fl_bytes + 512) {
-        PersistArgs pa;
+        PersistArgs pa = {};
         pa.a = a;
         char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
         pa.hx = (float *)tail;
@@ -2143,7 +2149,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       const size_t hx_bytes = align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(H, 32) * 512 : ceil_div(H, 16) * 256) * sizeof(float), 256);
       const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * sizeof(unsigned), 256) + 256;   // + role tickets
       if (!ws || ws_bytes < hx_bytes + fl_bytes + 512) { why = "workspace too small for the hand-off tiles"; break; }
-      PersistArgs pa;
+      PersistArgs pa = {};
       pa.a = a;
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
       pa.hx = (float *)tail;
@@ -2308,7 +2314,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       const int nx = mode ? ctcn_device_xcds() : 1;
       if (mode && nx <= 1) continue;
       const int wpx = ceil_div(groups, nx) * nsl;
-      PersistArgs pa;
+      PersistArgs pa = {};
       pa.a = a;
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
       pa.hx = (float *)tail;

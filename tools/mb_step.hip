@@ -161,7 +161,7 @@ int main() {
     struct Cfg { int local, hsu, nt, prec, pd; } cfgs[] = {{1, 8, 2, 1, 2}, {1, 12, 3, 1, 2}, {1, 16, 4, 1, 2}};   // measured besides: HSU 4 -> 2.55, HSU 10 (4-B publish pieces) -> 2.37, polls 1 / 3 / 4 -> 2.08 / 2.09 / 2.15 us
     for (auto &c : cfgs) {
       if (c.local && nx <= 1) continue;
-      PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
+      PersistArgs pa = {}; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
       pa.nbig = 0; pa.hsu_small = 0; pa.poll_delay = 0; pa.poll_depth = c.pd; pa.local = c.local; pa.nx = c.local ? nx : 1; pa.nbt = nbt; pa.hsu = c.hsu; pa.nsl = (H + c.hsu - 1) / c.hsu;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
@@ -198,7 +198,7 @@ int main() {
     }
     for (int pd : {0, 8}) {   // tagged-gather forward (round 2): 64-cycle sleeps before the first poll of a step
       if (nx <= 1) break;
-      PersistArgs pa; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
+      PersistArgs pa = {}; pa.a = a; pa.a.w0 = w; pa.a.w1 = w + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
       pa.poll_depth = 1; pa.poll_delay = pd; pa.local = 1; pa.nx = nx; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.nsl = H / 16; pa.tagmode = 1;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;
@@ -220,7 +220,7 @@ int main() {
     for (int lp = 0; lp < 3; ++lp) {
       const int local = 1, prec = 1, pd = 2, scatter = lp, bdelay = 0;
       if (nx <= 1) continue;
-      PersistArgs pa; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
+      PersistArgs pa = {}; pa.a = a; pa.a.w0 = wT; pa.a.w1 = wT + (size_t)G * H * H; pa.hx = hx; pa.flags = flags; pa.status = status; pa.spin_limit = 1 << 20; pa.stats = stats;
       pa.poll_depth = pd; pa.poll_delay = bdelay; pa.nbig = 0; pa.hsu_small = 0; pa.local = local; pa.nx = nx; pa.nbt = nbt; pa.hsu = 16; pa.nsl = (H + 15) / 16;
       const int wpx = (D * nbt + pa.nx - 1) / pa.nx * pa.nsl;
       pa.wpx = wpx; pa.tickets = flags + (fl_bytes - 256) / 4;

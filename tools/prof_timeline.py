@@ -17,7 +17,8 @@ print("# step between the last two adam_kernel ends: %.3f ms, %d kernels" % ((t1
 streams = {}
 for r in step:
     streams.setdefault(r[1], []).append(r)
-main = max(streams, key=lambda k: len(streams[k]))
+# the main stream is the one that carries the optimiser step (the side stream can hold more launches: chunked GEMMs, split passes)
+main = rows[adam[-1]][1]
 for sid, ks in sorted(streams.items(), key=lambda kv: -len(kv[1])):
     busy = sum(k[3] - k[2] for k in ks) / 1e3
     print("## stream %s%s: %d kernels, busy %.1f us" % (sid, " (main)" if sid == main else "", len(ks), busy))
