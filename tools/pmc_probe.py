@@ -24,6 +24,14 @@ for _ in range(3):
     yr = ops.rnn_layer(xr, wr[0], wr[1], wr[2], wr[3], "lstm")
     yr.backward(torch.ones_like(yr))
 torch.cuda.synchronize()
+# cfg3 front-end, layer 2 (32 -> 32, 3x3, stride 2x2): MFMA implicit-GEMM forward / dgrad / wgrad
+xc = torch.randn(32, 32, 800, 20, device=dev, requires_grad=True)
+wc = (torch.randn(32, 32, 3, 3, device=dev) / 17.0).requires_grad_(True)
+bc = torch.zeros(32, device=dev, requires_grad=True)
+for _ in range(2):
+    yc = ops.conv2d(xc, wc, bc, (2, 2), (1, 1))
+    yc.backward(torch.ones_like(yc))
+torch.cuda.synchronize()
 # cfg5 beam decode (peaky regime), two launches: beam_prep_kernel + beam_fast_kernel
 import numpy as np
 from ctc_pytorch_amd.utils.NgramLM import LanguageModel

@@ -4,18 +4,23 @@
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide coalesced reads at 64 B); both counters are KiB."""
 import json, sqlite3, sys
 
-ALGO = {   # algorithmic bytes per launch at the probe shapes (DESIGN.md section 5)
-    "rnn_fwd_persist": ("rnn_fwd_persist cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
-    "rnn_bwd_scatter": ("rnn_bwd_scatter cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
-    "gemm_planes_nt256_kernel": ("gemm_planes_nt256_kernel 25600x1280x640 (bf16 planes in, f32 out)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
-    "gemm_planes_nt256_af32_kernel": ("gemm_planes_nt256_af32_kernel 25600x1280x640 (f32 A in, f32 out)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
-    "split_rows_kernel": ("split_rows_kernel", None),
-    "dropout_kernel": ("dropout_kernel 25600x640", 131072000),
-    "bn_apply_kernel": ("bn_apply_kernel 25600x640", 131072000),
-    "bn_dx_kernel": ("bn_dx_kernel 25600x640", 196608000),
-    "beam_fast_kernel": ("beam_fast_kernel cfg5 peaky (128 x 800 x 62, W=20): reads ln p (double) of the processed frames", None),
-    "beam_prep_kernel": ("beam_prep_kernel cfg5 (128 x 800 x 62): lp f32 in, ln p f64 + p_blank + flags out", 800 * 128 * 62 * 12 + 800 * 128 * 5),
-}
+ALGO = [   # (substring of the kernel name, label, algorithmic bytes per launch at the probe shapes -- DESIGN.md section 5); first match wins
+    ("rnn_fwd_tagged", "rnn_fwd_tagged cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
+    ("rnn_fwd_persist", "rnn_fwd_persist cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
+    ("rnn_bwd_scatter", "rnn_bwd_scatter cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
+    ("gemm_planes_nt256_af32_kernel<2>", "gemm 25600x1280x640 (probe of bench.py; A = f32 split while staged)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
+    ("gemm_planes_nt256_af32_kernel<1>", "gemm 25600x640x2560 (dx of the layer; A = f32 d(pre-act) split while staged)", 25600 * 2560 * 4 + 640 * 2560 * 4 + 25600 * 640 * 4),
+    ("gemm_planes_nt256pp_kernel<2>", "gemm_planes_nt256pp_kernel<2> (256 x 256 ping-pong tile; bf16 planes in, f32 out)", None),
+    ("gemm_planes_nt256_kernel", "gemm_planes_nt256_kernel (bf16 planes in, f32 out)", None),
+    ("split_rows_kernel", "split_rows_kernel", None),
+    ("dropout_kernel", "dropout_kernel 25600x640", 131072000),
+    ("bn_apply_kernel", "bn_apply_kernel 25600x640", 131072000),
+    ("bn_dx_kernel", "bn_dx_kernel 25600x640", 196608000),
+    ("beam_fast_kernel", "beam_fast_kernel cfg5 peaky (128 x 800 x 62, W=20): reads ln p (double) of the processed frames", None),
+    ("beam_prep_kernel", "beam_prep_kernel cfg5 (128 x 800 x 62): lp f32 in, ln p f64 + p_blank + flags out", 800 * 128 * 62 * 12 + 800 * 128 * 5),
+    ("conv_mfma_kernel", "conv_mfma_kernel cfg3 layer 2 (32 -> 32, 3x3, stride 2x2; B=32, T=800): forward and the four dgrad classes", None),
+    ("conv_wgrad_mfma_kernel", "conv_wgrad_mfma_kernel cfg3 layer 2", None),
+]
 
 
 def table(db, counter):
@@ -30,12 +35,12 @@ fetch, write = table(sys.argv[1], "FETCH_SIZE"), table(sys.argv[2], "WRITE_SIZE"
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over tools/pmc_probe.py, precision 1; FETCH_SIZE doubled per "
                  "MI355X_MICROARCH.md (gfx950 counts the 128-B requests of wide coalesced reads as 64 B); round 2"}
 for name in sorted(set(fetch) | set(write)):
-    key = next((k for k in ALGO if k + "<" in name or k + "(" in name or name.endswith(k) or (k in name and "queue" not in name)), None)
-    if key is None:
+    hit = next((e for e in ALGO if e[0] in name and "queue" not in name), None)
+    if hit is None:
         continue
     f = fetch.get(name, (0, 0.0, 0.0))
     w = write.get(name, (0, 0.0, 0.0))
-    label, algo = ALGO[key]
+    label, algo = hit[1], hit[2]
     short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     res["%s [%s]" % (label, short)] = {"launches": f[0], "fetch_kib_raw": round(f[1], 1), "write_kib": round(w[1], 1),
                                        "hbm_bytes": int(2 * f[1] * 1024 + w[1] * 1024), "algorithmic_bytes": algo, "avg_us": round(f[2], 1)}

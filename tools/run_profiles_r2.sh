@@ -12,5 +12,6 @@ db=$(find $O/stats -name "*.db" | head -1); [ -n "$db" ] && python tools/prof_ti
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- python $R/tools/pmc_probe.py > $O/write.log 2>&1 )
 fd=$(find $O/fetch -name "*.db" | head -1); wd=$(find $O/write -name "*.db" | head -1)
 [ -n "$fd" ] && [ -n "$wd" ] && python tools/pmc_to_json.py $fd $wd $O/r02_pmc_hbm_traffic.json > $O/pmc.log 2>&1
+( timeout 120 ./tools/mb_step.bin > $O/r02_mb_step.txt 2>&1 )
 rm -rf $O/stats/*/*.db $O/fetch $O/write 2>/dev/null
 ls -la $O
