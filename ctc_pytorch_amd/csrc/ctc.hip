@@ -219,7 +219,11 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_lattice_kernel(const float *_
 }
 
 // (Measured and dropped: one wave per (utterance, pass) with the lattice in registers -- lane l holding states 2l and 2l + 1,
-// neighbour states through ds_bpermute, no LDS, no barrier -- is bit-identical but SLOWER at cfg2: 230 us against 193 us.)
+// no LDS, no barrier -- is bit-identical but not faster at cfg2: neighbour states through ds_bpermute 230 us (round 1); through DPP
+// wave shifts (one per alpha step), with hand-counted vmcnt for the gathers / lattice stores, pointer-stepped addressing and a
+// two-term lse for the blank states: 195 us, the same as the 193-195 us of this kernel (round 2).  With lse3 replaced by a max the
+// wave version takes 101 us: a step is ~280 cycles of quarter-rate transcendentals (5 exp2 + 2 log2 per lane holding two states)
+// + ~300 cycles of everything else, and neither is the exchange.)
 // alpha (blockIdx.y = 0) and beta (blockIdx.y = 1) of every utterance in one launch: the two passes are independent chains of
 // T dependent steps, so running them side by side halves the latency of the loss (2B workgroups instead of B twice).
 template <int NS>
