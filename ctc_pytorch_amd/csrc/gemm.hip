@@ -1084,12 +1084,181 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_af32_kernel(int M, int 
     }
 }
 
+// The float32-A tile in the ping-pong schedule of gemm_planes_nt256pp_kernel (one instruction stream, half B one barrier behind):
+//     read (s, k-half 0) | multiply + the wave's DMA pieces of B(s+1) | read (s, 1), convert + store A(s+1), own DMA landed |
+//     multiply + global loads of A(s+2)
+// A thread stages its own 16 floats of a row of A: loaded during the second multiply of stage s-1, split into hi / lo (the same
+// split_bf16 as everywhere: identical planes) and written into the other LDS buffer during the second read phase of stage s, three
+// phases later.  Waves 0-3 hold rows 0-127 of A -- the rows their own half multiplies.
+template <int WNT>
+__global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, int N, int K, int Kp, const float *__restrict__ A, int lda,
+                                                                       const unsigned short *__restrict__ Bh, const unsigned short *__restrict__ Bl,
+                                                                       float *__restrict__ C, int ldc, float beta, int tiles_m, int tiles_n) {
+  constexpr int TBM = 256, TBN = 128 * WNT;
+  constexpr int A_BYTES = TBM * 64, B_BYTES = TBN * 64;
+  constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+  constexpr int IB = TBN * 4 / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+
+  f32x16 acc[4][WNT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  unsigned offB[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int p = (i * 8 + wave) * 64 + lane, row = p >> 2, chunk = (p & 3) ^ ((row >> 2) & 3);
+    offB[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)Kp + chunk * 8;
+  }
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  auto issue_b_piece = [&](int n, int k0, int buf) {            // n = 0 .. 2*IB-1
+    unsigned char *sb = qsm + buf * STAGE + 2 * A_BYTES;
+    const int i = n >> 1, dst = (i * 8 + wave) * 1024;
+    if (n & 1) __builtin_amdgcn_global_load_lds((gptr_t)(Bl + offB[i] + k0), (lptr_t)(sb + B_BYTES + dst), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gptr_t)(Bh + offB[i] + k0), (lptr_t)(sb + dst), 16, 0, 0);
+  };
+  const int arow = tid >> 1, akh = (tid & 1) * 16;
+  const float *aptr = A + (size_t)min(m0 + arow, M - 1) * lda + akh;
+  f32x4 av[4];
+  auto load_a_piece = [&](int q, int k0) {
+    const int k = k0 + akh + 4 * q;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(aptr + min(k0 + 4 * q, max(K - akh - 4, 0)));
+    av[q] = k + 3 < K ? v : (f32x4){k < K ? v[0] : 0.f, k + 1 < K ? v[1] : 0.f, k + 2 < K ? v[2] : 0.f, 0.f};
+  };
+  auto store_a = [&](int buf) {
+    unsigned char *sb = qsm + buf * STAGE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned hw[4], lw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned short h0, l0, h1, l1;
+        split_bf16(av[2 * h + (e >> 1)][(e & 1) * 2], h0, l0);
+        split_bf16(av[2 * h + (e >> 1)][(e & 1) * 2 + 1], h1, l1);
+        hw[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+        lw[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+      const int o = qswz(arow, (tid & 1) * 2 + h);
+      *reinterpret_cast<u32x4 *>(sb + o) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
+      *reinterpret_cast<u32x4 *>(sb + A_BYTES + o) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+    }
+  };
+  const int nst = Kp / 32;
+  const int ml = lane & 31, g = lane >> 5;
+  bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
+  int oa[2][4], ob[2][WNT];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oa[ks][i] = qswz(wm * 128 + i * 32 + ml, ks * 2 + g);
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) ob[ks][j] = 2 * A_BYTES + qswz(wn * 32 * WNT + j * 32 + ml, ks * 2 + g);
+  }
+  auto load_frags = [&](int stage, int ks) {
+    const unsigned char *sb = qsm + (stage & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      bh[j] = *reinterpret_cast<const bf16x8_t *>(sb + ob[ks][j]);
+      bl[j] = *reinterpret_cast<const bf16x8_t *>(sb + B_BYTES + ob[ks][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8_t *>(sb + oa[ks][i]);
+      al[i] = *reinterpret_cast<const bf16x8_t *>(sb + A_BYTES + oa[ks][i]);
+    }
+  };
+  constexpr int NMM = 4 * WNT;
+  // MODE 0: bare MFMAs; 1: + the wave's 2*IB DMA pieces of B for the next stage; 2: + this thread's four 16-B loads of A two stages ahead
+  auto multiply = [&](auto mode, int k0, int buf) {
+    constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+          else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          const int n = t * NMM + i * WNT + j;
+          if ((n & 1) && (n >> 1) < (MODE == 1 ? 2 * IB : 4)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MODE == 1) issue_b_piece(n >> 1, k0, buf);
+            if constexpr (MODE == 2) load_a_piece(n >> 1, k0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+  };
+  constexpr std::integral_constant<int, 0> bare{};
+  constexpr std::integral_constant<int, 1> with_b{};
+  constexpr std::integral_constant<int, 2> with_a{};
+  // prologue: stage 0 into buffer 0 (A through the registers, B by DMA), A of stage 1 into the registers
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_a_piece(q, 0);
+#pragma unroll
+  for (int n = 0; n < 2 * IB; ++n) issue_b_piece(n, 0, 0);
+  store_a(0);
+  if (nst > 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_a_piece(q, 32);
+  }
+  pp_barrier_vm();
+  if (wm == 1) pp_barrier();
+  auto stage = [&](int s, auto c0, auto c1) {
+    load_frags(s, 0);
+    pp_barrier();
+    multiply(c0, (s + 1) * 32, (s + 1) & 1);
+    pp_barrier();
+    load_frags(s, 1);
+    if constexpr (decltype(c0)::value == 1) store_a((s + 1) & 1);   // A of stage s + 1 (loaded three phases ago) -> the other buffer (last read two phases ago)
+    pp_barrier_vm();                           // own DMA pieces of B(s + 1) landed
+    multiply(c1, (s + 2) * 32, 0);
+    pp_barrier();
+  };
+  int s = 0;
+  for (; s + 2 < nst; ++s) stage(s, with_b, with_a);
+  if (s + 1 < nst) { stage(s, with_b, bare); ++s; }
+  stage(s, bare, bare);
+  if (wm == 0) pp_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + wn * 32 * WNT + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float v = acc[i][j][e];
+          float *p = C + (size_t)row * ldc + col;
+          if (beta != 0.0f) v += beta * *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 template <int WNT>
 static int launch_planes256_af32(hipStream_t st, int M, int N, int K, int Kp, const float *A, int lda, const unsigned short *bh, const unsigned short *bl,
                                  float *C, int ldc, float beta) {
   const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
   const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
-  auto kern = gemm_planes_nt256_af32_kernel<WNT>;
+  auto kern = ctcn_get_option("gemm_pingpong") ? gemm_planes_nt256pp_af32_kernel<WNT> : gemm_planes_nt256_af32_kernel<WNT>;
   CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta, tiles_m, tiles_n);
   return CTCN_OK;

@@ -10,10 +10,10 @@ for M, N, K, ta, tb in shapes:
     A = torch.randn((K, M) if ta else (M, K), device=dev)
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     C = torch.empty(M, N, device=dev)
-    for t256, dbg in ((0, 0), (1, 0), (1, 1), (1, 4)):
+    for t256, dbg in ((1, 1), (1, 4), (1, 5)):
         ops.set_option("gemm_tile256", t256)
-        ops.set_option("gemm_pingpong", 1 if dbg == 1 else 0)
-        ops.set_option("gemm_a_inline", 1 if dbg == 4 else 0)
+        ops.set_option("gemm_pingpong", 1 if dbg in (1, 5) else 0)
+        ops.set_option("gemm_a_inline", 1 if dbg in (4, 5) else 0)
         for _ in range(3):
             ops.gemm(ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C, N)
         torch.cuda.synchronize()
@@ -24,7 +24,7 @@ for M, N, K, ta, tb in shapes:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print("%6d x %5d x %5d  tile256=%d variant=%d (1: ping-pong planes, 4: inline-A)  %8.1f us  %7.1f TFLOP/s (incl. split passes)" % (M, N, K, t256, dbg, us, 2.0 * M * N * K / us / 1e6))
+        print("%6d x %5d x %5d  tile256=%d variant=%d (1: ping-pong planes, 4: inline-A, 5: inline-A ping-pong)  %8.1f us  %7.1f TFLOP/s (incl. split passes)" % (M, N, K, t256, dbg, us, 2.0 * M * N * K / us / 1e6))
 ops.set_option("gemm_tile256", 1)
 ops.set_option("gemm_pingpong", 1)
 ops.set_option("gemm_a_inline", 1)
