@@ -122,10 +122,10 @@ def gemm_roofline(dev, c):
     tf = flops / (ms * 1e-3) / 1e12
     prec = ops.get_precision()
     # HBM bytes per launch from the committed rocprofv3 PMC passes (25 600 x 1 280 x 640 probe shape)
-    traffic = pmc_traffic("gemm_planes_nt256_af32_kernel<2>") if (prec == 1 and (M, N, K) == (25600, 1280, 640)) else None
+    traffic = pmc_traffic("gemm_planes_nt256pp_af32_kernel<2>") if (prec == 1 and (M, N, K) == (25600, 1280, 640)) else None
     # bf16x3 issues 3 bf16 MFMAs per algorithmic product: its ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s
     peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0 / 3.0
-    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_planes_nt256 (256-row tiles) + its operand-split pass(es),") + " %dx%dx%d" % (M, N, K), bound="mfma",
+    return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_planes_nt256pp_af32 (256-row ping-pong tile, A split while staged) + the operand-split pass of B,") + " %dx%dx%d" % (M, N, K), bound="mfma",
                 achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic, us_per_launch=ms * 1e3,
                 algorithmic_flops_per_launch=flops,
                 peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")

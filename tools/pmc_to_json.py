@@ -8,6 +8,8 @@ ALGO = [   # (substring of the kernel name, label, algorithmic bytes per launch 
     ("rnn_fwd_tagged", "rnn_fwd_tagged cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
     ("rnn_fwd_persist", "rnn_fwd_persist cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
     ("rnn_bwd_scatter", "rnn_bwd_scatter cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
+    ("gemm_planes_nt256pp_af32_kernel<2>", "gemm 25600x1280x640 (probe of bench.py; A = f32 split while staged, ping-pong tile)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
+    ("gemm_planes_nt256pp_af32_kernel<1>", "gemm 25600x640x2560 (dx of the layer; A = f32 d(pre-act) split while staged, ping-pong tile)", 25600 * 2560 * 4 + 640 * 2560 * 4 + 25600 * 640 * 4),
     ("gemm_planes_nt256_af32_kernel<2>", "gemm 25600x1280x640 (probe of bench.py; A = f32 split while staged)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
     ("gemm_planes_nt256_af32_kernel<1>", "gemm 25600x640x2560 (dx of the layer; A = f32 d(pre-act) split while staged)", 25600 * 2560 * 4 + 640 * 2560 * 4 + 25600 * 640 * 4),
     ("gemm_planes_nt256pp_kernel<2>", "gemm_planes_nt256pp_kernel<2> (256 x 256 ping-pong tile; bf16 planes in, f32 out)", None),
