@@ -1253,6 +1253,248 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
     }
 }
 
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc, int splits, float beta);
+
+// ------------------------------------------------------------------------------------------------
+// TN tile: C = A^T B for two CONTRACTION-MAJOR float32 operands (A: K x M, B: K x N, k the slow index) -- the weight gradients
+// dW = da^T x, whose operands are the activations exactly as the recurrences leave them (K = T*B rows).  The plane path above needs
+// them transposed AND split first (split_transpose_kernel: a read + write pass over both operands per GEMM); this tile takes the
+// float32 rows as they are:
+//   * a thread loads 16-B pieces of 4 neighbouring m of one k (8 lanes = one 128-B line of a row), splits them into hi / lo with
+//     the same split_bf16 as everywhere and writes them with ds_write_b64 into a K-MAJOR LDS image: [32-m subtile][32 k][32 m]
+//     bf16, rows of 64 B -- a wave's write covers 512 contiguous bytes, conflict-free;
+//   * the MFMA operand (lane = m, 8 consecutive k) is the transpose of that image: two ds_read_b64_tr_b16 per fragment (each
+//     16-lane group reads a 4 k x 16 m block and receives it transposed), so no shuffle and no second LDS pass;
+//   * the ping-pong schedule of gemm_planes_nt256pp_af32_kernel with BOTH operands through the registers: global loads of stage
+//     s + 2 between the MFMAs of the second multiply phase of stage s, split + LDS stores in the second read phase of stage s + 1;
+//   * split-K with an atomic (tile, split) queue on the XCDs of `xcd_mask`: partial tiles land in the workspace and
+//     splitk_reduce_kernel adds them up -- the order of the splits is fixed, so the result does not depend on which workgroup
+//     computed what.
+// Products and k order inside a 16-k step are those of the other bf16x3 tiles (al*bh, ah*bl, ah*bh).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+template <int WNT>
+__global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                             int ldb, float *__restrict__ C, int ldc, float beta, int kchunk, int splits,
+                                                             float *__restrict__ part, int tiles_m, int tiles_n, unsigned xcd_mask,
+                                                             unsigned *__restrict__ queue) {
+  constexpr int TBM = 256, TBN = 128 * WNT;
+  constexpr int A_BYTES = TBM * 64, B_BYTES = TBN * 64;
+  constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+  constexpr int NB = 2 * WNT;            // 16-B pieces of B per thread and stage (A: 4)
+  constexpr int NMM = 4 * WNT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  __shared__ int s_item;
+  // workgroups off the XCDs of `xcd_mask` leave; the others pull (split, tile) items from ONE queue, tiles of a split next to each other
+  // (an owner XCD per split -- its workgroups walking one k window together through their L2 -- measured 8-20 % slower: the L2s
+  // already catch 73 % of the requests and the fixed ownership costs balance)
+  {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (!((xcd_mask >> (xcc & 15u)) & 1u)) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = tiles_m * tiles_n;
+  const int krow = lane >> 3, c4 = 4 * (lane & 7);
+  const int bsub = WNT == 2 ? wave : (wave & 3), bk0 = WNT == 2 ? 0 : 16 * (wave >> 2);
+  // LDS byte offsets: this thread's pieces, and its transposing fragment reads (see tools/tr_probe: lane l of ds_read_b64_tr_b16 gets
+  // column (l & 15) + 16 * ((l >> 4) & 1), rows 8 * (l >> 5) + 0..3 when lane i of a 16-lane group addresses row i / 4, columns 4 * (i % 4))
+  const int st_a = wave * 2048 + krow * 64 + (lane & 7) * 8;
+  const int st_b = 2 * A_BYTES + bsub * 2048 + (bk0 + krow) * 64 + (lane & 7) * 8;
+  const int troff = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  typedef __attribute__((address_space(3))) s16x4_t *lds4_t;
+
+  for (;;) {
+    if (tid == 0) s_item = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nt * splits) return;
+    const int z = item / nt, tile = item - z * nt;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
+    const int nst = (kend - kbeg + 31) / 32;
+
+    f32x16 acc[4][WNT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int acol = m0 + 32 * wave + c4, bcol = n0 + 32 * bsub + c4;
+    const bool a_ok = acol < M, b_ok = bcol < N;                 // (M, N multiples of 4: a piece is inside or outside as a whole)
+    const float *aptr = A + min(acol, M - 4), *bptr = B + min(bcol, N - 4);
+    f32x4 av[4], bv[NB];
+    // (the loads are bare -- clamped addresses, no select -- so that nothing waits for them inside the multiply phase they are issued
+    // in; pieces beyond M / N / the k window are zeroed when they are split, two phases later)
+    auto load_piece = [&](int q, int k0) {                       // q = 0..3: A, 4..4+NB-1: B; k0 = first k of the stage
+      if (q < 4) av[q] = *reinterpret_cast<const f32x4 *>(aptr + (size_t)min(k0 + 8 * q + krow, K - 1) * lda);
+      else bv[q - 4] = *reinterpret_cast<const f32x4 *>(bptr + (size_t)min(k0 + bk0 + 8 * (q - 4) + krow, K - 1) * ldb);
+    };
+    // two neighbours at a time: hi = bf16(x) of both in one v_cvt_pk_bf16_f32, lo = bf16(x - hi) likewise (the split_bf16 values)
+    auto split_pair = [](float a, float b, unsigned &hw, unsigned &lw) {
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      hw = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+      const f32x2_t r = {a - __uint_as_float(hw << 16), b - __uint_as_float(hw & 0xffff0000u)};
+      lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    };
+    auto store_piece = [&](auto masked, unsigned char *p, int plane_bytes, const f32x4 &v, bool ok) {
+      unsigned h01, l01, h23, l23;
+      split_pair(v[0], v[1], h01, l01);
+      split_pair(v[2], v[3], h23, l23);
+      if constexpr (decltype(masked)::value == 1) {
+        const unsigned keep = ok ? 0xffffffffu : 0u;
+        h01 &= keep; l01 &= keep; h23 &= keep; l23 &= keep;
+      }
+      *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2 *>(p + plane_bytes) = make_uint2(l01, l23);
+    };
+    const bool edge_tile = m0 + TBM > M || n0 + TBN > N;          // (workgroup-uniform: interior tiles skip the zeroing of pieces)
+    auto store_ab = [&](int buf, int k0) {                       // k0 = first k of the stage the registers hold
+      unsigned char *sb = qsm + buf * STAGE;
+      if (edge_tile || k0 + 32 > kend) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_piece(std::integral_constant<int, 1>{}, sb + st_a + q * 512, A_BYTES, av[q], a_ok && k0 + 8 * q + krow < kend);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) store_piece(std::integral_constant<int, 1>{}, sb + st_b + q * 512, B_BYTES, bv[q], b_ok && k0 + bk0 + 8 * q + krow < kend);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_piece(std::integral_constant<int, 0>{}, sb + st_a + q * 512, A_BYTES, av[q], true);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) store_piece(std::integral_constant<int, 0>{}, sb + st_b + q * 512, B_BYTES, bv[q], true);
+      }
+    };
+    bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
+    auto tr_frag = [&](const unsigned char *p) {
+      const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p));
+      const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p + 256));
+      return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto load_frags = [&](int stage, int ks) {
+      const unsigned char *sb = qsm + (stage & 1) * STAGE + ks * 1024 + troff;
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const unsigned char *p = sb + 2 * A_BYTES + (wn * WNT + j) * 2048;
+        bh[j] = tr_frag(p);
+        bl[j] = tr_frag(p + B_BYTES);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned char *p = sb + (wm * 4 + i) * 2048;
+        ah[i] = tr_frag(p);
+        al[i] = tr_frag(p + A_BYTES);
+      }
+    };
+    // MODE 0: bare MFMAs; 1: + this thread's 4 + NB global loads of the stage that begins at k0, one after every other MFMA
+    auto multiply = [&](auto mode, int k0) {
+      constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < WNT; ++j) {
+            if (t == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // small terms first
+            else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            const int n = t * NMM + i * WNT + j;
+            if (MODE == 1 && (n & 1) && (n >> 1) < 4 + NB) {
+              __builtin_amdgcn_sched_barrier(0);
+              load_piece(n >> 1, k0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+    };
+    constexpr std::integral_constant<int, 0> bare{};
+    constexpr std::integral_constant<int, 1> with_loads{};
+    // prologue: stage 0 into buffer 0, stage 1 into the registers
+#pragma unroll
+    for (int q = 0; q < 4 + NB; ++q) load_piece(q, kbeg);
+    store_ab(0, kbeg);
+    if (nst > 1) {
+#pragma unroll
+      for (int q = 0; q < 4 + NB; ++q) load_piece(q, kbeg + 32);
+    }
+    pp_barrier();
+    if (wm == 1) pp_barrier();
+    auto stage = [&](int s, auto do_store, auto c1) {
+      load_frags(s, 0);
+      pp_barrier();
+      multiply(bare, 0);
+      pp_barrier();
+      load_frags(s, 1);
+      if constexpr (decltype(do_store)::value == 1) store_ab((s + 1) & 1, kbeg + (s + 1) * 32);   // stage s + 1 (loaded three phases ago) -> the buffer last read two phases ago
+      pp_barrier();
+      multiply(c1, kbeg + (s + 2) * 32);
+      pp_barrier();
+    };
+    int s = 0;
+    for (; s + 2 < nst; ++s) stage(s, with_loads, with_loads);
+    if (s + 1 < nst) { stage(s, with_loads, bare); ++s; }
+    stage(s, bare, bare);
+    if (wm == 0) pp_barrier();
+
+    float *o = splits > 1 ? part + (size_t)z * M * N : C;
+    const int ldo = splits > 1 ? N : ldc;
+    const float bt = splits > 1 ? 0.0f : beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        const int col = n0 + wn * 32 * WNT + j * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          if (row < M && col < N) {
+            float v = acc[i][j][e];
+            float *p = o + (size_t)row * ldo + col;
+            if (bt != 0.0f) v += bt * *p;
+            *p = v;
+          }
+        }
+      }
+    __syncthreads();
+  }
+}
+
+// split count and launch of the TN tile; `part` must hold splits * M * N floats when splits > 1
+static int tn_splits(int M, int N, int K, int wnt, size_t part_bytes) {
+  const int tiles = ceil_div(M, 256) * ceil_div(N, 128 * wnt);
+  int s = std::min(std::max(256 / tiles, 1), std::max(K / 512, 1));      // <= 256 items: one round on a whole device, two on half of it
+  s = std::min(s, (int)(part_bytes / ((size_t)M * N * sizeof(float))));
+  return s < 2 ? 1 : s;
+}
+template <int WNT>
+static int launch_tn(hipStream_t st, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float beta, int splits,
+                     float *part, unsigned xcd_allow, unsigned *queue) {
+  const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
+  int kchunk = ceil_div(ceil_div(K, splits), 32) * 32;
+  splits = ceil_div(K, kchunk);
+  const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
+  auto kern = gemm_tn_f32_pp_kernel<WNT>;
+  CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CTCN_HIP(hipMemsetAsync(queue, 0, 4, st));
+  const int nx = std::min(ctcn_device_xcds(), 16);
+  const unsigned xcd_mask = xcd_allow ? xcd_allow : (nx > 1 ? (1u << nx) - 1u : 0xffffu);
+  hipLaunchKernelGGL(kern, dim3(ctcn_device_cus()), dim3(512), lds, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, splits, part, tiles_m, tiles_n, xcd_mask,
+                     queue);
+  CTCN_LAUNCH_CHECK();
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min((size_t)2048, ceil_div_z(total, 256))), dim3(256), 0, st, (const float *)part, C, M, N, ldc,
+                       splits, beta);
+    CTCN_LAUNCH_CHECK();
+  }
+  return CTCN_OK;
+}
+
 template <int WNT>
 static int launch_planes256_af32(hipStream_t st, int M, int N, int K, int Kp, const float *A, int lda, const unsigned short *bh, const unsigned short *bl,
                                  float *C, int ldc, float beta) {
@@ -1328,6 +1570,13 @@ static thread_local struct { const float *A; int lda, M, K, transA; void *ws; hi
 void ctcn_gemm_hint_same_a(void) { g_last_a.armed = true; }
 
 static thread_local int g_b_shift = 0;      // one-shot, set by ctcn_gemm_shift_b for the plane path's B split
+// the TN tile (gemm_tn_f32_pp_kernel) takes C = A^T B with 16-B aligned rows of whole float4 pieces, large K, and a workspace for its
+// queue word (+ the split-K partials)
+static bool tn_eligible(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, int precision, const void *ws,
+                        size_t ws_bytes) {
+  return precision == 1 && transA && !transB && ws && ws_bytes >= 1024 && ctcn_get_option("gemm_tn") != 0 && M >= 128 && N >= 32 && K >= 1024 &&
+         M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+}
 // xcd_allow: 0 = whole device; otherwise (precision 1 plane path only) the XCDs the GEMM workgroups may run on
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
                       int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow) {
@@ -1349,6 +1598,15 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
   if (splits > 1) {
     kchunk = ceil_div(ceil_div(K, splits), XBK) * XBK;
     splits = ceil_div(K, kchunk);
+  }
+  if (tn_eligible(transA, transB, M, N, K, A, lda, B, ldb, precision, ws, ws_bytes) && g_b_shift == 0) {
+    // both operands contraction-major (weight gradients): the TN tile reads the float32 rows as they are -- no plane pass
+    g_last_a.valid = false; g_last_a.armed = false;
+    const int wnt = ceil_div(N, 256) * 256 == ceil_div(N, 128) * 128 ? 2 : 1;     // (N = 640 as 3 x 256 or 5 x 128: the same time)
+    unsigned *queue = (unsigned *)((char *)ws + ((ws_bytes - 256) & ~(size_t)255));
+    const int tsplits = tn_splits(M, N, K, wnt, ws_bytes - 512);
+    return wnt == 2 ? launch_tn<2>(st, M, N, K, A, lda, B, ldb, C, ldc, beta, tsplits, (float *)ws, xcd_allow, queue)
+                    : launch_tn<1>(st, M, N, K, A, lda, B, ldb, C, ldc, beta, tsplits, (float *)ws, xcd_allow, queue);
   }
   if (precision == 1 && K >= 64 && ws) {
     // pre-split planes in the workspace: [Ah | Al | Bh | Bl | split-K partials]
@@ -1502,7 +1760,8 @@ int ctcn_gemm_shift_b(int M, int N, int K, const float *A, int lda, const float 
   CTCN_REQUIRE(as < K, "ctcn_gemm_shift_b: |shift| %d >= K %d", as, K);
   const int Kp = ceil_div(K, PBK) * PBK;
   const size_t plane_bytes = align_up(2 * ((size_t)M * Kp + (size_t)N * Kp) * sizeof(unsigned short), 256);
-  const bool plane = precision == 1 && K >= 64 && ws && ws_bytes >= plane_bytes + 1024;
+  const bool plane = precision == 1 && K >= 64 && ws && ws_bytes >= plane_bytes + 1024 &&
+                     !tn_eligible(1, 0, M, N, K - as, A, lda, B, ldb, precision, ws, ws_bytes);   // (the TN tile narrows the window: no planes to share)
   if (!plane) {
     g_last_a.armed = false;
     const float *A2 = shift > 0 ? A + (size_t)as * lda : A, *B2 = shift < 0 ? B + (size_t)as * ldb : B;

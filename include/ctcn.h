@@ -60,6 +60,10 @@ int ctcn_device_xcds(void);
  * "gemm_pingpong" = 1 (default): the 256-row bf16x3 plane tiles run the ping-pong schedule (the two waves of a SIMD half a
  * 16-k step apart: one multiplies while the other reads its fragments; DMA pieces issued between MFMAs); 0: all waves in phase.
  * Bit-identical results either way.
+ * "gemm_tn" = 1 (default): bf16x3 products C = A^T B with BOTH operands contraction-major (transA = 1, transB = 0: the weight
+ * gradients dW = da^T x; M >= 128, N >= 32, K >= 1024, 16-B aligned rows) run on the TN tile -- float32 rows split into hi / lo while
+ * they are staged, ds_read_b64_tr_b16 fragments, split-K queue -- instead of a transposing plane pass + the NT plane tiles; the same
+ * bf16x3 operands and products, the k-sums grouped differently (results agree to float32 rounding of the sums).
  * "rnn_fwd_tagged" = 1 (default): forward persistent recurrence as a tagged gather (rnn_fwd_tagged: no flags, no store drain; the
  * h_t dwords carry the step tag and the gathering waves poll the data itself) where it applies -- precision 1, LSTM / GRU, H % 32 == 0,
  * XCD-local placement; 0: the flag + data kernel (rnn_fwd_persist) everywhere.  "tag_poll_delay" = 8: 64-cycle sleeps between the

@@ -111,6 +111,40 @@ def test_gemm(dev, ta, tb, M, N, K, prec):
     ops.set_precision(0)
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(1280, 640, 25600, 0), (1280, 320, 25568, 0), (388, 132, 1100, 8), (1536, 512, 4099, 4), (960, 320, 9600, 0),
+                                         (128, 64, 1024, 0), (2048, 2560, 2048, 0)])
+def test_gemm_tn_tile(dev, M, N, K, pad):
+    """precision 1, C = A^T B with both operands contraction-major (the weight gradients): the TN tile (`gemm_tn`, float32 rows split
+    while they are staged, ds_read_b64_tr_b16 fragments, split-K queue) against float64, against the plane path (same bf16x3 operands
+    and products, only the order of the k-sums differs), with ragged M / N / K, padded leading dimensions and beta = 1; a second run
+    is bit-identical (the split-K partials are reduced in a fixed order whichever workgroup made them)."""
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    A = torch.from_numpy(rs.standard_normal((K, M + pad)).astype(np.float32)).to(dev)
+    B = torch.from_numpy(rs.standard_normal((K, N + pad)).astype(np.float32)).to(dev)
+    C0 = torch.from_numpy(rs.standard_normal((M, N + 3)).astype(np.float32)).to(dev)
+    ref = A[:, :M].double().t() @ B[:, :N].double()
+    ops.set_precision(1)
+    try:
+        for beta in (0.0, 1.0):
+            outs = []
+            for tn in (1, 1, 0):
+                ops.set_option("gemm_tn", tn)
+                C = C0.clone()
+                ops.gemm(1, 0, M, N, K, A, M + pad, B, N + pad, C, N + 3, beta=beta)
+                outs.append(C)
+            want = ref + beta * C0[:, :N].double()
+            tol = 4e-5 * 4 * float(A.abs().max() * B.abs().max()) * K ** 0.5
+            for o in outs:
+                assert float((o[:, :N].double() - want).abs().max()) < tol
+                assert torch.equal(o[:, N:], C0[:, N:]), "wrote outside the ldc window"
+            assert torch.equal(outs[0], outs[1])
+            assert float((outs[0][:, :N] - outs[2][:, :N]).abs().max()) < 1e-5 * K ** 0.5
+    finally:
+        ops.set_option("gemm_tn", 1)
+        ops.set_precision(0)
+
+
 @pytest.mark.parametrize("M,N,K,ta,tb", [(8192, 1024, 200, 0, 1), (1024, 8192, 136, 0, 1), (8190, 1030, 72, 0, 0), (25600, 640, 1280, 0, 0)])
 def test_gemm_bf16x3_big_tiles_equal_small_tiles(dev, M, N, K, ta, tb):
     """precision 1: the optional 256x128 / 128x256 workgroup tiles (`gemm_big_tiles`; fewer LDS fragment reads per MFMA,
