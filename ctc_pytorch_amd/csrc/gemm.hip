@@ -1267,7 +1267,8 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__rest
 //   * the MFMA operand (lane = m, 8 consecutive k) is the transpose of that image: two ds_read_b64_tr_b16 per fragment (each
 //     16-lane group reads a 4 k x 16 m block and receives it transposed), so no shuffle and no second LDS pass;
 //   * the ping-pong schedule of gemm_planes_nt256pp_af32_kernel with BOTH operands through the registers: global loads of stage
-//     s + 2 between the MFMAs of the second multiply phase of stage s, split + LDS stores in the second read phase of stage s + 1;
+//     s + 2 between the MFMAs of the second multiply phase of stage s, their hi / lo split between the MFMAs of the first multiply
+//     phase of stage s + 1 (VALU work in the shadow of the wave's own MFMAs), LDS stores in the read phase after it;
 //   * split-K with an atomic (tile, split) queue on the XCDs of `xcd_mask`: partial tiles land in the workspace and
 //     splitk_reduce_kernel adds them up -- the order of the splits is fixed, so the result does not depend on which workgroup
 //     computed what.
@@ -1329,13 +1330,17 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
 
     const int acol = m0 + 32 * wave + c4, bcol = n0 + 32 * bsub + c4;
     const bool a_ok = acol < M, b_ok = bcol < N;                 // (M, N multiples of 4: a piece is inside or outside as a whole)
-    const float *aptr = A + min(acol, M - 4), *bptr = B + min(bcol, N - 4);
-    f32x4 av[4], bv[NB];
-    // (the loads are bare -- clamped addresses, no select -- so that nothing waits for them inside the multiply phase they are issued
-    // in; pieces beyond M / N / the k window are zeroed when they are split, two phases later)
-    auto load_piece = [&](int q, int k0) {                       // q = 0..3: A, 4..4+NB-1: B; k0 = first k of the stage
-      if (q < 4) av[q] = *reinterpret_cast<const f32x4 *>(aptr + (size_t)min(k0 + 8 * q + krow, K - 1) * lda);
-      else bv[q - 4] = *reinterpret_cast<const f32x4 *>(bptr + (size_t)min(k0 + bk0 + 8 * (q - 4) + krow, K - 1) * ldb);
+    const float *aptr = A + acol, *bptr = B + bcol;
+    // pw[q]: piece q of the stage in flight (0..3: A, 4..: B) -- first the four floats as loaded, then (convert_piece) the packed
+    // words {hi01, hi23, lo01, lo23} in the same registers.  A piece beyond M / N / the k window is loaded from 16 zero bytes next to
+    // the queue word instead: the select is on the ADDRESS, so nothing waits for the data inside the multiply phase the loads are
+    // issued in, and the split needs no special case
+    u32x4 pw[4 + NB];
+    const float *zero16 = reinterpret_cast<const float *>(queue + 16);
+    auto load_piece = [&](int q, int k0) {                       // k0 = first k of the stage
+      const int k = q < 4 ? k0 + 8 * q + krow : k0 + bk0 + 8 * (q - 4) + krow;
+      const float *src = q < 4 ? aptr + (size_t)k * lda : bptr + (size_t)k * ldb;
+      pw[q] = *reinterpret_cast<const u32x4 *>((q < 4 ? a_ok : b_ok) && k < kend ? src : zero16);
     };
     // two neighbours at a time: hi = bf16(x) of both in one v_cvt_pk_bf16_f32, lo = bf16(x - hi) likewise (the split_bf16 values)
     auto split_pair = [](float a, float b, unsigned &hw, unsigned &lw) {
@@ -1345,30 +1350,19 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
       const f32x2_t r = {a - __uint_as_float(hw << 16), b - __uint_as_float(hw & 0xffff0000u)};
       lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
     };
-    auto store_piece = [&](auto masked, unsigned char *p, int plane_bytes, const f32x4 &v, bool ok) {
+    auto convert_piece = [&](int q) {
       unsigned h01, l01, h23, l23;
-      split_pair(v[0], v[1], h01, l01);
-      split_pair(v[2], v[3], h23, l23);
-      if constexpr (decltype(masked)::value == 1) {
-        const unsigned keep = ok ? 0xffffffffu : 0u;
-        h01 &= keep; l01 &= keep; h23 &= keep; l23 &= keep;
-      }
-      *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2 *>(p + plane_bytes) = make_uint2(l01, l23);
+      split_pair(__uint_as_float(pw[q][0]), __uint_as_float(pw[q][1]), h01, l01);
+      split_pair(__uint_as_float(pw[q][2]), __uint_as_float(pw[q][3]), h23, l23);
+      pw[q] = (u32x4){h01, h23, l01, l23};
     };
-    const bool edge_tile = m0 + TBM > M || n0 + TBN > N;          // (workgroup-uniform: interior tiles skip the zeroing of pieces)
-    auto store_ab = [&](int buf, int k0) {                       // k0 = first k of the stage the registers hold
+    auto store_ab = [&](int buf) {                               // converted pieces -> the K-major image
       unsigned char *sb = qsm + buf * STAGE;
-      if (edge_tile || k0 + 32 > kend) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_piece(std::integral_constant<int, 1>{}, sb + st_a + q * 512, A_BYTES, av[q], a_ok && k0 + 8 * q + krow < kend);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) store_piece(std::integral_constant<int, 1>{}, sb + st_b + q * 512, B_BYTES, bv[q], b_ok && k0 + bk0 + 8 * q + krow < kend);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store_piece(std::integral_constant<int, 0>{}, sb + st_a + q * 512, A_BYTES, av[q], true);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) store_piece(std::integral_constant<int, 0>{}, sb + st_b + q * 512, B_BYTES, bv[q], true);
+      for (int q = 0; q < 4 + NB; ++q) {
+        unsigned char *p = sb + (q < 4 ? st_a + q * 512 : st_b + (q - 4) * 512);
+        *reinterpret_cast<uint2 *>(p) = make_uint2(pw[q][0], pw[q][1]);
+        *reinterpret_cast<uint2 *>(p + (q < 4 ? A_BYTES : B_BYTES)) = make_uint2(pw[q][2], pw[q][3]);
       }
     };
     bf16x8_t ah[4], al[4], bh[WNT], bl[WNT];
@@ -1392,7 +1386,8 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
         al[i] = tr_frag(p + A_BYTES);
       }
     };
-    // MODE 0: bare MFMAs; 1: + this thread's 4 + NB global loads of the stage that begins at k0, one after every other MFMA
+    // MODE 0: bare MFMAs; 1: + this thread's 4 + NB global loads of the stage that begins at k0, one after every other MFMA;
+    // 2: + the split of the pieces loaded last into hi / lo words, one piece after every other MFMA
     auto multiply = [&](auto mode, int k0) {
       constexpr int MODE = decltype(mode)::value;
 #pragma unroll
@@ -1405,32 +1400,39 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
             else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             const int n = t * NMM + i * WNT + j;
-            if (MODE == 1 && (n & 1) && (n >> 1) < 4 + NB) {
+            if (MODE != 0 && (n & 1) && (n >> 1) < 4 + NB) {
               __builtin_amdgcn_sched_barrier(0);
-              load_piece(n >> 1, k0);
+              if constexpr (MODE == 1) load_piece(n >> 1, k0);
+              if constexpr (MODE == 2) convert_piece(n >> 1);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
     };
     constexpr std::integral_constant<int, 0> bare{};
     constexpr std::integral_constant<int, 1> with_loads{};
+    constexpr std::integral_constant<int, 2> with_split{};
     // prologue: stage 0 into buffer 0, stage 1 into the registers
 #pragma unroll
     for (int q = 0; q < 4 + NB; ++q) load_piece(q, kbeg);
-    store_ab(0, kbeg);
+#pragma unroll
+    for (int q = 0; q < 4 + NB; ++q) convert_piece(q);
+    store_ab(0);
     if (nst > 1) {
 #pragma unroll
       for (int q = 0; q < 4 + NB; ++q) load_piece(q, kbeg + 32);
     }
     pp_barrier();
     if (wm == 1) pp_barrier();
+    // a stage = four phases: read (s, k-half 0) | multiply + split of the pieces of stage s + 1 (loaded two phases ago) |
+    //                        read (s, 1) + LDS stores of stage s + 1 (buffer last read two phases ago) | multiply + loads of stage s + 2
     auto stage = [&](int s, auto do_store, auto c1) {
       load_frags(s, 0);
       pp_barrier();
-      multiply(bare, 0);
+      if constexpr (decltype(do_store)::value == 1) multiply(with_split, 0);
+      else multiply(bare, 0);
       pp_barrier();
       load_frags(s, 1);
-      if constexpr (decltype(do_store)::value == 1) store_ab((s + 1) & 1, kbeg + (s + 1) * 32);   // stage s + 1 (loaded three phases ago) -> the buffer last read two phases ago
+      if constexpr (decltype(do_store)::value == 1) store_ab((s + 1) & 1);
       pp_barrier();
       multiply(c1, kbeg + (s + 2) * 32);
       pp_barrier();
@@ -1480,7 +1482,7 @@ static int launch_tn(hipStream_t st, int M, int N, int K, const float *A, int ld
   const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
   auto kern = gemm_tn_f32_pp_kernel<WNT>;
   CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CTCN_HIP(hipMemsetAsync(queue, 0, 4, st));
+  CTCN_HIP(hipMemsetAsync(queue, 0, 128, st));              // the queue word, and at +64 the 16 zero bytes pieces outside the operands are loaded from
   const int nx = std::min(ctcn_device_xcds(), 16);
   const unsigned xcd_mask = xcd_allow ? xcd_allow : (nx > 1 ? (1u << nx) - 1u : 0xffffu);
   hipLaunchKernelGGL(kern, dim3(ctcn_device_cus()), dim3(512), lds, st, M, N, K, A, lda, B, ldb, C, ldc, beta, kchunk, splits, part, tiles_m, tiles_n, xcd_mask,
