@@ -2195,6 +2195,10 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   const float *w_ih[2] = {w_ih0, w_ih1};
   float *dw_ih[2] = {dw_ih0, dw_ih1};
   float *dw_hh[2] = {dw_hh0, dw_hh1};
+  // (dx pipelined with the recurrence -- write-through d(pre-activation) stores, a counter per (direction, time chunk), one-lane
+  // waiters + chunk GEMMs on a third stream on the idle XCDs -- was built twice in round 2 and removed twice: with the weight
+  // gradients on the TN tile the idle XCDs hold ~1.0 ms of weight GEMMs per 1.44 ms recurrence, the 16 chunk products add ~0.7 ms
+  // there, the recurrence itself slows to 1.67 ms next to them, and the step goes from 14.0 to 14.9 ms at cfg2 (57.6 -> 57.1 at cfg4))
   // dx = [da_fwd | da_rev] [W_ih_fwd ; W_ih_rev]: the reserve already holds both directions side by side (row = dirs*GH floats),
   // so with the two weight matrices stacked in the workspace one K = 2*GH product replaces two K = GH products and the
   // read-modify-write of dx between them (65 MB each way at cfg2)
