@@ -1570,6 +1570,10 @@ __global__ void transpose01_kernel(const float *__restrict__ in, float *__restri
 // workspace, so the next call skips its split pass when pointer / shape / layout match.  One-shot, per host thread.
 static thread_local struct { const float *A; int lda, M, K, transA; void *ws; hipStream_t st; bool valid, armed; } g_last_a = {};
 void ctcn_gemm_hint_same_a(void) { g_last_a.armed = true; }
+// ... and the same for B (the chunk GEMMs of a pipelined input projection multiply by the same W_ih six times): its planes of the
+// previous call are reused when they sit at the same place in the same workspace (i.e. the A operand has the same size too)
+static thread_local struct { const float *B; int ldb, N, K, transB, shift; void *ws; hipStream_t st; const unsigned short *bh; bool valid, armed; } g_last_b = {};
+void ctcn_gemm_hint_same_b(void) { g_last_b.armed = true; }
 
 static thread_local int g_b_shift = 0;      // one-shot, set by ctcn_gemm_shift_b for the plane path's B split
 // the TN tile (gemm_tn_f32_pp_kernel) takes C = A^T B with 16-B aligned rows of whole float4 pieces, large K, and a workspace for its
@@ -1604,6 +1608,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
   if (tn_eligible(transA, transB, M, N, K, A, lda, B, ldb, precision, ws, ws_bytes) && g_b_shift == 0) {
     // both operands contraction-major (weight gradients): the TN tile reads the float32 rows as they are -- no plane pass
     g_last_a.valid = false; g_last_a.armed = false;
+    g_last_b.valid = false; g_last_b.armed = false;
     const int wnt = ceil_div(N, 256) * 256 == ceil_div(N, 128) * 128 ? 2 : 1;     // (N = 640 as 3 x 256 or 5 x 128: the same time)
     unsigned *queue = (unsigned *)((char *)ws + ((ws_bytes - 256) & ~(size_t)255));
     const int tsplits = tn_splits(M, N, K, wnt, ws_bytes - 512);
@@ -1638,6 +1643,11 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       const bool same_a = g_last_a.armed && g_last_a.valid && g_last_a.A == A && g_last_a.lda == lda && g_last_a.M == M && g_last_a.K == K &&
                           g_last_a.transA == transA && g_last_a.ws == ws && g_last_a.st == st;
       g_last_a.armed = false;
+      const bool same_b = g_last_b.armed && g_last_b.valid && g_last_b.B == B && g_last_b.ldb == ldb && g_last_b.N == N && g_last_b.K == K &&
+                          g_last_b.transB == transB && g_last_b.shift == g_b_shift && g_last_b.ws == ws && g_last_b.st == st && g_last_b.bh == bh;
+      g_last_b.armed = false;
+      g_last_b.B = B; g_last_b.ldb = ldb; g_last_b.N = N; g_last_b.K = K; g_last_b.transB = transB; g_last_b.shift = g_b_shift; g_last_b.ws = ws;
+      g_last_b.st = st; g_last_b.bh = bh; g_last_b.valid = true;            // (every branch below leaves B's planes at bh / bl)
       // activation-sized products (M = T*B): the 256-row tiles, when they give the device at least ~0.75 workgroups per CU; a
       // row-major A (k contiguous) is then split while it is staged, without a plane pass of its own
       const int wnt256 = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
@@ -1651,7 +1661,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
         g_last_a.valid = false;                     // no A planes in the workspace after this call
         const int bshift0 = g_b_shift;
         g_b_shift = 0;
-        split(B, ldb, transB == 0, N, bh, bl, bshift0);
+        if (!same_b) split(B, ldb, transB == 0, N, bh, bl, bshift0);
         CTCN_LAUNCH_CHECK();
         const int lrc = wnt256 == 2 ? launch_planes256_af32<2>(st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta)
                                     : launch_planes256_af32<1>(st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta);
@@ -1664,7 +1674,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       g_last_a.valid = true;
       const int bshift = g_b_shift;
       g_b_shift = 0;
-      split(B, ldb, transB == 0, N, bh, bl, bshift);
+      if (!same_b) split(B, ldb, transB == 0, N, bh, bl, bshift);
       CTCN_LAUNCH_CHECK();
       // tile shape: 128x128 (two workgroups per CU).  Option gemm_big_tiles: 256x128 / 128x256 tiles (one per CU, 96 KB of LDS)
       // when they fill the device at least once without more padding -- 25 % fewer LDS fragment reads per MFMA, yet measured
@@ -1716,6 +1726,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
     }
   }
   g_last_a.valid = false; g_last_a.armed = false;               // not the plane path: nothing to reuse
+  g_last_b.valid = false; g_last_b.armed = false;
   const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
   float *wsp = splits > 1 ? (float *)ws : nullptr;

@@ -2035,6 +2035,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   };
   if (piped) {
     int rc = project_chunk(0, ws, ws_bytes, stream, 0);
+    ctcn_gemm_hint_same_b();                              // W_ih: split into planes once per stream (reused when the chunk has the same size)
     if (!rc) rc = project_chunk(NCHUNK - 1, ws, ws_bytes, stream, 0);
     if (rc) return rc;
     proj_done = true;
@@ -2124,7 +2125,11 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
             hipStream_t sd = (hipStream_t)ov.stream;
             CTCN_HIP(hipStreamWaitEvent(sd, (hipEvent_t)ov.event, 0));
             for (int pr = 1; pr < NCHUNK / 2; ++pr) {
+              // (W_ih is split into planes by the first of these calls only; splitting x of all six side chunks in that call as well --
+              // one pass instead of six -- delays the first pair and measured 35 us per step slower)
+              if (pr > 1) ctcn_gemm_hint_same_b();
               int rc = project_chunk(pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
+              ctcn_gemm_hint_same_b();
               if (!rc) rc = project_chunk(NCHUNK - 1 - pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
               if (rc) return rc;
               hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, sd, pa.chunk_ready, (unsigned)pr);
@@ -2330,15 +2335,17 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;
 #endif
-      CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
       const dim3 pgrid = mode ? dim3(nx * (wpx + std::max(2, wpx / 8)), 1, 1) : grid;
+      // flags + tickets, and the hand-off tiles where they start from zero (tags / partial sums): the two areas are contiguous -> one memset
       if (scatter) {
         pa.tagmode = ctcn_opt_handoff_tags();
-        if (pa.tagmode) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));       // tags start from 0
+        if (pa.tagmode) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));
+        else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         record_prelaunch(st);
         done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
       } else {
-        if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes, st));
+        if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));
+        else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         record_prelaunch(st);
         done = launch_bwd_persist(prec, kq, pgrid, lds, st, pa, wpx);
       }
