@@ -788,24 +788,17 @@ __device__ __forceinline__ void pp_barrier_vm() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// one 256 x (128 * WNT) output tile (tile number `bid`, row-major over tiles_m x tiles_n) in the ping-pong schedule
 template <int WNT>
-__global__ __launch_bounds__(512) void gemm_planes_nt256pp_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
-                                                                  const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
-                                                                  const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
-                                                                  int tiles_m, int tiles_n, int dbg) {
+__device__ __forceinline__ void planes256pp_tile(unsigned char *qsm, int bid, int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                 const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                 const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta, int tiles_n, int dbg) {
   constexpr int TBM = 256, TBN = 128 * WNT;
   constexpr int A_BYTES = TBM * 64, B_BYTES = TBN * 64;
   constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
   constexpr int IA = TBM * 4 / 512, IB = TBN * 4 / 512;
-  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nt = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * TBM, n0 = tn * TBN;
 
@@ -947,6 +940,44 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_kernel(int M, int N, 
         }
       }
     }
+}
+
+template <int WNT>
+__global__ __launch_bounds__(512) void gemm_planes_nt256pp_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                                  const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                                  const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
+                                                                  int tiles_m, int tiles_n, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  const int nt = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  planes256pp_tile<WNT>(qsm, bid, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, tiles_n, dbg);
+}
+
+// XCD-filtered form for a side stream next to a persistent recurrence (see gemm_planes_nt_queue_kernel): workgroups off `xcd_allow`
+// leave, the others take tiles from an atomic queue.  The same tile code: bit-identical results.
+template <int WNT>
+__global__ __launch_bounds__(512) void gemm_planes_nt256pp_queue_kernel(int M, int N, int Kp, const unsigned short *__restrict__ Ah,
+                                                                        const unsigned short *__restrict__ Al, const unsigned short *__restrict__ Bh,
+                                                                        const unsigned short *__restrict__ Bl, float *__restrict__ C, int ldc, float beta,
+                                                                        int tiles_m, int tiles_n, unsigned xcd_allow, unsigned *__restrict__ queue) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+  __shared__ int s_item;
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (!((xcd_allow >> (x & 15)) & 1u)) return;
+  const int nt = tiles_m * tiles_n;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nt) return;
+    planes256pp_tile<WNT>(qsm, item, M, N, Kp, Ah, Al, Bh, Bl, C, ldc, beta, tiles_n, 0);
+    __syncthreads();
+  }
 }
 
 // The same tile with the A operand taken straight from the float32 matrix (row-major, k contiguous) and split into hi / lo bf16
@@ -1519,6 +1550,17 @@ static int launch_planes256(hipStream_t st, int M, int N, int Kp, const unsigned
   return CTCN_OK;
 }
 
+template <int WNT>
+static int launch_planes256_queue(hipStream_t st, int M, int N, int Kp, const unsigned short *ah, const unsigned short *al, const unsigned short *bh,
+                                  const unsigned short *bl, float *C, int ldc, float beta, unsigned xcd_allow, unsigned *queue) {
+  const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
+  const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
+  auto kern = gemm_planes_nt256pp_queue_kernel<WNT>;
+  CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(ctcn_device_cus()), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, tiles_m, tiles_n, xcd_allow, queue);
+  return CTCN_OK;
+}
+
 // launch one of the three tile shapes (dynamic LDS = 2 planes x (BM + BN) rows x 128 B)
 template <int TI, int TJ>
 static int launch_planes(bool queued, int nt, int psplits, hipStream_t st, int M, int N, int Kp, const unsigned short *ah, const unsigned short *al,
@@ -1697,6 +1739,19 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
         if (lrc256) return lrc256;
         CTCN_LAUNCH_CHECK();
         return CTCN_OK;
+      }
+      // side stream: the 256-row tiles from a queue when they fill the allowed XCDs' CUs at least 3/4 in whole rounds of one tile per CU
+      // (the chunk GEMMs of the pipelined input projection are sized for that: rnn.hip)
+      if (xcd_allow && ctcn_get_option("gemm_tile256") != 0 && ctcn_get_option("gemm_pingpong") != 0 && M >= 1024 && N >= 96) {
+        const int cus = ctcn_device_cus() / std::max(1, std::min(ctcn_device_xcds(), 16)) * __builtin_popcount(xcd_allow);
+        const int t256 = ceil_div(M, 256) * ceil_div(N, 128 * wnt256), rounds = ceil_div(t256, std::max(cus, 1));
+        if (cus > 0 && t256 * 4 >= rounds * cus * 3) {
+          const int lrc = wnt256 == 2 ? launch_planes256_queue<2>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, xcd_allow, queue)
+                                      : launch_planes256_queue<1>(st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, xcd_allow, queue);
+          if (lrc) return lrc;
+          CTCN_LAUNCH_CHECK();
+          return CTCN_OK;
+        }
       }
       const int pnt = ptm * ptn;
       int psplits = 1;

@@ -2017,9 +2017,22 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   const FwdOverlap ov = g_fwd_overlap;
   g_fwd_overlap = FwdOverlap{nullptr, nullptr, nullptr, 0, 0};
   // pipelined projection: needs the tagged-gather kernel (the only one that checks the chunk counter), both W_ih stacked, idle XCDs
-  constexpr int NCHUNK = 8;
-  const int chunk_T = ceil_div(T, NCHUNK);
   const int nxd_p = ctcn_opt_handoff() ? ctcn_device_xcds() : 1;
+  // time chunks: 8, or the first even count whose chunk GEMM ((T / n) * B rows x 2*GH columns) the side stream's 256-row tile queue
+  // (gemm_planes_nt256pp_queue_kernel) digests in ONE round on the allowed XCDs' CUs, at least 3/4 of them busy: cfg2 (T = 800, B = 32,
+  // H = 320): 10 chunks of 2 560 rows = 10 x 10 tiles on 128 CUs -- a pair then takes less time than the recurrence needs for a chunk,
+  // which with 8 chunks of 3 200 rows on the 128 x 128 tiles it did not (the recurrence waited ~50 us per layer for its pre-activations)
+  int NCHUNK = 8;
+  if (ov.xcd_allow && nxd_p > 1) {
+    const int cus_side = ctcn_device_cus() / nxd_p * __builtin_popcount(ov.xcd_allow), N2 = 2 * GH;
+    const int wnt = (N2 % 256 == 0 || (N2 > 512 && ceil_div(N2, 256) * 256 - N2 <= N2 / 8)) ? 2 : 1, tiles_n = ceil_div(N2, 128 * wnt);
+    for (int n : {8, 10, 12, 14, 16, 20, 24}) {
+      const int ct = ceil_div(T, n);
+      const long rows = (long)ct * B, tiles = rows / 256 * tiles_n;
+      if (rows % 256 == 0 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; break; }
+    }
+  }
+  const int chunk_T = ceil_div(T, NCHUNK);
   const bool piped = !proj_done && ov.stream && ov.event && ov.ws && ov.xcd_allow != 0 && dirs == 2 && w_ih1 == w_ih0 + (size_t)GH * I &&
                      ctcn_opt_rnn_persistent() && ctcn_get_option("rnn_fwd_tagged") && precision == 1 && cell != CTCN_CELL_TANH && H % 32 == 0 &&
                      H / 32 <= 24 && nxd_p > 1 && T >= 4 * NCHUNK && chunk_T * (NCHUNK - 1) < T &&
