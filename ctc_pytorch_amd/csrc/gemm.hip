@@ -1501,6 +1501,7 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
 static int tn_splits(int M, int N, int K, int wnt, size_t part_bytes) {
   const int tiles = ceil_div(M, 256) * ceil_div(N, 128 * wnt);
   int s = std::min(std::max(256 / tiles, 1), std::max(K / 512, 1));      // <= 256 items: one round on a whole device, two on half of it
+  s = std::min(s, 32);                                                    // (a handful of tiles: the reduce pass over the partials would take over)
   s = std::min(s, (int)(part_bytes / ((size_t)M * N * sizeof(float))));
   return s < 2 ? 1 : s;
 }
@@ -1584,8 +1585,17 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__rest
                                      int splits, float beta) {
   const size_t total = (size_t)M * N;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // the partials are summed in split order (the result does not depend on the launch), eight loads in flight at a time
     float s = 0.0f;
-    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * total + i];
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(z + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < splits; ++z) s += ws[(size_t)z * total + i];
     const size_t m = i / N, n = i - m * N;
     float *p = C + m * ldc + n;
     if (beta != 0.0f) s += beta * *p;

@@ -2216,7 +2216,11 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   // (dx pipelined with the recurrence -- write-through d(pre-activation) stores, a counter per (direction, time chunk), one-lane
   // waiters + chunk GEMMs on a third stream on the idle XCDs -- was built twice in round 2 and removed twice: with the weight
   // gradients on the TN tile the idle XCDs hold ~1.0 ms of weight GEMMs per 1.44 ms recurrence, the 16 chunk products add ~0.7 ms
-  // there, the recurrence itself slows to 1.67 ms next to them, and the step goes from 14.0 to 14.9 ms at cfg2 (57.6 -> 57.1 at cfg4))
+  // there, the recurrence itself slows to 1.67 ms next to them, and the step goes from 14.0 to 14.9 ms at cfg2 (57.6 -> 57.1 at cfg4).
+  // The same machinery for the BOTTOM layer's weight gradients -- the time chunks are the natural split-K partials of dW, so only the
+  // last pair would be left for the ~320 us tail after the last recurrence -- loses as well: 16 x 7 small launches on a third stream
+  // finish ~1 ms after the recurrence (which slows from 1.48 to 1.57 ms next to them): 13.8 -> 14.3 ms.  The write-through stores and
+  // the counters themselves cost 12 us per layer.)
   // dx = [da_fwd | da_rev] [W_ih_fwd ; W_ih_rev]: the reserve already holds both directions side by side (row = dirs*GH floats),
   // so with the two weight matrices stacked in the workspace one K = 2*GH product replaces two K = GH products and the
   // read-modify-write of dx between them (65 MB each way at cfg2)
