@@ -12,6 +12,7 @@ ALGO = [   # (substring of the kernel name, label, algorithmic bytes per launch 
     ("gemm_planes_nt256pp_af32_kernel<1>", "gemm 25600x640x2560 (dx of the layer; A = f32 d(pre-act) split while staged, ping-pong tile)", 25600 * 2560 * 4 + 640 * 2560 * 4 + 25600 * 640 * 4),
     ("gemm_planes_nt256_af32_kernel<2>", "gemm 25600x1280x640 (probe of bench.py; A = f32 split while staged)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
     ("gemm_planes_nt256_af32_kernel<1>", "gemm 25600x640x2560 (dx of the layer; A = f32 d(pre-act) split while staged)", 25600 * 2560 * 4 + 640 * 2560 * 4 + 25600 * 640 * 4),
+    ("gemm_tn_f32_pp_kernel", "gemm_tn_f32_pp_kernel (weight gradients of the probe layer: dW_ih 1280x640x25600 and dW_hh 1280x320x25568, both directions, averaged; algorithmic bytes of dW_ih: both operands once + the output)", 25600 * (1280 + 640) * 4 + 1280 * 640 * 4),
     ("gemm_planes_nt256pp_kernel<2>", "gemm_planes_nt256pp_kernel<2> (256 x 256 ping-pong tile; bf16 planes in, f32 out)", None),
     ("gemm_planes_nt256_kernel", "gemm_planes_nt256_kernel (bf16 planes in, f32 out)", None),
     ("split_rows_kernel", "split_rows_kernel", None),
