@@ -347,29 +347,52 @@ def decode_leg(dev, steps=5):
     i2c = synth.int2char(V)
     arpa = os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")
     tab = LanguageModel(arpa).table([i2c[i] for i in range(V)])
-    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM alpha=0.1, 128 x 800 x 62 log-probs in HBM)", "unit": "utt/s", "n_gpus": 1,
+    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM alpha=0.1, 128 x 800 x 62 log-probs in HBM; two batches in flight, results handed to the host)", "unit": "utt/s", "n_gpus": 1,
            "config": {"workload": "cfg5: BeamDecoder W=20 + phone bigram LM over 128 utterances x 800 frames x 62 classes, lens U{400..800}"},
            "regimes": {}}
+    tab_dev = torch.as_tensor(tab, dtype=torch.float64).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
     for regime in ("peaky", "flat"):
         lp = synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)
         lens = list(np.random.RandomState(2).randint(400, 801, size=B))
         x = torch.from_numpy(lp).to(dev)
+        lens_dev = torch.as_tensor(lens, dtype=torch.int32).to(dev)         # resident like the log-probs
         ids, _, st = ops.beam_decode(x, lens, tab, 0.1, W)                  # warm-up + the strings that are checked
         torch.cuda.synchronize()
+        # one batch at a time on one stream: the kernel time of a batch (HIP events) ...
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
         for _ in range(steps):
-            dev_out = ops.beam_decode_device(x, lens, tab, 0.1, W)
+            dev_out = ops.beam_decode_device(x, lens_dev, tab_dev, 0.1, W)
         e1.record()
         ids_c, len_c = dev_out[0].cpu(), dev_out[1].cpu()                   # host hand-over of the last batch (synchronises)
-        dt = (time.perf_counter() - t0) / steps
+        dt1 = (time.perf_counter() - t0) / steps
         kernel_us = e0.elapsed_time(e1) * 1e3 / steps
+        # ... and the way steps/test_ctc.decode_and_score runs it: two batches in flight on two streams (a batch is one workgroup per
+        # utterance = half of the CUs), every batch handed to the host through pinned memory (ops.beam_decode_async)
+        nfl = 4 * max(steps, 4)
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                ops.beam_decode_async(x, lens_dev, tab_dev, 0.1, W).result()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pend = []
+        for k in range(nfl):
+            with torch.cuda.stream(streams[k % 2]):
+                pend.append(ops.beam_decode_async(x, lens_dev, tab_dev, 0.1, W))
+            if len(pend) == 4:                                              # two searches running, two queued behind them
+                last = pend.pop(0).result()
+        for h in pend:
+            last = h.result()
+        dt = (time.perf_counter() - t0) / nfl
+        assert last[0] == ids
         # frames the search really processes: the reference skips a frame when 1 - p(blank) < 0.1 (BeamSearch.py:93-94)
         pb = np.exp(lp[:, :, 0])
         processed = int(sum(int(((1.0 - pb[:lens[b], b]) >= 0.1).sum()) for b in range(B)))
         longest = max(int(((1.0 - pb[:lens[b], b]) >= 0.1).sum()) for b in range(B))
-        r = {"value": B / dt, "ms_per_batch": dt * 1e3, "kernel_us_per_batch": kernel_us, "processed_frames": processed,
+        r = {"value": B / dt, "ms_per_batch": dt * 1e3, "batches_in_flight": "2 running on two streams + 2 queued", "value_one_batch_at_a_time": B / dt1, "kernel_us_per_batch": kernel_us,
+             "processed_frames": processed,
              "us_per_processed_frame_on_the_longest_utterance": kernel_us / max(longest, 1)}
         nref = 4 if regime == "flat" else 16
         probs = np.exp(lp[:, :nref, :]).transpose(1, 0, 2)

@@ -6,6 +6,7 @@ tensor raises (the product has no CPU path; the CPU restatement lives in oracle/
 """
 import ctypes
 import os
+import numpy as np
 
 import torch
 
@@ -849,21 +850,63 @@ def beam_decode_device(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_
     x = _f32c(x_tbv.detach())
     T, B, V = x.shape
     dev = x.device
-    lens_t = torch.as_tensor(lens, dtype=torch.int32, device=dev).contiguous()
+    if torch.is_tensor(lens) and lens.is_cuda:
+        lens_t = lens.to(dtype=torch.int32).contiguous()
+    else:       # through pinned memory: a pageable upload would make the host wait for everything queued on this stream before it
+        lens_h = torch.as_tensor(lens, dtype=torch.int32).contiguous().pin_memory()
+        lens_t = lens_h.to(dev, non_blocking=True)
     lm = torch.as_tensor(lm_table, dtype=torch.float64, device=dev).contiguous()
     if lm.numel() != (V + 1) * (V + 1):
         raise ValueError("lm table must be (V+1)x(V+1)")
     L = _lib.lib()
     nb = L.ctcn_beam_ws_bytes(T, B, V, int(beam_width))
     ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
-    out_ids = torch.zeros((B, T), dtype=torch.int32, device=dev)
-    out_len = torch.zeros(B, dtype=torch.int32, device=dev)
-    score = torch.zeros(B, dtype=torch.float64, device=dev)
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    # one zeroed buffer for the four results (one fill, one copy to the host): score | ids | lengths | status
+    out = torch.zeros(B * (8 + 4 * T + 4 + 4), dtype=torch.uint8, device=dev)
+    score = out[: 8 * B].view(torch.float64)
+    out_ids = out[8 * B: 8 * B + 4 * B * T].view(torch.int32).view(B, T)
+    out_len = out[8 * B + 4 * B * T: 8 * B + 4 * B * T + 4 * B].view(torch.int32)
+    status = out[8 * B + 4 * B * T + 4 * B:].view(torch.int32)
     _lib.check(L.ctcn_beam_decode(_ptr(x), int(bool(input_is_prob)), _ptr(lens_t), _ptr(lm), float(alpha), int(beam_width), int(blank),
                                   _ptr(out_ids), _ptr(out_len), _ptr(score), _ptr(status), T, B, V, _ptr(ws), ws.numel(),
                                   _lib.stream_ptr()), "beam_decode")
     return out_ids, out_len, score, status
+
+
+class BeamResult(object):
+    """Handle of a prefix beam search enqueued on the current stream (beam_decode_async): the device results are copied into pinned host
+    memory behind the search, `result()` waits for that copy alone -- other streams keep running -- and returns what beam_decode returns."""
+
+    def __init__(self, dev_out):
+        out_ids, out_len, score, status = dev_out
+        B, T = out_ids.shape
+        whole = score._base if score._base is not None else None        # the four are views of one buffer (beam_decode_device)
+        if whole is None or whole.numel() != B * (8 + 4 * T + 8):
+            whole = torch.cat([t.contiguous().view(-1).view(torch.uint8) for t in (score, out_ids, out_len, status)])
+        self._host = torch.empty(whole.shape, dtype=torch.uint8, pin_memory=True)
+        self._host.copy_(whole, non_blocking=True)
+        self._dims = (B, T)
+        self._keep = (whole, dev_out)                # the device tensors stay alive until the copy has run
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(out_ids.device))
+
+    def result(self):
+        self._event.synchronize()
+        self._keep = None
+        B, T = self._dims
+        h = self._host.numpy()
+        score = h[: 8 * B].view(np.float64)
+        ids_c = h[8 * B: 8 * B + 4 * B * T].view(np.int32).reshape(B, T)
+        len_c = h[8 * B + 4 * B * T: 8 * B + 4 * B * T + 4 * B].view(np.int32)
+        status = h[8 * B + 4 * B * T + 4 * B:].view(np.int32)
+        return [ids_c[b, : len_c[b]].tolist() for b in range(B)], score.copy(), status.copy()
+
+
+def beam_decode_async(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):
+    """beam_decode without the host synchronisation: enqueues the search on the CURRENT stream and returns a BeamResult.  Two searches
+    enqueued on two streams run side by side (a 128-utterance batch is 128 workgroups, half of the device's CUs); `lm_table` may be a
+    device tensor (it is uploaded per call otherwise)."""
+    return BeamResult(beam_decode_device(x_tbv, lens, lm_table, alpha, beam_width, blank, input_is_prob))
 
 
 def beam_decode(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):

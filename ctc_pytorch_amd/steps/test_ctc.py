@@ -22,21 +22,44 @@ def decode_and_score(model, loader, decoder, index2word, device, verbose=False, 
     model.eval()
     total_wer = 0
     total_cer = 0
+
+    def score(decoded, targets, target_sizes):
+        nonlocal total_wer, total_cer
+        targets, target_sizes = targets.numpy(), target_sizes.numpy()
+        labels = [" ".join(index2word[int(k)] for k in targets[i][: target_sizes[i]]) for i in range(len(targets))]
+        for x in range(len(labels)):
+            if verbose:
+                log("origin : " + labels[x])
+                log("decoded: " + decoded[x])
+            total_cer += decoder.cer(decoded[x], labels[x])
+            total_wer += decoder.wer(decoded[x], labels[x])
+            decoder.num_word += len(labels[x].split())
+            decoder.num_char += len(labels[x])
+
+    # the beam search of a batch runs on one of two extra streams (the model forward stays on the current one: it owns the library
+    # workspace) and its strings are collected one batch later: two searches in flight fill the device (a batch is one workgroup per
+    # utterance) and the host-side scoring of batch i overlaps with the search of batch i + 1.  Same order of batches, same results.
+    pipelined = hasattr(decoder, "decode_async") and torch.device(device).type == "cuda"
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)] if pipelined else []
+    pending = []
     with torch.no_grad():
-        for inputs, input_sizes, targets, target_sizes, utt_list in loader:
+        for i, (inputs, input_sizes, targets, target_sizes, utt_list) in enumerate(loader):
             probs = model(inputs.to(device))
             lens = frames_from_fraction(input_sizes, probs.size(0)).tolist()
-            decoded = decoder.decode(probs, lens)
-            targets, target_sizes = targets.numpy(), target_sizes.numpy()
-            labels = [" ".join(index2word[int(k)] for k in targets[i][: target_sizes[i]]) for i in range(len(targets))]
-            for x in range(len(labels)):
-                if verbose:
-                    log("origin : " + labels[x])
-                    log("decoded: " + decoded[x])
-                total_cer += decoder.cer(decoded[x], labels[x])
-                total_wer += decoder.wer(decoded[x], labels[x])
-                decoder.num_word += len(labels[x].split())
-                decoder.num_char += len(labels[x])
+            if not pipelined:
+                score(decoder.decode(probs, lens), targets, target_sizes)
+                continue
+            st = streams[i % 2]
+            st.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(st):
+                wait = decoder.decode_async(probs, lens)
+            probs.record_stream(st)
+            pending.append((wait, targets, target_sizes))
+            if len(pending) == 3:                # two searches running, one queued behind them
+                w, t, ts = pending.pop(0)
+                score(w(), t, ts)
+        for w, t, ts in pending:
+            score(w(), t, ts)
     CER = (float(total_cer) / decoder.num_char) * 100
     WER = (float(total_wer) / decoder.num_word) * 100
     log("Character error rate on test set: %.4f" % CER)

@@ -23,6 +23,29 @@ class ctcBeamSearch(object):
             self._table = self.lm.table([self.classes[i] for i in range(n)], self.blank_index)
         return self._table
 
+    def _lm_table_on(self, device):
+        """The (V+1) x (V+1) table as a float64 tensor on `device`, uploaded once."""
+        key = (device.type, device.index)
+        if getattr(self, "_table_dev", None) is None or self._table_dev[0] != key:
+            self._table_dev = (key, torch.as_tensor(self._lm_table(), dtype=torch.float64).to(device))
+        return self._table_dev[1]
+
+    @staticmethod
+    def _checked(ids, score, status):
+        if (status == 2).any():
+            raise ValueError("math domain error")
+        if (status == 1).any():
+            raise IndexError("tuple index out of range")
+        if (status != 0).any():
+            raise RuntimeError("beam search kernel status %s" % status)
+        return ids, score
+
+    def decode_ids_async(self, x_tbv, lens, input_is_prob=False):
+        """decode_ids enqueued on the current stream; returns a callable that waits for this search alone and returns (ids, scores)
+        or raises what decode_ids raises."""
+        h = ops.beam_decode_async(x_tbv, lens, self._lm_table_on(x_tbv.device), self.lm_alpha, self.beamWidth, self.blank_index, input_is_prob)
+        return lambda: self._checked(*h.result())
+
     def decode_ids(self, x_tbv, lens, input_is_prob=False):
         """x (T,B,V) device tensor -> (list of id lists, float64 scores).  Raises what the reference raises:
         IndexError when an empty labelling reaches the final LM step (BeamSearch.py:135), ValueError on log(0)."""

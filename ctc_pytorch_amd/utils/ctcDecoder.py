@@ -135,3 +135,13 @@ class BeamDecoder(Decoder):
             frame_seq_len = [lp.shape[0]] * lp.shape[1]
         ids, _ = self._decoder.decode_ids(lp, frame_seq_len, input_is_prob=False)
         return [" ".join(self.int_to_char[k] for k in seq) for seq in ids]
+
+    def decode_async(self, prob_tensor, frame_seq_len=None):
+        """decode() enqueued on the current stream: returns a callable that waits for this batch alone and returns its strings
+        (steps/test_ctc.decode_and_score keeps two batches in flight on two streams: a batch of <= 128 utterances occupies at most
+        half of the device, and the host-side string assembly and scoring of one batch overlaps with the search of the next)."""
+        lp = _to_device(prob_tensor)
+        if frame_seq_len is None:
+            frame_seq_len = [lp.shape[0]] * lp.shape[1]
+        wait = self._decoder.decode_ids_async(lp, frame_seq_len, input_is_prob=False)
+        return lambda: [" ".join(self.int_to_char[k] for k in seq) for seq in wait()[0]]

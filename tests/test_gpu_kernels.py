@@ -1156,6 +1156,34 @@ def test_device_prefetcher_yields_the_loader_batches(dev):
     assert list(DevicePrefetcher([], dev)) == []
 
 
+def test_beam_decode_async_two_streams_equals_sync(dev):
+    """ops.beam_decode_async (search enqueued on the current stream, results through pinned memory, `result()` waits for that batch alone):
+    four batches alternating over two streams -- the way steps/test_ctc.decode_and_score keeps two searches in flight -- return exactly
+    what the synchronous call returns for each of them."""
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    V, T, B, W = 62, 160, 24, 8
+    i2c = synth.int2char(V)
+    tab = LanguageModel(os.path.join(G, "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    tab_dev = torch.as_tensor(tab, dtype=torch.float64).to(dev)
+    xs, lens, want = [], [], []
+    for k in range(4):
+        lp = synth.make_logprobs(seed=11 + k, T=T, B=B, V=V, regime="peaky" if k % 2 else "flat")
+        xs.append(torch.from_numpy(lp).to(dev))
+        lens.append(list(np.random.RandomState(k).randint(T // 2, T + 1, size=B)))
+        want.append(ops.beam_decode(xs[-1], lens[-1], tab, 0.1, W))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for _ in range(3):
+        handles = []
+        for k in range(4):
+            with torch.cuda.stream(streams[k % 2]):
+                handles.append(ops.beam_decode_async(xs[k], lens[k], tab_dev, 0.1, W))
+        for k in (1, 0, 3, 2):                                  # collected out of order
+            ids, score, st = handles[k].result()
+            assert ids == want[k][0] and np.array_equal(score, want[k][1]) and np.array_equal(st, want[k][2])
+
+
 def test_end_to_end_train_checkpoint_decode(dev, tmp_path):
     """The reference's workflow on a toy corpus, through the drop-in drivers: Kaldi ark/scp + label + vocab files ->
     steps/train_ctc.main (SpeechDataset, async prefetcher, run_epoch, FlatAdam, LR controller, save_package) ->
