@@ -371,10 +371,14 @@ def decode_leg(dev, steps=5):
         kernel_us = e0.elapsed_time(e1) * 1e3 / steps
         # ... and the way steps/test_ctc.decode_and_score runs it: two batches in flight on two streams (a batch is one workgroup per
         # utterance = half of the CUs), every batch handed to the host through pinned memory (ops.beam_decode_async)
-        nfl = 4 * max(steps, 4)
-        for k in range(2):
-            with torch.cuda.stream(streams[k]):
-                ops.beam_decode_async(x, lens_dev, tab_dev, 0.1, W).result()
+        nfl = 16 * max(steps, 4)
+        warm = []
+        for k in range(4):                                                  # (the pinned hand-over buffers of four batches in flight exist after this)
+            with torch.cuda.stream(streams[k % 2]):
+                warm.append(ops.beam_decode_async(x, lens_dev, tab_dev, 0.1, W))
+        for h in warm:
+            h.result()
+        del warm
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pend = []
