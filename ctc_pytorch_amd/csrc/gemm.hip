@@ -1035,16 +1035,19 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_af32_kernel(int M, int 
   const int arow = tid >> 1, akh = (tid & 1) * 16;
   const float *aptr = A + (size_t)min(m0 + arow, M - 1) * lda + akh;
   f32x4 av[4];
+  // (bare loads from clamped addresses: a select on the loaded value would make the wave wait for the load where it is issued;
+  // K % 4 == 0, so a 16-B piece is inside the matrix or outside it as a whole, and the ones outside are zeroed when they are split)
   auto load_a = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = k0 + akh + 4 * q;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(aptr + min(k0 + 4 * q, max(K - akh - 4, 0)));
-      av[q] = k + 3 < K ? v : (f32x4){k < K ? v[0] : 0.f, k + 1 < K ? v[1] : 0.f, k + 2 < K ? v[2] : 0.f, 0.f};
-    }
+    for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4 *>(aptr + min(k0 + 4 * q, max(K - akh - 4, 0)));
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, int k0) {
     unsigned char *sb = qsm + buf * STAGE;
+    if (k0 + 32 > K) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (k0 + akh + 4 * q >= K) av[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       unsigned hw[4], lw[4];
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_af32_kernel(int M, int 
   const int ml = lane & 31, g = lane >> 5;
   load_a(0);
   issue_b(0, 0);
-  store_a(0);
+  store_a(0, 0);
   for (int s = 0; s < nst; ++s) {
     __syncthreads();                       // stage s is in LDS (A written by the waves, B landed), everybody is done with stage s - 1
     if (s + 1 < nst) { load_a((s + 1) * 32); issue_b((s + 1) * 32, (s + 1) & 1); }
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_af32_kernel(int M, int 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (s + 1 < nst) store_a((s + 1) & 1);  // (the other buffer: last read in stage s - 1, released by the barrier above)
+    if (s + 1 < nst) store_a((s + 1) & 1, (s + 1) * 32);  // (the other buffer: last read in stage s - 1, released by the barrier above)
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1120,7 +1123,7 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256_af32_kernel(int M, int 
 //     multiply + global loads of A(s+2)
 // A thread stages its own 16 floats of a row of A: loaded during the second multiply of stage s-1, split into hi / lo (the same
 // split_bf16 as everywhere: identical planes) and written into the other LDS buffer during the second read phase of stage s, three
-// phases later.  Waves 0-3 hold rows 0-127 of A -- the rows their own half multiplies.
+// phases later.
 template <int WNT>
 __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, int N, int K, int Kp, const float *__restrict__ A, int lda,
                                                                        const unsigned short *__restrict__ Bh, const unsigned short *__restrict__ Bl,
@@ -1163,28 +1166,36 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
     if (n & 1) __builtin_amdgcn_global_load_lds((gptr_t)(Bl + offB[i] + k0), (lptr_t)(sb + B_BYTES + dst), 16, 0, 0);
     else __builtin_amdgcn_global_load_lds((gptr_t)(Bh + offB[i] + k0), (lptr_t)(sb + dst), 16, 0, 0);
   };
-  const int arow = tid >> 1, akh = (tid & 1) * 16;
-  const float *aptr = A + (size_t)min(m0 + arow, M - 1) * lda + akh;
+  // A staging of this thread: the 16-B bf16 chunk `ach` (8 consecutive k = two float4) of rows arow0 and 128 + arow0 of the tile -- four
+  // lanes per row, so that the eight lanes of a ds_write_b128 group cover two whole rows = 128 contiguous bytes (two lanes per row, 32 B
+  // apart, hit every bank twice: 22 % of the kernel's LDS cycles were write conflicts).  The loads are bare, from clamped addresses: a
+  // select on the loaded value made the wave wait for every load where it is issued, i.e. inside the multiply phase.  K % 4 == 0: a
+  // piece is inside the matrix or outside it as a whole, and the ones outside are zeroed when they are split.
+  const int arow0 = tid >> 2, ach = tid & 3;
+  const float *aptr0 = A + (size_t)min(m0 + arow0, M - 1) * lda, *aptr1 = A + (size_t)min(m0 + 128 + arow0, M - 1) * lda;
   f32x4 av[4];
-  auto load_a_piece = [&](int q, int k0) {
-    const int k = k0 + akh + 4 * q;
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(aptr + min(k0 + 4 * q, max(K - akh - 4, 0)));
-    av[q] = k + 3 < K ? v : (f32x4){k < K ? v[0] : 0.f, k + 1 < K ? v[1] : 0.f, k + 2 < K ? v[2] : 0.f, 0.f};
+  auto load_a_piece = [&](int q, int k0) {                     // q = 2 * row + half
+    av[q] = *reinterpret_cast<const f32x4 *>((q >> 1 ? aptr1 : aptr0) + min(k0 + 8 * ach + 4 * (q & 1), K - 4));
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int buf, int k0) {
     unsigned char *sb = qsm + buf * STAGE;
+    if (k0 + 32 > K) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+      for (int q = 0; q < 4; ++q)
+        if (k0 + 8 * ach + 4 * (q & 1) >= K) av[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
       unsigned hw[4], lw[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned short h0, l0, h1, l1;
-        split_bf16(av[2 * h + (e >> 1)][(e & 1) * 2], h0, l0);
-        split_bf16(av[2 * h + (e >> 1)][(e & 1) * 2 + 1], h1, l1);
+        split_bf16(av[2 * r + (e >> 1)][(e & 1) * 2], h0, l0);
+        split_bf16(av[2 * r + (e >> 1)][(e & 1) * 2 + 1], h1, l1);
         hw[e] = (unsigned)h0 | ((unsigned)h1 << 16);
         lw[e] = (unsigned)l0 | ((unsigned)l1 << 16);
       }
-      const int o = qswz(arow, (tid & 1) * 2 + h);
+      const int o = qswz(arow0 + 128 * r, ach);
       *reinterpret_cast<u32x4 *>(sb + o) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
       *reinterpret_cast<u32x4 *>(sb + A_BYTES + o) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
     }
@@ -1243,7 +1254,7 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
   for (int q = 0; q < 4; ++q) load_a_piece(q, 0);
 #pragma unroll
   for (int n = 0; n < 2 * IB; ++n) issue_b_piece(n, 0, 0);
-  store_a(0);
+  store_a(0, 0);
   if (nst > 1) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) load_a_piece(q, 32);
@@ -1256,7 +1267,7 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
     multiply(c0, (s + 1) * 32, (s + 1) & 1);
     pp_barrier();
     load_frags(s, 1);
-    if constexpr (decltype(c0)::value == 1) store_a((s + 1) & 1);   // A of stage s + 1 (loaded three phases ago) -> the other buffer (last read two phases ago)
+    if constexpr (decltype(c0)::value == 1) store_a((s + 1) & 1, (s + 1) * 32);   // A of stage s + 1 (loaded three phases ago) -> the other buffer (last read two phases ago)
     pp_barrier_vm();                           // own DMA pieces of B(s + 1) landed
     multiply(c1, (s + 2) * 32, 0);
     pp_barrier();
@@ -1705,8 +1716,10 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       const int wnt256 = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
       const bool use256 = !xcd_allow && ctcn_get_option("gemm_tile256") != 0 && M >= 1024 && N >= 96 &&
                           (long)ceil_div(M, 256) * ceil_div(N, 128 * wnt256) * 4 >= (long)ctcn_device_cus() * 3;
-      // (every N-tile converts its A rows again: measured faster than the plane pass up to 5 N-tiles -- 25 600 x 1 280 x 640: 160 vs
-      // 170 us, 25 600 x 640 x 2 560: 336 vs 363 us -- and slower beyond -- 25 600 x 2 560 x 640: 310 vs 271 us)
+      // (every N-tile converts its A rows again.  Stand-alone the inline split wins at every shape of the bench configurations since its
+      // loads are bare -- 25 600 x 1 280 x 640: 134 vs 150 us, 25 600 x 640 x 2 560: 278 vs 354 us, 25 600 x 2 560 x 640 (10 N-tiles): 253 vs
+      // 262 us, 76 800 x 3 072 x 1 024 (12 N-tiles): 1 333 vs 1 351 us -- but inside the cfg2 step a limit of 16 N-tiles instead of 5 measured
+      // 0.15-0.3 ms SLOWER (A/B in one session), so products with more than 5 N-tiles keep the plane pass)
       const bool a_inline = use256 && !same_a && !transA && ctcn_get_option("gemm_a_inline") != 0 && K >= 32 && K % 4 == 0 && lda % 4 == 0 &&
                             ((uintptr_t)A & 15) == 0 && ceil_div(N, 128 * wnt256) <= 5;
       if (a_inline) {
