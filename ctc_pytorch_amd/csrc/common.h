@@ -11,6 +11,7 @@
 void ctcn_set_error(const char *fmt, ...);
 int *ctcn_status_word(void);      // device int registered with ctcn_set_status_buffer (may be null)
 int ctcn_opt_rnn_persistent(void);
+int ctcn_transpose01_pair(const float *in0, const float *in1, float *out0, float *out1, int A, int B, int C, void *stream);   // two ctcn_transpose01 in one launch
 void ctcn_gemm_hint_same_b(void);   // ... the same, unmodified B (its planes are reused if A has the same size as well)
 void ctcn_gemm_hint_same_a(void);   // next ctcn_gemm on this thread has the same, unmodified A as the previous one
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,

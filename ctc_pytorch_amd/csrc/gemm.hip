@@ -1870,6 +1870,29 @@ extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const floa
   return ctcn_gemm_on_xcds(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, 0u);
 }
 
+// the same transposition of two equally shaped tensors in ONE launch (W_hh of the two directions before a backward recurrence)
+__global__ void transpose01_pair_kernel(const float *__restrict__ in0, const float *__restrict__ in1, float *__restrict__ out0, float *__restrict__ out1,
+                                        int A, int B, int C) {
+  const float *in = blockIdx.y ? in1 : in0;
+  float *out = blockIdx.y ? out1 : out0;
+  const size_t total = (size_t)A * B * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const size_t ab = i / C;
+    const int a = ab % A;
+    const int b = ab / A;
+    out[i] = in[((size_t)a * B + b) * C + c];
+  }
+}
+int ctcn_transpose01_pair(const float *in0, const float *in1, float *out0, float *out1, int A, int B, int C, void *stream) {
+  CTCN_REQUIRE(in0 && in1 && out0 && out1 && A > 0 && B > 0 && C > 0, "ctcn_transpose01_pair: bad args");
+  const size_t total = (size_t)A * B * C;
+  const int blocks = (int)min((size_t)4096, ceil_div_z(total, 256));
+  hipLaunchKernelGGL(transpose01_pair_kernel, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, in0, in1, out0, out1, A, B, C);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
 extern "C" int ctcn_transpose01(const float *in, float *out, int A, int B, int C, void *stream) {
   CTCN_REQUIRE(in && out && A > 0 && B > 0 && C > 0, "ctcn_transpose01: bad args");
   const size_t total = (size_t)A * B * C;

@@ -2309,12 +2309,11 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   const float *w_hh[2] = {w_hh0, w_hh1};
   float *whhT = (float *)scratch;
   float *state = (float *)((char *)scratch + align_up((size_t)dirs * GH * H * sizeof(float), 256));
-  for (int d = 0; d < dirs; ++d) {
-    int rc = ctcn_transpose01(w_hh[d], whhT + (size_t)d * GH * H, GH, H, 1, stream);
-    if (rc) return rc;
+  if (dirs == 2) {
+    if (int rc = ctcn_transpose01_pair(w_hh[0], w_hh[1], whhT, whhT + (size_t)GH * H, GH, H, 1, stream)) return rc;
+  } else if (int rc = ctcn_transpose01(w_hh[0], whhT, GH, H, 1, stream)) {
+    return rc;
   }
-  CTCN_HIP(hipMemsetAsync(state, 0, (size_t)B * dirs * H * sizeof(float), st));
-
   RnnArgs a;
   a.cell = cell; a.T = T; a.B = B; a.H = H; a.D = dirs; a.G = G; a.step = 0;
   a.w0 = whhT; a.w1 = whhT + (size_t)GH * H; a.y = const_cast<float *>(y); a.gates = gates; a.aux = aux; a.dy = dy;
@@ -2373,6 +2372,8 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     log_fallback("ctcn_rnn_bwd", T, B, H, dirs, !fits32 ? "a reserve tensor of 4 GB or more"
                                                      : (ceil_div(GH, 256) > 8 ? "gate width G*H above 2048" : "not co-resident / workspace too small"));
   if (!done) {
+    // (the carried dc / dh*z of the per-timestep kernels lives in `state`; the persistent kernels keep it in registers)
+    CTCN_HIP(hipMemsetAsync(state, 0, (size_t)B * dirs * H * sizeof(float), st));
     const int kq4 = pick_kq4(GH, 16, 1, 5);
     for (int s = 0; s < T; ++s) {
       a.step = s;
