@@ -235,7 +235,7 @@ def run_train(args):
         return loss
 
     # the host enqueues a step ~7x faster than the GPU runs it; like a training loop that reads its statistics one step behind
-    # (steps/train_ctc.run_epoch) it stays at most two steps ahead -- thousands of queued launches made the timing bimodal (13.7 / 14.5 ms)
+    # (steps/train_ctc.run_epoch) it stays at most two steps ahead
     ring = [torch.cuda.Event() for _ in range(3)]
 
     def paced(i):
@@ -245,9 +245,9 @@ def run_train(args):
             ring[(i - 2) % 3].synchronize()
         return out
 
-    # start-up transient: the first ~30 steps of a fresh process run up to 8 % slower (clock ramp / allocator growth; five runs with
-    # 5 warm-up steps: 13.7-14.9 ms, with 40: 13.75-13.77), so the device is brought to its steady state by PREWARM untimed steps
-    # before the W warm-up steps the command line asks for; the timed region is unchanged (exactly K steps between two barriers)
+    # start-up transient: the first tens of steps of a fresh process carry allocator growth and the interpreter's first cyclic-GC passes
+    # (five runs with 5 warm-up steps: 13.7-14.9 ms, with 40: 13.75-13.77), so PREWARM untimed steps run before the W warm-up steps the
+    # command line asks for; the timed region is unchanged (exactly K steps between two barriers)
     for i in range(PREWARM):
         paced(i)
     torch.cuda.synchronize()
@@ -256,10 +256,18 @@ def run_train(args):
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    # (as timeit does: no cyclic-GC pass of the interpreter inside the timed region -- a generation-2 collection of a process that holds
+    # the torch module tree takes ~50 ms, i.e. 25 cfg1 steps; it was the 13.7 / 14.9 ms bimodality of short cfg2 runs as well)
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses.append(paced(i))
     torch.cuda.synchronize()
+    if gc_was:
+        gc.enable()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0

@@ -239,6 +239,11 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
     ctl = LRController(opts.end_adjust_acc, opts.lr_decay)
     loss_results, dev_loss_results, dev_cer_results = [], [], []
     count = 0
+    # the long-lived objects built so far (module tree, optimizer, loaders) leave the interpreter's cyclic collector: its generation-2
+    # passes over them took ~50 ms each -- three or four whole training steps -- and the loop only stays two steps ahead of the device
+    import gc
+    gc.collect()
+    gc.freeze()
     start = time.time()
     while not ctl.stop and count < opts.num_epoches:
         count += 1
