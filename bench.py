@@ -341,12 +341,16 @@ def run_train(args):
         run_epoch(0, model, pf, loss_fn, dev, optimizer=opt, print_every=10 ** 9, is_training=True,
                   global_batch=global_b, log=lambda *_: None)
         torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        gc.freeze()                                  # as steps/train_ctc.main does before its first epoch
         t0 = time.perf_counter()
         pf.loader = [hb] * nloop
         run_epoch(0, model, pf, loss_fn, dev, optimizer=opt, print_every=10 ** 9, is_training=True,
                   global_batch=global_b, log=lambda *_: None)
         torch.cuda.synchronize()
         dte = (time.perf_counter() - t0) / nloop
+        gc.unfreeze()
         res["epoch_loop"] = {"ms_per_step": dte * 1e3, "frames_per_s": c["B"] * c["T"] * world / dte, "steps": nloop,
                              "note": "steps/train_ctc.run_epoch with DevicePrefetcher (pinned host batch -> async H2D each step), on-device greedy "
                                      "error count, step statistics read one step behind through pinned memory; not the headline `value`"}
