@@ -1716,10 +1716,10 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       const int wnt256 = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
       const bool use256 = !xcd_allow && ctcn_get_option("gemm_tile256") != 0 && M >= 1024 && N >= 96 &&
                           (long)ceil_div(M, 256) * ceil_div(N, 128 * wnt256) * 4 >= (long)ctcn_device_cus() * 3;
-      // (every N-tile converts its A rows again.  Stand-alone the inline split wins at every shape of the bench configurations since its
-      // loads are bare -- 25 600 x 1 280 x 640: 134 vs 150 us, 25 600 x 640 x 2 560: 278 vs 354 us, 25 600 x 2 560 x 640 (10 N-tiles): 253 vs
-      // 262 us, 76 800 x 3 072 x 1 024 (12 N-tiles): 1 333 vs 1 351 us -- but inside the cfg2 step a limit of 16 N-tiles instead of 5 measured
-      // 0.15-0.3 ms SLOWER (A/B in one session), so products with more than 5 N-tiles keep the plane pass)
+      // (every N-tile converts its A rows again.  Stand-alone the inline split now wins at every shape of the bench configurations --
+      // 25 600 x 1 280 x 640: 134 vs 150 us, 25 600 x 640 x 2 560: 278 vs 354 us, 25 600 x 2 560 x 640 (10 N-tiles): 253 vs 262 us,
+      // 76 800 x 3 072 x 1 024 (12 N-tiles): 1 333 vs 1 351 us -- but with a limit of 16 N-tiles instead of 5 no step got faster (cfg2
+      // 13.74 / 13.75 ms in an A/B inside one session, cfg4 58.2 vs 57.6-58.3), so the limit stays where it was tested longest)
       const bool a_inline = use256 && !same_a && !transA && ctcn_get_option("gemm_a_inline") != 0 && K >= 32 && K % 4 == 0 && lda % 4 == 0 &&
                             ((uintptr_t)A & 15) == 0 && ceil_div(N, 128 * wnt256) <= 5;
       if (a_inline) {
