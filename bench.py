@@ -334,7 +334,7 @@ def run_train(args):
         # of the timed step above it runs the greedy error count (arg-max, collapse, edit distance) and ONE small D2H per step
         from ctc_pytorch_amd.steps.train_ctc import run_epoch
         from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher
-        nloop = max(8, min(args.steps, 20))
+        nloop = max(20, min(args.steps, 40))      # (long enough to amortise the fill and drain of the prefetch pipeline)
         hb = (torch.from_numpy(batch["x"]), torch.ones(c["B"], dtype=torch.float32), torch.from_numpy(batch["targets"]),
               torch.from_numpy(batch["tgt_len"]), ["u%d" % i for i in range(c["B"])])
         pf = DevicePrefetcher([hb] * 3, dev)        # one prefetcher for the run, as in steps/train_ctc.main: its pinned slots persist
