@@ -249,6 +249,12 @@ struct Lse {
 
 // SEP: alpha and beta are separate lattices (`ab` = alpha, `bt` = beta) and are added here -- the same single f32 add the
 // in-place beta pass performs, so both reserves give bit-identical gradients.
+// One workgroup = GRAD_TCH frames of ONE utterance (grid (ceil(T / GRAD_TCH), B), a wave per frame in turn).  The gradient of class c
+// at a frame is exp(lp) - exp(logsumexp over the label positions j with target[j] == c of alpha+beta - ...): instead of every class
+// lane scanning all L labels at every frame (O(V L) per frame: 81 us at cfg2), the workgroup sorts the label positions by class once
+// (counting sort in LDS, positions of a class in increasing order) and a class lane walks its own positions only -- the same terms
+// added in the same order, so the result is bit-identical to the scan.
+constexpr int GRAD_TCH = 16;
 template <bool SEP>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__ lp, const int64_t *__restrict__ targets,
                                                        const int64_t *__restrict__ in_len, const int64_t *__restrict__ tgt_len,
@@ -256,45 +262,71 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float *__restrict__
                                                        const float *__restrict__ nll,
                                                        const float *__restrict__ gscale, float *__restrict__ grad, int T, int B, int V,
                                                        int Lmax) {
-  const int lane = threadIdx.x & 63;
-  const size_t pair = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pair >= (size_t)T * B) return;
-  const int t = (int)(pair / B), b = (int)(pair - (size_t)t * B);
-  const int Tb = (int)in_len[b], L = (int)tgt_len[b];
-  float *g = grad + pair * V;
-  if (in_len[b] < 0 || in_len[b] > T || tgt_len[b] < 0 || tgt_len[b] > Lmax) {          // see ctc_lattice_body
-    for (int c = lane; c < V; c += 64) g[c] = __uint_as_float(0x7fc00000u);
-    return;
-  }
-  if (t >= Tb) {
-    for (int c = lane; c < V; c += 64) g[c] = 0.0f;
-    return;
+  extern __shared__ int gsm[];                 // start[V + 1] | pos[Lmax]
+  int *start = gsm, *pos = gsm + V + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * GRAD_TCH, t1 = min(T, t0 + GRAD_TCH);
+  const bool bad = in_len[b] < 0 || in_len[b] > T || tgt_len[b] < 0 || tgt_len[b] > Lmax;          // see ctc_lattice_body
+  const int Tb = bad ? 0 : (int)in_len[b], L = bad ? 0 : (int)tgt_len[b];
+  const int64_t *tg = targets + (size_t)b * Lmax;
+  if (!bad && t0 < Tb) {
+    // class c (thread c) counts its label positions, a serial prefix sum over the V classes, then every class writes its positions
+    for (int c = threadIdx.x; c < V; c += blockDim.x) {
+      int n = 0;
+      if (c > 0)
+        for (int j = 0; j < L; ++j) n += (int)tg[j] == c;
+      start[c + 1] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      start[0] = 0;
+      for (int c = 0; c < V; ++c) start[c + 1] += start[c];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < V; c += blockDim.x) {
+      int k = start[c];
+      if (c > 0)
+        for (int j = 0; j < L; ++j)
+          if ((int)tg[j] == c) pos[k++] = j;
+    }
+    __syncthreads();
   }
   const int Smax = 2 * Lmax + 1;
-  const float *abr = ab + pair * Smax;
-  const float *btr = SEP ? bt + pair * Smax : nullptr;
-  auto AB = [&](int s) -> float { return SEP ? abr[s] + btr[s] : abr[s]; };
-  const float *lpr = lp + pair * V;
-  const float n = nll[b], gs = gscale[0];
-  const int64_t *tg = targets + (size_t)b * Lmax;
-  // blank: even states 0,2,..,2L
-  Lse bl{-INFINITY, 0.0f};
-  for (int j = lane; j <= L; j += 64) bl.add(AB(2 * j));
-  const float M = wave_max(bl.m);
-  float ssum = bl.m == -INFINITY ? 0.0f : bl.s * expf(bl.m - M);
-  ssum = wave_sum(ssum);
-  const float lcab0 = M == -INFINITY ? -INFINITY : M + logf(ssum);
-  for (int c = lane; c < V; c += 64) {
-    float lcab;
-    if (c == 0) lcab = lcab0;
-    else {
-      Lse a{-INFINITY, 0.0f};
-      for (int j = 0; j < L; ++j)
-        if ((int)tg[j] == c) a.add(AB(2 * j + 1));
-      lcab = a.m == -INFINITY ? -INFINITY : a.m + logf(a.s);
+  const float gs = gscale[0];
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const size_t pair = (size_t)t * B + b;
+    float *g = grad + pair * V;
+    if (bad) {
+      for (int c = lane; c < V; c += 64) g[c] = __uint_as_float(0x7fc00000u);
+      continue;
     }
-    const float l = lpr[c];
-    g[c] = (expf(l) - expf(lcab + n - l)) * gs;
+    if (t >= Tb) {
+      for (int c = lane; c < V; c += 64) g[c] = 0.0f;
+      continue;
+    }
+    const float *abr = ab + pair * Smax;
+    const float *btr = SEP ? bt + pair * Smax : nullptr;
+    auto AB = [&](int s_) -> float { return SEP ? abr[s_] + btr[s_] : abr[s_]; };
+    const float *lpr = lp + pair * V;
+    const float n = nll[b];
+    // blank: even states 0,2,..,2L
+    Lse bl{-INFINITY, 0.0f};
+    for (int j = lane; j <= L; j += 64) bl.add(AB(2 * j));
+    const float M = wave_max(bl.m);
+    float ssum = bl.m == -INFINITY ? 0.0f : bl.s * expf(bl.m - M);
+    ssum = wave_sum(ssum);
+    const float lcab0 = M == -INFINITY ? -INFINITY : M + logf(ssum);
+    for (int c = lane; c < V; c += 64) {
+      float lcab;
+      if (c == 0) lcab = lcab0;
+      else {
+        Lse a{-INFINITY, 0.0f};
+        for (int k = start[c]; k < start[c + 1]; ++k) a.add(AB(2 * pos[k] + 1));
+        lcab = a.m == -INFINITY ? -INFINITY : a.m + logf(a.s);
+      }
+      const float l = lpr[c];
+      g[c] = (expf(l) - expf(lcab + n - l)) * gs;
+    }
   }
 }
 
@@ -469,9 +501,8 @@ extern "C" int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64
   if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
 #undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
-  const size_t pairs = (size_t)T * B;
-  hipLaunchKernelGGL(ctc_grad_kernel<false>, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, st, lp, targets, in_len, tgt_len, alpha,
-                     (const float *)nullptr, nll, gscale, grad_lp, T, B, V, Lmax);
+  hipLaunchKernelGGL(ctc_grad_kernel<false>, dim3(ceil_div(T, GRAD_TCH), B), dim3(256), (size_t)(V + 1 + Lmax) * sizeof(int), st, lp, targets, in_len, tgt_len,
+                     alpha, (const float *)nullptr, nll, gscale, grad_lp, T, B, V, Lmax);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
@@ -495,9 +526,8 @@ extern "C" int ctcn_ctc_grad(const float *lp, const int64_t *targets, const int6
                              void *stream) {
   CTCN_REQUIRE(lp && in_len && tgt_len && alpha && beta && nll && gscale && grad_lp && (targets || Lmax == 0), "ctcn_ctc_grad: null pointer");
   CTCN_REQUIRE(T > 0 && B > 0 && V > 0 && Lmax >= 0, "ctcn_ctc_grad: bad dims");
-  const size_t pairs = (size_t)T * B;
-  hipLaunchKernelGGL(ctc_grad_kernel<true>, dim3((unsigned)ceil_div_z(pairs, 4)), dim3(256), 0, (hipStream_t)stream, lp, targets, in_len, tgt_len,
-                     alpha, beta, nll, gscale, grad_lp, T, B, V, Lmax);
+  hipLaunchKernelGGL(ctc_grad_kernel<true>, dim3(ceil_div(T, GRAD_TCH), B), dim3(256), (size_t)(V + 1 + Lmax) * sizeof(int), (hipStream_t)stream, lp, targets,
+                     in_len, tgt_len, alpha, beta, nll, gscale, grad_lp, T, B, V, Lmax);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
