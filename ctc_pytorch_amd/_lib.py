@@ -71,6 +71,7 @@ _SIGS = {
     "ctcn_adam_step": (I, [P, P, P, P, Z, F, F, F, F, F, I, P]),
     "ctcn_greedy_collapse": (I, [P, Z, Z, P, P, P, I, I, I, P]),
     "ctcn_edit_distance": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ctcn_step_stats": (I, [P, P, P, I, P, P, P]),
     "ctcn_comm_unique_id": (I, [P]),
     "ctcn_comm_init": (I, [P, I, I, ctypes.POINTER(ctypes.c_void_p)]),
     "ctcn_comm_allreduce_sum_f32": (I, [P, P, Z, P]),

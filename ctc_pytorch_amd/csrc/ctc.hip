@@ -532,6 +532,29 @@ extern "C" int ctcn_ctc_grad(const float *lp, const int64_t *targets, const int6
   return CTCN_OK;
 }
 
+// (loss, sum of the edit distances, sum of the label lengths, status word) of a training step as four doubles: what
+// steps/train_ctc.run_epoch copies to the host one step behind -- one launch instead of nine small torch kernels
+__global__ void step_stats_kernel(const float *__restrict__ loss, const int32_t *__restrict__ dist, const int64_t *__restrict__ tgt_len, int B,
+                                  const int32_t *__restrict__ status, double *__restrict__ out) {
+  const int lane = threadIdx.x;
+  long long d = 0, n = 0;
+  for (int b = lane; b < B; b += 64) { d += dist[b]; n += tgt_len[b]; }
+  for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o, 64); n += __shfl_down(n, o, 64); }
+  if (lane == 0) {
+    out[0] = (double)loss[0];
+    out[1] = (double)d;
+    out[2] = (double)n;
+    out[3] = status ? (double)status[0] : 0.0;
+  }
+}
+extern "C" int ctcn_step_stats(const float *loss, const int32_t *dist, const int64_t *tgt_len, int B, const int32_t *status, double *out4,
+                               void *stream) {
+  CTCN_REQUIRE(loss && dist && tgt_len && out4 && B > 0, "ctcn_step_stats: bad args");
+  hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, dist, tgt_len, B, status, out4);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
 extern "C" int ctcn_greedy_collapse(const int32_t *idx, size_t stride_t, size_t stride_b, const int32_t *lens, int32_t *out_ids,
                                     int32_t *out_len, int T, int B, int blank, void *stream) {
   CTCN_REQUIRE(idx && lens && out_ids && out_len && T > 0 && B > 0, "ctcn_greedy_collapse: bad args");

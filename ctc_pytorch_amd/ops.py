@@ -843,6 +843,19 @@ def edit_distance(ids, ids_len, targets, tgt_len):
     return out
 
 
+def step_stats(loss, dist, tgt_len):
+    """(loss, sum(dist), sum(tgt_len), hand-off status word) as a float64 device tensor of 4 -- one launch (ctcn_step_stats)."""
+    _need_gpu(loss, dist, tgt_len)
+    dev = loss.device
+    l32 = loss.detach().reshape(-1)[:1].to(torch.float32).contiguous()
+    dist = dist.to(dtype=torch.int32).contiguous()
+    tgt_len = tgt_len.to(device=dev, dtype=torch.int64).contiguous()
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().ctcn_step_stats(_ptr(l32), _ptr(dist), _ptr(tgt_len), dist.numel(), _ptr(_lib.status_word(dev)), _ptr(out),
+                                          _lib.stream_ptr()), "step_stats")
+    return out
+
+
 def beam_decode_device(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob=False):
     """Enqueue the prefix beam search (ctcn_beam_decode) on the current stream; returns DEVICE tensors
     (out_ids (B,T) int32, out_len (B) int32, score (B) float64, status (B) int32) without synchronising."""

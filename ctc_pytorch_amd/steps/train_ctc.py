@@ -105,8 +105,10 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
                 parallel.allreduce_grads(optimizer.grad)
             optimizer.step()
         # loss, error count, token count and the sticky hand-off status word of the persistent kernels
-        health = _lib.status_word(inputs.device).reshape(1).double() if inputs.is_cuda else torch.zeros(1, dtype=torch.float64)
-        stats = torch.cat([torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]), health])
+        if inputs.is_cuda:
+            stats = ops.step_stats(loss, dist, target_sizes_d)               # one launch
+        else:
+            stats = torch.cat([torch.stack([loss.detach().double(), dist.sum().double(), target_sizes_d.sum().double()]), torch.zeros(1, dtype=torch.float64)])
         if step_global:
             stats = parallel.allreduce_stats(stats)          # global loss / error / token counts (and any rank's bad health)
         buf = host_stats[i % 2]

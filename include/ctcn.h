@@ -263,6 +263,10 @@ int ctcn_greedy_collapse(const int32_t *idx, size_t stride_t, size_t stride_b, c
  * (model_ctc.py:200).  max_b_len >= max(b_len). */
 int ctcn_edit_distance(const int32_t *a, const int32_t *a_len, const int64_t *b, const int64_t *b_len, int32_t *out, int B,
                        int lda, int ldb, int max_b_len, void *stream);
+/* (loss, sum of dist[0..B), sum of tgt_len[0..B), *status or 0) as four doubles in out4 (device memory): the per-step statistics of the
+ * reference's run_epoch (loss.item(), total_wer's numerator and denominator, timit/steps/train_ctc.py:55-60) plus the sticky hand-off
+ * status, gathered in one launch so that the host can fetch them with one small copy a step later. */
+int ctcn_step_stats(const float *loss, const int32_t *dist, const int64_t *tgt_len, int B, const int32_t *status, double *out4, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * CTC prefix beam search with bigram LM; replaces BeamDecoder.decode -> ctcBeamSearch.decode

@@ -1156,6 +1156,19 @@ def test_device_prefetcher_yields_the_loader_batches(dev):
     assert list(DevicePrefetcher([], dev)) == []
 
 
+def test_step_stats_equals_torch(dev):
+    """ctcn_step_stats (the four per-step statistics of run_epoch in one launch) against the torch expressions it replaces."""
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(3)
+    for B in (1, 7, 64, 200):
+        loss = torch.tensor(rs.rand() * 100, dtype=torch.float32, device=dev)
+        dist = torch.from_numpy(rs.randint(0, 90, size=B).astype(np.int32)).to(dev)
+        tl = torch.from_numpy(rs.randint(1, 70, size=B).astype(np.int64)).to(dev)
+        got = ops.step_stats(loss, dist, tl).cpu().numpy()
+        want = np.array([float(loss.double()), float(dist.sum()), float(tl.sum()), 0.0])
+        assert np.array_equal(got, want), (B, got, want)
+
+
 def test_beam_decode_async_two_streams_equals_sync(dev):
     """ops.beam_decode_async (search enqueued on the current stream, results through pinned memory, `result()` waits for that batch alone):
     four batches alternating over two streams -- the way steps/test_ctc.decode_and_score keeps two searches in flight -- return exactly
