@@ -1884,8 +1884,34 @@ __global__ void transpose01_pair_kernel(const float *__restrict__ in0, const flo
     out[i] = in[((size_t)a * B + b) * C + c];
   }
 }
+// C == 1: a plain matrix transpose, out[b][a] = in[a][b], through a 32 x 33 LDS tile (both sides coalesced: 8.6 -> ~3 us for the
+// two 1 280 x 320 W_hh of a cfg2 layer)
+__global__ __launch_bounds__(256) void transpose2d_pair_kernel(const float *__restrict__ in0, const float *__restrict__ in1, float *__restrict__ out0,
+                                                               float *__restrict__ out1, int A, int B) {
+  __shared__ float tile[32][33];
+  const float *in = blockIdx.z ? in1 : in0;
+  float *out = blockIdx.z ? out1 : out0;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const int b0 = blockIdx.x * 32, a0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int a = a0 + ty + 8 * k, b = b0 + tx;
+    if (a < A && b < B) tile[ty + 8 * k][tx] = in[(size_t)a * B + b];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = b0 + ty + 8 * k, a = a0 + tx;
+    if (a < A && b < B) out[(size_t)b * A + a] = tile[tx][ty + 8 * k];
+  }
+}
 int ctcn_transpose01_pair(const float *in0, const float *in1, float *out0, float *out1, int A, int B, int C, void *stream) {
   CTCN_REQUIRE(in0 && in1 && out0 && out1 && A > 0 && B > 0 && C > 0, "ctcn_transpose01_pair: bad args");
+  if (C == 1) {
+    hipLaunchKernelGGL(transpose2d_pair_kernel, dim3(ceil_div(B, 32), ceil_div(A, 32), 2), dim3(256), 0, (hipStream_t)stream, in0, in1, out0, out1, A, B);
+    CTCN_LAUNCH_CHECK();
+    return CTCN_OK;
+  }
   const size_t total = (size_t)A * B * C;
   const int blocks = (int)min((size_t)4096, ceil_div_z(total, 256));
   hipLaunchKernelGGL(transpose01_pair_kernel, dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, in0, in1, out0, out1, A, B, C);
