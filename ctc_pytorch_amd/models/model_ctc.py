@@ -46,7 +46,7 @@ class BatchRNN(nn.Module):
                                self.batch_norm.running_var, T * B, C, 1, self.batch_norm.training,
                                0.1 if self.batch_norm.momentum is None else self.batch_norm.momentum, self.batch_norm.eps)
             if self.batch_norm.training:
-                self.batch_norm._count_batch()
+                self.batch_norm.num_batches_tracked += 1
         x, _ = self.rnn(x)
         return self.dropout(x)
 

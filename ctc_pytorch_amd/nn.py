@@ -84,31 +84,7 @@ class RNN(_RecurrentMixin, _tnn.RNN):
             raise NotImplementedError("only nonlinearity='tanh' (the nn.RNN default the reference uses)")
 
 
-class _LazyBatchCount(object):
-    """`num_batches_tracked` is counted on the host and written into the device buffer when the buffer is looked at (state_dict /
-    checkpoint save; a load resets the pending count).  The `+= 1` on the device tensor was one kernel launch per BatchNorm layer and
-    training step, and nothing on the hot path reads the buffer (the momentum is a number here, as in the reference's configuration)."""
-
-    _nbt_pending = 0
-
-    def _count_batch(self):
-        self._nbt_pending += 1
-
-    def _flush_batch_count(self):
-        if self._nbt_pending:
-            self.num_batches_tracked += self._nbt_pending
-            self._nbt_pending = 0
-
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        self._flush_batch_count()
-        super()._save_to_state_dict(destination, prefix, keep_vars)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._nbt_pending = 0
-        super()._load_from_state_dict(*args, **kwargs)
-
-
-class BatchNorm1d(_LazyBatchCount, _tnn.BatchNorm1d):
+class BatchNorm1d(_tnn.BatchNorm1d):
     """(N,C) or (N,C,L) input, statistics per channel over N*L -- BatchRNN feeds (T,C,B) views (model_ctc.py:29-32)."""
 
     fuse_relu = False
@@ -120,7 +96,7 @@ class BatchNorm1d(_LazyBatchCount, _tnn.BatchNorm1d):
         training = self.training
         mom = 0.1 if self.momentum is None else self.momentum
         if training:
-            self._count_batch()
+            self.num_batches_tracked += 1
         if x.dim() == 2:
             return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], C, 1, training,
                                   mom, self.eps, self.fuse_relu)
@@ -137,7 +113,7 @@ class BatchNorm1d(_LazyBatchCount, _tnn.BatchNorm1d):
                               mom, self.eps, self.fuse_relu)
 
 
-class BatchNorm2d(_LazyBatchCount, _tnn.BatchNorm2d):
+class BatchNorm2d(_tnn.BatchNorm2d):
     """NCHW, statistics per channel over (B,T,F) (model_ctc.py:47,63)."""
 
     fuse_relu = False
@@ -148,7 +124,7 @@ class BatchNorm2d(_LazyBatchCount, _tnn.BatchNorm2d):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError("BatchNorm2d expects (B,C,H,W)")
         if self.training:
-            self._count_batch()
+            self.num_batches_tracked += 1
         mom = 0.1 if self.momentum is None else self.momentum
         x = ops.contiguous(x)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], x.shape[1],

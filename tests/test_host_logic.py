@@ -395,24 +395,3 @@ def test_decode_driver_picks_the_decoder_from_the_yaml_keys(tmp_path):
     with pytest.raises(RuntimeError, match="use_gpu"):
         TE.main({"use_gpu": False})
 
-
-def test_batchnorm_batch_count_is_lazy_but_exact():
-    """num_batches_tracked is counted on the host (no kernel launch per layer and step) and reaches the buffer whenever the buffer is
-    looked at through state_dict(); loading a state resets the pending count."""
-    import copy
-    from ctc_pytorch_amd import nn
-    bn = nn.BatchNorm1d(8)
-    for _ in range(3):
-        bn._count_batch()
-    assert int(bn.state_dict()["num_batches_tracked"]) == 3 and bn._nbt_pending == 0
-    bn._count_batch()
-    twin = copy.deepcopy(bn)
-    assert int(twin.state_dict()["num_batches_tracked"]) == 4
-    sd = {k: v.clone() for k, v in bn.state_dict().items()}
-    sd["num_batches_tracked"].fill_(10)
-    bn._count_batch()
-    bn.load_state_dict(sd)
-    assert int(bn.state_dict()["num_batches_tracked"]) == 10
-    bn2 = nn.BatchNorm2d(4)
-    bn2._count_batch()
-    assert int(bn2.state_dict()["num_batches_tracked"]) == 1
