@@ -154,6 +154,43 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, float *__restrict__
   }
 }
 
+// rows of C channels (inner == 1), C % 4 == 0, 16-B aligned tensors: four channels per lane, one 32-bit modulo per four elements (the
+// general kernel pays a 64-bit division and modulo per element: 29.9 -> ~22 us for 25 600 x 640, the time of the dropout pass);
+// the same expression per element
+__global__ void bn_apply_rows4_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, const float *__restrict__ mean, const float *__restrict__ rstd_or_var,
+                                      float eps, int var_is_variance, size_t total4, int C4, int relu) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (unsigned)C4) * 4;
+    const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+    const float4 m = *reinterpret_cast<const float4 *>(mean + c), r = *reinterpret_cast<const float4 *>(rstd_or_var + c);
+    const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ms[4] = {m.x, m.y, m.z, m.w}, rv[4] = {r.x, r.y, r.z, r.w}, gv[4] = {g.x, g.y, g.z, g.w},
+                bv[4] = {b.x, b.y, b.z, b.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float rs = var_is_variance ? 1.0f / sqrtf(rv[k] + eps) : rv[k];
+      float v = (xs[k] - ms[k]) * rs * gv[k] + bv[k];
+      if (relu) v = fmaxf(v, 0.0f);
+      o[k] = v;
+    }
+    reinterpret_cast<float4 *>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+static void launch_bn_apply(hipStream_t st, const float *x, float *y, const float *gamma, const float *beta, const float *mean, const float *rstd_or_var,
+                            float eps, int var_is_variance, size_t total, int C, int inner, int relu) {
+  const bool al = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd_or_var) & 15) == 0);
+  if (inner == 1 && C % 4 == 0 && al) {
+    const size_t total4 = total / 4;
+    const int blocks = (int)std::min((size_t)4096, ceil_div_z(total4, 256));
+    hipLaunchKernelGGL(bn_apply_rows4_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, mean, rstd_or_var, eps, var_is_variance, total4, C / 4, relu);
+  } else {
+    const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, mean, rstd_or_var, eps, var_is_variance, total, C, inner, relu);
+  }
+}
+
 // dx = gamma*rstd*(dy' - sum(dy')/N - xhat*sum(dy' xhat)/N)
 __global__ void bn_dx_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
                              const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -221,9 +258,7 @@ extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, c
                      save_mean, save_rstd, running_mean, running_var);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
-  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C,
-                     inner, relu);
+  launch_bn_apply(st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C, inner, relu);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
@@ -254,8 +289,7 @@ extern "C" int ctcn_bn_fwd_finish(const float *x, float *y, const float *gamma, 
                      save_rstd, running_mean, running_var);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
-  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C, inner, relu);
+  launch_bn_apply(st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C, inner, relu);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
@@ -302,9 +336,7 @@ extern "C" int ctcn_bn_fwd_eval(const float *x, float *y, const float *gamma, co
   CTCN_REQUIRE(x && y && gamma && beta && running_mean && running_var, "ctcn_bn_fwd_eval: null pointer");
   CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_fwd_eval: bad dims");
   const size_t total = (size_t)outer * C * inner;
-  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, running_mean,
-                     running_var, eps, 1, total, C, inner, relu);
+  launch_bn_apply((hipStream_t)stream, x, y, gamma, beta, running_mean, running_var, eps, 1, total, C, inner, relu);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
