@@ -205,6 +205,47 @@ __global__ void bn_dx_kernel(const float *__restrict__ x, const float *__restric
   }
 }
 
+// the rows-of-channels form of bn_dx_kernel (see bn_apply_rows4_kernel): four channels per lane, the same expression per element
+__global__ void bn_dx_rows4_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                                   const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                   const float *__restrict__ sums, float *__restrict__ dx, size_t total4, int C4, float inv_n, int relu) {
+  const int C = C4 * 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (unsigned)C4) * 4;
+    const float4 xv = reinterpret_cast<const float4 *>(x)[i], gv4 = reinterpret_cast<const float4 *>(dy)[i];
+    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (relu) yv = reinterpret_cast<const float4 *>(y)[i];
+    const float4 m = *reinterpret_cast<const float4 *>(mean + c), r = *reinterpret_cast<const float4 *>(rstd + c);
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), s0 = *reinterpret_cast<const float4 *>(sums + c),
+                 s1 = *reinterpret_cast<const float4 *>(sums + C + c);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+    const float ms[4] = {m.x, m.y, m.z, m.w}, rs[4] = {r.x, r.y, r.z, r.w}, gm[4] = {ga.x, ga.y, ga.z, ga.w};
+    const float a0[4] = {s0.x, s0.y, s0.z, s0.w}, a1[4] = {s1.x, s1.y, s1.z, s1.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float g = gs[k];
+      if (relu && !(ys[k] > 0.0f)) g = 0.0f;
+      const float xh = (xs[k] - ms[k]) * rs[k];
+      o[k] = gm[k] * rs[k] * (g - a0[k] * inv_n - xh * a1[k] * inv_n);
+    }
+    reinterpret_cast<float4 *>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+static void launch_bn_dx(hipStream_t st, const float *x, const float *y, const float *dy, const float *gamma, const float *mean, const float *rstd,
+                         const float *sums, float *dx, size_t total, int C, int inner, float inv_n, int relu) {
+  const bool al = ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)sums |
+                     (relu ? (uintptr_t)y : 0)) & 15) == 0);
+  if (inner == 1 && C % 4 == 0 && al) {
+    const size_t total4 = total / 4;
+    hipLaunchKernelGGL(bn_dx_rows4_kernel, dim3((int)std::min((size_t)4096, ceil_div_z(total4, 256))), dim3(256), 0, st, x, y, dy, gamma, mean, rstd, sums, dx,
+                       total4, C / 4, inv_n, relu);
+  } else {
+    hipLaunchKernelGGL(bn_dx_kernel, dim3((int)std::min((size_t)4096, ceil_div_z(total, 256))), dim3(256), 0, st, x, y, dy, gamma, mean, rstd, sums, dx, total, C,
+                       inner, inv_n, relu);
+  }
+}
+
 int chunks_rows(int rows, int C) {
   const int colblocks = ceil_div(C, 64);
   int n = std::max(1, 1024 / colblocks);
@@ -324,9 +365,7 @@ extern "C" int ctcn_bn_bwd_finish(const float *x, const float *y, const float *d
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, global_sums, 1, C, (float *)nullptr, (float *)nullptr, sums, 0.0f);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
-  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
-  hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, sums, dx, total, C, inner,
-                     (float)(1.0 / count_total), relu);
+  launch_bn_dx(st, x, y, dy, gamma, save_mean, save_rstd, sums, dx, total, C, inner, (float)(1.0 / count_total), relu);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
@@ -358,9 +397,7 @@ extern "C" int ctcn_bn_bwd(const float *x, const float *y, const float *dy, cons
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, dgamma, dbeta, sums, beta_acc);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
-  const int blocks = (int)std::min((size_t)4096, ceil_div_z(total, 256));
-  hipLaunchKernelGGL(bn_dx_kernel, dim3(blocks), dim3(256), 0, st, x, y, dy, gamma, save_mean, save_rstd, sums, dx, total, C, inner,
-                     (float)(1.0 / ((double)outer * inner)), relu);
+  launch_bn_dx(st, x, y, dy, gamma, save_mean, save_rstd, sums, dx, total, C, inner, (float)(1.0 / ((double)outer * inner)), relu);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
