@@ -17,8 +17,8 @@ ALGO = [   # (substring of the kernel name, label, algorithmic bytes per launch 
     ("gemm_planes_nt256_kernel", "gemm_planes_nt256_kernel (bf16 planes in, f32 out)", None),
     ("split_rows_kernel", "split_rows_kernel", None),
     ("dropout_kernel", "dropout_kernel 25600x640", 131072000),
-    ("bn_apply_kernel", "bn_apply_kernel 25600x640", 131072000),
-    ("bn_dx_kernel", "bn_dx_kernel 25600x640", 196608000),
+    ("bn_apply_", "bn_apply (rows of channels: four channels per lane) 25600x640", 131072000),
+    ("bn_dx_", "bn_dx (rows of channels: four channels per lane) 25600x640", 196608000),
     ("beam_fast_kernel", "beam_fast_kernel cfg5 peaky (128 x 800 x 62, W=20): reads ln p (double) of the processed frames", None),
     ("beam_prep_kernel", "beam_prep_kernel cfg5 (128 x 800 x 62): lp f32 in, ln p f64 + p_blank + flags out", 800 * 128 * 62 * 12 + 800 * 128 * 5),
     ("conv_mfma_kernel", "conv_mfma_kernel cfg3 layer 2 (32 -> 32, 3x3, stride 2x2; B=32, T=800): forward and the four dgrad classes", None),
