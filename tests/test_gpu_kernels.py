@@ -112,12 +112,12 @@ def test_gemm(dev, ta, tb, M, N, K, prec):
 
 
 @pytest.mark.parametrize("M,N,K,pad", [(1280, 640, 25600, 0), (1280, 320, 25568, 0), (388, 132, 1100, 8), (1536, 512, 4099, 4), (960, 320, 9600, 0),
-                                         (128, 64, 1024, 0), (2048, 2560, 2048, 0)])
+                                         (128, 64, 1024, 0), (2048, 2560, 2048, 0), (4096, 4100, 1056, 4)])
 def test_gemm_tn_tile(dev, M, N, K, pad):
     """precision 1, C = A^T B with both operands contraction-major (the weight gradients): the TN tile (`gemm_tn`, float32 rows split
     while they are staged, ds_read_b64_tr_b16 fragments, split-K queue) against float64, against the plane path (same bf16x3 operands
-    and products, only the order of the k-sums differs), with ragged M / N / K, padded leading dimensions and beta = 1; a second run
-    is bit-identical (the split-K partials are reduced in a fixed order whichever workgroup made them)."""
+    and products, only the order of the k-sums differs), with ragged M / N / K, padded leading dimensions and beta = 1 (the last shape has
+    so many tiles that it runs without split-K: beta is applied in the tile's own epilogue); a second run is bit-identical (the split-K partials are reduced in a fixed order whichever workgroup made them)."""
     from ctc_pytorch_amd import ops
     rs = np.random.RandomState(M + N + K)
     A = torch.from_numpy(rs.standard_normal((K, M + pad)).astype(np.float32)).to(dev)
