@@ -76,6 +76,24 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter = element-group index, key = seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) philox_round(c, k);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
 // round-to-nearest-even f32 -> bf16 (bits)
 __device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even: one v_cvt_pk_bf16_f32 on gfx950
   return __builtin_bit_cast(unsigned short, (__bf16)f);

@@ -38,6 +38,7 @@ static int g_opt_conv_mfma = 1;         // 1: Conv2d forward / dgrad / wgrad as 
 static int g_opt_gemm_pingpong = 1;     // 1: 256-row plane tiles run the ping-pong schedule (wave halves half a k-step apart)
 static int g_opt_rnn_mixed_slices = 0;  // forward recurrence: one workgroup per CU with mixed 12- / 4-unit slices (experiment)
 static int g_opt_rnn_fwd_tagged = 1;    // forward persistent recurrence: 1 = tagged gather (rnn_fwd_tagged) where it applies
+static int g_opt_rnn_fused_dropout = 1; // 1: ctcn_rnn_fwd_dropout stores the dropped output from inside rnn_fwd_tagged; 0: dropout kernel behind the recurrence
 static int g_opt_gemm_tn = 1;           // 1: weight-gradient products (both operands contraction-major) on the TN tile, no plane pass
 static int g_opt_tag_poll_delay = 8;    // rnn_fwd_tagged: 64-cycle sleeps before an exchange wave's first poll of a step
 static int g_opt_edit_wave = 1;         // 1: edit distance on one wavefront per utterance (anti-diagonals); 0: one lane per utterance
@@ -57,6 +58,7 @@ extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "conv_mfma")) { g_opt_conv_mfma = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "edit_wave")) { g_opt_edit_wave = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_tn")) { g_opt_gemm_tn = value != 0; return CTCN_OK; }
+  if (name && !strcmp(name, "rnn_fused_dropout")) { g_opt_rnn_fused_dropout = value != 0; return CTCN_OK; }
   if (name && !strcmp(name, "tag_poll_delay")) { g_opt_tag_poll_delay = value < 0 ? 0 : (value > 64 ? 64 : value); return CTCN_OK; }
   if (name && !strcmp(name, "rnn_fwd_tagged")) { g_opt_rnn_fwd_tagged = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "rnn_mixed_slices")) { g_opt_rnn_mixed_slices = value ? 1 : 0; return CTCN_OK; }
@@ -80,6 +82,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "conv_mfma")) return g_opt_conv_mfma;
   if (name && !strcmp(name, "edit_wave")) return g_opt_edit_wave;
   if (name && !strcmp(name, "gemm_tn")) return g_opt_gemm_tn;
+  if (name && !strcmp(name, "rnn_fused_dropout")) return g_opt_rnn_fused_dropout;
   if (name && !strcmp(name, "tag_poll_delay")) return g_opt_tag_poll_delay;
   if (name && !strcmp(name, "rnn_fwd_tagged")) return g_opt_rnn_fwd_tagged;
   if (name && !strcmp(name, "rnn_mixed_slices")) return g_opt_rnn_mixed_slices;

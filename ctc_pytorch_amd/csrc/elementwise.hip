@@ -9,24 +9,7 @@
 
 namespace {
 
-// Philox4x32-10 (Salmon et al., SC'11): counter = element-group index, key = seed.
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-  const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t (&out)[4]) {
-  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-  for (int i = 0; i < 10; ++i) philox_round(c, k);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = c[i];
-}
-
+// (Philox4x32-10: philox4 in common.h, shared with the fused dropout store of rnn_fwd_tagged)
 // y[i] = keep(i) ? x[i]/(1-p) : 0, keep(i) <=> u(i) >= p, u = 24-bit uniform of Philox word (i&3) of group (offset+i)>>2
 __global__ void dropout_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n, float p, float scale,
                                uint64_t seed, uint64_t offset) {

@@ -394,6 +394,9 @@ struct PersistArgs {
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
                         // gathering wave polls the block itself; 0 = stores drained, then a flag per block
+  float *ydrop;         // rnn_fwd_tagged: when set, the inverted dropout of y (Philox4x32-10, the dropout kernel's counters) is stored here as well
+  float drop_p, drop_scale;
+  unsigned long long drop_seed, drop_off;
 #ifdef CTCN_PERSIST_STATS
   long long *stats;   // development instrumentation (tools/mb_step.hip only)
 #endif
@@ -971,6 +974,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   constexpr int PQ = 17;                                     // parked slots per (tile, unit) row: 16 batch rows + 1 (bank spread)
   const RnnArgs &p = pa.a;
   __shared__ __attribute__((aligned(16))) float red[NGW * NMT * 4 * PQ * 4];
+  __shared__ uint4 dropw[4][64];                   // fused dropout: the Philox groups of an item wave's next four steps
   __shared__ int s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -1013,6 +1017,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   const unsigned vg1 = vg0 + (unsigned)(H * 4), vg2 = vg0 + (unsigned)(2 * H * 4), vg3 = vg0 + (unsigned)(min(3, G - 1) * H * 4);
   const unsigned vh = (unsigned)(((bcl * D + d) * H + jcl) * 4);
   const __amdgpu_buffer_rsrc_t rg = whole_rsrc(p.gates, (size_t)T * slab_g), ra = whole_rsrc(p.aux, (size_t)T * slab_h), ry = whole_rsrc(p.y, (size_t)T * slab_h);
+  const __amdgpu_buffer_rsrc_t ryd = whole_rsrc(pa.ydrop ? pa.ydrop : p.y, (size_t)T * slab_h);
   const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);
   // the item's dword in the published tile: block j >> 5, unit u = j & 31 -> [half (u>>2)&1][octet u>>3][row][dword u&3]
   const unsigned pub_off = (unsigned)((j >> 5) * 2048 + (((((j >> 2) & 1) * 4 + ((j & 31) >> 3)) * 16 + bl) * 4 + (j & 3)) * 4);
@@ -1179,6 +1184,23 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
         pre[0] = ld_slab(rg, vg0, on); pre[1] = ld_slab(rg, vg1, on); pre[2] = ld_slab(rg, vg2, on);
         if constexpr (CELL == CTCN_CELL_LSTM) pre[3] = ld_slab(rg, vg3, on);
       }
+      if (pa.ydrop && tid < 256) {
+        // the layer's dropout, fused (ctcn_rnn_fwd_dropout): the keep bit of element i of y is word (i & 3) of Philox group offset + (i >> 2)
+        // -- exactly what dropout_kernel computes.  An item wave needs 16 groups per step (4 rows x 4 unit quads), so every fourth step
+        // its 64 lanes compute the 64 groups of the next four steps (one Philox4x32-10 per lane, ~900 wave cycles) and park them in
+        // LDS; per step a lane then reads its word (a per-step Philox in every lane cost the recurrence as much as the pass it saved).
+        // The dropped value goes into an HBM that is idle during the recurrence instead of a pass over y after it.
+        if ((s & 3) == 0) {
+          const int sk = min(s + (lane >> 4), T - 1), tk = d == 0 ? sk : T - 1 - sk;
+          const int br = min(b0 + 4 * (tid >> 6) + ((lane >> 2) & 3), B - 1), j4 = min(j0 + 4 * (lane & 3), H - 4);
+          const unsigned idxk = (unsigned)((((size_t)tk * B + br) * D + d) * H + j4);
+          uint32_t rr[4];
+          philox4(pa.drop_seed, pa.drop_off + (idxk >> 2), rr);
+          dropw[tid >> 6][lane] = make_uint4(rr[0], rr[1], rr[2], rr[3]);
+        }
+        const uint32_t w = reinterpret_cast<const uint32_t *>(&dropw[tid >> 6][(s & 3) * 16 + (lane >> 4) * 4 + ((lane & 15) >> 2)])[lane & 3];
+        if (item) st_slab(ryd, vh, oh, ((w >> 8) * (1.0f / 16777216.0f) >= pa.drop_p) ? hval * pa.drop_scale : 0.0f);
+      }
 #ifdef CTCN_PERSIST_STATS
       { const long long z_e = clock64(); zi[0] += z_b - z_prev; zi[1] += z_i1 - z_b; zi[2] += z_i2 - z_i1; zi[3] += z_i3 - z_i2; zi[4] += z_e - z_i3; z_prev = z_e; }
 #endif
@@ -1190,7 +1212,10 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
 #endif
   const bool bad = pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   if (bad && item)             // a hand-off timed out: poison the whole output column (see rnn_fwd_persist)
-    for (int tt = 0; tt < T; ++tt) st_slab(ry, vh, (unsigned)tt * sh_b, __uint_as_float(0x7fc00000u));
+    for (int tt = 0; tt < T; ++tt) {
+      st_slab(ry, vh, (unsigned)tt * sh_b, __uint_as_float(0x7fc00000u));
+      if (pa.ydrop) st_slab(ryd, vh, (unsigned)tt * sh_b, __uint_as_float(0x7fc00000u));
+    }
 }
 
 template <int CELL>
@@ -1984,6 +2009,11 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
 // the backward recurrence leaves idle are already full with the weight-gradient GEMMs of the layer above (6.9 ms of side-stream work
 // per step against 6.4 ms of recurrences): the chunk GEMMs finish 0.5 ms AFTER the recurrence and the write-through stores cost it
 // 0.13 ms per launch.  Not kept.)
+// Dropout of the layer output fused into the forward recurrence (ctcn_rnn_fwd_dropout): the request is consumed by the tagged-gather
+// launch; any other path leaves it pending and the dropout kernel runs behind the recurrence instead (the same values either way).
+struct FwdDropout { float *ydrop; float p; unsigned long long seed, off; bool pending; };
+static thread_local FwdDropout g_fwd_dropout = {nullptr, 0.0f, 0, 0, false};
+
 // One-shot request of the host for the NEXT ctcn_rnn_fwd on this thread: pipeline the input projection with the recurrence.  Only the
 // first pair of time chunks (the first frames of the forward direction, the last of the reverse one) is projected before the
 // recurrence is launched; the other pairs are projected on `side_stream`, restricted to the XCDs in `xcd_allow` (the ones the
@@ -2130,10 +2160,16 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
         pa.stats = nullptr;
 #endif
         pa.chunk_T = piped ? chunk_T : 0; pa.nchunk = NCHUNK; pa.chunk_ready = pa.flags;       // (first word of the flag area; tickets sit 256 B further)
+        const bool fuse_drop = g_fwd_dropout.pending && ctcn_get_option("rnn_fused_dropout") != 0;
+        if (fuse_drop) {
+          pa.ydrop = g_fwd_dropout.ydrop; pa.drop_p = g_fwd_dropout.p; pa.drop_scale = 1.0f / (1.0f - g_fwd_dropout.p);
+          pa.drop_seed = g_fwd_dropout.seed; pa.drop_off = g_fwd_dropout.off;
+        }
         CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | chunk counter | role tickets
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();
+          if (fuse_drop) g_fwd_dropout.pending = false;
           if (piped) {          // the remaining chunk pairs, next to the recurrence on the XCDs it does not use
             hipStream_t sd = (hipStream_t)ov.stream;
             CTCN_HIP(hipStreamWaitEvent(sd, (hipEvent_t)ov.event, 0));
@@ -2200,6 +2236,19 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   }
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
+}
+
+extern "C" int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+extern "C" int ctcn_rnn_fwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                                    const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, float *y_drop, float p, uint64_t seed,
+                                    uint64_t offset, int precision, void *ws, size_t ws_bytes, void *stream) {
+  CTCN_REQUIRE(y_drop && p >= 0.0f && p < 1.0f, "ctcn_rnn_fwd_dropout: y_drop NULL or p=%f outside [0,1)", (double)p);
+  g_fwd_dropout = FwdDropout{y_drop, p, (unsigned long long)seed, (unsigned long long)offset, true};
+  const int rc = ctcn_rnn_fwd(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, precision, ws, ws_bytes, stream);
+  const bool pending = g_fwd_dropout.pending;
+  g_fwd_dropout.pending = false;
+  if (rc) return rc;
+  return pending ? ctcn_dropout(y, y_drop, (size_t)T * B * dirs * H, p, seed, offset, stream) : CTCN_OK;
 }
 
 // The time-parallel GEMMs of the backward pass over the d(pre-activation) slab `gates` (and `aux` for the GRU n-gate):

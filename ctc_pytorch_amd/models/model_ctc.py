@@ -47,6 +47,11 @@ class BatchRNN(nn.Module):
                                0.1 if self.batch_norm.momentum is None else self.batch_norm.momentum, self.batch_norm.eps)
             if self.batch_norm.training:
                 self.batch_norm.num_batches_tracked += 1
+        if isinstance(self.rnn, (nn.LSTM, nn.GRU, nn.RNN)):
+            # the dropout rides along with the recurrent layer (same mask, same values as self.dropout(x); the recurrence stores the
+            # dropped output itself where its tagged-gather kernel applies)
+            x, _ = self.rnn(x, drop_p=float(self.dropout.p) if self.dropout.training else 0.0)
+            return x
         x, _ = self.rnn(x)
         return self.dropout(x)
 

@@ -33,14 +33,16 @@ class _RecurrentMixin:
         if float(self.dropout) != 0.0:
             raise NotImplementedError("inter-layer dropout of a 1-layer RNN is a no-op; got dropout=%r" % self.dropout)
 
-    def forward(self, x, hx=None):
+    def forward(self, x, hx=None, drop_p=0.0):
+        """drop_p: the dropout that FOLLOWS this layer (BatchRNN), applied to the returned output in training mode -- inside the
+        recurrent kernel where that is possible (ops.rnn_layer), as a dropout pass otherwise; the same values either way."""
         if hx is not None:
             raise NotImplementedError("initial state is always zero on the reference path (model_ctc.py:33)")
         self._check()
         w1 = (self.weight_ih_l0_reverse, self.weight_hh_l0_reverse) if self.bidirectional else (None, None)
         H = self.hidden_size
         if H % 4 == 0:
-            y = ops.rnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, w1[0], w1[1], self._cell, self.training)
+            y = ops.rnn_layer(x, self.weight_ih_l0, self.weight_hh_l0, w1[0], w1[1], self._cell, self.training, drop_p if self.training else 0.0)
             return y, None
         # The kernels move rows of W_hh / h in 16-byte pieces (H % 4 == 0).  Any other hidden size (nn.LSTM takes every H,
         # model_ctc.py:24-25) runs as the next multiple of 4 with all-zero weights for the extra units: their pre-activations are 0,
@@ -58,7 +60,8 @@ class _RecurrentMixin:
         yp = ops.rnn_layer(x, p0[0], p0[1], p1[0], p1[1], self._cell, self.training)
         T, B, _ = yp.shape
         D = 2 if self.bidirectional else 1
-        return ops.contiguous(yp.view(T, B, D, Hp)[..., :H]).view(T, B, D * H), None       # drop the padded units (strided gather kernel)
+        y = ops.contiguous(yp.view(T, B, D, Hp)[..., :H]).view(T, B, D * H)               # drop the padded units (strided gather kernel)
+        return ops.dropout(y, drop_p, self.training), None
 
     def flatten_parameters(self):
         return None

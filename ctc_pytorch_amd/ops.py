@@ -293,7 +293,7 @@ def linear(x2d, w):
 # --------------------------------------------------------------------------------------------------
 class _RNNLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training):
+    def forward(ctx, x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training, drop_p=0.0):
         _need_gpu(x, w_ih0, w_hh0, w_ih1, w_hh1)
         ctx.gviews = [_gview(w) for w in (w_ih0, w_hh0, w_ih1, w_hh1)]
         x = _f32c(x)
@@ -318,9 +318,22 @@ class _RNNLayer(torch.autograd.Function):
             ev = _prelaunch_event(dev)
             w2, wp2, wn2 = _ws(x, tag="side")
             _lib.check(L.ctcn_set_fwd_overlap(ctypes.c_void_p(st.cuda_stream), ctypes.c_void_p(ev.cuda_event), wp2, wn2, allow), "set_fwd_overlap")
+        # the layer's dropout (BatchRNN: rnn -> nn.Dropout) in the same call: the recurrence stores the dropped output itself where its
+        # tagged-gather kernel applies (ctcn_rnn_fwd_dropout); the random stream advances exactly as for a separate dropout of y
+        ctx.drop = None
+        y_drop = None
+        if training and drop_p > 0.0:
+            y_drop = torch.empty_like(y)
+            seed, off = _next_dropout_stream(y.numel())
+            ctx.drop = (float(drop_p), seed, off)
         try:
-            _lib.check(L.ctcn_rnn_fwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
-                                      _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
+            if y_drop is None:
+                _lib.check(L.ctcn_rnn_fwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
+                                          _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
+            else:
+                _lib.check(L.ctcn_rnn_fwd_dropout(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
+                                                  _ptr(y), _ptr(gates), _ptr(aux), _ptr(y_drop), float(drop_p), seed, off, get_precision(), wp, wn,
+                                                  _lib.stream_ptr()), "rnn_fwd_dropout")
         finally:
             if piped:
                 L.ctcn_set_fwd_overlap(None, None, None, 0, 0)
@@ -341,7 +354,7 @@ class _RNNLayer(torch.autograd.Function):
             _side["live"][key] = _side["live"].get(key, 0) + 1
         saved = [x, y, gates] + ([aux] if aux is not None else []) + [t for t in ws if t is not None]
         ctx.save_for_backward(*saved)
-        return y
+        return y if y_drop is None else y_drop
 
     @staticmethod
     def backward(ctx, gy):
@@ -362,6 +375,11 @@ class _RNNLayer(torch.autograd.Function):
         w_ih1, w_hh1 = (wts[2], wts[3]) if dirs == 2 else (None, None)
         gy = _f32c(gy)
         dev = x.device
+        if ctx.drop is not None:                    # gradient of the fused dropout: the same mask, regenerated
+            p_, seed_, off_ = ctx.drop
+            gd = torch.empty_like(gy)
+            _lib.check(_lib.lib().ctcn_dropout(_ptr(gy), _ptr(gd), gy.numel(), p_, seed_, off_, _lib.stream_ptr()), "dropout_bwd")
+            gy = gd
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gv = ctx.gviews
         into_flat = gv[0] is not None and gv[1] is not None and (dirs == 1 or (gv[2] is not None and gv[3] is not None))
@@ -453,13 +471,14 @@ class _RNNLayer(torch.autograd.Function):
             # one join per layer is harmless and keeps the path safe if an earlier backward pass died before its callback ran
             torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if into_flat:
-            return dx, None, None, None, None, None, None
-        return dx, d_ih0, d_hh0, d_ih1, d_hh1, None, None
+            return dx, None, None, None, None, None, None, None
+        return dx, d_ih0, d_hh0, d_ih1, d_hh1, None, None, None
 
 
-def rnn_layer(x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training=True):
-    """x (T,B,I) -> y (T,B,dirs*H); cell in {'lstm','gru','tanh'} (nn.LSTM/GRU/RNN, bias=False, model_ctc.py:24-25)."""
-    return _RNNLayer.apply(x, w_ih0, w_hh0, w_ih1, w_hh1, CELL[cell] if isinstance(cell, str) else cell, training)
+def rnn_layer(x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training=True, drop_p=0.0):
+    """x (T,B,I) -> y (T,B,dirs*H); cell in {'lstm','gru','tanh'} (nn.LSTM/GRU/RNN, bias=False, model_ctc.py:24-25).
+    drop_p > 0 (training only): returns dropout(y, drop_p) instead -- the dropout that follows the layer in BatchRNN (model_ctc.py:34)."""
+    return _RNNLayer.apply(x, w_ih0, w_hh0, w_ih1, w_hh1, CELL[cell] if isinstance(cell, str) else cell, training, float(drop_p))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -118,6 +118,13 @@ size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs);
 int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
                  const float *w_hh0, const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux,
                  int precision, void *ws, size_t ws_bytes, void *stream);
+/* ctcn_rnn_fwd followed by the layer's inverted dropout (BatchRNN: rnn -> nn.Dropout, timit/models/model_ctc.py:33-34): y as above (the
+ * backward pass needs it) and y_drop = ctcn_dropout(y, p, seed, offset), bit for bit.  Where the tagged-gather recurrence applies the
+ * dropped values are stored by the recurrence itself (option "rnn_fused_dropout" = 1, the default: Philox in the item waves' idle time,
+ * no pass over y afterwards); everywhere else the dropout kernel runs behind the recurrence. */
+int ctcn_rnn_fwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                         const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, float *y_drop, float p, uint64_t seed,
+                         uint64_t offset, int precision, void *ws, size_t ws_bytes, void *stream);
 /* dy (T,B,dirs*H); dx (T,B,I) or NULL; dw_* same shapes as w_*; beta_w: 0 overwrite / 1 accumulate into dw.
  * scratch: ctcn_rnn_scratch_bytes() bytes (transposed W_hh + carried dh/dc state). */
 int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,

@@ -884,6 +884,49 @@ def test_forward_projection_overlap_equals_inline(dev, rnn, H, B, T):
     assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
 
 
+@pytest.mark.parametrize("rnn,H,B,T,I,bidir", [("LSTM", 320, 32, 100, 640, True), ("GRU", 256, 20, 77, 40, True), ("LSTM", 64, 5, 33, 24, False),
+                                               ("LSTM", 24, 3, 9, 8, True), ("RNN", 32, 4, 12, 8, True), ("LSTM", 30, 2, 7, 6, True)])
+def test_rnn_layer_with_fused_dropout_equals_layer_then_dropout(dev, rnn, H, B, T, I, bidir):
+    """BatchRNN's `dropout(rnn(x))` in one call (ctcn_rnn_fwd_dropout): where the tagged-gather recurrence applies the dropped output is
+    stored by the recurrence itself (Philox in the item waves), elsewhere -- other kernels, hidden sizes that are padded -- a dropout pass
+    follows; in every case output, input gradient and weight gradients are bit-identical to the layer followed by ops.dropout with the
+    same position in the random stream, at both matmul precisions."""
+    from ctc_pytorch_amd import nn, ops
+    rs = np.random.RandomState(H + T)
+    layer = getattr(nn, rnn)(I, H, bidirectional=bidir, bias=False).to(dev).train()
+    x = torch.from_numpy(rs.standard_normal((T, B, I)).astype(np.float32)).to(dev)
+    D = 2 if bidir else 1
+    gy = torch.from_numpy(rs.standard_normal((T, B, D * H)).astype(np.float32)).to(dev)
+    for prec in (1, 0):
+        ops.set_precision(prec)
+        outs = []
+        try:
+            for mode in ("separate", "fused", "fused_kernel_off"):
+                ops.set_option("rnn_fused_dropout", 0 if mode == "fused_kernel_off" else 1)
+                ops._drop_counter[0] = 1000                       # the same position in the Philox stream for every mode
+                torch.manual_seed(5)
+                xin = x.clone().requires_grad_()
+                for p_ in layer.parameters():
+                    p_.grad = None
+                if mode == "separate":
+                    y, _ = layer(xin)
+                    y = ops.dropout(y, 0.25, True)
+                else:
+                    y, _ = layer(xin, drop_p=0.25)
+                y.backward(gy)
+                torch.cuda.synchronize()
+                ops.check_health()
+                outs.append([y.detach().clone(), xin.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()])
+                assert ops._drop_counter[0] == 1000 + (y.numel() + 3) // 4
+        finally:
+            ops.set_option("rnn_fused_dropout", 1)
+            ops.set_precision(0)
+        kept = float((outs[0][0] != 0).float().mean())
+        assert 0.6 < kept < 0.9
+        for o in outs[1:]:
+            assert all(torch.equal(a, b_) for a, b_ in zip(o, outs[0]))
+
+
 @pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 128, 8, 60), ("GRU", 192, 40, 25)])
 def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
