@@ -44,6 +44,7 @@ _SIGS = {
     "ctcn_rnn_fwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, Z, P]),
     "ctcn_rnn_fwd_dropout": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, F, U, U, I, P, Z, P]),
     "ctcn_rnn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P]),
+    "ctcn_rnn_bwd_dropout": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P, F, U, U, P]),
     "ctcn_rnn_bwd_weights": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, F, I, ctypes.c_uint, P, Z, P]),
     "ctcn_bn_ws_bytes": (Z, [I, I, I]),
     "ctcn_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, Z, P]),

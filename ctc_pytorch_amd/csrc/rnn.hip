@@ -395,6 +395,7 @@ struct PersistArgs {
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
                         // gathering wave polls the block itself; 0 = stores drained, then a flag per block
   float *ydrop;         // rnn_fwd_tagged: when set, the inverted dropout of y (Philox4x32-10, the dropout kernel's counters) is stored here as well
+  int drop_bwd;         // rnn_bwd_scatter: dy is the gradient of the DROPPED output: the keep mask (same counters) is applied as dy is consumed
   float drop_p, drop_scale;
   unsigned long long drop_seed, drop_off;
 #ifdef CTCN_PERSIST_STATS
@@ -1548,6 +1549,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   const RnnArgs &p = pa.a;
   __shared__ __attribute__((aligned(16))) float red[NW * RT_T];        // parked partial tiles (one per wave)
   __shared__ __attribute__((aligned(16))) float stage[1024];           // this workgroup's da block as MFMA A operand
+  __shared__ uint4 dropw[4][64];                                       // fused dropout gradient: the Philox groups of an item wave's next four steps
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -1631,6 +1633,17 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     ld_slab_untracked(sv[ps][3], rg, vg3, og);
     ld_slab_untracked(dyv[ps], rdy, vh, oh); ld_slab_untracked(e0[ps], r0, vh, oh); ld_slab_untracked(e1[ps], r1, vh, (unsigned)tu1 * sh_b);
   };
+  // fused dropout gradient (ctcn_rnn_bwd_dropout): as in rnn_fwd_tagged, an item wave computes the 64 Philox groups of its next four steps
+  // at once (lane = step * 16 + row * 4 + unit quad) and parks them in LDS; the element index is that of dy[t][b][d*H + j]
+  auto drop_block = [&](int s0) {
+    const int sk = min(s0 + (lane >> 4), T - 1), tk = d == 0 ? T - 1 - sk : sk;
+    const int br = min(b0 + 4 * wave + ((lane >> 2) & 3), B - 1), j4 = min(j0 + 4 * (lane & 3), H - 4);
+    const unsigned idxk = (unsigned)((((size_t)tk * B + br) * D + d) * H + j4);
+    uint32_t rr[4];
+    philox4(pa.drop_seed, pa.drop_off + (idxk >> 2), rr);
+    dropw[wave][lane] = make_uint4(rr[0], rr[1], rr[2], rr[3]);
+  };
+  if (pa.drop_bwd && tid < 256) drop_block(0);
   if (item) {
     load_set(0, std::integral_constant<int, 0>{});
     load_set(1, std::integral_constant<int, 1>{});
@@ -1647,6 +1660,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     long long z_p = z_a, z_g = z_a, z_m = z_a, z_s = z_a, z_d = z_a;
 #endif
     const int t = d == 0 ? T - 1 - s : s;
+    uint32_t dropword = 0;
+    if (pa.drop_bwd && tid < 256)
+      dropword = reinterpret_cast<const uint32_t *>(&dropw[wave][(s & 3) * 16 + (lane >> 4) * 4 + ((lane & 15) >> 2)])[lane & 3];
     float rec = 0.0f;                                      // (da_{next} W_hh)[row bl][unit jl]
     if (s > 0) {
       const int par = (s - 1) & 1;
@@ -1721,7 +1737,10 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     // later, in order behind them) are still in flight; stores, which vmcnt counts too, can only make this wait longer
     asm volatile("s_waitcnt vmcnt(7)" : "+v"(sv[ps][0]), "+v"(sv[ps][1]), "+v"(sv[ps][2]), "+v"(sv[ps][3]), "+v"(dyv[ps]), "+v"(e0[ps]), "+v"(e1[ps])::"memory");
     if (item) {
-      float dh = dyv[ps] + rec;
+      float dyd = dyv[ps];
+      if (pa.drop_bwd)            // (a separate multiply, as the dropout pass would round it, then the add)
+        dyd = ((dropword >> 8) * (1.0f / 16777216.0f) >= pa.drop_p) ? __fmul_rn(dyd, pa.drop_scale) : 0.0f;
+      float dh = dyd + rec;
       const float e1u = (s + 1 < T && !is_tanh) ? e1[ps] : 0.0f;   // c / h of a step before the sequence start is 0
       if constexpr (CELL == CTCN_CELL_LSTM) {
         const float i_ = sv[ps][0], f_ = sv[ps][1], g_ = sv[ps][2], o_ = sv[ps][3];
@@ -1850,6 +1869,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         }
         load_set(s + 2, PSC);                                 // this set is free again: refill it for step s + 2
       }
+      if (pa.drop_bwd && tid < 256 && (s & 3) == 3) drop_block(s + 1);
     }
 #ifdef CTCN_PERSIST_STATS
     { const long long z_z = clock64(); zt[0] += z_p - z_a; zt[1] += z_g - z_p; zt[2] += z_m - z_g; zt[3] += z_s - z_m; zt[4] += z_d - z_s; zt[5] += z_z - z_d; }
@@ -2238,6 +2258,11 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   return CTCN_OK;
 }
 
+// ... and its gradient (ctcn_rnn_bwd_dropout): dy of the next ctcn_rnn_bwd is the gradient of the DROPPED output; rnn_bwd_scatter applies the
+// keep mask as it consumes dy, every other path first runs the dropout kernel into `tmp` and reads that
+struct BwdDropout { float p; unsigned long long seed, off; float *tmp; bool pending; };
+static thread_local BwdDropout g_bwd_dropout = {0.0f, 0, 0, nullptr, false};
+
 extern "C" int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
 extern "C" int ctcn_rnn_fwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
                                     const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, float *y_drop, float p, uint64_t seed,
@@ -2355,6 +2380,9 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   hipStream_t st = (hipStream_t)stream;
   const int G = gates_of(cell);
   const int GH = G * H;
+  const BwdDropout bd = g_bwd_dropout;
+  g_bwd_dropout.pending = false;
+  bool dy_dropped = !bd.pending;      // true once dy needs no mask any more: no request, or the dropout kernel has produced bd.tmp
   const float *w_hh[2] = {w_hh0, w_hh1};
   float *whhT = (float *)scratch;
   float *state = (float *)((char *)scratch + align_up((size_t)dirs * GH * H * sizeof(float), 256));
@@ -2406,9 +2434,19 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
         pa.tagmode = ctcn_opt_handoff_tags();
         if (pa.tagmode) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));
         else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
+        if (!dy_dropped && ctcn_get_option("rnn_fused_dropout") != 0) {
+          pa.drop_bwd = 1; pa.drop_p = bd.p; pa.drop_scale = 1.0f / (1.0f - bd.p); pa.drop_seed = bd.seed; pa.drop_off = bd.off;
+        } else if (!dy_dropped) {
+          if (int rc = ctcn_dropout(dy, bd.tmp, (size_t)T * B * dirs * H, bd.p, bd.seed, bd.off, stream)) return rc;
+          a.dy = bd.tmp; pa.a.dy = bd.tmp; dy_dropped = true;
+        }
         record_prelaunch(st);
         done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
       } else {
+        if (!dy_dropped) {
+          if (int rc = ctcn_dropout(dy, bd.tmp, (size_t)T * B * dirs * H, bd.p, bd.seed, bd.off, stream)) return rc;
+          a.dy = bd.tmp; pa.a.dy = bd.tmp; dy_dropped = true;
+        }
         if (prec) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));
         else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         record_prelaunch(st);
@@ -2421,6 +2459,10 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     log_fallback("ctcn_rnn_bwd", T, B, H, dirs, !fits32 ? "a reserve tensor of 4 GB or more"
                                                      : (ceil_div(GH, 256) > 8 ? "gate width G*H above 2048" : "not co-resident / workspace too small"));
   if (!done) {
+    if (!dy_dropped) {
+      if (int rc = ctcn_dropout(dy, bd.tmp, (size_t)T * B * dirs * H, bd.p, bd.seed, bd.off, stream)) return rc;
+      a.dy = bd.tmp; dy_dropped = true;
+    }
     // (the carried dc / dh*z of the per-timestep kernels lives in `state`; the persistent kernels keep it in registers)
     CTCN_HIP(hipMemsetAsync(state, 0, (size_t)B * dirs * H * sizeof(float), st));
     const int kq4 = pick_kq4(GH, 16, 1, 5);
@@ -2449,4 +2491,16 @@ extern "C" int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int di
   if (ctcn_opt_recurrence_only()) return CTCN_OK;
   return rnn_bwd_gemms(cell, T, B, I, H, dirs, x, nullptr, nullptr, y, gates, aux, nullptr, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w,
                        precision, true, xcd_allow, ws, ws_bytes, stream);
+}
+
+extern "C" int ctcn_rnn_bwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                                    const float *w_ih1, const float *w_hh1, const float *y, float *gates, float *aux, const float *dy, float *dx,
+                                    float *dw_ih0, float *dw_hh0, float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
+                                    size_t ws_bytes, void *stream, float p, uint64_t seed, uint64_t offset, float *dy_tmp) {
+  CTCN_REQUIRE(dy_tmp && p >= 0.0f && p < 1.0f, "ctcn_rnn_bwd_dropout: dy_tmp NULL or p=%f outside [0,1)", (double)p);
+  g_bwd_dropout = BwdDropout{p, (unsigned long long)seed, (unsigned long long)offset, dy_tmp, true};
+  const int rc = ctcn_rnn_bwd(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, dy, dx, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w,
+                              precision, scratch, ws, ws_bytes, stream);
+  g_bwd_dropout.pending = false;
+  return rc;
 }

@@ -375,11 +375,6 @@ class _RNNLayer(torch.autograd.Function):
         w_ih1, w_hh1 = (wts[2], wts[3]) if dirs == 2 else (None, None)
         gy = _f32c(gy)
         dev = x.device
-        if ctx.drop is not None:                    # gradient of the fused dropout: the same mask, regenerated
-            p_, seed_, off_ = ctx.drop
-            gd = torch.empty_like(gy)
-            _lib.check(_lib.lib().ctcn_dropout(_ptr(gy), _ptr(gd), gy.numel(), p_, seed_, off_, _lib.stream_ptr()), "dropout_bwd")
-            gy = gd
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gv = ctx.gviews
         into_flat = gv[0] is not None and gv[1] is not None and (dirs == 1 or (gv[2] is not None and gv[3] is not None))
@@ -417,12 +412,17 @@ class _RNNLayer(torch.autograd.Function):
             ev = _prelaunch_event(dev)
             _lib.check(L.ctcn_set_prelaunch_event(ctypes.c_void_p(ev.cuda_event)), "set_prelaunch_event")
         try:
-            _lib.check(L.ctcn_rnn_bwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
-                                      _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
-                                      null if (side or split_dirs) else _ptr(d_ih0), null if (side or split_dirs) else _ptr(d_hh0),
-                                      null if (side or split_dirs) else _ptr(d_ih1), null if (side or split_dirs) else _ptr(d_hh1),
-                                      1.0 if into_flat else 0.0, get_precision(), _ptr(scratch),
-                                      wp, wn, _lib.stream_ptr()), "rnn_bwd")
+            args = (cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
+                    _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
+                    null if (side or split_dirs) else _ptr(d_ih0), null if (side or split_dirs) else _ptr(d_hh0),
+                    null if (side or split_dirs) else _ptr(d_ih1), null if (side or split_dirs) else _ptr(d_hh1),
+                    1.0 if into_flat else 0.0, get_precision(), _ptr(scratch), wp, wn, _lib.stream_ptr())
+            if ctx.drop is None:
+                _lib.check(L.ctcn_rnn_bwd(*args), "rnn_bwd")
+            else:       # gy is the gradient of the dropped output: the same mask, applied by the recurrence as it consumes gy (or by a
+                p_, seed_, off_ = ctx.drop                  # dropout pass into gd where that kernel does not apply)
+                gd = torch.empty_like(gy)
+                _lib.check(L.ctcn_rnn_bwd_dropout(*args, p_, seed_, off_, _ptr(gd)), "rnn_bwd_dropout")
         except Exception:
             if above is not None:                       # keep the parked work for the join, drop the armed event
                 L.ctcn_set_prelaunch_event(None)

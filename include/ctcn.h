@@ -132,6 +132,13 @@ int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x,
                  float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0, float *dw_ih1,
                  float *dw_hh1, float beta_w, int precision, void *scratch, void *ws, size_t ws_bytes,
                  void *stream);
+/* ctcn_rnn_bwd for a layer whose output went through ctcn_rnn_fwd_dropout: dy is the gradient of the DROPPED output, and the layer sees
+ * ctcn_dropout(dy, p, seed, offset) -- bit for bit.  The scatter recurrence applies the keep mask as it consumes dy (option
+ * "rnn_fused_dropout"); every other path first runs the dropout kernel into dy_tmp (T*B*dirs*H floats) and reads that. */
+int ctcn_rnn_bwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                         const float *w_ih1, const float *w_hh1, const float *y, float *gates, float *aux, const float *dy, float *dx,
+                         float *dw_ih0, float *dw_hh0, float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
+                         size_t ws_bytes, void *stream, float p, uint64_t seed, uint64_t offset, float *dy_tmp);
 /* One-shot: the next ctcn_rnn_bwd issued by this host thread records `event` (a hipEvent_t) on its stream immediately before
  * it launches the recurrence, behind its own preparatory memsets / transposes.  Work meant to run next to that recurrence
  * on another stream (ctcn_rnn_bwd_weights of the layer above) waits for this event.  NULL clears it. */
