@@ -124,19 +124,24 @@ def gemm_roofline(dev, c):
     prec = ops.get_precision()
     # HBM bytes per launch from the committed rocprofv3 PMC passes (25 600 x 1 280 x 640 probe shape)
     traffic = pmc_traffic("gemm_planes_nt256pp_af32_kernel<2>") if (prec == 1 and (M, N, K) == (25600, 1280, 640)) else None
-    # bf16x3 issues 3 bf16 MFMAs per algorithmic product: its ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s
-    peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0 / 3.0
+    # `frac` = algorithmic flops against the guide's dense peak of the arithmetic used; bf16x3 issues 3 bf16 MFMAs per algorithmic product,
+    # so its own ceiling for ALGORITHMIC flops is 2500/3 TFLOP/s (`frac_of_bf16x3_ceiling`)
+    peak = PEAK_F32_MFMA_TFLOPS if prec == 0 else 2500.0
     return dict(kernel=("gemm_f32_kernel<NT>" if prec == 0 else "gemm_planes_nt256pp_af32 (256-row ping-pong tile, A split while staged) + the operand-split pass of B,") + " %dx%dx%d" % (M, N, K), bound="mfma",
-                achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic, us_per_launch=ms * 1e3,
-                algorithmic_flops_per_launch=flops,
-                peak_note="f32 MFMA 157.3 TFLOP/s" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
+                achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, frac_of_bf16x3_ceiling=None if prec == 0 else tf / (peak / 3.0),
+                traffic=traffic, traffic_source=None if traffic is None else "committed rocprofv3 PMC passes (profiles/%s)" % PMC_FILE,
+                us_per_launch=ms * 1e3, algorithmic_flops_per_launch=flops,
+                peak_note="f32 MFMA 157.3 TFLOP/s (dense)" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s; 3 bf16 MFMAs per algorithmic product (bf16x3)")
+
+
+PMC_FILE = "r03_pmc_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")) else "r02_pmc_hbm_traffic.json"
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_hbm_traffic.json, collected
-    by tools/run_profiles_r2.sh: counters cannot be read from inside bench.py).  None when the kernel is not in the table."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_hbm_traffic.json, collected
+    by tools/run_profiles_r*.sh: counters cannot be read from inside bench.py).  None when the kernel is not in the table."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         for k, v in pm.items():
             if isinstance(v, dict) and ("[" + kernel) in k:
                 return v["hbm_bytes"]
@@ -185,7 +190,9 @@ def recurrence_probe(dev, c):
         ops.set_option("rnn_recurrence_only", 0)
     ops.check_health()
     flops = 2.0 * T * 2 * B * (G * H) * H              # recurrent matmul of one launch (both directions)
+    names = ops.rnn_last_kernels()                     # what the library really launched for this shape (not what the host expects)
     return dict(layer_fwd_us=lf, layer_bwd_us=lb, kernel_fwd_us=kf, kernel_bwd_us=kb, fwd_us_per_timestep=kf / T, bwd_us_per_timestep=kb / T,
+                fwd_kernel=names[0], bwd_kernel=names[1],
                 algorithmic_flops_per_launch=flops,
                 note="kernel_*: persistent recurrent launch alone (T dependent timesteps, both directions; includes its <10 us of memsets / "
                      "W_hh transposes); layer_*: with the input-projection (fwd) / deferred gradient (bwd) GEMMs")
@@ -198,7 +205,8 @@ def run_train(args):
     rank, world, local = parallel.init_from_env()
     parallel.enable_sync_bn(bool(getattr(args, "sync_bn", False)))
     parallel.enable_overlap(True)       # per-layer gradient slices are all-reduced behind their weight GEMMs (no-op without collectives)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -220,7 +228,9 @@ def run_train(args):
     losses = []
     overlapped = [0]
 
-    def step():
+    early_bytes = [0]
+
+    def step(mark=None):
         nonlocal in_len
         out = model(x)
         if in_len is None:
@@ -230,7 +240,12 @@ def run_train(args):
         loss.backward()
         _ops.join_side_stream()
         overlapped[0] = len(parallel._overlap["done"])         # gradient slices already all-reduced behind their weight GEMMs
+        early_bytes[0] = sum(hi - lo for lo, hi in parallel._overlap["done"])
+        if mark is not None:
+            mark[0].record()
         parallel.allreduce_grads(opt.grad)
+        if mark is not None:
+            mark[1].record()
         opt.step()
         return loss
 
@@ -262,9 +277,12 @@ def run_train(args):
     gc_was = gc.isenabled()
     gc.collect()
     gc.disable()
+    ticks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step GPU time stamps (for the median only)
     t0 = time.perf_counter()
+    ticks[0].record()
     for i in range(args.steps):
         losses.append(paced(i))
+        ticks[i + 1].record()
     torch.cuda.synchronize()
     if gc_was:
         gc.enable()
@@ -285,7 +303,8 @@ def run_train(args):
     res = {
         "metric": "acoustic frames/sec/GPU (train) + utterances/sec beam-decode (`decode` object), TIMIT 4x320 BiLSTM" if args.workload == "cfg2" else "acoustic frames/sec (train), " + args.workload,
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median([ticks[i].elapsed_time(ticks[i + 1]) for i in range(args.steps)])) if args.steps else None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == 0 else "f32 via bf16x3 split-operand MFMA (f32 accumulate)", "data": "synthetic",
         "config": {"workload": "%s: %dx%d Bi%s + BN + Linear(%d) + CTC, B=%d/GPU, T=%d, F=40%s, dropout 0.1, Adam" % (
             args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], ", 2-layer CNN front-end" if c["cnn"] else ""),
@@ -295,24 +314,47 @@ def run_train(args):
         "model_tflops_per_s": train_flops_per_step * world / (dt / args.steps) / 1e12,
         "per_gpu_frames_per_s": value / world,
     }
+    try:    # the exchange step, so that a SCALE record can be checked: who carried it, how many bytes, how much of it the main stream saw
+        import torch.distributed as tdist
+        marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for mk in marks:
+            step(mk)
+        torch.cuda.synchronize()
+        exposed = sorted(a.elapsed_time(b) * 1e3 for a, b in marks)
+        on = parallel._collectives_on()
+        res["comm"] = dict(ranks=world, collectives_issued=bool(on),
+                           backend=("none (single rank: allreduce_grads returns at once)" if not on else
+                                    ("ctcn_comm_* (RCCL behind the C ABI)" if os.environ.get("CTCN_COMM", "0") == "1" else "torch.distributed/" + tdist.get_backend() + " (= RCCL on ROCm)")),
+                           allreduce_bytes_per_step=int(opt.grad.numel() * 4), early_slices=overlapped[0], early_slice_bytes=int(early_bytes[0]),
+                           exposed_allreduce_us_median=exposed[len(exposed) // 2],
+                           note="exposed = HIP-event time of parallel.allreduce_grads on the main stream (waits for the early slices + reduces the remainder); "
+                                "early slices are all-reduced on the side stream behind their layer's weight-gradient GEMMs, next to the recurrence of the layer below")
+    except Exception as e:
+        res["comm"] = {"error": repr(e)}
     try:
         # dominant kernels by GPU time (profiles/): the persistent recurrences.  Each is a chain of T dependent
         # [B x H] x [H x 4H] products, so its ceiling is the MFMA peak of the arithmetic it uses -- which B = 32 rows and an
         # 800-step dependence chain cannot approach: the per-timestep cost is two in-XCD L2 hand-offs, not flops.
         rec = recurrence_probe(dev, c)
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0 / 3.0
+        # `peak` is the guide's DENSE figure for the arithmetic the kernel issues (bf16 MFMA 2 500 TFLOP/s; f32 MFMA 157.3): `frac` is the
+        # algorithmic fraction of that.  bf16x3 issues three bf16 MFMAs per algorithmic product, so the matrix pipes themselves are
+        # 3x busier than `frac` says: `frac_of_bf16x3_ceiling` (peak / 3) is reported next to it, never instead of it.
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else 2500.0
         # the roofline object describes the DOMINANT kernel: whichever recurrence (forward / backward) is the longer launch
         fwd_dom = rec["kernel_fwd_us"] >= rec["kernel_bwd_us"]
-        fwd_name = "rnn_fwd_tagged" if (args.precision == 1 and c["rnn"] != "RNN" and c["H"] % 32 == 0 and _ops.get_option("rnn_fwd_tagged")) else "rnn_fwd_persist"
-        kname, kus, kstep = ((fwd_name, rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
-                             ("rnn_bwd_scatter", rec["kernel_bwd_us"], rec["bwd_us_per_timestep"]))
+        kname, kus, kstep = ((rec["fwd_kernel"], rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
+                             (rec["bwd_kernel"], rec["kernel_bwd_us"], rec["bwd_us_per_timestep"]))
         tf = rec["algorithmic_flops_per_launch"] / (kus * 1e-6) / 1e12
+        traffic = recurrence_traffic(args.workload, kname)
         res["roofline"] = dict(kernel="%s (%s recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (
                                    kname, "forward" if fwd_dom else "backward", c["rnn"], c["T"]),
-                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=recurrence_traffic(args.workload, kname),
+                               bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic,
+                               traffic_source=None if traffic is None else "HBM bytes per launch of this kernel instantiation from the committed rocprofv3 PMC "
+                               "passes (profiles/%s), not a counter read of this run" % PMC_FILE,
+                               frac_of_bf16x3_ceiling=None if args.precision == 0 else tf / (peak / 3.0),
                                us_per_launch=kus, us_per_dependent_step=kstep,
                                algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],
-                               peak_note=("f32 MFMA 157.3 TFLOP/s" if args.precision == 0 else "dense bf16 MFMA 2500 TFLOP/s / 3 MFMAs per product")
+                               peak_note=("f32 MFMA 157.3 TFLOP/s (dense)" if args.precision == 0 else "dense bf16 MFMA 2500 TFLOP/s; the kernel issues 3 bf16 MFMAs per algorithmic product (bf16x3)")
                                + "; latency-bound: see DESIGN.md section 5 for the per-step critical path")
         res["recurrence"] = rec
         res["roofline_gemm"] = gemm_roofline(dev, c)
@@ -467,4 +509,14 @@ if __name__ == "__main__":
     ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "1")), choices=[0, 1],
                     help="0: exact f32 MFMA GEMMs; 1: bf16x3 split-operand MFMA GEMMs (f32-class accuracy)")
     a = ap.parse_args()
+    if a.mode == "train" and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+        # <same arguments>` -- one rank per GPU over RCCL, the form the driver uses for N > 1 (which keeps working: WORLD_SIZE is set there)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        os.execvpe(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env)
     (run_train if a.mode == "train" else run_decode)(a)

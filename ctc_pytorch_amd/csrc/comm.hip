@@ -23,6 +23,7 @@ constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;        // ncclDataType_t / ncclRed
 
 struct Rccl {
   void *handle = nullptr;
+  char why[256] = "";          // dlerror() text of the LAST failed dlopen (dlerror clears itself when read: captured once, here)
   get_unique_id_fn get_unique_id = nullptr;
   comm_init_rank_fn comm_init_rank = nullptr;
   all_reduce_fn all_reduce = nullptr;
@@ -30,19 +31,27 @@ struct Rccl {
   get_error_string_fn get_error_string = nullptr;
 };
 
+Rccl &rccl_state() { static Rccl r; return r; }
 Rccl *rccl() {
-  static Rccl r;
+  Rccl &r = rccl_state();
   static bool tried = false;
   if (!tried) {
     tried = true;
     const char *names[3] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (int i = 0; i < 3 && !r.handle; ++i) r.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    for (int i = 0; i < 3 && !r.handle; ++i) {
+      r.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+      if (!r.handle) {
+        const char *e = dlerror();
+        snprintf(r.why, sizeof(r.why), "%s", e ? e : "dlopen failed");
+      }
+    }
     if (r.handle) {
       r.get_unique_id = (get_unique_id_fn)dlsym(r.handle, "ncclGetUniqueId");
       r.comm_init_rank = (comm_init_rank_fn)dlsym(r.handle, "ncclCommInitRank");
       r.all_reduce = (all_reduce_fn)dlsym(r.handle, "ncclAllReduce");
       r.comm_destroy = (comm_destroy_fn)dlsym(r.handle, "ncclCommDestroy");
       r.get_error_string = (get_error_string_fn)dlsym(r.handle, "ncclGetErrorString");
+      if (!(r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy)) snprintf(r.why, sizeof(r.why), "missing ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy");
     }
   }
   return (r.handle && r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy) ? &r : nullptr;
@@ -59,7 +68,7 @@ int fail(const char *what, int rc) {
 extern "C" int ctcn_comm_unique_id(void *id128) {
   CTCN_REQUIRE(id128, "ctcn_comm_unique_id: null pointer");
   Rccl *r = rccl();
-  if (!r) { ctcn_set_error("ctcn_comm_unique_id: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols"); return CTCN_EUNSUPPORTED; }
+  if (!r) { ctcn_set_error("ctcn_comm_unique_id: librccl.so could not be loaded (%s)", rccl_state().why); return CTCN_EUNSUPPORTED; }
   UniqueId id;
   const int rc = r->get_unique_id(&id);
   if (rc) return fail("ctcn_comm_unique_id", rc);
@@ -70,7 +79,7 @@ extern "C" int ctcn_comm_unique_id(void *id128) {
 extern "C" int ctcn_comm_init(const void *id128, int rank, int world, void **comm) {
   CTCN_REQUIRE(id128 && comm && world >= 1 && rank >= 0 && rank < world, "ctcn_comm_init: bad arguments (rank %d of %d)", rank, world);
   Rccl *r = rccl();
-  if (!r) { ctcn_set_error("ctcn_comm_init: librccl.so could not be loaded"); return CTCN_EUNSUPPORTED; }
+  if (!r) { ctcn_set_error("ctcn_comm_init: librccl.so could not be loaded (%s)", rccl_state().why); return CTCN_EUNSUPPORTED; }
   UniqueId id;
   memcpy(&id, id128, sizeof(id));
   void *c = nullptr;

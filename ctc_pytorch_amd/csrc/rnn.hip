@@ -374,6 +374,11 @@ __global__ __launch_bounds__(1024) void rnn_bwd_step(RnnArgs p) {
 // grid: device scope (slices, dirs, batch tiles); XCD-local nx * (wpx + spare) x 1 x 1.  256 threads, all working
 // workgroups co-resident (occupancy-checked on the host).
 // ================================================================================================
+// Bound of every in-launch spin, in poll round trips (~0.25-0.6 us each): ~10-20 s.  Long enough for a foreign resident kernel -- an
+// RCCL all-reduce parked on some CUs until its slowest peer arrives -- to finish and let the rest of the grid become resident
+// (DESIGN.md section 6); short enough that a genuinely lost role still ends the launch (status word set, output poisoned).
+constexpr int SPIN_LIMIT = 1 << 25;
+
 struct PersistArgs {
   RnnArgs a;
   float *hx;            // fwd: [2 parity][D][btiles][16][H] h payload;  bwd: [2][D][btiles][16][G*H] d(pre-act) payload
@@ -2002,6 +2007,10 @@ void launch_bwd(int kq4, dim3 grid, hipStream_t st, const RnnArgs &a) {
 
 int gates_of(int cell) { return cell == CTCN_CELL_LSTM ? 4 : (cell == CTCN_CELL_GRU ? 3 : 1); }
 
+// which recurrent kernel the last forward / backward call of this process launched (diagnostics: ctcn_rnn_last_kernel; bench.py names
+// the kernel its roofline object describes from this, not from what the host expects)
+const char *g_last_kernel[2] = {"", ""};
+
 // One line on stderr (per distinct reason, per process) when a layer that asked for the persistent recurrence runs one launch
 // per timestep instead: that path is 4x slower and nothing else would tell the user.  CTCN_QUIET=1 silences it.
 void log_fallback(const char *which, int T, int B, int H, int dirs, const char *reason) {
@@ -2017,6 +2026,8 @@ void log_fallback(const char *which, int T, int B, int H, int dirs, const char *
 }
 
 }  // namespace
+
+extern "C" const char *ctcn_rnn_last_kernel(int which) { return g_last_kernel[which ? 1 : 0]; }
 
 extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
   const size_t G = gates_of(cell);
@@ -2172,7 +2183,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
         pa.hx = (float *)tail;
         pa.flags = (unsigned *)(tail + hx_bytes);
         pa.status = ctcn_status_word();
-        pa.spin_limit = 1 << 22;
+        pa.spin_limit = SPIN_LIMIT;
         pa.local = 1; pa.nx = nxd; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
         pa.poll_depth = 1; pa.tagmode = 1; pa.poll_delay = ctcn_get_option("tag_poll_delay");
         pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
@@ -2189,6 +2200,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();
+          g_last_kernel[0] = "rnn_fwd_tagged";
           if (fuse_drop) g_fwd_dropout.pending = false;
           if (piped) {          // the remaining chunk pairs, next to the recurrence on the XCDs it does not use
             hipStream_t sd = (hipStream_t)ov.stream;
@@ -2200,7 +2212,11 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
               int rc = project_chunk(pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
               ctcn_gemm_hint_same_b();
               if (!rc) rc = project_chunk(NCHUNK - 1 - pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
-              if (rc) return rc;
+              if (rc) {         // the recurrence is already queued and will wait for this counter: release it (its output is invalid, the
+                                // caller sees rc) instead of letting it spin to the hand-off timeout and poison the status word
+                hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, sd, pa.chunk_ready, (unsigned)NCHUNK);
+                return rc;
+              }
               hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, sd, pa.chunk_ready, (unsigned)pr);
             }
             CTCN_LAUNCH_CHECK();
@@ -2229,7 +2245,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.hx = (float *)tail;
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
-      pa.spin_limit = 1 << 22;
+      pa.spin_limit = SPIN_LIMIT;
       pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.nbig = nbig; pa.hsu_small = hsu_small;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
@@ -2240,6 +2256,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
       if (launch_fwd_persist(prec, NT, kq, pgrid, lds, st, pa, wpx)) {
         CTCN_LAUNCH_CHECK();
+        g_last_kernel[0] = "rnn_fwd_persist";
         return CTCN_OK;
       }
     }
@@ -2248,6 +2265,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
     log_fallback("ctcn_rnn_fwd", T, B, H, dirs, "a reserve tensor of 4 GB or more");
   }
   const int kq4 = pick_kq4(H, 4, MT, 20);
+  g_last_kernel[0] = "rnn_fwd_step";
   for (int s = 0; s < T; ++s) {
     a.step = s;
     if (MT == 1) launch_fwd<1>(kq4, grid, st, a);
@@ -2422,7 +2440,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       pa.hx = (float *)tail;
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = ctcn_status_word();
-      pa.spin_limit = 1 << 22;
+      pa.spin_limit = SPIN_LIMIT;
       pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
@@ -2442,6 +2460,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
         }
         record_prelaunch(st);
         done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
+        if (done) g_last_kernel[1] = "rnn_bwd_scatter";
       } else {
         if (!dy_dropped) {
           if (int rc = ctcn_dropout(dy, bd.tmp, (size_t)T * B * dirs * H, bd.p, bd.seed, bd.off, stream)) return rc;
@@ -2451,6 +2470,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
         else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         record_prelaunch(st);
         done = launch_bwd_persist(prec, kq, pgrid, lds, st, pa, wpx);
+        if (done) g_last_kernel[1] = "rnn_bwd_persist";
       }
     }
   }
@@ -2466,6 +2486,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     // (the carried dc / dh*z of the per-timestep kernels lives in `state`; the persistent kernels keep it in registers)
     CTCN_HIP(hipMemsetAsync(state, 0, (size_t)B * dirs * H * sizeof(float), st));
     const int kq4 = pick_kq4(GH, 16, 1, 5);
+    g_last_kernel[1] = "rnn_bwd_step";
     for (int s = 0; s < T; ++s) {
       a.step = s;
       launch_bwd(kq4, grid, st, a);

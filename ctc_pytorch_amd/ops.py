@@ -77,6 +77,19 @@ def get_option(name):
     return int(_lib.lib().ctcn_get_option(name.encode()))
 
 
+def rnn_last_kernels():
+    """(forward, backward) names of the recurrent kernels the library launched last (ctcn_rnn_last_kernel)."""
+    L = _lib.lib()
+    return (L.ctcn_rnn_last_kernel(0) or b"").decode(), (L.ctcn_rnn_last_kernel(1) or b"").decode()
+
+
+def diag_squat(wgs_per_xcd, usec, threads=256, lds_bytes=0, stream=None):
+    """Diagnostics: occupy `wgs_per_xcd` workgroups on every XCD for `usec` microseconds on `stream` (default: the current one) --
+    the footprint of an RCCL kernel waiting for a slow peer (ctcn_diag_squat)."""
+    st = stream.cuda_stream if stream is not None else _lib.stream_ptr()
+    _lib.check(_lib.lib().ctcn_diag_squat(int(wgs_per_xcd), int(threads), int(lds_bytes), int(usec), ctypes.c_void_p(st)), "diag_squat")
+
+
 def check_health(device=None):
     """Synchronising check of the sticky status word written by persistent kernels on a hand-off timeout."""
     _lib.check_status(torch.device("cuda", torch.cuda.current_device()) if device is None else device)

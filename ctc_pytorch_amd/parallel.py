@@ -113,8 +113,17 @@ def enable_overlap(flag=True):
     _overlap["works"], _overlap["done"], _overlap["events"] = [], [], []
 
 
+def overlap_is_rank_invariant():
+    """The early all-reduce of a layer's gradient slice is a COLLECTIVE: every rank must take the same decision for the same layer, or
+    the RCCL call sequences diverge (hang / silent corruption).  ops.py decides per layer from (T, B_local, H, dirs): T, H and dirs are
+    global, so the decision is rank-invariant exactly when every rank holds the same number of utterances.  With uneven shards
+    (B_global % world != 0, e.g. the last minibatch of an epoch) no slice is reduced early: everything goes with the step-end call."""
+    g = _batch["global"]
+    return g is None or g % world_size() == 0
+
+
 def _slice_ready(tensors):
-    if not _collectives_on() or not tensors:
+    if not _collectives_on() or not tensors or not overlap_is_rank_invariant():
         return
     ts = sorted(tensors, key=lambda t: t.data_ptr())
     lo, n = ts[0].data_ptr(), sum(t.numel() for t in ts)
@@ -225,6 +234,31 @@ def enable_sync_bn(flag=True):
     per-shard statistics, the fast documented deviation."""
     from . import ops
     ops.set_sync_bn(_sync_bn_reduce if flag else None)
+
+
+def sync_bn_buffers(model):
+    """Per-shard BatchNorm (the default, sync_bn off) leaves every rank with running_mean / running_var of its OWN shards; evaluation and
+    the checkpoint (written by rank 0) would then depend on the rank.  Called at the end of a training epoch: the floating-point buffers
+    are averaged over the ranks (num_batches_tracked is identical everywhere).  A no-op without collectives or with sync_bn on (the
+    statistics are already global there, averaging identical values changes nothing but rounding -- skipped)."""
+    if not _collectives_on() or world_size() == 1:
+        return 0
+    from . import ops
+    if ops._sync_bn["reduce"] is not None:
+        return 0
+    bufs = [b for _, b in model.named_buffers() if b.is_floating_point()]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world_size()
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view_as(b))
+            off += n
+    return len(bufs)
 
 
 def broadcast_params(flat_params, src=0):

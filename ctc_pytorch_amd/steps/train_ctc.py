@@ -210,7 +210,8 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
     # The host side of a step is collation and a 4 MB staging copy: a torch CPU op that fans out to every core (128 OpenMP
     # threads on the GPU box) between two steps stalls the launch thread for 8-10 ms (tools/epoch_probe.py).  CTCN_HOST_THREADS
     # overrides; one process per GPU shares the host anyway.
-    torch.set_num_threads(max(1, int(os.environ.get("CTCN_HOST_THREADS", "4"))))
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(max(1, int(os.environ.get("CTCN_HOST_THREADS", "4"))))       # (restored when main returns)
     torch.manual_seed(opts.seed)
     np.random.seed(opts.seed)
     if train_loader is None:
@@ -243,24 +244,31 @@ def main(conf, train_loader=None, dev_loader=None, num_class=None, log=print):
     count = 0
     # the long-lived objects built so far (module tree, optimizer, loaders) leave the interpreter's cyclic collector: its generation-2
     # passes over them took ~50 ms each -- three or four whole training steps -- and the loop only stays two steps ahead of the device
+    # (both are undone when the loop ends, however it ends: main is also a library entry point -- tests)
     import gc
     gc.collect()
     gc.freeze()
     start = time.time()
-    while not ctl.stop and count < opts.num_epoches:
-        count += 1
-        ctl.begin_epoch(optimizer)
-        log("Start training epoch: %d, learning_rate: %.5f" % (count, optimizer.param_groups[0]["lr"]))
-        _, loss = run_epoch(count, model, train_loader, loss_fn, device, optimizer=optimizer, print_every=opts.verbose_step,
-                            is_training=True, log=log)
-        acc, dev_loss = run_epoch(count, model, dev_loader, loss_fn, device, optimizer=None, print_every=opts.verbose_step,
-                                  is_training=False, log=log)
-        loss_results.append(loss)
-        dev_loss_results.append(dev_loss)
-        dev_cer_results.append(acc)
-        ctl.end_epoch(model, optimizer, acc, dev_loss)
-        log(json.dumps(dict(epoch=count, train_loss=loss, dev_loss=dev_loss, dev_acc=acc, adjust_time=ctl.adjust_time,
-                            minutes=(time.time() - start) / 60)))
+    try:
+        while not ctl.stop and count < opts.num_epoches:
+            count += 1
+            ctl.begin_epoch(optimizer)
+            log("Start training epoch: %d, learning_rate: %.5f" % (count, optimizer.param_groups[0]["lr"]))
+            _, loss = run_epoch(count, model, train_loader, loss_fn, device, optimizer=optimizer, print_every=opts.verbose_step,
+                                is_training=True, log=log)
+            # per-shard BatchNorm: one set of running statistics for the evaluation below and for rank 0's checkpoint
+            parallel.sync_bn_buffers(model)
+            acc, dev_loss = run_epoch(count, model, dev_loader, loss_fn, device, optimizer=None, print_every=opts.verbose_step,
+                                      is_training=False, log=log)
+            loss_results.append(loss)
+            dev_loss_results.append(dev_loss)
+            dev_cer_results.append(acc)
+            ctl.end_epoch(model, optimizer, acc, dev_loss)
+            log(json.dumps(dict(epoch=count, train_loss=loss, dev_loss=dev_loss, dev_acc=acc, adjust_time=ctl.adjust_time,
+                                minutes=(time.time() - start) / 60)))
+    finally:
+        gc.unfreeze()
+        torch.set_num_threads(threads_before)
     if ctl.best_model_state is not None:
         model.load_state_dict(ctl.best_model_state)
         optimizer.load_state_dict(ctl.best_op_state)

@@ -3,6 +3,7 @@
 
     python dp_worker.py equiv <out.json>          2-rank DP step == single-process step on the same global batch
     python dp_worker.py main  <corpus_dir> <out>  steps/train_ctc.main on a toy corpus; writes history + parameter checksum
+    python dp_worker.py overlap <out.json>        early all-reduce of gradient slices: even shards reduce early, uneven ones never diverge
 """
 import json
 import os
@@ -91,6 +92,56 @@ def equiv(out_path):
         json.dump(results, open(out_path, "w"))
 
 
+def overlap(out_path):
+    """Early (overlapped) all-reduce of a layer's gradient slice under 2 ranks.  `even`: 16 + 16 utterances, every rank takes the same
+    decision and the top layer's slice is reduced behind its weight GEMMs; `uneven`: 17 + 16 with the side-stream threshold placed
+    BETWEEN the two shard sizes -- rank 0 alone would issue the early collective: parallel.overlap_is_rank_invariant() must
+    keep both ranks on the step-end all-reduce.  Both must equal the single-process gradient."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ops.set_precision(0)
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    results = {}
+    T, H = 48, 32
+    for name, B, min_items in (("even", 32, 1), ("uneven", 33, T * 16 * H + 1)):
+        batch = synth.make_batch(seed=9, B=B, T=T, F=40, V=30, lab_lo=3, lab_hi=6, full_length=True)
+        ops.set_side_stream(True, min_items=1 << 30)        # reference: everything inline
+        parallel.enable_overlap(False)
+        ref = None
+        if rank == 0:
+            m = build(dev, False)
+            opt = FlatAdam(m, lr=1e-3)
+            loss, _ = one_step(m, opt, batch, 0, B, B, dev)
+            ref = (float(loss), opt.grad.clone())
+        if not torch.distributed.is_initialized():
+            parallel.init_from_env(backend="gloo")
+        torch.distributed.barrier()
+        parallel.enable_sync_bn(True)
+        ops.set_side_stream(True, min_items=min_items)
+        parallel.enable_overlap(True)
+        m = build(dev, False)
+        opt = FlatAdam(m, lr=1e-3)
+        parallel.broadcast_params(opt.flat)
+        lo, hi = parallel.shard_range(B, rank, world)
+        loss, _ = one_step(m, opt, batch, lo, hi, B, dev)
+        early = len(parallel._overlap["done"])
+        parallel.allreduce_grads(opt.grad)
+        tot = parallel.allreduce_stats(loss.reshape(1).clone())
+        early_all = parallel.allreduce_stats(torch.tensor([float(early)], dtype=torch.float64, device=dev))
+        torch.cuda.synchronize()
+        ops.check_health()
+        parallel.enable_sync_bn(False)
+        parallel.enable_overlap(False)
+        parallel.set_batch_split(None, None)
+        if rank == 0:
+            g_ref, g = ref[1].double(), opt.grad.double()
+            results[name] = dict(loss_rel=abs(float(tot[0]) - ref[0]) / abs(ref[0]), grad_rel_l2=float((g - g_ref).norm() / g_ref.norm()),
+                                 early_slices_rank0=early, early_slices_all_ranks=float(early_all[0]))
+        torch.distributed.barrier()
+    if rank == 0:
+        json.dump(results, open(out_path, "w"))
+
+
 def main_mode(corpus, out_path):
     from ctc_pytorch_amd.steps import train_ctc as TR
     rank = int(os.environ.get("RANK", "0"))
@@ -115,5 +166,7 @@ def main_mode(corpus, out_path):
 if __name__ == "__main__":
     if sys.argv[1] == "equiv":
         equiv(sys.argv[2])
+    elif sys.argv[1] == "overlap":
+        overlap(sys.argv[2])
     else:
         main_mode(sys.argv[2], sys.argv[3])

@@ -1420,6 +1420,24 @@ def test_bench_under_torchrun_with_rccl_collectives(dev, workload, comm):
         assert res["overlapped_allreduce_slices_last_step"] >= 2, res.get("overlapped_allreduce_slices_last_step")
 
 
+@pytest.mark.parametrize("workload,steps", [("cfg2", 60), ("cfg4", 12)])
+def test_persistent_recurrences_survive_foreign_resident_kernels(dev, workload, steps):
+    """VERDICT r2 #1b / DESIGN section 6 (co-residency contract with RCCL): squatter kernels -- up to 12 workgroups per XCD parked for up
+    to 4 ms on a third stream, what an RCCL kernel waiting for a slow peer looks like -- are launched at random points of training steps at
+    precision 1 with the side stream, the pipelined projection and the gradient-slice hook on.  No hand-off may time out and the loss
+    trajectory must equal the undisturbed run bit for bit.  cfg4 (H = 512, B = 64): the recurrence takes EVERY CU of all 8 XCDs, so a
+    squatter that got there first delays whole launches."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import squat_stress
+    base = squat_stress.run(workload, steps, squat=False, dev=dev)
+    hit = squat_stress.run(workload, steps, squat=True, seed=3, dev=dev)
+    assert hit["squats"] >= steps // 2
+    assert np.isfinite(hit["losses"]).all()
+    assert hit["losses"] == base["losses"], [(i, a, b) for i, (a, b) in enumerate(zip(hit["losses"], base["losses"])) if a != b][:5]
+    assert hit["kernels"][0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and hit["kernels"][1] in ("rnn_bwd_scatter", "rnn_bwd_persist"), hit["kernels"]
+
+
 def _spawn_ranks(args, world, port, extra_env=None, timeout=600):
     """`world` ranks on the ONE GPU of the box (LOCAL_RANK 0 for all; gloo carries the collectives, RCCL refuses two ranks per
     device).  The persistent recurrences need their whole grid co-resident, which two processes sharing the chip cannot promise
@@ -1449,6 +1467,19 @@ def test_data_parallel_two_ranks_equal_single_process(dev, tmp_path):
         assert r["loss_rel"] < 1e-5, r
         assert r["grad_rel_l2"] < 2e-6 and r["grad_norm"] > 0, r
         assert r["lp_shard_maxabs"] < 2e-5 and r["running_stats_maxabs"] < 1e-6, r
+
+
+def test_data_parallel_overlap_is_rank_invariant(dev, tmp_path):
+    """the early all-reduce of a recurrent layer's gradient slice is a collective, so every rank must decide alike.
+    even = 16 + 16 utterances: both ranks reduce the top layer's slice early; uneven = 17 + 16 with the side-stream threshold between the
+    two shard sizes (rank 0 alone would have issued the collective): nobody reduces early.  Both equal the single-process gradient."""
+    out = str(tmp_path / "overlap.json")
+    _spawn_ranks(["overlap", out], 2, 29637, timeout=300)
+    res = json.load(open(out))
+    assert res["even"]["early_slices_all_ranks"] == 2 * res["even"]["early_slices_rank0"] and res["even"]["early_slices_rank0"] >= 1, res
+    assert res["uneven"]["early_slices_all_ranks"] == 0, res
+    for k in ("even", "uneven"):
+        assert res[k]["loss_rel"] < 1e-5 and res[k]["grad_rel_l2"] < 2e-6, res
 
 
 def test_train_driver_data_parallel_matches_single_process(dev, tmp_path):
