@@ -29,6 +29,9 @@ WORKLOADS = {   # per-GPU shapes
     "cfg2": dict(B=32, T=800, V=62, H=320, L=4, rnn="LSTM", cnn=False, lab=(30, 60)),
     "cfg3": dict(B=32, T=800, V=62, H=320, L=4, rnn="LSTM", cnn=True, lab=(30, 60)),
     "cfg4": dict(B=64, T=1200, V=200, H=512, L=5, rnn="GRU", cnn=False, lab=(60, 100)),
+    # the reference's SHIPPED configuration (timit/conf/ctc_config.yaml:11-40): 81-d fbank spliced with right_ctx 2 -> 243-d, n_skip_frame 2
+    # (400 kept frames = an 8 s utterance), 2-layer CNN -> 1 952-wide RNN input, 4 x 384 BiLSTM, batch 8, drop_out 0.2, 39 phones + blank + UNK
+    "ref_yaml": dict(B=8, T=400, V=41, H=384, L=4, rnn="LSTM", cnn=True, lab=(20, 40), F=243, drop=0.2),
 }
 CNN_LAYERS = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
@@ -49,7 +52,7 @@ def gemm_weights(c, feat_in):
 def build(c, dev, drop_out):
     from ctc_pytorch_amd import nn
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
-    rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(nn, c["rnn"]),
+    rp = {"rnn_input_size": c.get("F", 40), "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(nn, c["rnn"]),
           "bidirectional": True, "batch_norm": True}
     if c["cnn"]:
         cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": CNN_LAYERS}
@@ -65,11 +68,11 @@ def cpu_baseline_train(c, batch, steps=1, sweep=(8, 16, 32, 64)):
     thread count is swept and the BEST setting is the baseline."""
     import torch.nn as tnn
     from oracle import torch_cpu
-    rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(tnn, c["rnn"]),
+    rp = {"rnn_input_size": c.get("F", 40), "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(tnn, c["rnn"]),
           "bidirectional": True, "batch_norm": True}
     cp = {"batch_norm": True, "activate_function": tnn.ReLU, "layer": CNN_LAYERS} if c["cnn"] else None
     torch.manual_seed(1)
-    m = torch_cpu.TorchCpuCTCModel(add_cnn=c["cnn"], cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=0.1)
+    m = torch_cpu.TorchCpuCTCModel(add_cnn=c["cnn"], cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=c.get("drop", 0.1))
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
     x, frac = torch.from_numpy(batch["x"]), torch.from_numpy(batch["frac"])
@@ -93,8 +96,8 @@ def cpu_baseline_train(c, batch, steps=1, sweep=(8, 16, 32, 64)):
     best = min(tried, key=tried.get)
     dt = tried[best]
     return dict(value=c["B"] * c["T"] / dt, unit="frames/s", cores=best, kind="port",
-                sample="%d train step(s) per setting of the same %dx%dx40 batch through oracle/torch_cpu.py (torch %s CPU); thread sweep "
-                       "%s of %d host cores, best = %d threads" % (steps, c["B"], c["T"], torch.__version__,
+                sample="%d train step(s) per setting of the same %dx%dx%d batch through oracle/torch_cpu.py (torch %s CPU); thread sweep "
+                       "%s of %d host cores, best = %d threads" % (steps, c["B"], c["T"], c.get("F", 40), torch.__version__,
                                                                   {k: round(v, 2) for k, v in tried.items()}, ncpu, best),
                 seconds_per_step=dt, seconds_per_step_by_threads=tried)
 
@@ -214,10 +217,10 @@ def run_train(args):
     from ctc_pytorch_amd import ops as _ops
     _ops.set_precision(args.precision)
     torch.manual_seed(1)
-    model = build(c, dev, drop_out=0.1).train()
+    model = build(c, dev, drop_out=c.get("drop", 0.1)).train()
     opt = FlatAdam(model, lr=1e-3, weight_decay=5e-4)
     parallel.broadcast_params(opt.flat)
-    batch = synth.make_batch(seed=1 + rank, B=c["B"], T=c["T"], F=40, V=c["V"], lab_lo=c["lab"][0], lab_hi=c["lab"][1],
+    batch = synth.make_batch(seed=1 + rank, B=c["B"], T=c["T"], F=c.get("F", 40), V=c["V"], lab_lo=c["lab"][0], lab_hi=c["lab"][1],
                              full_length=True)
     x = torch.from_numpy(batch["x"]).to(dev)
     tg = torch.from_numpy(batch["targets"]).to(dev)
@@ -296,7 +299,8 @@ def run_train(args):
         return
     frames = c["B"] * c["T"] * world * args.steps
     value = frames / dt
-    feat_in = 320 if c["cnn"] else 40
+    Fd = c.get("F", 40)
+    feat_in = 32 * (((Fd + 2 - 3) // 2 + 1 + 2 - 3) // 2 + 1) if c["cnn"] else Fd          # two 3x3 convs, frequency stride 2 each, 32 channels
     wts = gemm_weights(c, feat_in)
     t_frames = c["T"] // 2 if c["cnn"] else c["T"]
     train_flops_per_step = 3 * 2 * wts * c["B"] * t_frames
@@ -306,8 +310,8 @@ def run_train(args):
         "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median([ticks[i].elapsed_time(ticks[i + 1]) for i in range(args.steps)])) if args.steps else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == 0 else "f32 via bf16x3 split-operand MFMA (f32 accumulate)", "data": "synthetic",
-        "config": {"workload": "%s: %dx%d Bi%s + BN + Linear(%d) + CTC, B=%d/GPU, T=%d, F=40%s, dropout 0.1, Adam" % (
-            args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], ", 2-layer CNN front-end" if c["cnn"] else ""),
+        "config": {"workload": "%s: %dx%d Bi%s + BN + Linear(%d) + CTC, B=%d/GPU, T=%d, F=%d%s, dropout %.1f, Adam" % (
+            args.workload, c["L"], c["H"], c["rnn"], c["V"], c["B"], c["T"], Fd, ", 2-layer CNN front-end" if c["cnn"] else "", c.get("drop", 0.1)),
             "global_batch": global_b, "seq_len": c["T"], "parallelism": "dp%d" % world, "full_length_utterances": True,
             "sync_bn": bool(getattr(args, "sync_bn", False))},
         "final_loss": last_loss, "overlapped_allreduce_slices_last_step": overlapped[0],

@@ -480,6 +480,86 @@ def gen_large():
             json.dump(res, f, indent=1)
 
 
+# ---------------------------------------------------------------------------------------------
+# (7) the reference's SHIPPED configuration (timit/conf/ctc_config.yaml:11-40): 81-d fbank spliced with right_ctx 2 -> 243-d input,
+#     2-layer CNN (-> 61 x 32 = 1 952-wide RNN input), 4 x 384 BiLSTM, batch 8.  The model is 15.6 M parameters, so the fixture keeps
+#     the INPUTS (tiny) and, of the outputs, everything that is small (log-probs, arg-max, losses of three Adam steps, eval log-probs
+#     after them) plus per-parameter gradient / updated-parameter NORMS and a strided SAMPLE (every 1 009th element) of every gradient
+#     and every updated parameter: the weights themselves are regenerated from the seed (synth.fill_state_dict).
+# ---------------------------------------------------------------------------------------------
+REF_YAML = dict(F=243, H=384, L=4, V=41, B=8, drop_out=0.2)      # V = 39 phones + "blank" + "UNK" (data_loader.py:16-19)
+SAMPLE_STRIDE = 1009
+
+
+def ref_yaml_model(drop=0.0):
+    cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": CNN_LAYERS}
+    rp = {"rnn_input_size": REF_YAML["F"], "rnn_hidden_size": REF_YAML["H"], "rnn_layers": REF_YAML["L"], "rnn_type": nn.LSTM,
+          "bidirectional": True, "batch_norm": True}
+    return CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=REF_YAML["V"], drop_out=drop)
+
+
+def gen_ref_yaml():
+    V, Fd = REF_YAML["V"], REF_YAML["F"]
+    b = synth.make_batch(seed=71, B=3, T=47, F=Fd, V=V, lab_lo=3, lab_hi=6)
+    model = ref_yaml_model()
+    load_seeded(model, 72)
+    x, frac = torch.from_numpy(b["x"]), torch.from_numpy(b["frac"])
+    tg, tl = torch.from_numpy(b["targets"]), torch.from_numpy(b["tgt_len"])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    loss_fn = nn.CTCLoss(reduction="sum")
+    out = dict(x=b["x"], frac=b["frac"], lens=b["lens"], targets=b["targets"], tgt_len=b["tgt_len"], seed_w=np.int64(72),
+               sample_stride=np.int64(SAMPLE_STRIDE))
+    model.train()
+    losses = []
+    for step in range(3):
+        lp, vis = model(x, visualize=True)
+        in_len = (frac * lp.size(0)).long()
+        loss = loss_fn(lp, tg, in_len, tl) / x.shape[0]
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["in_len"], out["lp"], out["argmax"] = t2n(in_len), t2n(lp), t2n(torch.max(lp, dim=-1)[1])
+            out["rnn_in_sample"] = t2n(vis[2].reshape(-1)[::SAMPLE_STRIDE])
+            out["rnn_in_shape"] = np.array(vis[2].shape, dtype=np.int64)
+            for k, p in model.named_parameters():
+                out["gnorm." + k] = np.float64(p.grad.double().norm().item())
+                out["gsample." + k] = t2n(p.grad.reshape(-1)[::SAMPLE_STRIDE])
+        losses.append(float(loss.item()))
+        opt.step()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in model.state_dict().items():
+        if v.numel() > 4096:
+            out["afternorm." + k] = np.float64(v.double().norm().item())
+            out["aftersample." + k] = t2n(v.reshape(-1)[::SAMPLE_STRIDE])
+        else:
+            out["after." + k] = t2n(v)
+    model.eval()
+    with torch.no_grad():
+        lpe = model(x)
+    out["lp_eval_after"], out["argmax_eval_after"] = t2n(lpe), t2n(torch.max(lpe, dim=-1)[1])
+    save("model_ref_yaml", **out)
+    print("ref_yaml losses", losses, "rnn input", tuple(vis[2].shape))
+    # full size: batch 8 of 400 spliced + skipped frames (a 8 s TIMIT utterance at 10 ms, n_skip_frame 2) -> 200 recurrent steps
+    path = os.path.join(GOLD, "large_checksums.json")
+    res = json.load(open(path)) if os.path.exists(path) else {}
+    bb = synth.make_batch(seed=1, B=REF_YAML["B"], T=400, F=Fd, V=V, lab_lo=20, lab_hi=40)
+    model = ref_yaml_model()
+    load_seeded(model, 91)
+    model.train()
+    lp = model(torch.from_numpy(bb["x"]))
+    in_len = (torch.from_numpy(bb["frac"]) * lp.size(0)).long()
+    loss = nn.CTCLoss(reduction="sum")(lp, torch.from_numpy(bb["targets"]), in_len, torch.from_numpy(bb["tgt_len"])) / REF_YAML["B"]
+    loss.backward()
+    res["ref_yaml"] = dict(loss=float(loss.item()), n_params=int(sum(p.numel() for p in model.parameters())),
+                           lp_sum=float(lp.double().sum().item()), lp_abs_mean=float(lp.double().abs().mean().item()),
+                           grad_norm={k: float(p.grad.double().norm().item()) for k, p in model.named_parameters()},
+                           argmax_sum=int(torch.max(lp, dim=-1)[1].sum().item()),
+                           shape=dict(B=REF_YAML["B"], T=400, V=V, H=REF_YAML["H"], L=REF_YAML["L"], rnn="LSTM", cnn=True, F=Fd, lab=[20, 40]))
+    print("ref_yaml full size: loss", res["ref_yaml"]["loss"], "params", res["ref_yaml"]["n_params"], "T_out", lp.size(0))
+    with open(path, "w") as f:
+        json.dump(res, f, indent=1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
@@ -487,7 +567,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
-                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm)
+                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml)
     if a.large:
         gen_large()
     else:

@@ -126,6 +126,35 @@ def test_torch_cpu_counterpart_is_pinned(tag, cls, H, bi, bn):
         assert np.allclose(v.numpy(), z["after." + k], atol=1e-6), k
 
 
+def test_torch_cpu_counterpart_is_pinned_at_the_shipped_yaml_shape():
+    """The reference's shipped configuration (timit/conf/ctc_config.yaml:11-40: 243-d spliced input, 2-layer CNN -> 1 952-wide RNN
+    input, 4 x 384 BiLSTM): the torch-CPU counterpart against the fixture captured from the reference (model_ref_yaml.npz: log-probs,
+    three losses, norms + strided samples of every gradient and every updated parameter)."""
+    z = load("model_ref_yaml")
+    rp = {"rnn_input_size": 243, "rnn_hidden_size": 384, "rnn_layers": 4, "rnn_type": tnn.LSTM, "bidirectional": True, "batch_norm": True}
+    cp = {"batch_norm": True, "activate_function": tnn.ReLU, "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
+    m = torch_cpu.TorchCpuCTCModel(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=41, drop_out=0.0)
+    vals = synth.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=int(z["seed_w"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+    x, frac = torch.from_numpy(z["x"]), torch.from_numpy(z["frac"])
+    tg, tl = torch.from_numpy(z["targets"]), torch.from_numpy(z["tgt_len"])
+    stride = int(z["sample_stride"])
+    lp = m(x)
+    assert tuple(lp.shape) == tuple(z["lp"].shape) and np.allclose(lp.detach().numpy(), z["lp"], atol=1e-5)
+    in_len = (frac * lp.size(0)).long()
+    assert np.array_equal(in_len.numpy(), z["in_len"])
+    loss = tnn.CTCLoss(reduction="sum")(lp, tg, in_len, tl) / x.shape[0]
+    opt.zero_grad()
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert np.allclose(p.grad.reshape(-1)[::stride].numpy(), z["gsample." + k], atol=1e-6, rtol=1e-4), k
+    opt.step()
+    losses = [float(loss)] + [torch_cpu.train_step(m, opt, x, frac, tg, tl) for _ in range(2)]
+    assert np.allclose(losses, z["losses"], rtol=1e-5), (losses, z["losses"])
+
+
 def test_length_conversion_matches_reference_table():
     from ctc_pytorch_amd.steps.train_ctc import frames_from_fraction
     rows = load("length_table")["rows"]
