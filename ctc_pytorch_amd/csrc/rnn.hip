@@ -1897,11 +1897,354 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
     for (int tt = 0; tt < T; ++tt) st_slab(rg, vg0, (unsigned)tt * sg_b, __uint_as_float(0x7fc00000u));
 }
 
+// ================================================================================================
+// Persistent backward recurrence, SCATTER formulation with ITEM-WAVE GATHER (round 3; precision 1, tagged hand-off).
+//
+// rnn_bwd_scatter above pays two workgroup barriers per step: gathering waves sum the partial tiles addressed to the workgroup and park
+// them (barrier), the item waves add the twelve parked partials, run the gate math and stage the A operand (barrier), the exchange
+// waves multiply and scatter.  Here the item waves gather THEMSELVES: lane (row, unit) of item wave w needs, of every source block,
+// exactly one float, and the 64 floats of the wave are one contiguous 256-B quarter of the block (MFMA C layout: rows 4w .. 4w+3) --
+// nsl coalesced dword loads per lane, all in flight together, each dword carrying its own tag, summed in a fixed order in registers.
+// No park, no partial sums through LDS, ONE barrier per step (staged A operand).
+// That only works if nothing else sits in the item waves' in-order load queue, so ALL reserve traffic moves to the exchange waves,
+// which have nothing on the chain any more between their scatter and the next barrier:
+//   * loads: an exchange wave brings an array (one of the four saved gates, dy, c / W_hn h, c_prev / h_prev) of all 256 items of a step
+//     into LDS with ONE global_load_lds_dwordx4 (lane = row x unit quad), three steps ahead into a ring of three sets; before the barrier
+//     of each step it waits with vmcnt(k), k = its loads per step: loads return in order, so "at most k operations outstanding" means
+//     every load older than the youngest k has landed -- two whole steps per load, as before, and 64-bit addresses (no 4-GB limit);
+//   * stores: the item waves leave d(pre-activation) as float32 in LDS next to the bf16 A operand, each exchange wave stores one gate
+//     with 16-B stores (64 B contiguous per row instead of 4-B pieces).
+// The A operand, the float32 copy and the reserve sets are double / triple buffered, so the one barrier orders everything.
+// 512 threads: four item waves + FOUR exchange waves (one of each per SIMD, 256 VGPRs per wave: the W_hh fragments of NTE = ceil(nsl / 4)
+// output tiles per exchange wave and the nsl polled dwords of an item lane cannot share 128).  The matrix pipes see the same 6 MFMAs per
+// tile as before, issued as NTE independent chains per wave; a tile's block is stored as soon as its chain ends.
+// W_hh fragments, tags, tile layout in the hand-off buffer and the role placement are those of rnn_bwd_scatter; the sum over sources
+// runs 0 .. nsl-1 on two interleaved accumulators (even + odd sources).  NTE = 9 covers nsl <= 36 (H <= 576).
+// ================================================================================================
+template <int NEW, int NTE, int CELL>
+__global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs pa) {
+  const RnnArgs &p = pa.a;
+  constexpr int NTHR = 256 + 64 * NEW, NPL = (NEW * NTE + 3) / 4;       // NPL: 16-B poll loads per item lane (4 blocks each)
+  __shared__ __attribute__((aligned(16))) float stage[2][1024];        // da block as MFMA A operand (bf16 hi | lo), double buffered
+  __shared__ __attribute__((aligned(16))) float outf[2][4][256];       // da block as float32 [gate][row][unit]: the reserve stores
+  __shared__ __attribute__((aligned(16))) float resv[3][7][256];       // reserve values of three steps: [array][row][unit]
+  __shared__ uint4 dropw[4][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // scalar: every role decision below is a scalar branch
+  const int r = lane & 15, q = lane >> 4;
+  constexpr int G = CELL == CTCN_CELL_LSTM ? 4 : (CELL == CTCN_CELL_GRU ? 3 : 1);
+  constexpr bool is_lstm = CELL == CTCN_CELL_LSTM, is_gru = CELL == CTCN_CELL_GRU, is_tanh = CELL == CTCN_CELL_TANH;
+  const int H = p.H, D = p.D, B = p.B, T = p.T;
+  __shared__ int s_ticket;
+  const PersistRole role = persist_role(pa, D, &s_ticket);
+  if (!role.active) return;
+  const int d = role.d, bt = role.bt, nbt = pa.nbt, nsl = pa.nsl, slice = role.slice, local = pa.local;
+  const int b0 = bt * 16, j0 = slice * 16;
+  const int Bc = min(16, B - b0);
+  const int K = G * H;
+  const float *WT = d == 0 ? p.w0 : p.w1;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 2048; i += NTHR) (&stage[0][0])[i] = 0.0f;        // rows / units nobody owns stay 0
+
+  const int ew = wave - 4;                         // exchange wave 0 .. NEW-1 owns output tiles ew, ew + NEW, ...
+  bf16x8_t whi[NTE][2], wlo[NTE][2];
+#pragma unroll
+  for (int tw = 0; tw < NTE; ++tw) {
+    const int own = wave >= 4 ? ew + NEW * tw : 0;
+    const int n = 16 * own + r;
+    const bool nvalid = wave >= 4 && own < nsl && n < H;
+    const float *wrow = WT + (size_t)min(n, H - 1) * K;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int gate = 2 * blk + (q >> 1), u0 = j0 + 8 * (q & 1);
+      const bool kv = nvalid && gate < G && u0 < H;
+      load_w8(kv ? wrow + (size_t)gate * H + u0 : nullptr, 0, 8, whi[tw][blk], wlo[tw][blk]);
+    }
+  }
+  const size_t tile_f = (size_t)nsl * nsl * 256;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pa.hx, 0, (int)((size_t)2 * D * nbt * tile_f * 4), 0x00020000);
+  const unsigned tile_b[2] = {(unsigned)((((size_t)0 * D + d) * nbt + bt) * tile_f * 4), (unsigned)((((size_t)1 * D + d) * nbt + bt) * tile_f * 4)};
+
+  const int bl = tid >> 4, jl = tid & 15, j = j0 + jl, b = b0 + bl;
+  const bool item = tid < 256 && bl < Bc && j < H;
+  float state = 0.0f;
+  const int tdir = d == 0 ? -1 : 1;
+  const size_t slab_g = (size_t)B * D * K, slab_h = (size_t)B * D * H;
+
+  // ---- reserve traffic of the exchange waves -------------------------------------------------------------------------------
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  // lane = (row lane >> 2, unit quad lane & 3); rows / quads outside the tile read a clamped (valid) address and are never used
+  const int xrow = min(b0 + (lane >> 2), B - 1), xj = min(j0 + 4 * (lane & 3), H - 4);
+  const size_t xg = ((size_t)xrow * D + d) * K + xj, xh = ((size_t)xrow * D + d) * H + xj;      // float offsets inside a timestep slab
+  const bool xvalid = (lane >> 2) < Bc && j0 + 4 * (lane & 3) < H;
+  // arrays of the cell: LSTM 0..6; GRU 0, 1, 2, 4, 5, 6; tanh 4, 5.  Exchange wave e loads arrays e and e + NEW.
+  auto needed = [&](int a) { return a < 7 && (is_lstm || (is_gru ? a != 3 : (a == 4 || a == 5))); };
+  auto dma1 = [&](int a, int x, int set) {         // array a of step x (clamped) -> resv[set][a]
+    const int xc = min(x, T - 1), tx = d == 0 ? T - 1 - xc : xc, tx1 = xc + 1 < T ? tx + tdir : tx;
+    const float *src;
+    if (a < 4) src = p.gates + (size_t)tx * slab_g + xg + (size_t)min(a, G - 1) * H;
+    else if (a == 4) src = p.dy + (size_t)tx * slab_h + xh;
+    else if (a == 5) src = (is_tanh ? p.y : p.aux) + (size_t)tx * slab_h + xh;
+    else src = (is_lstm ? p.aux : p.y) + (size_t)tx1 * slab_h + xh;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&resv[set][a][0], 16, 0, 0);
+  };
+  auto dma = [&](int x, int set) {
+    if (needed(ew)) dma1(ew, x, set);
+    if (needed(ew + NEW)) dma1(ew + NEW, x, set);
+  };
+  const int ndma = wave >= 4 ? (needed(ew) ? 1 : 0) + (needed(ew + NEW) ? 1 : 0) : 0;
+  // fused dropout gradient: as rnn_bwd_scatter
+  auto drop_block = [&](int s0) {
+    const int sk = min(s0 + (lane >> 4), T - 1), tk = d == 0 ? T - 1 - sk : sk;
+    const int br = min(b0 + 4 * wave + ((lane >> 2) & 3), B - 1), j4 = min(j0 + 4 * (lane & 3), H - 4);
+    const unsigned idxk = (unsigned)((((size_t)tk * B + br) * D + d) * H + j4);
+    uint32_t rr[4];
+    philox4(pa.drop_seed, pa.drop_off + (idxk >> 2), rr);
+    dropw[wave][lane] = make_uint4(rr[0], rr[1], rr[2], rr[3]);
+  };
+  if (pa.drop_bwd && wave < 4) drop_block(0);
+  if (wave >= 4) { dma(0, 0); dma(1, 1); dma(2, 2); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // byte offset of this item lane's float inside a partial block (MFMA C layout: float ((row >> 2) * 16 + unit) * 4 + (row & 3))
+  const unsigned poll_off = (unsigned)(slice * nsl) * 1024u + (unsigned)(wave & 3) * 256u + (unsigned)((lane & 15) * 16 + (lane >> 4) * 4);
+  int set = 0;                                     // s % 3
+#ifdef CTCN_PERSIST_STATS
+  long long zs[6] = {0, 0, 0, 0, 0, 0}, zq[3] = {0, 0, 0}, z0 = clock64();
+#endif
+  for (int s = 0; s < T; ++s) {
+    const int t = d == 0 ? T - 1 - s : s;
+    const int sb = s & 1;
+#ifdef CTCN_PERSIST_STATS
+    const long long z_a = clock64();
+    long long z_b = z_a, z_c = z_a;
+#endif
+    if (wave < 4) {
+      // ---------------- item waves: gather, gate math, stage ------------------------------------------------------------------
+      uint32_t dropword = 0;
+      if (pa.drop_bwd) dropword = reinterpret_cast<const uint32_t *>(&dropw[wave][(s & 3) * 16 + (lane >> 4) * 4 + ((lane & 15) >> 2)])[lane & 3];
+      const float *rv = &resv[set][0][0] + tid;
+      const float sv0 = rv[0], sv1 = rv[256], sv2 = rv[512], sv3 = rv[768], dyv = rv[1024], e0 = rv[1280], e1 = rv[1536];
+      float rec = 0.0f;
+      if (s > 0) {
+        const int par = (s - 1) & 1;
+        const unsigned tb = ((((unsigned)(s - 1)) >> 1) & 1u) ^ 1u;
+        const unsigned base = tile_b[par] + poll_off;
+        for (int i = 0; i < pa.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+        // 16-B loads: lane group g = lane >> 4 reads, of block 4 i + g, the wave's 256-B quarter (16 lanes x 16 B: the four rows of one
+        // unit per lane) -- NTE loads per lane cover all nsl blocks.  (One dword per lane and block -- the item's own float of every
+        // block -- was built first: with L1 bypassed every LANE is an L2 request, 4x as many, and a poll round took ~4 000 cycles.)
+        u32x4 v[NPL];
+        const unsigned lbase = base - (unsigned)((lane & 15) * 16 + (lane >> 4) * 4) + (unsigned)(lane & 15) * 16u;
+        for (int spins = 0;; ++spins) {
+          // one round, then all tags at once: tb = 1 -> the AND of the LSBs must be 1, tb = 0 -> their OR must be 0.  A round that finds
+          // a block missing is simply repeated (a failed round must be cheap, the successful one minimal)
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, lbase + (unsigned)min(4 * i + q, nsl - 1) * 1024u, 0, 16);   // past nsl: the last block again
+          unsigned va = v[0].x & v[0].y & v[0].z & v[0].w, vo = v[0].x | v[0].y | v[0].z | v[0].w;
+#pragma unroll
+          for (int i = 1; i < NPL; ++i) { va &= v[i].x & v[i].y & v[i].z & v[i].w; vo |= v[i].x | v[i].y | v[i].z | v[i].w; }
+          const bool okl = ((tb ? va : ~vo) & 1u) != 0;
+#ifdef CTCN_PERSIST_STATS
+          zs[4] += 1;
+#endif
+          if (__builtin_amdgcn_ballot_w64(okl) == ~0ull) break;
+          if (spins > pa.spin_limit || ((spins & 63) == 63 && pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (pa.status) atomicCAS(pa.status, 0, 203);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        // lane (g, unit): partial sums over the blocks 4 i + g, for the four rows e of its unit (blocks in ascending order)
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const bool in = 4 * i + q < nsl;                  // (x + 0.0f == x: a select, not a branch)
+          ps[0] += in ? __uint_as_float(v[i].x & ~1u) : 0.0f; ps[1] += in ? __uint_as_float(v[i].y & ~1u) : 0.0f;
+          ps[2] += in ? __uint_as_float(v[i].z & ~1u) : 0.0f; ps[3] += in ? __uint_as_float(v[i].w & ~1u) : 0.0f;
+        }
+        // transpose-reduce over the four lane groups: the item of lane (g, unit) is row e = g.  v_permlane32_swap exchanges the upper
+        // half of its first operand with the lower half of the second: (p_e, p_{e+2}) -> {lower group's, upper group's} contribution to
+        // the row pair this half keeps; v_permlane16_swap does the same for odd / even 16-lane rows.  Fixed order: lower group first.
+        const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[0]), __float_as_uint(ps[2]), false, false);
+        const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps[1]), __float_as_uint(ps[3]), false, false);
+        const float h0 = __uint_as_float(s02[0]) + __uint_as_float(s02[1]), h1 = __uint_as_float(s13[0]) + __uint_as_float(s13[1]);
+        const auto sf = __builtin_amdgcn_permlane16_swap(__float_as_uint(h0), __float_as_uint(h1), false, false);
+        rec = __uint_as_float(sf[0]) + __uint_as_float(sf[1]);
+      }
+#ifdef CTCN_PERSIST_STATS
+      if (rec == 12345.678f) zs[5] += 1;
+      z_b = clock64();
+#endif
+      float out[4] = {0.f, 0.f, 0.f, 0.f};
+      float dan = 0.f;
+      if (item) {
+        float dyd = dyv;
+        if (pa.drop_bwd) dyd = ((dropword >> 8) * (1.0f / 16777216.0f) >= pa.drop_p) ? __fmul_rn(dyd, pa.drop_scale) : 0.0f;
+        float dh = dyd + rec;
+        const float e1u = (s + 1 < T && !is_tanh) ? e1 : 0.0f;
+        if constexpr (is_lstm) {
+          const float i_ = sv0, f_ = sv1, g_ = sv2, o_ = sv3;
+          const float tc = act_tanh(e0);
+          const float do_ = dh * tc;
+          const float dc = dh * o_ * (1.0f - tc * tc) + state;
+          out[0] = dc * g_ * i_ * (1.0f - i_);
+          out[1] = dc * e1u * f_ * (1.0f - f_);
+          out[2] = dc * i_ * (1.0f - g_ * g_);
+          out[3] = do_ * o_ * (1.0f - o_);
+          state = dc * f_;
+        } else if constexpr (is_gru) {
+          dh += state;
+          const float r_ = sv0, z_ = sv1, n_ = sv2, hn = e0, hp = e1u;
+          const float dn = dh * (1.0f - z_);
+          const float dz = dh * (hp - n_);
+          dan = dn * (1.0f - n_ * n_);
+          out[0] = dan * hn * r_ * (1.0f - r_);
+          out[1] = dz * z_ * (1.0f - z_);
+          out[2] = dan * r_;
+          state = dh * z_;
+        } else {
+          out[0] = dh * (1.0f - e0 * e0);
+        }
+        if (s + 1 < T) {
+          unsigned short *sp = reinterpret_cast<unsigned short *>(&stage[sb][0]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < G) {
+              const unsigned hi = f2bf(out[k]);
+              const int o = ((((k >> 1) * 4) + (k & 1) * 2 + (jl >> 3)) * 16 + bl) * 8 + (jl & 7);     // [blk][q][row][8]
+              sp[o] = (unsigned short)hi;
+              sp[1024 + o] = f2bf(out[k] - __uint_as_float(hi << 16));
+            }
+        }
+        // float32 copy for the reserve: LSTM 4 gates; GRU r, z, dan | dan * r (-> aux); tanh 1
+        outf[sb][0][tid] = out[0];
+        if constexpr (!is_tanh) { outf[sb][1][tid] = out[1]; outf[sb][2][tid] = is_gru ? dan : out[2]; outf[sb][3][tid] = is_gru ? out[2] : out[3]; }
+      }
+    } else {
+      // every reserve load but this wave's youngest `ndma` has landed (see header)
+      if (ndma == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (ndma == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#ifdef CTCN_PERSIST_STATS
+      z_b = clock64();
+#endif
+    }
+#ifdef CTCN_PERSIST_STATS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    z_c = clock64();
+#endif
+    lds_barrier();
+#ifdef CTCN_PERSIST_STATS
+    const long long z_d = clock64();
+    long long z_e = z_d;
+#endif
+    if (wave >= 4) {
+      // ---------------- exchange waves: multiply, scatter, reserve traffic ----------------------------------------------------
+      if (s + 1 < T) {
+        const int par = s & 1;
+        const unsigned short *sp = reinterpret_cast<const unsigned short *>(&stage[sb][0]);
+        bf16x8_t ah[2], al[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          ah[blk] = *reinterpret_cast<const bf16x8_t *>(sp + ((blk * 4 + q) * 16 + r) * 8);
+          al[blk] = *reinterpret_cast<const bf16x8_t *>(sp + 1024 + ((blk * 4 + q) * 16 + r) * 8);
+        }
+        const unsigned tbs = ((((unsigned)s) >> 1) & 1u) ^ 1u;
+#ifdef CTCN_PERSIST_STATS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const long long z_x0 = clock64();
+        zq[0] += z_x0 - z_d;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        // one chain after the other (a dependent chain issues at the same 16 cycles per MFMA as independent ones, tools/mb_mfma16.hip),
+        // each tile's block stored as soon as its chain ends: the CU's store path (20 x 1 KB per step, ~200 cycles per block when all
+        // exchange waves store together) then works WHILE the matrix pipes do, instead of after them
+#pragma unroll
+        for (int tw = 0; tw < NTE; ++tw) {
+          const int owner = ew + NEW * tw;
+          if (owner < nsl) {
+            f32x4 acc = zero;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[blk], whi[tw][blk], acc, 0, 0, 0);   // small terms first
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[blk], wlo[tw][blk], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[blk], whi[tw][blk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __uint_as_float((__float_as_uint(acc[e]) & ~1u) | tbs);
+            st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc, local);
+          }
+        }
+#ifdef CTCN_PERSIST_STATS
+        __builtin_amdgcn_sched_barrier(0);
+        { const long long z_x3 = clock64(); zq[2] += z_x3 - z_x0; }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+#ifdef CTCN_PERSIST_STATS
+      z_e = clock64();
+#endif
+      if (ew < (is_tanh ? 1 : 4)) {
+        const f32x4 vst = *reinterpret_cast<const f32x4 *>(&outf[sb][ew][lane * 4]);
+        float *dst = (is_gru && ew == 3) ? p.aux + (size_t)t * slab_h + xh : p.gates + (size_t)t * slab_g + xg + (size_t)ew * H;
+        if (xvalid) *reinterpret_cast<f32x4 *>(dst) = vst;
+      }
+      // LAST in program order: the vmcnt(ndma) wait before the next barrier then lets exactly these loads stay in flight, whatever the
+      // order in which the counter retires loads against stores
+      dma(s + 3, set);                             // set s % 3 was consumed before the barrier above
+    } else {
+      if (pa.drop_bwd && (s & 3) == 3) drop_block(s + 1);
+    }
+    set = set == 2 ? 0 : set + 1;
+#ifdef CTCN_PERSIST_STATS
+    { const long long z_f = clock64(); zs[0] += z_b - z_a; zs[1] += z_c - z_b; zs[2] += z_d - z_c; zs[3] += z_e - z_d; zs[5] += z_f - z_e; }
+#endif
+  }
+#ifdef CTCN_PERSIST_STATS
+  if (pa.stats && slice == 3 && d == 0 && bt == 0 && (tid == 0 || tid == 256)) {
+    long long *o = pa.stats + (tid == 0 ? 0 : 8);
+    for (int i = 0; i < 6; ++i) o[i] = zs[i];
+    o[6] = clock64() - z0;
+    if (tid == 256) { pa.stats[16] = zq[0]; pa.stats[17] = zq[1]; pa.stats[18] = zq[2]; }
+  }
+#endif
+  const bool bad = pa.status && __hip_atomic_load(pa.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (bad && item)           // poison d(pre-activation) of every frame: dx and both weight gradients of the layer become NaN
+    for (int tt = 0; tt < T; ++tt) p.gates[(size_t)tt * slab_g + ((size_t)b * D + d) * K + j] = __uint_as_float(0x7fc00000u);
+}
+
+template <int NEW, int CELL>
+bool launch_bwd_scatter2_c(int nte, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  constexpr int THR = 256 + 64 * NEW;
+  switch (nte) {
+    case 1: return launch_resident(rnn_bwd_scatter2<NEW, 1, CELL>, grid, THR, 0, st, a, wpx);
+    case 2: return launch_resident(rnn_bwd_scatter2<NEW, 2, CELL>, grid, THR, 0, st, a, wpx);
+    case 3: return launch_resident(rnn_bwd_scatter2<NEW, 3, CELL>, grid, THR, 0, st, a, wpx);
+    case 4: return launch_resident(rnn_bwd_scatter2<NEW, 4, CELL>, grid, THR, 0, st, a, wpx);
+    case 5: return launch_resident(rnn_bwd_scatter2<NEW, 5, CELL>, grid, THR, 0, st, a, wpx);
+    default: return false;
+  }
+}
+// nsl slices -> exchange waves (8: two per SIMD, 768 threads, 168 VGPRs per wave) and tiles per exchange wave
+bool launch_bwd_scatter2(int nsl, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  const int nte = (nsl + 7) / 8;
+  switch (a.a.cell) {
+    case CTCN_CELL_LSTM: return launch_bwd_scatter2_c<8, CTCN_CELL_LSTM>(nte, grid, st, a, wpx);
+    case CTCN_CELL_GRU: return launch_bwd_scatter2_c<8, CTCN_CELL_GRU>(nte, grid, st, a, wpx);
+    case CTCN_CELL_TANH: return launch_bwd_scatter2_c<8, CTCN_CELL_TANH>(nte, grid, st, a, wpx);
+    default: return false;
+  }
+}
+
 template <bool TAGGED, int CELL>
 bool launch_bwd_scatter_c(int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
   switch (ntw) {      // precision 1 only: the host never picks the scatter formulation for the f32 matmul
     case 1: return launch_resident(rnn_bwd_scatter<1, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
     case 2: return launch_resident(rnn_bwd_scatter<2, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
+    case 3: return launch_resident(rnn_bwd_scatter<3, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
     default: return false;
   }
 }
@@ -2424,13 +2767,18 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
     // scatter formulation (default): partial dh tiles travel, 1 KB per (owner, source) pair; gather formulation: the da tile
     // measured: scatter wins at H = 320 (2.46 vs 2.68 us per step), ties at H = 128, loses at H = 512 (nsl^2 KB of partial tiles
     // per group and step) and at precision 0 (f32 MFMA: 32 cycles x 16 per tile on 4 waves per SIMD)
-    const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= 24;
-    const int ntw = nsl <= 12 ? 1 : (nsl <= 24 ? 2 : 4);      // output tiles per scattering wave (12 of them)
+    // item-wave gather (rnn_bwd_scatter2, option "bwd_item_gather"): tagged hand-off only, up to 36 slices (H <= 576), 16-B aligned reserves
+    // "bwd_item_gather": 0 never, 1 (default) where it measured faster -- more than 20 slices, i.e. H > 320 (tools/mb_bwd2.hip: H = 384 1.58 vs
+    // 1.63 us per step, H = 512 2.44 vs 3.38 for the gather formulation, the only other kernel there; H = 320 1.90 vs 1.88, H = 128 1.25 vs 1.19) --, 2 always
+    const int ig = ctcn_get_option("bwd_item_gather");
+    const bool gather2 = (ig == 2 || (ig == 1 && nsl > 20)) && nsl <= 40 && ctcn_opt_handoff_tags() && H % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)y % 16 == 0;
+    const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= (gather2 ? 40 : 24);
+    const int ntw = nsl <= 12 ? 1 : (nsl <= 24 ? 2 : 3);      // output tiles per scattering wave (12 of them)
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
                                     : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
     const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * (scatter ? nsl : 1) * sizeof(unsigned), 256) + 256;   // + role tickets
     const size_t lds = 0;
-    for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && kq <= 8 && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
+    for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && (kq <= 8 || scatter) && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
       const int nx = mode ? ctcn_device_xcds() : 1;
       if (mode && nx <= 1) continue;
       const int wpx = ceil_div(groups, nx) * nsl;
@@ -2459,8 +2807,15 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
           a.dy = bd.tmp; pa.a.dy = bd.tmp; dy_dropped = true;
         }
         record_prelaunch(st);
-        done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
-        if (done) g_last_kernel[1] = "rnn_bwd_scatter";
+        if (gather2) {
+          pa.poll_delay = ctcn_get_option("bwd_poll_delay");
+          if (pa.poll_delay < 0) pa.poll_delay = nsl <= 24 ? 16 : 24;        // auto: the exchange phase grows with the tiles per wave (cfg4: 2.69 -> 2.55 us per step)
+          done = launch_bwd_scatter2(nsl, pgrid, st, pa, wpx);
+          if (done) g_last_kernel[1] = "rnn_bwd_scatter2";
+        } else {
+          done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
+          if (done) g_last_kernel[1] = "rnn_bwd_scatter";
+        }
       } else {
         if (!dy_dropped) {
           if (int rc = ctcn_dropout(dy, bd.tmp, (size_t)T * B * dirs * H, bd.p, bd.seed, bd.off, stream)) return rc;

@@ -73,6 +73,10 @@ int ctcn_device_xcds(void);
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
+ * "bwd_item_gather" = 1 (default): the scatter formulation of the backward recurrence runs as rnn_bwd_scatter2 (item waves gather their own
+ * 256-B quarters of the partial tiles, one barrier per step, all reserve traffic on the exchange waves through LDS DMA, 64-bit reserve
+ * addresses, up to 40 slices = H <= 640) where it measured faster: more than 20 slices (H > 320); 0: never; 2: wherever it applies.
+ * "bwd_poll_delay" = -1 (auto): 64-cycle sleeps before an item wave's first poll of a step in rnn_bwd_scatter2.
  * "rnn_recurrence_only" = 0 (default); 1 is a MEASUREMENT aid: ctcn_rnn_fwd / ctcn_rnn_bwd skip their input-projection
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */
 int ctcn_set_option(const char *name, int value);

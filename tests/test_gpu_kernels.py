@@ -1221,10 +1221,21 @@ def _oracle_full_size(name):
         in_len = torch.from_numpy(R.frames_from_fraction(b["frac"], lp.size(0)))
         loss = tnn.CTCLoss(reduction="sum")(lp, torch.from_numpy(b["targets"]), in_len, torch.from_numpy(b["tgt_len"])) / c["B"]
         loss.backward()
+        out = dict(lp=lp.detach(), loss=float(loss), grads={k: p.grad.detach().clone() for k, p in ref.named_parameters()},
+                   argmax=R.argmax_first(lp.detach().numpy()))
+        # the same torch calls in float64: the yardstick for what "f32-exact" can mean at this depth -- the float32 oracle's OWN distance
+        # from it is the rounding floor of an 800-1 200-step recurrence (summation order, 1-ulp transcendentals), not an error of either side
+        ref64 = torch_cpu.TorchCpuCTCModel(add_cnn=c["cnn"], cnn_param=cp, rnn_param=rp, num_class=c["V"], drop_out=0.0).double()
+        ref64.load_state_dict({k: torch.from_numpy(np.asarray(v)).double() if np.asarray(v).dtype.kind == "f" else torch.from_numpy(np.asarray(v))
+                               for k, v in vals.items()})
+        ref64.train()
+        lp64 = ref64(torch.from_numpy(b["x"]).double())
+        loss64 = tnn.CTCLoss(reduction="sum")(lp64, torch.from_numpy(b["targets"]), in_len, torch.from_numpy(b["tgt_len"])) / c["B"]
+        loss64.backward()
+        out["lp64"], out["loss64"] = lp64.detach(), float(loss64)
+        out["grads64"] = {k: p.grad.detach().clone() for k, p in ref64.named_parameters()}
     finally:
         torch.set_num_threads(before)
-    out = dict(lp=lp.detach(), loss=float(loss), grads={k: p.grad.detach().clone() for k, p in ref.named_parameters()},
-               argmax=R.argmax_first(lp.detach().numpy()))
     _ORACLE_RUNS[name] = out
     return out
 
@@ -1248,17 +1259,30 @@ def test_full_size_elementwise_vs_torch_cpu_oracle(dev, name, prec):
     torch.cuda.synchronize()
     ops.check_health()
     # no silent fall-back to one launch per timestep at these shapes (H = 384 of ref_yaml is the largest hidden size on the scatter path)
-    assert ops.rnn_last_kernels()[0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and ops.rnn_last_kernels()[1] in ("rnn_bwd_scatter", "rnn_bwd_persist"), ops.rnn_last_kernels()
-    tol_act, tol_grad, tol_loss = gates(prec, 5e-5, 2e-4, 2e-5)
+    assert ops.rnn_last_kernels()[0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and ops.rnn_last_kernels()[1] in ("rnn_bwd_scatter2", "rnn_bwd_scatter", "rnn_bwd_persist"), ops.rnn_last_kernels()
+    tol_act, tol_grad, tol_loss = gates(prec, 2e-5, 4e-4, 1e-5)
     e_lp = maxabs(lp, want["lp"])
     e_loss = abs(float(loss) - want["loss"]) / abs(want["loss"])
     errs = {k: rel_l2(p.grad, want["grads"][k]) for k, p in m.named_parameters() if not k.endswith("conv.bias")}
     worst = max((v, k) for k, v in errs.items())
-    print("\n[%s prec %d] max|dlp| %.3e  loss rel %.3e  worst grad rel-L2 %.3e (%s)  median %.3e" % (
-        name, prec, e_lp, e_loss, worst[0], worst[1], float(np.median(list(errs.values())))))
+    # against the float64 yardstick: the HIP path's distance and the float32 oracle's own distance, per parameter
+    ours64 = {k: rel_l2(p.grad.double(), want["grads64"][k]) for k, p in m.named_parameters() if not k.endswith("conv.bias")}
+    orac64 = {k: rel_l2(want["grads"][k].double(), want["grads64"][k]) for k in ours64}
+    ratio = max((ours64[k] / max(orac64[k], 1e-7), k) for k in ours64)
+    e_lp64, o_lp64 = maxabs(lp.double(), want["lp64"]), maxabs(want["lp"].double(), want["lp64"])
+    print("\n[%s prec %d] vs f32 oracle: max|dlp| %.3e  loss rel %.3e  grad rel-L2 worst %.3e (%s) median %.3e | vs f64: max|dlp| ours %.3e oracle-f32 %.3e; "
+          "grad rel-L2 median ours %.3e oracle-f32 %.3e, worst ratio ours/oracle %.2f (%s)" % (
+              name, prec, e_lp, e_loss, worst[0], worst[1], float(np.median(list(errs.values()))), e_lp64, o_lp64,
+              float(np.median(list(ours64.values()))), float(np.median(list(orac64.values()))), ratio[0], ratio[1]))
     assert e_lp < tol_act, e_lp
     assert e_loss < tol_loss, e_loss
     assert worst[0] < tol_grad, worst
+    if prec == 0:
+        # f32-strict, as the float64 run defines it: no parameter gradient may be further from the float64 result than 2.5 x the float32
+        # ORACLE's own distance (+ 2e-5): the HIP path is an f32 implementation of the same function, not a less accurate one
+        bad = [(k, ours64[k], orac64[k]) for k in ours64 if ours64[k] > 2.5 * orac64[k] + 2e-5]
+        assert not bad, bad[:4]
+        assert e_lp64 < 2.5 * o_lp64 + 5e-6, (e_lp64, o_lp64)
     for k, p in m.named_parameters():
         if k.endswith("conv.bias"):           # identically zero in exact arithmetic (bias -> BatchNorm): rounding noise on both sides
             assert float(p.grad.abs().max()) < 5e-3, k
@@ -1554,7 +1578,7 @@ def test_persistent_recurrences_survive_foreign_resident_kernels(dev, workload, 
     assert hit["squats"] >= steps // 2
     assert np.isfinite(hit["losses"]).all()
     assert hit["losses"] == base["losses"], [(i, a, b) for i, (a, b) in enumerate(zip(hit["losses"], base["losses"])) if a != b][:5]
-    assert hit["kernels"][0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and hit["kernels"][1] in ("rnn_bwd_scatter", "rnn_bwd_persist"), hit["kernels"]
+    assert hit["kernels"][0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and hit["kernels"][1] in ("rnn_bwd_scatter2", "rnn_bwd_scatter", "rnn_bwd_persist"), hit["kernels"]
 
 
 def _spawn_ranks(args, world, port, extra_env=None, timeout=600):
