@@ -63,8 +63,8 @@ _SIGS = {
     "ctcn_log_softmax_fwd": (I, [P, P, P, I, I, P]),
     "ctcn_log_softmax_bwd": (I, [P, P, P, I, I, P]),
     "ctcn_argmax": (I, [P, P, I, I, P]),
-    "ctcn_set_prelaunch_event": (I, [P]),
-    "ctcn_set_fwd_overlap": (I, [P, P, P, Z, ctypes.c_uint]),
+    "ctcn_rnn_fwd_ex": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, I, P, Z, P, P]),
+    "ctcn_rnn_bwd_ex": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P, P]),
     "ctcn_ctc_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ctcn_ctc_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "ctcn_ctc_fwd_both": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
@@ -83,6 +83,13 @@ _SIGS = {
     "ctcn_beam_ws_bytes": (Z, [I, I, I, I]),
     "ctcn_beam_decode": (I, [P, I, P, P, D, I, I, P, P, P, P, I, I, I, P, Z, P]),
 }
+
+
+class RnnCall(ctypes.Structure):
+    """ctcn_rnn_call of include/ctcn.h: the per-call extras of ctcn_rnn_fwd_ex / ctcn_rnn_bwd_ex (the library keeps no state between calls)."""
+    _fields_ = [("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint64), ("drop_offset", ctypes.c_uint64), ("y_drop", ctypes.c_void_p),
+                ("dy_tmp", ctypes.c_void_p), ("side_stream", ctypes.c_void_p), ("side_event", ctypes.c_void_p), ("side_ws", ctypes.c_void_p),
+                ("side_ws_bytes", ctypes.c_size_t), ("xcd_allow", ctypes.c_uint), ("prelaunch_event", ctypes.c_void_p), ("status", ctypes.c_void_p)]
 
 
 def sources():

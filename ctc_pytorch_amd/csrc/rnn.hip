@@ -2385,25 +2385,16 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
 // 0.13 ms per launch.  Not kept.)
 // Dropout of the layer output fused into the forward recurrence (ctcn_rnn_fwd_dropout): the request is consumed by the tagged-gather
 // launch; any other path leaves it pending and the dropout kernel runs behind the recurrence instead (the same values either way).
-struct FwdDropout { float *ydrop; float p; unsigned long long seed, off; bool pending; };
-static thread_local FwdDropout g_fwd_dropout = {nullptr, 0.0f, 0, 0, false};
-
-// One-shot request of the host for the NEXT ctcn_rnn_fwd on this thread: pipeline the input projection with the recurrence.  Only the
-// first pair of time chunks (the first frames of the forward direction, the last of the reverse one) is projected before the
-// recurrence is launched; the other pairs are projected on `side_stream`, restricted to the XCDs in `xcd_allow` (the ones the
-// persistent kernel leaves idle), behind `event` (recorded by the library right before the launch), each pair followed by a counter
-// update that the recurrence checks when it enters a new chunk.  `side_ws`: workspace of the side-stream GEMMs.
-struct FwdOverlap { void *stream, *event, *ws; size_t ws_bytes; unsigned xcd_allow; };
-static thread_local FwdOverlap g_fwd_overlap = {nullptr, nullptr, nullptr, 0, 0};
-extern "C" int ctcn_set_fwd_overlap(void *side_stream, void *event, void *side_ws, size_t side_ws_bytes, unsigned xcd_allow) {
-  g_fwd_overlap = FwdOverlap{side_stream, event, side_ws, side_ws_bytes, xcd_allow};
-  return CTCN_OK;
-}
+// (round 3: the ABI keeps no state between calls any more.  What used to be armed by ctcn_set_fwd_overlap / ctcn_set_prelaunch_event and
+// handed over in thread-locals by the _dropout entry points travels in the caller's `ctcn_rnn_call` (include/ctcn.h); a NULL pointer or a
+// zeroed struct is the plain call.)
+static const ctcn_rnn_call k_plain_call = {};
 __global__ void set_counter_kernel(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
-extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
-                            const float *w_hh0, const float *w_ih1, const float *w_hh1, float *y, float *gates,
-                            float *aux, int precision, void *ws, size_t ws_bytes, void *stream) {
+// the recurrence of ctcn_rnn_fwd_ex; `drop_pending`: in: the call asks for the dropped output, out: false once a recurrent kernel has stored it
+static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
+                        const float *w_hh0, const float *w_ih1, const float *w_hh1, float *y, float *gates,
+                        float *aux, int precision, void *ws, size_t ws_bytes, void *stream, const ctcn_rnn_call &call, bool &drop_pending) {
   CTCN_REQUIRE(cell >= 0 && cell <= 2, "ctcn_rnn_fwd: unknown cell %d", cell);
   CTCN_REQUIRE(T > 0 && B > 0 && I > 0 && H > 0 && (dirs == 1 || dirs == 2), "ctcn_rnn_fwd: bad dims");
   if (H % 4 != 0) { ctcn_set_error("ctcn_rnn_fwd: hidden size %d must be a multiple of 4", H); return CTCN_EUNSUPPORTED; }
@@ -2418,8 +2409,8 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   // both directions project the same x and the gate reserve holds their pre-activations side by side (row = dirs*GH floats):
   // with the two W_ih stacked in the workspace one N = 2*GH product does the work of two (one pass over x, one launch)
   bool proj_done = ctcn_opt_recurrence_only();
-  const FwdOverlap ov = g_fwd_overlap;
-  g_fwd_overlap = FwdOverlap{nullptr, nullptr, nullptr, 0, 0};
+  struct { void *stream, *event, *ws; size_t ws_bytes; unsigned xcd_allow; } const ov = {call.side_stream, call.side_event, call.side_ws, call.side_ws_bytes, call.xcd_allow};
+  int *const status_word = call.status ? call.status : ctcn_status_word();
   // pipelined projection: needs the tagged-gather kernel (the only one that checks the chunk counter), both W_ih stacked, idle XCDs
   const int nxd_p = ctcn_opt_handoff() ? ctcn_device_xcds() : 1;
   // time chunks: 8, or the first even count whose chunk GEMM ((T / n) * B rows x 2*GH columns) the side stream's 256-row tile queue
@@ -2525,7 +2516,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
         char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
         pa.hx = (float *)tail;
         pa.flags = (unsigned *)(tail + hx_bytes);
-        pa.status = ctcn_status_word();
+        pa.status = status_word;
         pa.spin_limit = SPIN_LIMIT;
         pa.local = 1; pa.nx = nxd; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
         pa.poll_depth = 1; pa.tagmode = 1; pa.poll_delay = ctcn_get_option("tag_poll_delay");
@@ -2534,17 +2525,17 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
         pa.stats = nullptr;
 #endif
         pa.chunk_T = piped ? chunk_T : 0; pa.nchunk = NCHUNK; pa.chunk_ready = pa.flags;       // (first word of the flag area; tickets sit 256 B further)
-        const bool fuse_drop = g_fwd_dropout.pending && ctcn_get_option("rnn_fused_dropout") != 0;
+        const bool fuse_drop = drop_pending && ctcn_get_option("rnn_fused_dropout") != 0;
         if (fuse_drop) {
-          pa.ydrop = g_fwd_dropout.ydrop; pa.drop_p = g_fwd_dropout.p; pa.drop_scale = 1.0f / (1.0f - g_fwd_dropout.p);
-          pa.drop_seed = g_fwd_dropout.seed; pa.drop_off = g_fwd_dropout.off;
+          pa.ydrop = call.y_drop; pa.drop_p = call.drop_p; pa.drop_scale = 1.0f / (1.0f - call.drop_p);
+          pa.drop_seed = call.drop_seed; pa.drop_off = call.drop_offset;
         }
         CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | chunk counter | role tickets
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();
           g_last_kernel[0] = "rnn_fwd_tagged";
-          if (fuse_drop) g_fwd_dropout.pending = false;
+          if (fuse_drop) drop_pending = false;
           if (piped) {          // the remaining chunk pairs, next to the recurrence on the XCDs it does not use
             hipStream_t sd = (hipStream_t)ov.stream;
             CTCN_HIP(hipStreamWaitEvent(sd, (hipEvent_t)ov.event, 0));
@@ -2587,7 +2578,7 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
       pa.hx = (float *)tail;
       pa.flags = (unsigned *)(tail + hx_bytes);
-      pa.status = ctcn_status_word();
+      pa.status = status_word;
       pa.spin_limit = SPIN_LIMIT;
       pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.nbig = nbig; pa.hsu_small = hsu_small;
@@ -2619,22 +2610,30 @@ extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, cons
   return CTCN_OK;
 }
 
-// ... and its gradient (ctcn_rnn_bwd_dropout): dy of the next ctcn_rnn_bwd is the gradient of the DROPPED output; rnn_bwd_scatter applies the
-// keep mask as it consumes dy, every other path first runs the dropout kernel into `tmp` and reads that
-struct BwdDropout { float p; unsigned long long seed, off; float *tmp; bool pending; };
-static thread_local BwdDropout g_bwd_dropout = {0.0f, 0, 0, nullptr, false};
-
 extern "C" int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+extern "C" int ctcn_rnn_fwd_ex(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                               const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, int precision, void *ws, size_t ws_bytes,
+                               void *stream, const ctcn_rnn_call *call) {
+  const ctcn_rnn_call &c = call ? *call : k_plain_call;
+  CTCN_REQUIRE(!c.y_drop || (c.drop_p >= 0.0f && c.drop_p < 1.0f), "ctcn_rnn_fwd_ex: dropout p=%f outside [0,1)", (double)c.drop_p);
+  bool drop_pending = c.y_drop != nullptr;
+  const int rc = rnn_fwd_impl(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, precision, ws, ws_bytes, stream, c, drop_pending);
+  if (rc) return rc;
+  // the dropped output was not stored by the recurrence (another kernel than the tagged gather ran): the dropout pass, the same values
+  return drop_pending ? ctcn_dropout(y, c.y_drop, (size_t)T * B * dirs * H, c.drop_p, c.drop_seed, c.drop_offset, stream) : CTCN_OK;
+}
+extern "C" int ctcn_rnn_fwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
+                            const float *w_hh0, const float *w_ih1, const float *w_hh1, float *y, float *gates,
+                            float *aux, int precision, void *ws, size_t ws_bytes, void *stream) {
+  return ctcn_rnn_fwd_ex(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, precision, ws, ws_bytes, stream, nullptr);
+}
 extern "C" int ctcn_rnn_fwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
                                     const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, float *y_drop, float p, uint64_t seed,
                                     uint64_t offset, int precision, void *ws, size_t ws_bytes, void *stream) {
   CTCN_REQUIRE(y_drop && p >= 0.0f && p < 1.0f, "ctcn_rnn_fwd_dropout: y_drop NULL or p=%f outside [0,1)", (double)p);
-  g_fwd_dropout = FwdDropout{y_drop, p, (unsigned long long)seed, (unsigned long long)offset, true};
-  const int rc = ctcn_rnn_fwd(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, precision, ws, ws_bytes, stream);
-  const bool pending = g_fwd_dropout.pending;
-  g_fwd_dropout.pending = false;
-  if (rc) return rc;
-  return pending ? ctcn_dropout(y, y_drop, (size_t)T * B * dirs * H, p, seed, offset, stream) : CTCN_OK;
+  ctcn_rnn_call c = {};
+  c.y_drop = y_drop; c.drop_p = p; c.drop_seed = seed; c.drop_offset = offset;
+  return ctcn_rnn_fwd_ex(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, precision, ws, ws_bytes, stream, &c);
 }
 
 // The time-parallel GEMMs of the backward pass over the d(pre-activation) slab `gates` (and `aux` for the GRU n-gate):
@@ -2712,23 +2711,24 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   return CTCN_OK;
 }
 
-// One-shot event (hipEvent_t) that ctcn_rnn_bwd records on its stream right before it launches the recurrence, i.e. behind
-// its own preparatory memsets / transposes: work that the host wants to run NEXT TO the recurrence on another stream waits
-// for this event -- waiting for "everything before ctcn_rnn_bwd" instead lets it start early and delay those small kernels
-// (measured: a 5 us memset took 116-122 us when the side stream's queue kernels were dispatched first).
-static thread_local void *g_prelaunch_event = nullptr;
-extern "C" int ctcn_set_prelaunch_event(void *event) { g_prelaunch_event = event; return CTCN_OK; }
-static void record_prelaunch(hipStream_t st) {
-  if (!g_prelaunch_event) return;
-  (void)hipEventRecord((hipEvent_t)g_prelaunch_event, st);
-  g_prelaunch_event = nullptr;
-}
-
-extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
-                            const float *w_hh0, const float *w_ih1, const float *w_hh1, const float *y,
-                            float *gates, float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0,
-                            float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
-                            size_t ws_bytes, void *stream) {
+// `call.prelaunch_event` (hipEvent_t): recorded on the stream right before the recurrence is launched, i.e. behind this call's own preparatory
+// memsets / transposes: work that the host wants to run NEXT TO the recurrence on another stream waits for this event -- waiting for
+// "everything before ctcn_rnn_bwd" instead lets it start early and delay those small kernels (measured: a 5 us memset took 116-122 us when
+// the side stream's queue kernels were dispatched first).
+extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
+                               const float *w_hh0, const float *w_ih1, const float *w_hh1, const float *y,
+                               float *gates, float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0,
+                               float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
+                               size_t ws_bytes, void *stream, const ctcn_rnn_call *call_p) {
+  const ctcn_rnn_call &call = call_p ? *call_p : k_plain_call;
+  CTCN_REQUIRE(!call.dy_tmp || (call.drop_p >= 0.0f && call.drop_p < 1.0f), "ctcn_rnn_bwd_ex: dropout p=%f outside [0,1)", (double)call.drop_p);
+  int *const status_word = call.status ? call.status : ctcn_status_word();
+  void *prelaunch_event = call.prelaunch_event;
+  auto record_prelaunch = [&](hipStream_t s_) {
+    if (!prelaunch_event) return;
+    (void)hipEventRecord((hipEvent_t)prelaunch_event, s_);
+    prelaunch_event = nullptr;
+  };
   CTCN_REQUIRE(cell >= 0 && cell <= 2, "ctcn_rnn_bwd: unknown cell %d", cell);
   CTCN_REQUIRE(T > 0 && B > 0 && I > 0 && H > 0 && (dirs == 1 || dirs == 2), "ctcn_rnn_bwd: bad dims");
   if (H % 4 != 0) { ctcn_set_error("ctcn_rnn_bwd: hidden size %d must be a multiple of 4", H); return CTCN_EUNSUPPORTED; }
@@ -2741,9 +2741,8 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
   hipStream_t st = (hipStream_t)stream;
   const int G = gates_of(cell);
   const int GH = G * H;
-  const BwdDropout bd = g_bwd_dropout;
-  g_bwd_dropout.pending = false;
-  bool dy_dropped = !bd.pending;      // true once dy needs no mask any more: no request, or the dropout kernel has produced bd.tmp
+  struct { float p; unsigned long long seed, off; float *tmp; } const bd = {call.drop_p, (unsigned long long)call.drop_seed, (unsigned long long)call.drop_offset, call.dy_tmp};
+  bool dy_dropped = call.dy_tmp == nullptr;      // true once dy needs no mask any more: no request, or the dropout kernel has produced bd.tmp
   const float *w_hh[2] = {w_hh0, w_hh1};
   float *whhT = (float *)scratch;
   float *state = (float *)((char *)scratch + align_up((size_t)dirs * GH * H * sizeof(float), 256));
@@ -2787,7 +2786,7 @@ extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, cons
       char *tail = (char *)ws + ((ws_bytes - hx_bytes - fl_bytes) & ~(size_t)255);
       pa.hx = (float *)tail;
       pa.flags = (unsigned *)(tail + hx_bytes);
-      pa.status = ctcn_status_word();
+      pa.status = status_word;
       pa.spin_limit = SPIN_LIMIT;
       pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
@@ -2869,14 +2868,22 @@ extern "C" int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int di
                        precision, true, xcd_allow, ws, ws_bytes, stream);
 }
 
+extern "C" int ctcn_rnn_bwd(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0,
+                            const float *w_hh0, const float *w_ih1, const float *w_hh1, const float *y,
+                            float *gates, float *aux, const float *dy, float *dx, float *dw_ih0, float *dw_hh0,
+                            float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
+                            size_t ws_bytes, void *stream) {
+  return ctcn_rnn_bwd_ex(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, dy, dx, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w, precision,
+                         scratch, ws, ws_bytes, stream, nullptr);
+}
+
 extern "C" int ctcn_rnn_bwd_dropout(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
                                     const float *w_ih1, const float *w_hh1, const float *y, float *gates, float *aux, const float *dy, float *dx,
                                     float *dw_ih0, float *dw_hh0, float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
                                     size_t ws_bytes, void *stream, float p, uint64_t seed, uint64_t offset, float *dy_tmp) {
   CTCN_REQUIRE(dy_tmp && p >= 0.0f && p < 1.0f, "ctcn_rnn_bwd_dropout: dy_tmp NULL or p=%f outside [0,1)", (double)p);
-  g_bwd_dropout = BwdDropout{p, (unsigned long long)seed, (unsigned long long)offset, dy_tmp, true};
-  const int rc = ctcn_rnn_bwd(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, dy, dx, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w,
-                              precision, scratch, ws, ws_bytes, stream);
-  g_bwd_dropout.pending = false;
-  return rc;
+  ctcn_rnn_call c = {};
+  c.dy_tmp = dy_tmp; c.drop_p = p; c.drop_seed = seed; c.drop_offset = offset;
+  return ctcn_rnn_bwd_ex(cell, T, B, I, H, dirs, x, w_ih0, w_hh0, w_ih1, w_hh1, y, gates, aux, dy, dx, dw_ih0, dw_hh0, dw_ih1, dw_hh1, beta_w, precision,
+                         scratch, ws, ws_bytes, stream, &c);
 }

@@ -135,7 +135,7 @@ def set_side_stream(flag, min_items=None):
 
 
 def set_fwd_overlap(flag):
-    """Pipeline the input projection of a recurrent layer with its persistent forward recurrence (ctcn_set_fwd_overlap); default on
+    """Pipeline the input projection of a recurrent layer with its persistent forward recurrence (ctcn_rnn_call.side_stream of ctcn_rnn_fwd_ex); default on
     (environment: CTCN_FWD_OVERLAP=0 turns it off)."""
     _side["fwd_overlap"] = bool(flag)
 
@@ -150,7 +150,7 @@ def _side_stream(dev):
 
 
 def _prelaunch_event(dev):
-    """Per-device event that ctcn_rnn_bwd records right before it launches its recurrence (ctcn_set_prelaunch_event)."""
+    """Per-device event that ctcn_rnn_bwd records right before it launches its recurrence (ctcn_rnn_call.prelaunch_event of ctcn_rnn_bwd_ex)."""
     key = (dev.type, dev.index)
     ev = _side["events"].get(key)
     if ev is None:
@@ -326,30 +326,24 @@ class _RNNLayer(torch.autograd.Function):
         nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
         allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
         piped = _side["enabled"] and _side["fwd_overlap"] and allow != 0 and dirs == 2 and T * B * H >= _side["min_items"]
+        call = _lib.RnnCall()                      # everything the call needs beyond its tensors (the library keeps no state between calls)
+        call.status = _lib.status_word(dev).data_ptr()
         if piped:
             st = _side_stream(dev)
             ev = _prelaunch_event(dev)
             w2, wp2, wn2 = _ws(x, tag="side")
-            _lib.check(L.ctcn_set_fwd_overlap(ctypes.c_void_p(st.cuda_stream), ctypes.c_void_p(ev.cuda_event), wp2, wn2, allow), "set_fwd_overlap")
+            call.side_stream, call.side_event, call.side_ws, call.side_ws_bytes, call.xcd_allow = st.cuda_stream, ev.cuda_event, w2.data_ptr(), wn2, allow
         # the layer's dropout (BatchRNN: rnn -> nn.Dropout) in the same call: the recurrence stores the dropped output itself where its
-        # tagged-gather kernel applies (ctcn_rnn_fwd_dropout); the random stream advances exactly as for a separate dropout of y
+        # tagged-gather kernel applies; the random stream advances exactly as for a separate dropout of y
         ctx.drop = None
         y_drop = None
         if training and drop_p > 0.0:
             y_drop = torch.empty_like(y)
             seed, off = _next_dropout_stream(y.numel())
             ctx.drop = (float(drop_p), seed, off)
-        try:
-            if y_drop is None:
-                _lib.check(L.ctcn_rnn_fwd(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
-                                          _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr()), "rnn_fwd")
-            else:
-                _lib.check(L.ctcn_rnn_fwd_dropout(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
-                                                  _ptr(y), _ptr(gates), _ptr(aux), _ptr(y_drop), float(drop_p), seed, off, get_precision(), wp, wn,
-                                                  _lib.stream_ptr()), "rnn_fwd_dropout")
-        finally:
-            if piped:
-                L.ctcn_set_fwd_overlap(None, None, None, 0, 0)
+            call.y_drop, call.drop_p, call.drop_seed, call.drop_offset = y_drop.data_ptr(), float(drop_p), seed, off
+        _lib.check(L.ctcn_rnn_fwd_ex(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
+                                     _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr(), ctypes.byref(call)), "rnn_fwd_ex")
         if piped:
             # by the time the recurrence ends the side stream's GEMMs have long finished (the kernel waited for their counter); the join
             # only tells the allocator and the following kernels so
@@ -421,24 +415,24 @@ class _RNNLayer(torch.autograd.Function):
         # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right
         # before that launch, behind its own small preparatory kernels, and the side stream waits for it
         above, ev = _side["deferred"].pop(key, None), None
+        call = _lib.RnnCall()
+        call.status = _lib.status_word(dev).data_ptr()
         if above is not None:
             ev = _prelaunch_event(dev)
-            _lib.check(L.ctcn_set_prelaunch_event(ctypes.c_void_p(ev.cuda_event)), "set_prelaunch_event")
+            call.prelaunch_event = ev.cuda_event
+        gd = None
+        if ctx.drop is not None:    # gy is the gradient of the dropped output: the same mask, applied by the recurrence as it consumes gy (or by
+            p_, seed_, off_ = ctx.drop                      # a dropout pass into gd where that kernel does not apply)
+            gd = torch.empty_like(gy)
+            call.dy_tmp, call.drop_p, call.drop_seed, call.drop_offset = gd.data_ptr(), p_, seed_, off_
         try:
-            args = (cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
-                    _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
-                    null if (side or split_dirs) else _ptr(d_ih0), null if (side or split_dirs) else _ptr(d_hh0),
-                    null if (side or split_dirs) else _ptr(d_ih1), null if (side or split_dirs) else _ptr(d_hh1),
-                    1.0 if into_flat else 0.0, get_precision(), _ptr(scratch), wp, wn, _lib.stream_ptr())
-            if ctx.drop is None:
-                _lib.check(L.ctcn_rnn_bwd(*args), "rnn_bwd")
-            else:       # gy is the gradient of the dropped output: the same mask, applied by the recurrence as it consumes gy (or by a
-                p_, seed_, off_ = ctx.drop                  # dropout pass into gd where that kernel does not apply)
-                gd = torch.empty_like(gy)
-                _lib.check(L.ctcn_rnn_bwd_dropout(*args, p_, seed_, off_, _ptr(gd)), "rnn_bwd_dropout")
+            _lib.check(L.ctcn_rnn_bwd_ex(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
+                                         _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
+                                         null if (side or split_dirs) else _ptr(d_ih0), null if (side or split_dirs) else _ptr(d_hh0),
+                                         null if (side or split_dirs) else _ptr(d_ih1), null if (side or split_dirs) else _ptr(d_hh1),
+                                         1.0 if into_flat else 0.0, get_precision(), _ptr(scratch), wp, wn, _lib.stream_ptr(), ctypes.byref(call)), "rnn_bwd_ex")
         except Exception:
-            if above is not None:                       # keep the parked work for the join, drop the armed event
-                L.ctcn_set_prelaunch_event(None)
+            if above is not None:                       # keep the parked work for the join
                 _side["deferred"][key] = above
             raise
         if above is not None:

@@ -82,7 +82,8 @@ int ctcn_device_xcds(void);
 int ctcn_set_option(const char *name, int value);
 int ctcn_get_option(const char *name);
 /* optional device int that persistent kernels set to a non-zero code if an in-launch hand-off times out (sticky);
- * the caller zeroes it and reads it at its own synchronisation points. */
+ * the caller zeroes it and reads it at its own synchronisation points.  PROCESS-WIDE default (one word for every call that does not
+ * bring its own in ctcn_rnn_call.status): a caller with several models / devices passes per-call words instead. */
 int ctcn_set_status_buffer(int *dev_word);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -143,17 +144,43 @@ int ctcn_rnn_bwd_dropout(int cell, int T, int B, int I, int H, int dirs, const f
                          const float *w_ih1, const float *w_hh1, const float *y, float *gates, float *aux, const float *dy, float *dx,
                          float *dw_ih0, float *dw_hh0, float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
                          size_t ws_bytes, void *stream, float p, uint64_t seed, uint64_t offset, float *dy_tmp);
-/* One-shot: the next ctcn_rnn_bwd issued by this host thread records `event` (a hipEvent_t) on its stream immediately before
- * it launches the recurrence, behind its own preparatory memsets / transposes.  Work meant to run next to that recurrence
- * on another stream (ctcn_rnn_bwd_weights of the layer above) waits for this event.  NULL clears it. */
-int ctcn_set_prelaunch_event(void *event);
-/* One-shot request for the NEXT ctcn_rnn_fwd on this thread: pipeline the input projection with the persistent recurrence.  The
- * library projects the first pair of time chunks on `stream` of ctcn_rnn_fwd, records `event` (hipEvent_t) right before the recurrence
- * launch, and issues the remaining chunk GEMMs on `side_stream` behind that event, restricted to the XCDs of `xcd_allow` (bit x = XCD
- * x; the ones the recurrence leaves idle), each pair followed by a counter update the recurrence checks when it enters a new chunk.
- * `side_ws` / `side_ws_bytes`: workspace of the side-stream GEMMs.  Ignored (whole projection first, as without the call) when the
- * tagged-gather recurrence does not apply.  The caller joins `side_stream` before it reuses x or the side workspace. */
-int ctcn_set_fwd_overlap(void *side_stream, void *event, void *side_ws, size_t side_ws_bytes, unsigned xcd_allow);
+/* Per-call extras of the recurrent layer (ctcn_rnn_fwd_ex / ctcn_rnn_bwd_ex).  The library keeps NO state between calls (round 3: the
+ * one-shot setters ctcn_set_prelaunch_event / ctcn_set_fwd_overlap and the thread-local hand-over of the _dropout entry points are gone):
+ * everything a call needs beyond its tensors is in this struct, owned by the caller, read during the call only.  Zero-initialise it;
+ * a NULL pointer = all zero = the plain ctcn_rnn_fwd / ctcn_rnn_bwd.  Two models on two streams (or two host threads) share nothing but
+ * the option table (ctcn_set_option: process-wide tuning switches, read-only during calls) and, unless `status` is given, the process
+ * default status word. */
+typedef struct ctcn_rnn_call {
+  /* dropout of the layer output (BatchRNN: rnn -> nn.Dropout, model_ctc.py:33-34).  fwd: y_drop != NULL asks for y_drop =
+   * ctcn_dropout(y, drop_p, drop_seed, drop_offset) beside y.  bwd: dy_tmp != NULL says dy is the gradient of the DROPPED output (same
+   * p / seed / offset); dy_tmp (T*B*dirs*H floats) is scratch for the paths that run the dropout kernel first. */
+  float drop_p;
+  uint64_t drop_seed, drop_offset;
+  float *y_drop;
+  float *dy_tmp;
+  /* fwd: pipeline the input projection with the persistent recurrence.  The library projects the first pair of time chunks on the call's
+   * stream, records side_event (hipEvent_t) right before the recurrence launch and issues the remaining chunk GEMMs on side_stream behind
+   * that event, restricted to the XCDs of xcd_allow (bit x = XCD x: the ones the recurrence leaves idle), each pair followed by a counter
+   * update the recurrence checks when it enters a new chunk.  side_ws / side_ws_bytes: workspace of the side-stream GEMMs.  Ignored (whole
+   * projection first) where the tagged-gather recurrence does not apply.  The caller joins side_stream before it reuses x or side_ws. */
+  void *side_stream, *side_event, *side_ws;
+  size_t side_ws_bytes;
+  unsigned xcd_allow;
+  /* bwd: hipEvent_t recorded on the call's stream immediately before the recurrence is launched, behind the call's own preparatory
+   * memsets / transposes; work meant to run next to that recurrence on another stream (ctcn_rnn_bwd_weights of the layer above) waits
+   * for it. */
+  void *prelaunch_event;
+  /* device int32 the persistent kernels of THIS call set on a hand-off timeout (sticky); NULL: the process default of
+   * ctcn_set_status_buffer (which may be NULL too: timeouts then only poison the output). */
+  int *status;
+} ctcn_rnn_call;
+int ctcn_rnn_fwd_ex(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                    const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, int precision, void *ws, size_t ws_bytes,
+                    void *stream, const ctcn_rnn_call *call);
+int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
+                    const float *w_ih1, const float *w_hh1, const float *y, float *gates, float *aux, const float *dy, float *dx,
+                    float *dw_ih0, float *dw_hh0, float *dw_ih1, float *dw_hh1, float beta_w, int precision, void *scratch, void *ws,
+                    size_t ws_bytes, void *stream, const ctcn_rnn_call *call);
 /* ctcn_rnn_bwd with dw_ih0 == dw_hh0 == NULL runs the recurrence and dx only and leaves d(pre-activation) in gates
  * (and aux for the GRU n-gate); this call then produces the weight gradients from it: dW_ih = da^T x, dW_hh = da^T h_prev.
  * It has no consumer inside the backward pass, so the host side issues it on a second stream next to the NEXT layer's

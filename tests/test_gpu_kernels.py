@@ -854,7 +854,7 @@ def _build_model(tag, dev):
 
 @pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 320, 32, 208), ("GRU", 256, 20, 419), ("LSTM", 128, 16, 1031)])
 def test_forward_projection_overlap_equals_inline(dev, rnn, H, B, T):
-    """Pipelined input projection (ctcn_set_fwd_overlap: only the first pair of time chunks is projected before the persistent
+    """Pipelined input projection (ctcn_rnn_call.side_stream of ctcn_rnn_fwd_ex: only the first pair of time chunks is projected before the persistent
     recurrence starts, the rest on the side stream behind a chunk counter) against the plain order: outputs, saved activations and
     the gradients computed from them are bit-identical, five times in a row (a chunk read before its GEMM landed would show)."""
     from ctc_pytorch_amd import nn, ops
@@ -925,6 +925,76 @@ def test_rnn_layer_with_fused_dropout_equals_layer_then_dropout(dev, rnn, H, B, 
         assert 0.6 < kept < 0.9
         for o in outs[1:]:
             assert all(torch.equal(a, b_) for a, b_ in zip(o, outs[0]))
+
+
+def test_rnn_abi_is_stateless_two_layers_two_streams_two_threads(dev):
+    """no hidden state behind the C ABI.  Two recurrent layers (different shapes, different dropout streams, their
+    own status words) are driven through ctcn_rnn_fwd_ex / ctcn_rnn_bwd_ex from two host THREADS on two HIP streams at the same time, many
+    times over; every result must equal the one the same call produces alone.  (Before round 3 the dropout request, the projection
+    pipeline and the pre-launch event travelled in thread-locals armed by separate setter calls.)"""
+    import threading
+    from ctc_pytorch_amd import _lib, ops
+    L = _lib.lib()
+    ops.set_precision(1)
+
+    class Layer:
+        def __init__(self, seed, T, B, I, H, cell, p):
+            g = torch.Generator(device="cpu").manual_seed(seed)
+            G = {0: 4, 1: 3}[cell]
+            self.dims, self.cell, self.p, self.seed = (T, B, I, H), cell, p, seed
+            self.x = (torch.randn(T, B, I, generator=g) * 0.5).to(dev)
+            self.w = (torch.randn(2 * G * H, I, generator=g) * 0.1).to(dev)          # [W_ih fwd ; W_ih rev] stacked
+            self.u = [(torch.randn(G * H, H, generator=g) * 0.1).to(dev) for _ in range(2)]
+            self.gy = torch.randn(T, B, 2 * H, generator=g).to(dev)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+
+        def run(self):
+            T, B, I, H = self.dims
+            G = {0: 4, 1: 3}[self.cell]
+            with torch.cuda.stream(self.stream):
+                y, yd = torch.empty(T, B, 2 * H, device=dev), torch.empty(T, B, 2 * H, device=dev)
+                gates, aux = torch.empty(T, B, 2, G * H, device=dev), torch.empty(T, B, 2, H, device=dev)
+                call = _lib.RnnCall()
+                call.status, call.y_drop, call.drop_p, call.drop_seed, call.drop_offset = self.status.data_ptr(), yd.data_ptr(), self.p, self.seed, 1000 * self.seed
+                st = ctypes.c_void_p(self.stream.cuda_stream)
+                wp = ctypes.c_void_p(self.ws.data_ptr())
+                P = lambda t: ctypes.c_void_p(t.data_ptr())
+                w1 = self.w[G * H:]
+                _lib.check(L.ctcn_rnn_fwd_ex(self.cell, T, B, I, H, 2, P(self.x), P(self.w), P(self.u[0]), P(w1), P(self.u[1]), P(y), P(gates), P(aux), 1,
+                                             wp, self.ws.numel(), st, ctypes.byref(call)), "rnn_fwd_ex")
+                dx, gd = torch.empty_like(self.x), torch.empty_like(self.gy)
+                dw = [torch.empty(G * H, I, device=dev), torch.empty(G * H, H, device=dev), torch.empty(G * H, I, device=dev), torch.empty(G * H, H, device=dev)]
+                scratch = torch.empty(L.ctcn_rnn_scratch_bytes(self.cell, B, H, 2), dtype=torch.uint8, device=dev)
+                call2 = _lib.RnnCall()
+                call2.status, call2.dy_tmp, call2.drop_p, call2.drop_seed, call2.drop_offset = self.status.data_ptr(), gd.data_ptr(), self.p, self.seed, 1000 * self.seed
+                _lib.check(L.ctcn_rnn_bwd_ex(self.cell, T, B, I, H, 2, P(self.x), P(self.w), P(self.u[0]), P(w1), P(self.u[1]), P(y), P(gates), P(aux), P(self.gy),
+                                             P(dx), P(dw[0]), P(dw[1]), P(dw[2]), P(dw[3]), 0.0, 1, P(scratch), wp, self.ws.numel(), st, ctypes.byref(call2)), "rnn_bwd_ex")
+                self.stream.synchronize()
+            return [t.clone() for t in (y, yd, dx, dw[0], dw[1], dw[2], dw[3])]
+
+    a, b = Layer(3, 70, 32, 48, 320, 0, 0.1), Layer(5, 45, 20, 64, 128, 1, 0.3)
+    ref_a, ref_b = a.run(), b.run()                      # each alone
+    assert float(ref_a[1].eq(0).float().mean()) > 0.05 and float(ref_b[1].eq(0).float().mean()) > 0.2      # the dropout really ran, at its own p
+    errs = []
+
+    def worker(layer, ref):
+        try:
+            for _ in range(12):
+                got = layer.run()
+                for g_, r_ in zip(got, ref):
+                    if not torch.equal(g_, r_):
+                        errs.append("mismatch")
+        except Exception as e:                       # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(a, ref_a)), threading.Thread(target=worker, args=(b, ref_b))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs, errs[:3]
+    assert int(a.status.item()) == 0 and int(b.status.item()) == 0
 
 
 @pytest.mark.parametrize("prec", [1, 0])
