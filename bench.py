@@ -499,6 +499,22 @@ def run_decode(args):
     print(json.dumps(decode_leg(torch.device("cuda", 0), steps=args.steps)))
 
 
+def self_launch_argv(args, argv, environ):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): the command line and environment of
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`
+    -- one rank per GPU over RCCL, the form the driver uses for N > 1 (which keeps working: WORLD_SIZE is set there).  None when no
+    re-launch is needed."""
+    if args.mode != "train" or args.gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(environ, HSA_ENABLE_IPC_MODE_LEGACY=environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+             "--master-port", str(port), os.path.abspath(__file__)] + list(argv), env)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -513,14 +529,7 @@ if __name__ == "__main__":
     ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "1")), choices=[0, 1],
                     help="0: exact f32 MFMA GEMMs; 1: bf16x3 split-operand MFMA GEMMs (f32-class accuracy)")
     a = ap.parse_args()
-    if a.mode == "train" and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
-        # <same arguments>` -- one rank per GPU over RCCL, the form the driver uses for N > 1 (which keeps working: WORLD_SIZE is set there)
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        os.execvpe(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-                                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env)
+    relaunch = self_launch_argv(a, sys.argv[1:], os.environ)
+    if relaunch is not None:
+        os.execvpe(relaunch[0][0], relaunch[0], relaunch[1])
     (run_train if a.mode == "train" else run_decode)(a)
