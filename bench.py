@@ -295,6 +295,19 @@ def run_train(args):
     _ops.check_health()                # a hand-off timeout in a persistent kernel poisons the step: never report such a run
     dt = parallel.max_over_ranks(dt, dev)
     last_loss = float(losses[-1].detach()) * world if losses else float("nan")
+    # Everything below that issues a collective must run on EVERY rank (the other ranks are gone after the return): the exchange-step
+    # measurement here, on all ranks; the rank-0-only probes further down contain no collective, and the two that do (host enqueue time,
+    # epoch loop) are single-rank measurements that N > 1 skips.
+    comm_marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    comm_err = None
+    try:
+        for mk in comm_marks:
+            step(mk)
+        torch.cuda.synchronize()
+    except Exception as e:          # noqa: BLE001
+        comm_err = repr(e)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
     if rank != 0:
         return
     frames = c["B"] * c["T"] * world * args.steps
@@ -320,11 +333,9 @@ def run_train(args):
     }
     try:    # the exchange step, so that a SCALE record can be checked: who carried it, how many bytes, how much of it the main stream saw
         import torch.distributed as tdist
-        marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-        for mk in marks:
-            step(mk)
-        torch.cuda.synchronize()
-        exposed = sorted(a.elapsed_time(b) * 1e3 for a, b in marks)
+        if comm_err is not None:
+            raise RuntimeError(comm_err)
+        exposed = sorted(a.elapsed_time(b) * 1e3 for a, b in comm_marks)
         on = parallel._collectives_on()
         res["comm"] = dict(ranks=world, collectives_issued=bool(on),
                            backend=("none (single rank: allreduce_grads returns at once)" if not on else
@@ -365,6 +376,8 @@ def run_train(args):
     except Exception as e:      # keep the headline line even if a probe fails
         res["roofline"] = {"error": repr(e)}
     try:        # host side of one step: time to ENQUEUE it (python + autograd + ~300 launches) with the device idle at the start
+        if world > 1:
+            raise RuntimeError("single-rank measurement (its steps contain collectives the other ranks no longer answer)")
         torch.cuda.synchronize()
         th = []
         for _ in range(3):
@@ -374,10 +387,12 @@ def run_train(args):
             torch.cuda.synchronize()
         res["host_enqueue_ms_per_step"] = 1e3 * min(th)
     except Exception as e:
-        res["host_enqueue_ms_per_step"] = repr(e)
+        res["host_enqueue_ms_per_step"] = None if world > 1 else repr(e)
     try:
         # the real training loop: steps/train_ctc.run_epoch over host batches staged by DevicePrefetcher -- on top
         # of the timed step above it runs the greedy error count (arg-max, collapse, edit distance) and ONE small D2H per step
+        if world > 1:
+            raise RuntimeError("single-rank measurement (run_epoch all-reduces its statistics)")
         from ctc_pytorch_amd.steps.train_ctc import run_epoch
         from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher
         nloop = max(20, min(args.steps, 40))      # (long enough to amortise the fill and drain of the prefetch pipeline)
@@ -401,7 +416,7 @@ def run_train(args):
                              "note": "steps/train_ctc.run_epoch with DevicePrefetcher (pinned host batch -> async H2D each step), on-device greedy "
                                      "error count, step statistics read one step behind through pinned memory; not the headline `value`"}
     except Exception as e:
-        res["epoch_loop"] = {"error": repr(e)}
+        res["epoch_loop"] = {"skipped": str(e)} if world > 1 else {"error": repr(e)}
     if world == 1 and not args.no_decode:
         try:        # the utterances/sec beam-decode half of BASELINE.json's metric (cfg5), with its own roofline / cpu_baseline
             res["decode"] = decode_leg(dev)
