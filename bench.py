@@ -154,7 +154,11 @@ def pmc_traffic(kernel):
 
 
 def recurrence_traffic(workload, kernel="rnn_bwd_scatter"):
-    return pmc_traffic(kernel) if workload == "cfg2" else None
+    """HBM bytes per launch of the dominant recurrence from the committed PMC passes, for the two shapes tools/pmc_probe.py runs (a cfg2
+    layer; a ref_yaml layer for rnn_bwd_scatter2)."""
+    if workload == "cfg2" or (workload == "ref_yaml" and kernel == "rnn_bwd_scatter2"):
+        return pmc_traffic(kernel + "<")
+    return None
 
 
 def recurrence_probe(dev, c):
@@ -164,7 +168,7 @@ def recurrence_probe(dev, c):
     from ctc_pytorch_amd import ops
     G = 4 if c["rnn"] == "LSTM" else 3
     cell = {"LSTM": "lstm", "GRU": "gru"}[c["rnn"]]
-    T, B, H = c["T"], c["B"], c["H"]
+    T, B, H = (c["T"] // 2 if c["cnn"] else c["T"]), c["B"], c["H"]          # (the CNN front-end halves the frame rate)
     x = torch.randn(T, B, 2 * H, device=dev, requires_grad=True)
     w = [(torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True),
          (torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True)]
@@ -195,7 +199,7 @@ def recurrence_probe(dev, c):
     flops = 2.0 * T * 2 * B * (G * H) * H              # recurrent matmul of one launch (both directions)
     names = ops.rnn_last_kernels()                     # what the library really launched for this shape (not what the host expects)
     return dict(layer_fwd_us=lf, layer_bwd_us=lb, kernel_fwd_us=kf, kernel_bwd_us=kb, fwd_us_per_timestep=kf / T, bwd_us_per_timestep=kb / T,
-                fwd_kernel=names[0], bwd_kernel=names[1],
+                fwd_kernel=names[0], bwd_kernel=names[1], T=T,
                 algorithmic_flops_per_launch=flops,
                 note="kernel_*: persistent recurrent launch alone (T dependent timesteps, both directions; includes its <10 us of memsets / "
                      "W_hh transposes); layer_*: with the input-projection (fwd) / deferred gradient (bwd) GEMMs")
@@ -362,12 +366,12 @@ def run_train(args):
         tf = rec["algorithmic_flops_per_launch"] / (kus * 1e-6) / 1e12
         traffic = recurrence_traffic(args.workload, kname)
         res["roofline"] = dict(kernel="%s (%s recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (
-                                   kname, "forward" if fwd_dom else "backward", c["rnn"], c["T"]),
+                                   kname, "forward" if fwd_dom else "backward", c["rnn"], rec["T"]),
                                bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic,
                                traffic_source=None if traffic is None else "HBM bytes per launch of this kernel instantiation from the committed rocprofv3 PMC "
                                "passes (profiles/%s), not a counter read of this run" % PMC_FILE,
                                frac_of_bf16x3_ceiling=None if args.precision == 0 else tf / (peak / 3.0),
-                               us_per_launch=kus, us_per_dependent_step=kstep,
+                               us_per_launch=kus, us_per_dependent_step=kstep, dependent_steps_per_launch=rec["T"],
                                algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],
                                peak_note=("f32 MFMA 157.3 TFLOP/s (dense)" if args.precision == 0 else "dense bf16 MFMA 2500 TFLOP/s; the kernel issues 3 bf16 MFMAs per algorithmic product (bf16x3)")
                                + "; latency-bound: see DESIGN.md section 5 for the per-step critical path")
@@ -438,7 +442,7 @@ def decode_leg(dev, steps=5):
     i2c = synth.int2char(V)
     arpa = os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")
     tab = LanguageModel(arpa).table([i2c[i] for i in range(V)])
-    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM alpha=0.1, 128 x 800 x 62 log-probs in HBM; two batches in flight, results handed to the host)", "unit": "utt/s", "n_gpus": 1,
+    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM alpha=0.1, 128 x 800 x 62 log-probs in HBM; two batches in flight, results handed to the host and assembled into phone strings)", "unit": "utt/s", "n_gpus": 1,
            "config": {"workload": "cfg5: BeamDecoder W=20 + phone bigram LM over 128 utterances x 800 frames x 62 classes, lens U{400..800}"},
            "regimes": {}}
     tab_dev = torch.as_tensor(tab, dtype=torch.float64).to(dev)
@@ -471,6 +475,8 @@ def decode_leg(dev, steps=5):
             h.result()
         del warm
         torch.cuda.synchronize()
+        # (the id -> phone-string assembly BeamDecoder.decode performs on the host is part of a decoded batch: inside the timed loop)
+        to_strings = lambda res: [" ".join(i2c[i] for i in seq) for seq in res[0]]
         t0 = time.perf_counter()
         pend = []
         for k in range(nfl):
@@ -478,10 +484,12 @@ def decode_leg(dev, steps=5):
                 pend.append(ops.beam_decode_async(x, lens_dev, tab_dev, 0.1, W))
             if len(pend) == 4:                                              # two searches running, two queued behind them
                 last = pend.pop(0).result()
+                strings = to_strings(last)
         for h in pend:
             last = h.result()
+            strings = to_strings(last)
         dt = (time.perf_counter() - t0) / nfl
-        assert last[0] == ids
+        assert last[0] == ids and len(strings) == B
         # frames the search really processes: the reference skips a frame when 1 - p(blank) < 0.1 (BeamSearch.py:93-94)
         pb = np.exp(lp[:, :, 0])
         processed = int(sum(int(((1.0 - pb[:lens[b], b]) >= 0.1).sum()) for b in range(B)))

@@ -1158,6 +1158,8 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
         const unsigned lo = f2bf(hval - __uint_as_float(hi << 16));
         const unsigned tbit = ((((unsigned)s) >> 1) & 1u) ^ 1u;
         const unsigned word = hi | (((lo & ~1u) | tbit) << 16);
+        // (16-B publishes -- the four dwords of a lane quad gathered with DPP broadcasts, one store from 16 lanes per wave, 64 write requests
+        // per workgroup instead of 256 -- measured in round 3: 1.66-1.67 vs 1.60-1.64 us per step: not kept)
         __builtin_amdgcn_raw_buffer_store_b32(word, rs, tile_b[s & 1] + pub_off, 0, 0);   // write-back into this XCD's L2
       }
 #ifdef CTCN_PERSIST_STATS
@@ -1817,6 +1819,18 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
             acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[blk], wlo[tw][blk], acc[tw], 0, 0, 0);
             acc[tw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[blk], whi[tw][blk], acc[tw], 0, 0, 0);
           }
+          if constexpr (TAGGED) {
+            // round 3: a tile's block leaves as soon as its chain ends -- the CU's store path (nsl x 1 KB per step, ~50 cycles of issue per
+            // block and wave, section 5c of DESIGN.md) then works while the matrix pipes finish the wave's other tile(s)
+            const int owner = gw + NGW * tw;
+            if (owner < nsl) {
+              const unsigned tb = ((((unsigned)s) >> 1) & 1u) ^ 1u;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[tw][e] = __uint_as_float((__float_as_uint(acc[tw][e]) & ~1u) | tb);
+              st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       } else {
         float af[16];
@@ -1830,6 +1844,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
         }
       }
       // scatter: tile tw of this wave belongs to owner slice gw + 12*tw; block (owner, source = this slice)
+      if constexpr (!TAGGED || PREC != 1) {
 #pragma unroll
       for (int tw = 0; tw < NTW; ++tw) {
         const int owner = gw + NGW * tw;
@@ -1841,6 +1856,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
           }
           st_f4(rs, tile_b[par] + (unsigned)(((owner * nsl + slice) * 64 + lane) * 16), acc[tw], local);
         }
+      }
       }
 #ifdef CTCN_PERSIST_STATS
       z_s = clock64();

@@ -4,6 +4,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ctc_pytorch_amd import ops
 dev = torch.device("cuda:0")
 ops.set_precision(int(os.environ.get("CTCN_PRECISION", "1")))
+if os.environ.get("PMC_PROBE_SET") == "scatter2":
+    # round 3: one BiLSTM layer of the reference's shipped YAML shape (T=200 recurrent steps, B=8, I=1952 -> here 768, H=384): rnn_bwd_scatter2
+    T, B, H = 200, 8, 384
+    xr = torch.randn(T, B, 2 * H, device=dev, requires_grad=True)
+    wr = [(torch.randn(4 * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(4 * H, H, device=dev) * 0.05).requires_grad_(True),
+          (torch.randn(4 * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(4 * H, H, device=dev) * 0.05).requires_grad_(True)]
+    for _ in range(3):
+        yr = ops.rnn_layer(xr, wr[0], wr[1], wr[2], wr[3], "lstm")
+        yr.backward(torch.ones_like(yr))
+    torch.cuda.synchronize()
+    print(ops.rnn_last_kernels())
+    sys.exit(0)
 M, K, N = 25600, 640, 1280
 A, W, C = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev)
 for _ in range(4):

@@ -7,6 +7,7 @@ import json, sqlite3, sys
 ALGO = [   # (substring of the kernel name, label, algorithmic bytes per launch at the probe shapes -- DESIGN.md section 5); first match wins
     ("rnn_fwd_tagged", "rnn_fwd_tagged cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
     ("rnn_fwd_persist", "rnn_fwd_persist cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
+    ("rnn_bwd_scatter2", "rnn_bwd_scatter2 ref_yaml layer (T=200,B=8,H=384,D=2)", 200 * 8 * 2 * 384 * 4 * 10),
     ("rnn_bwd_scatter", "rnn_bwd_scatter cfg2 layer (T=800,B=32,H=320,D=2)", 655360000),
     ("gemm_planes_nt256pp_af32_kernel<2>", "gemm 25600x1280x640 (probe of bench.py; A = f32 split while staged, ping-pong tile)", 25600 * 640 * 4 + 1280 * 640 * 4 + 25600 * 1280 * 4),
     ("gemm_planes_nt256pp_af32_kernel<1>", "gemm 25600x640x2560 (dx of the layer; A = f32 d(pre-act) split while staged, ping-pong tile)", 25600 * 2560 * 4 + 640 * 2560 * 4 + 25600 * 640 * 4),
@@ -36,7 +37,11 @@ def table(db, counter):
 
 fetch, write = table(sys.argv[1], "FETCH_SIZE"), table(sys.argv[2], "WRITE_SIZE")
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over tools/pmc_probe.py, precision 1; FETCH_SIZE doubled per "
-                 "MI355X_MICROARCH.md (gfx950 counts the 128-B requests of wide coalesced reads as 64 B); round 2"}
+                 "MI355X_MICROARCH.md (gfx950 counts the 128-B requests of wide coalesced reads as 64 B)"}
+if len(sys.argv) > 5:      # a second pair of passes (PMC_PROBE_SET=scatter2) merged into the same table
+    f2, w2 = table(sys.argv[4], "FETCH_SIZE"), table(sys.argv[5], "WRITE_SIZE")
+    fetch.update({k: v for k, v in f2.items() if "scatter2" in k})
+    write.update({k: v for k, v in w2.items() if "scatter2" in k})
 for name in sorted(set(fetch) | set(write)):
     hit = next((e for e in ALGO if e[0] in name and "queue" not in name), None)
     if hit is None:
