@@ -476,7 +476,8 @@ def decode_leg(dev, steps=5):
         del warm
         torch.cuda.synchronize()
         # (the id -> phone-string assembly BeamDecoder.decode performs on the host is part of a decoded batch: inside the timed loop)
-        to_strings = lambda res: [" ".join(i2c[i] for i in seq) for seq in res[0]]
+        phones = [i2c[i] for i in range(V)]
+        to_strings = lambda res: [" ".join(map(phones.__getitem__, seq)) for seq in res[0]]
         t0 = time.perf_counter()
         pend = []
         for k in range(nfl):
