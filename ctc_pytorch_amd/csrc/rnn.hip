@@ -2014,7 +2014,7 @@ __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs p
   auto drop_block = [&](int s0) {
     const int sk = min(s0 + (lane >> 4), T - 1), tk = d == 0 ? T - 1 - sk : sk;
     const int br = min(b0 + 4 * wave + ((lane >> 2) & 3), B - 1), j4 = min(j0 + 4 * (lane & 3), H - 4);
-    const unsigned idxk = (unsigned)((((size_t)tk * B + br) * D + d) * H + j4);
+    const size_t idxk = (((size_t)tk * B + br) * D + d) * H + j4;           // 64-bit: this kernel also serves reserves past 4 GB
     uint32_t rr[4];
     philox4(pa.drop_seed, pa.drop_off + (idxk >> 2), rr);
     dropw[wave][lane] = make_uint4(rr[0], rr[1], rr[2], rr[3]);
@@ -2774,7 +2774,9 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
   dim3 grid(ceil_div(H, 16), dirs, ceil_div(B, 16));
   bool done = false;
   const bool fits32 = (size_t)T * B * dirs * GH * sizeof(float) < ((size_t)1 << 32);   // one 32-bit-offset resource per tensor
-  if (ctcn_opt_rnn_persistent() && T > 1 && fits32) {
+  // (a reserve of 4 GB or more: only rnn_bwd_scatter2 -- 64-bit reserve addresses -- may take it; the other persistent kernels address a
+  // reserve through one 32-bit buffer resource)
+  if (ctcn_opt_rnn_persistent() && T > 1) {
     int kq = ceil_div(GH, 256);
     if (kq == 7) kq = 8;
     const int nbt = grid.z, nsl = grid.x, groups = dirs * nbt;
@@ -2786,14 +2788,14 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
     // "bwd_item_gather": 0 never, 1 (default) where it measured faster -- more than 20 slices, i.e. H > 320 (tools/mb_bwd2.hip: H = 384 1.58 vs
     // 1.63 us per step, H = 512 2.44 vs 3.38 for the gather formulation, the only other kernel there; H = 320 1.90 vs 1.88, H = 128 1.25 vs 1.19) --, 2 always
     const int ig = ctcn_get_option("bwd_item_gather");
-    const bool gather2 = (ig == 2 || (ig == 1 && nsl > 20)) && nsl <= 40 && ctcn_opt_handoff_tags() && H % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)y % 16 == 0;
+    const bool gather2 = (ig == 2 || (ig >= 1 && (nsl > 20 || !fits32))) && nsl <= 40 && ctcn_opt_handoff_tags() && H % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)y % 16 == 0;
     const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= (gather2 ? 40 : 24);
     const int ntw = nsl <= 12 ? 1 : (nsl <= 24 ? 2 : 3);      // output tiles per scattering wave (12 of them)
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
                                     : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
     const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * (scatter ? nsl : 1) * sizeof(unsigned), 256) + 256;   // + role tickets
     const size_t lds = 0;
-    for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && (kq <= 8 || scatter) && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
+    for (int mode = ctcn_opt_handoff() ? 1 : 0; mode >= 0 && !done && (kq <= 8 || scatter) && (fits32 || (scatter && gather2)) && ws && ws_bytes >= hx_bytes + fl_bytes + 512; --mode) {
       const int nx = mode ? ctcn_device_xcds() : 1;
       if (mode && nx <= 1) continue;
       const int wpx = ceil_div(groups, nx) * nsl;
