@@ -399,7 +399,7 @@ def run_train(args):
             raise RuntimeError("single-rank measurement (run_epoch all-reduces its statistics)")
         from ctc_pytorch_amd.steps.train_ctc import run_epoch
         from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher
-        nloop = max(20, min(args.steps, 40))      # (long enough to amortise the fill and drain of the prefetch pipeline)
+        nloop = max(60, min(3 * args.steps, 120))  # (long enough to amortise the fill and drain of the prefetch pipeline: with 20 steps they were 3 % of the figure)
         hb = (torch.from_numpy(batch["x"]), torch.ones(c["B"], dtype=torch.float32), torch.from_numpy(batch["targets"]),
               torch.from_numpy(batch["tgt_len"]), ["u%d" % i for i in range(c["B"])])
         pf = DevicePrefetcher([hb] * 3, dev)        # one prefetcher for the run, as in steps/train_ctc.main: its pinned slots persist
