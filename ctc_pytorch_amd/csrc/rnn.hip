@@ -1931,11 +1931,13 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
 //   * stores: the item waves leave d(pre-activation) as float32 in LDS next to the bf16 A operand, each exchange wave stores one gate
 //     with 16-B stores (64 B contiguous per row instead of 4-B pieces).
 // The A operand, the float32 copy and the reserve sets are double / triple buffered, so the one barrier orders everything.
-// 512 threads: four item waves + FOUR exchange waves (one of each per SIMD, 256 VGPRs per wave: the W_hh fragments of NTE = ceil(nsl / 4)
-// output tiles per exchange wave and the nsl polled dwords of an item lane cannot share 128).  The matrix pipes see the same 6 MFMAs per
-// tile as before, issued as NTE independent chains per wave; a tile's block is stored as soon as its chain ends.
-// W_hh fragments, tags, tile layout in the hand-off buffer and the role placement are those of rnn_bwd_scatter; the sum over sources
-// runs 0 .. nsl-1 on two interleaved accumulators (even + odd sources).  NTE = 9 covers nsl <= 36 (H <= 576).
+// 256 + 64 * NEW threads: four item waves + NEW exchange waves, each owning NTE = ceil(nsl / NEW) output tiles (W_hh fragments: 16 VGPRs per
+// tile) -- the product is run with NEW = 8 (768 threads, two exchange waves per SIMD, 168 VGPRs per wave: the fragments and the polled
+// registers of an item lane cannot share the 128 of a 1024-thread workgroup, and ONE exchange wave per SIMD issues an MFMA only every 16
+// cycles where the pipe takes one every ~8 from two).  A tile's 6 MFMAs run as one dependent chain and its block is stored as soon as the
+// chain ends, so the CU's store path works during the other tiles' MFMAs.
+// W_hh fragments, tags, tile layout in the hand-off buffer and the role placement are those of rnn_bwd_scatter; an item lane group g sums
+// the blocks 4 i + g in ascending order, the four groups are combined lower group first.  NTE <= 5: up to 40 slices (H <= 640).
 // ================================================================================================
 template <int NEW, int NTE, int CELL>
 __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs pa) {
@@ -2260,7 +2262,6 @@ bool launch_bwd_scatter_c(int ntw, dim3 grid, hipStream_t st, const PersistArgs 
   switch (ntw) {      // precision 1 only: the host never picks the scatter formulation for the f32 matmul
     case 1: return launch_resident(rnn_bwd_scatter<1, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
     case 2: return launch_resident(rnn_bwd_scatter<2, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
-    case 3: return launch_resident(rnn_bwd_scatter<3, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
     default: return false;
   }
 }
@@ -2790,7 +2791,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
     const int ig = ctcn_get_option("bwd_item_gather");
     const bool gather2 = (ig == 2 || (ig >= 1 && (nsl > 20 || !fits32))) && nsl <= 40 && ctcn_opt_handoff_tags() && H % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)y % 16 == 0;
     const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= (gather2 ? 40 : 24);
-    const int ntw = nsl <= 12 ? 1 : (nsl <= 24 ? 2 : 3);      // output tiles per scattering wave (12 of them)
+    const int ntw = nsl <= 12 ? 1 : 2;                        // rnn_bwd_scatter: output tiles per scattering wave (12 of them; nsl <= 24)
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)
                                     : align_up((size_t)2 * dirs * nbt * (prec ? ceil_div(GH, 32) * 512 : ceil_div(GH, 16) * 256) * sizeof(float), 256);
     const size_t fl_bytes = align_up((size_t)2 * dirs * nbt * nsl * (scatter ? nsl : 1) * sizeof(unsigned), 256) + 256;   // + role tickets
