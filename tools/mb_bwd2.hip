@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
       if (delay < 0) {
         if (nsl <= 12) hipLaunchKernelGGL((rnn_bwd_scatter<1, 1, true, 0>), gp, dim3(1024), 0, st, pa);
         else if (nsl <= 24) hipLaunchKernelGGL((rnn_bwd_scatter<2, 1, true, 0>), gp, dim3(1024), 0, st, pa);
-        else hipLaunchKernelGGL((rnn_bwd_scatter<3, 1, true, 0>), gp, dim3(1024), 0, st, pa);
+        // (more than 24 slices: rnn_bwd_scatter has no instantiation -- three tiles per wave spilled the W_hh fragments, 4.9 us per step at H = 512)
       } else {
         if (NEWV == 4) {
           if (nsl <= 12) hipLaunchKernelGGL((rnn_bwd_scatter2<4, 3, 0>), gp, dim3(512), 0, st, pa);
