@@ -27,6 +27,14 @@ struct StatVal {   // (x, x*x)
     const double v = x[idx];
     return {v, v * v};
   }
+  // four consecutive elements (idx % 4 == 0, 16-B aligned base): one 16-B load per operand; added in element order
+  struct Quad { f32x4 x; };
+  __device__ __forceinline__ Quad load4(size_t idx) const { return {*reinterpret_cast<const f32x4 *>(x + idx)}; }
+  __device__ __forceinline__ void add4(const Quad &q, int, double &a, double &b) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const double v = q.x[e]; a += v; b += v * v; }
+  }
+  __host__ __device__ __forceinline__ bool aligned16() const { return ((uintptr_t)x & 15) == 0; }
 };
 struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu
   const float *x, *y, *dy, *mean, *rstd;
@@ -37,6 +45,25 @@ struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu
     const float xh = (x[idx] - mean[c]) * rstd[c];
     return {(double)g, (double)g * (double)xh};
   }
+  struct Quad { f32x4 x, y, dy; };
+  __device__ __forceinline__ Quad load4(size_t idx) const {
+    Quad q;
+    q.x = *reinterpret_cast<const f32x4 *>(x + idx);
+    q.dy = *reinterpret_cast<const f32x4 *>(dy + idx);
+    q.y = relu ? *reinterpret_cast<const f32x4 *>(y + idx) : q.x;
+    return q;
+  }
+  __device__ __forceinline__ void add4(const Quad &q, int c, double &a, double &b) const {
+    const float m = mean[c], rs = rstd[c];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = q.dy[e];
+      if (relu && !(q.y[e] > 0.0f)) g = 0.0f;
+      const float xh = (q.x[e] - m) * rs;
+      a += (double)g; b += (double)g * (double)xh;
+    }
+  }
+  __host__ __device__ __forceinline__ bool aligned16() const { return (((uintptr_t)x | (uintptr_t)dy | (relu ? (uintptr_t)y : 0)) & 15) == 0; }
 };
 
 template <class F>
@@ -72,17 +99,37 @@ __global__ __launch_bounds__(256) void colreduce_rows_kernel(F f, int rows, int 
   }
 }
 
+// NCHW: chunk k of a channel = plane o = k / ich (outer index), inner range [ic * ilen, (ic + 1) * ilen) with ic = k % ich.  Round 3 (the
+// shipped-YAML shape, 8 x 32 x 400 x 122: one workgroup per (channel, image) walked 195 KB with one dword load in flight per lane: 100 /
+// 163 us for the backward sums against a ~30 us HBM floor): the planes are cut along the inner dimension as well (`ich` pieces of <= 64 KB),
+// lanes take 16-B pieces, four of them in flight per operand; the partials stay float64, one per chunk, added by the finalize pass in chunk
+// order (deterministic).
 template <class F>
-__global__ __launch_bounds__(256) void colreduce_nchw_kernel(F f, int outer, int C, int inner, int outer_per_chunk, double *__restrict__ part) {
+__global__ __launch_bounds__(256) void colreduce_nchw_kernel(F f, int outer, int C, int inner, int opc, int ich, int ilen, int vec, double *__restrict__ part) {
   __shared__ double sa[4], sb[4];
   const int c = blockIdx.x;
-  const int o0 = blockIdx.y * outer_per_chunk, o1 = min(outer, o0 + outer_per_chunk);
+  // chunk -> planes [o0, o1) (opc of them; 1 when the planes are cut into ich pieces) and the inner range [i0, i1)
+  const int oc = blockIdx.y / ich, ic = blockIdx.y - oc * ich;
+  const int o0 = oc * opc, o1 = min(outer, o0 + opc);
+  const int i0 = ic * ilen, i1 = min(inner, i0 + ilen);
   double a = 0.0, b = 0.0;
   for (int o = o0; o < o1; ++o) {
     const size_t base = ((size_t)o * C + c) * inner;
-    for (int i = threadIdx.x; i < inner; i += 256) {
-      const Pair p = f(base + i, c);
-      a += p.a; b += p.b;
+    if (vec) {                      // inner % 4 == 0, ilen % 1024 == 0, 16-B aligned operands
+      int i = i0 + threadIdx.x * 4;
+      for (; i + 3 * 1024 < i1; i += 4096) {
+        typename F::Quad q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = f.load4(base + i + 1024 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.add4(q[u], c, a, b);
+      }
+      for (; i < i1; i += 1024) f.add4(f.load4(base + i), c, a, b);
+    } else {
+      for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const Pair p = f(base + i, c);
+        a += p.a; b += p.b;
+      }
     }
   }
   a = wave_sum_d(a); b = wave_sum_d(b);
@@ -252,10 +299,23 @@ int chunks_rows(int rows, int C) {
   n = std::min(n, ceil_div(rows, 64));
   return std::max(n, 1);
 }
-int chunks_nchw(int outer, int C) {
-  int n = std::max(1, 1024 / std::max(C, 1));
-  n = std::min(n, outer);
-  return std::max(n, 1);
+// NCHW chunking: at most max(1, 4096 / C) chunks per channel.  Few planes (a CNN feature map: outer = batch): every plane is cut into `ich`
+// pieces of <= 64 KB (whole 4-KB wave rounds); many planes: `opc` whole planes per chunk.
+struct NchwChunks { int opc, ich, ilen, n; };
+NchwChunks chunks_nchw(int outer, int C, int inner) {
+  const int nmax = std::max(1, 4096 / std::max(C, 1));
+  NchwChunks k;
+  if (outer >= nmax) {
+    k.opc = ceil_div(outer, nmax); k.ich = 1; k.ilen = ceil_div(std::max(inner, 1), 1024) * 1024;
+    k.n = ceil_div(outer, k.opc);
+  } else {
+    int ich = std::min(ceil_div(inner, 16384), nmax / outer);
+    ich = std::max(ich, 1);
+    k.ilen = ceil_div(ceil_div(inner, ich), 1024) * 1024;
+    k.ich = ceil_div(inner, k.ilen); k.opc = 1;
+    k.n = outer * k.ich;
+  }
+  return k;
 }
 
 template <class F>
@@ -267,10 +327,10 @@ int launch_reduce(F f, int outer, int C, int inner, double *part, int *nchunks_o
     hipLaunchKernelGGL((colreduce_rows_kernel<F>), dim3(ceil_div(C, 64), nn), dim3(256), 0, st, f, outer, C, rpc, part);
     *nchunks_out = nn;
   } else {
-    const int n = chunks_nchw(outer, C);
-    const int opc = ceil_div(outer, n);
-    const int nn = ceil_div(outer, opc);
-    hipLaunchKernelGGL((colreduce_nchw_kernel<F>), dim3(C, nn), dim3(256), 0, st, f, outer, C, inner, opc, part);
+    const NchwChunks k = chunks_nchw(outer, C, inner);
+    const int nn = k.n;
+    const int vec = inner % 4 == 0 && f.aligned16() ? 1 : 0;
+    hipLaunchKernelGGL((colreduce_nchw_kernel<F>), dim3(C, nn), dim3(256), 0, st, f, outer, C, inner, k.opc, k.ich, k.ilen, vec, part);
     *nchunks_out = nn;
   }
   return 0;
@@ -279,7 +339,7 @@ int launch_reduce(F f, int outer, int C, int inner, double *part, int *nchunks_o
 }  // namespace
 
 extern "C" size_t ctcn_bn_ws_bytes(int outer, int C, int inner) {
-  const int n = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C);
+  const int n = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C, inner).n;
   return align_up((size_t)(n + 1) * C * 2 * sizeof(double), 256) + (size_t)2 * C * sizeof(float);
 }
 
@@ -389,7 +449,7 @@ extern "C" int ctcn_bn_bwd(const float *x, const float *y, const float *dy, cons
   if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_bwd: workspace too small"); return CTCN_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   double *part = (double *)ws;
-  const int nmax = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C);
+  const int nmax = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C, inner).n;
   float *sums = (float *)((char *)ws + align_up((size_t)(nmax + 1) * C * 2 * sizeof(double), 256));
   int nchunks = 0;
   launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu}, outer, C, inner, part, &nchunks, st);

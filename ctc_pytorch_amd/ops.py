@@ -123,7 +123,8 @@ def set_grad_ready_hook(fn):
     _grad_ready["hook"] = fn
 
 
-_side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": 1 << 21}
+_side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": int(os.environ.get("CTCN_SIDE_MIN_ITEMS", str(1 << 21))),
+         "small_split": os.environ.get("CTCN_SMALL_SPLIT", "1") != "0"}
 
 
 def set_side_stream(flag, min_items=None):
@@ -412,6 +413,11 @@ class _RNNLayer(torch.autograd.Function):
             # (eight small dependent launches per direction that do not fill 256 CUs one at a time: 440 -> ~250 us at cfg2)
             split_dirs = side and dirs == 2
             side = False
+        # small layers (below min_items: weight GEMMs inline): the two directions' weight gradients are independent chains of small launches
+        # that do not fill the device one at a time -- one direction per stream, joined at once (nothing runs next to a recurrence)
+        small_split = (not side and not split_dirs and into_flat and _side["enabled"] and _side["small_split"] and dirs == 2 and T > 1)
+        if small_split:
+            split_dirs = True
         # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right
         # before that launch, behind its own small preparatory kernels, and the side stream waits for it
         above, ev = _side["deferred"].pop(key, None), None
@@ -451,8 +457,11 @@ class _RNNLayer(torch.autograd.Function):
             for t in (x, y, gates, aux):
                 if t is not None:
                     t.record_stream(st)
-            _side["pending"][key] = st
-            torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
+            if small_split:
+                torch.cuda.current_stream(dev).wait_stream(st)
+            else:
+                _side["pending"][key] = st
+                torch.autograd.Variable._execution_engine.queue_callback(_join_side(key))
         if side:
             st = _side_stream(dev)
             prec = get_precision()
