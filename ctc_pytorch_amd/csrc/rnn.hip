@@ -974,13 +974,20 @@ bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStr
 // set by the slowest of the ten exchange waves, a ~1 000-cycle tail); the same + pre-activations fetched two steps ahead into
 // alternating register sets (as rnn_bwd_scatter does): 1.76-1.93.  Left as it is.
 // ================================================================================================
-template <int NBW, int CELL>
+// RSV (round 3, option "fwd_rsv_lds"): the item waves' reserve traffic -- 6-7 scattered dword stores and 3-4 dword loads per item and step, ~28
+// + 16 wave instructions per workgroup issued through waterfall loops -- goes through LDS instead: the items park their saved activations,
+// c / hn, h and the dropped h as float32 [array][row][unit]; after the next barrier, in the pause before its first poll, exchange wave a
+// stores array a of the PREVIOUS step with ONE 16-B store per lane (64 B contiguous per row); item wave g brings gate g's pre-activations of
+// step s + 2 into a 3-deep LDS ring with ONE global_load_lds_dwordx4 (counted vmcnt wait before the barrier, as rnn_bwd_scatter2).
+template <int NBW, int CELL, bool RSV = false>
 __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   constexpr int NGW = 12, NMT = 4;                           // exchange waves, MFMA tiles (4 units x 4 gates each) per workgroup
   constexpr int PQ = 17;                                     // parked slots per (tile, unit) row: 16 batch rows + 1 (bank spread)
   const RnnArgs &p = pa.a;
   __shared__ __attribute__((aligned(16))) float red[NGW * NMT * 4 * PQ * 4];
   __shared__ uint4 dropw[4][64];                   // fused dropout: the Philox groups of an item wave's next four steps
+  __shared__ __attribute__((aligned(16))) float outq[RSV ? 2 : 1][RSV ? 7 : 1][RSV ? 256 : 4];   // RSV: values to store, by step parity
+  __shared__ __attribute__((aligned(16))) float preq[RSV ? 3 : 1][RSV ? 4 : 1][RSV ? 256 : 4];   // RSV: pre-activations of three steps
   __shared__ int s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -1027,13 +1034,36 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   const unsigned sg_b = (unsigned)(slab_g * 4), sh_b = (unsigned)(slab_h * 4);
   // the item's dword in the published tile: block j >> 5, unit u = j & 31 -> [half (u>>2)&1][octet u>>3][row][dword u&3]
   const unsigned pub_off = (unsigned)((j >> 5) * 2048 + (((((j >> 2) & 1) * 4 + ((j & 31) >> 3)) * 16 + bl) * 4 + (j & 3)) * 4);
-  if (item) {
+  // RSV: lane = (row lane >> 2, unit quad lane & 3) of the 16 x 16 item tile; clamped (valid) addresses for rows / quads outside it
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  const int xrow = min(b0 + (lane >> 2), B - 1), xj = min(j0 + 4 * (lane & 3), H - 4);
+  const size_t xg = ((size_t)xrow * D + d) * (size_t)(G * H) + xj, xh = ((size_t)xrow * D + d) * H + xj;
+  const bool xvalid = (lane >> 2) < Bc && j0 + 4 * (lane & 3) < H;
+  auto pre_dma = [&](int step, int set) {          // item wave g: gate g's pre-activations of `step` (clamped) -> preq[set][g]
+    const int sc = min(step, T - 1), ts = d == 0 ? sc : T - 1 - sc;
+    __builtin_amdgcn_global_load_lds((gptr_t)(p.gates + (size_t)ts * slab_g + xg + (size_t)wave * H), (lptr_t)&preq[set][RSV ? wave : 0][0], 16, 0, 0);
+  };
+  auto service_store = [&](int step) {             // exchange wave a: array a of `step`, one 16-B store per lane
+    const int ts = d == 0 ? step : T - 1 - step, a = gw;
+    if (a < 7 && xvalid && (a < G || a == 4 || a == 5 || (a == 6 && pa.ydrop))) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&outq[RSV ? step & 1 : 0][RSV ? a : 0][RSV ? lane * 4 : 0]);
+      float *dst = a < 4 ? p.gates + (size_t)ts * slab_g + xg + (size_t)a * H
+                         : (a == 4 ? p.aux : (a == 5 ? p.y : pa.ydrop)) + (size_t)ts * slab_h + xh;
+      *reinterpret_cast<f32x4 *>(dst) = v;
+    }
+  };
+  if constexpr (RSV) {
+    if (wave < G) { pre_dma(0, 0); pre_dma(1, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (item) {
     const unsigned o = (unsigned)(d == 0 ? 0 : T - 1) * sg_b;
     pre[0] = ld_slab(rg, vg0, o); pre[1] = ld_slab(rg, vg1, o); pre[2] = ld_slab(rg, vg2, o);
     if (G == 4) pre[3] = ld_slab(rg, vg3, o);
   }
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   int have_chunks = 0;                                         // chunk pairs known to be complete (pair 0 is computed before the launch)
+  int pset = 0;                                                // RSV: ring set of the current step (s % 3)
   __syncthreads();
 #ifdef CTCN_PERSIST_STATS
   long long zx[4] = {0, 0, 0, 0}, zi[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64(), z_prev = zt0, zq = 0;
@@ -1049,6 +1079,9 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       f32x4 acc[NMT];
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt) acc[mt] = zero;
+      // in the pause before the first poll: the reserve values of step s - 2 (its item phase ended before the barrier this wave has just
+      // passed; the item phase of step s - 1 runs NOW and fills the other parity)
+      if constexpr (RSV) { if (s > 1) service_store(s - 2); }
       if (s > 0) {
         const int par = (s - 1) & 1;
         const unsigned tb = (((((unsigned)(s - 1)) >> 1) & 1u) ^ 1u) << 16;
@@ -1110,6 +1143,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       z_m = clock64();
 #endif
     }
+    if constexpr (RSV) { if (wave < G) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }   // this wave's pre-activation DMA of step s has landed (the youngest, s + 1, may be in flight)
     lds_barrier();
 #ifdef CTCN_PERSIST_STATS
     const long long z_b = clock64();
@@ -1117,6 +1151,10 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
     long long z_i1 = z_b, z_i2 = z_b, z_i3 = z_b;
 #endif
     if (wave < 4) {
+      if constexpr (RSV) {
+        pre[0] = preq[pset][0][tid]; pre[1] = preq[pset][1][tid]; pre[2] = preq[pset][2][tid];
+        if constexpr (G == 4) pre[3] = preq[pset][RSV ? 3 : 0][tid];
+      }
       float o[4] = {0.f, 0.f, 0.f, 0.f};
       const float *rp = red + ((((jl >> 2) * 4 + (jl & 3)) * PQ + bl) << 2);
 #pragma unroll
@@ -1168,10 +1206,10 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       // reserve traffic, behind the publish in this wave's queue: saved activations, c / hn, y out; next step's pre-activations in
       const unsigned og = (unsigned)t * sg_b, oh = (unsigned)t * sh_b;
       const unsigned on = (unsigned)(s + 1 < T ? (d == 0 ? t + 1 : t - 1) : t) * sg_b;
-      if (pa.chunk_T > 0 && s + 1 < T) {
-        // pipelined input projection: the pre-activations of the time chunk the next step falls into are written by a GEMM on the
-        // side stream (other XCDs) while this kernel runs; chunk pair p is complete once the counter shows p
-        const int tn = d == 0 ? t + 1 : t - 1, c = tn / pa.chunk_T, need = min(c, pa.nchunk - 1 - c);
+      if (pa.chunk_T > 0 && s + (RSV ? 2 : 1) < T) {
+        // pipelined input projection: the pre-activations of the time chunk the next step falls into (RSV: the step after it, fetched now)
+        // are written by a GEMM on the side stream (other XCDs) while this kernel runs; chunk pair p is complete once the counter shows p
+        const int tn = d == 0 ? t + (RSV ? 2 : 1) : t - (RSV ? 2 : 1), c = tn / pa.chunk_T, need = min(c, pa.nchunk - 1 - c);
         if (need > have_chunks) {
           for (int spins = 0;; ++spins) {
             have_chunks = (int)__hip_atomic_load(pa.chunk_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1184,7 +1222,15 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
           }
         }
       }
-      if (item) {
+      if constexpr (RSV) {
+        if (item) {
+          float *oq = &outq[s & 1][0][tid];
+          oq[0] = sv0; oq[256] = sv1; oq[512] = sv2;
+          if constexpr (CELL == CTCN_CELL_LSTM) oq[768] = sv3;
+          oq[1024] = sv4; oq[1280] = hval;
+        }
+        if (wave < G) pre_dma(s + 2, pset == 0 ? 2 : pset - 1);        // ring set (s + 2) % 3
+      } else if (item) {
         st_slab(rg, vg0, og, sv0); st_slab(rg, vg1, og, sv1); st_slab(rg, vg2, og, sv2);
         if constexpr (CELL == CTCN_CELL_LSTM) st_slab(rg, vg3, og, sv3);
         st_slab(ra, vh, oh, sv4);
@@ -1207,12 +1253,18 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
           dropw[tid >> 6][lane] = make_uint4(rr[0], rr[1], rr[2], rr[3]);
         }
         const uint32_t w = reinterpret_cast<const uint32_t *>(&dropw[tid >> 6][(s & 3) * 16 + (lane >> 4) * 4 + ((lane & 15) >> 2)])[lane & 3];
-        if (item) st_slab(ryd, vh, oh, ((w >> 8) * (1.0f / 16777216.0f) >= pa.drop_p) ? hval * pa.drop_scale : 0.0f);
+        if constexpr (RSV) { if (item) outq[s & 1][RSV ? 6 : 0][tid] = ((w >> 8) * (1.0f / 16777216.0f) >= pa.drop_p) ? hval * pa.drop_scale : 0.0f; }
+        else if (item) st_slab(ryd, vh, oh, ((w >> 8) * (1.0f / 16777216.0f) >= pa.drop_p) ? hval * pa.drop_scale : 0.0f);
       }
+      if constexpr (RSV) pset = pset == 2 ? 0 : pset + 1;
 #ifdef CTCN_PERSIST_STATS
       { const long long z_e = clock64(); zi[0] += z_b - z_prev; zi[1] += z_i1 - z_b; zi[2] += z_i2 - z_i1; zi[3] += z_i3 - z_i2; zi[4] += z_e - z_i3; z_prev = z_e; }
 #endif
     }
+  }
+  if constexpr (RSV) {
+    lds_barrier();
+    if (wave >= 4) { if (T > 1) service_store(T - 2); service_store(T - 1); }
   }
 #ifdef CTCN_PERSIST_STATS
   if (pa.stats && slice == 3 && d == 0 && bt == 0 && tid == 4 * 64) { pa.stats[0] = zx[0]; pa.stats[1] = zx[1]; pa.stats[2] = zx[2]; pa.stats[3] = clock64() - zt0; pa.stats[4] = zx[3]; pa.stats[5] = zq; }
@@ -1228,6 +1280,13 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
 
 template <int CELL>
 bool launch_fwd_tagged_c(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  if (a.poll_depth & 256) {       // option "fwd_rsv_lds": reserve traffic through LDS (16-B aligned reserves)
+    switch (nbw) {
+      case 1: return launch_resident(rnn_fwd_tagged<1, CELL, true>, grid, 1024, 0, st, a, wpx);
+      case 2: return launch_resident(rnn_fwd_tagged<2, CELL, true>, grid, 1024, 0, st, a, wpx);
+      default: return false;
+    }
+  }
   switch (nbw) {
     case 1: return launch_resident(rnn_fwd_tagged<1, CELL>, grid, 1024, 0, st, a, wpx);
     case 2: return launch_resident(rnn_fwd_tagged<2, CELL>, grid, 1024, 0, st, a, wpx);
@@ -2536,7 +2595,12 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
         pa.status = status_word;
         pa.spin_limit = SPIN_LIMIT;
         pa.local = 1; pa.nx = nxd; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
-        pa.poll_depth = 1; pa.tagmode = 1; pa.poll_delay = ctcn_get_option("tag_poll_delay");
+        // "fwd_rsv_lds": 0 off, 1 on, 2 (default) where it measured faster: more than 24 slices (cfg4, H = 512: 2.30 -> 2.24 us per step, 53.9 -> 53.2 ms
+        // per step; cfg2 1.60 -> 1.70, ref_yaml 1.51 -> 1.59: there the waterfall-paced dword traffic of the item waves is the better neighbour of
+        // the polls)
+        const int rsv_opt = ctcn_get_option("fwd_rsv_lds");
+        const bool rsv = (rsv_opt == 1 || (rsv_opt == 2 && nsl > 24)) && ((uintptr_t)gates | (uintptr_t)aux | (uintptr_t)y | (uintptr_t)(drop_pending ? call.y_drop : nullptr)) % 16 == 0;
+        pa.poll_depth = 1 | (rsv ? 256 : 0); pa.tagmode = 1; pa.poll_delay = ctcn_get_option("tag_poll_delay");
         pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
         pa.stats = nullptr;

@@ -73,6 +73,9 @@ int ctcn_device_xcds(void);
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
+ * "fwd_rsv_lds" = 2 (default): rnn_fwd_tagged moves its reserve traffic through LDS (the items park their values, exchange waves store
+ * them with 16-B stores in the pause before their first poll, pre-activations arrive by LDS DMA two steps ahead) for H > 384; 1: wherever the
+ * reserves are 16-B aligned; 0: never (scattered dword stores / loads from the item waves).  Same values either way.
  * "bwd_item_gather" = 1 (default): the scatter formulation of the backward recurrence runs as rnn_bwd_scatter2 (item waves gather their own
  * 256-B quarters of the partial tiles, one barrier per step, all reserve traffic on the exchange waves through LDS DMA, 64-bit reserve
  * addresses, up to 40 slices = H <= 640) where it measured faster: more than 20 slices (H > 320); 0: never; 2: wherever it applies.
