@@ -350,6 +350,30 @@ parallel.enable_sync_bn(True)
 assert ops._sync_bn["reduce"] is parallel._sync_bn_reduce
 parallel.enable_sync_bn(False)
 assert ops._sync_bn["reduce"] is None
+# uneven shards: no rank may issue the early slice all-reduce (ADVICE r2) -- the whole buffer goes with the step-end call, once
+parallel.enable_overlap(True)
+parallel.set_batch_split(33, 17 if rank == 0 else 16)
+assert not parallel.overlap_is_rank_invariant()
+flat = torch.arange(50, dtype=torch.float32) * (rank + 1)
+if rank == 0:
+    parallel._slice_ready([flat[10:20]])             # what ops.py would do on the rank whose shard crosses the side-stream threshold
+assert parallel._overlap["works"] == [] and parallel._overlap["done"] == []
+parallel.allreduce_grads(flat)
+assert torch.equal(flat, torch.arange(50, dtype=torch.float32) * 3)
+parallel.set_batch_split(32, 16)
+assert parallel.overlap_is_rank_invariant()
+parallel.set_batch_split(None, None)
+parallel.enable_overlap(False)
+# per-shard BatchNorm: the running statistics are averaged over the ranks at the end of a training epoch (parallel.sync_bn_buffers)
+import torch.nn as tnn
+bn = tnn.Sequential(tnn.BatchNorm1d(3), tnn.Linear(3, 2))
+with torch.no_grad():
+    bn[0].running_mean.fill_(1.0 + rank); bn[0].running_var.fill_(2.0 + 2 * rank); bn[0].num_batches_tracked.fill_(5)
+assert parallel.sync_bn_buffers(bn) == 2
+assert torch.equal(bn[0].running_mean, torch.full((3,), 1.5)) and torch.equal(bn[0].running_var, torch.full((3,), 3.0)) and int(bn[0].num_batches_tracked) == 5
+parallel.enable_sync_bn(True)
+assert parallel.sync_bn_buffers(bn) == 0              # global statistics already: nothing to do
+parallel.enable_sync_bn(False)
 dist.barrier()
 print("rank", rank, "ok")
 """
