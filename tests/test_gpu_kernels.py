@@ -350,6 +350,43 @@ def test_rnn_bwd_item_gather_equals_scatter(dev, kind, T, B, I, H, bi, drop):
         assert rel_l2(g1, g0) < 5e-6, rel_l2(g1, g0)
 
 
+@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 2, 1, 4, 8, True), ("gru", 3, 17, 8, 40, True), ("rnn", 5, 3, 4, 16, False), ("lstm", 2, 64, 16, 512, True),
+                                            ("gru", 7, 2, 4, 24, False)])
+def test_rnn_bwd_item_gather_edge_shapes(dev, kind, T, B, I, H, bi):
+    """rnn_bwd_scatter2 and the RSV forward at the edges: two or three timesteps (shorter than the 3-deep reserve ring), one row, one slice
+    (H = 8: a quarter of a tile), one direction, and the largest group count -- against the per-timestep kernels."""
+    from ctc_pytorch_amd import ops
+    ops.set_precision(1)
+    G = {"lstm": 4, "gru": 3, "rnn": 1}[kind]
+    torch.manual_seed(3)
+    x = torch.randn(T, B, I, device=dev)
+    w = [torch.randn(G * H, I, device=dev) * 0.3, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)]
+    w += [torch.randn(G * H, I, device=dev) * 0.3, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)] if bi else [None, None]
+    dy = torch.randn(T, B, (2 if bi else 1) * H, device=dev)
+    runs = {}
+    try:
+        for mode in (0, 1):
+            ops.set_rnn_persistent(mode)
+            ops.set_option("bwd_item_gather", 2)
+            ops.set_option("fwd_rsv_lds", 1)
+            xs = x.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) if t is not None else None for t in w]
+            y = ops.rnn_layer(xs, ws[0], ws[1], ws[2], ws[3], {"rnn": "tanh"}.get(kind, kind))
+            y.backward(dy)
+            torch.cuda.synchronize()
+            ops.check_health(dev)
+            runs[mode] = (y.detach().clone(), [xs.grad.clone()] + [t.grad.clone() for t in ws if t is not None], ops.rnn_last_kernels())
+    finally:
+        ops.set_rnn_persistent(1)
+        ops.set_option("bwd_item_gather", 1)
+        ops.set_option("fwd_rsv_lds", 2)
+    assert runs[1][2][1] == "rnn_bwd_scatter2", runs[1][2]
+    assert maxabs(runs[1][0], runs[0][0]) < 2e-5            # (the tagged forward carries h at 2^-16 relative; the per-timestep kernel at f32)
+    for g0, g1 in zip(runs[0][1], runs[1][1]):
+        assert torch.isfinite(g1).all()
+        assert rel_l2(g1, g0) < 1e-4, rel_l2(g1, g0)
+
+
 def test_rnn_bwd_item_gather_past_4gb_reserve(dev):
     """VERDICT r2 #7 (the backward half): a gate reserve of 4.3 GB (T = 6 600, B = 64, 2 x 4 x 320) -- beyond the one 32-bit buffer resource
     the other persistent kernels address a reserve through -- runs on rnn_bwd_scatter2 (64-bit reserve addresses, LDS-DMA reserve loads)
