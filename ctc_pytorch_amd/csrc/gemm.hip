@@ -788,6 +788,26 @@ __device__ __forceinline__ void pp_barrier_vm() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef CTCN_GEMM_STATS
+// development (tools/mb_gemm_pp.hip): per barrier site of the main loop, the cycles a wave spends before it reaches the barrier (its phase's own
+// work) and inside it (waiting for the other waves), summed over the stages of one tile: waves 0 and 4 of blocks 0 and 1000
+__device__ long long *g_gemm_stats;
+#define PPB_SITE(i, vm)                                                                                                   \
+  do {                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    if (vm) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    const long long ta_ = clock64();                                                                                      \
+    asm volatile("s_barrier" ::: "memory");                                                                               \
+    const long long tb_ = clock64();                                                                                      \
+    gs_work[i] += ta_ - gs_prev; gs_wait[i] += tb_ - ta_; gs_prev = tb_;                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  } while (0)
+#define PPB(i) PPB_SITE(i, false)
+#define PPB_VM(i) PPB_SITE(i, true)
+#else
+#define PPB(i) pp_barrier()
+#define PPB_VM(i) pp_barrier_vm()
+#endif
 // one 256 x (128 * WNT) output tile (tile number `bid`, row-major over tiles_m x tiles_n) in the ping-pong schedule
 template <int WNT>
 __device__ __forceinline__ void planes256pp_tile(unsigned char *qsm, int bid, int M, int N, int Kp, const unsigned short *__restrict__ Ah,
@@ -801,6 +821,9 @@ __device__ __forceinline__ void planes256pp_tile(unsigned char *qsm, int bid, in
   const int wm = wave >> 2, wn = wave & 3;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * TBM, n0 = tn * TBN;
+#ifdef CTCN_GEMM_STATS
+  const long long gs_entry = clock64();
+#endif
 
   f32x16 acc[4][WNT];
 #pragma unroll
@@ -905,16 +928,28 @@ __device__ __forceinline__ void planes256pp_tile(unsigned char *qsm, int bid, in
   if (wm == 1) pp_barrier();
   constexpr std::integral_constant<bool, true> with_dma{};
   constexpr std::integral_constant<bool, false> no_dma{};
+#ifdef CTCN_GEMM_STATS
+  long long gs_work[4] = {0, 0, 0, 0}, gs_wait[4] = {0, 0, 0, 0};
+  const long long gs_t0 = clock64();
+  long long gs_prev = gs_t0;
+#endif
   for (int s = 0; s + 1 < nst; ++s) {
     load_frags(s, 0);
-    pp_barrier();
+    PPB(0);
     multiply(with_dma, (s + 1) * 32, (s + 1) & 1);          // + DMA share of stage s + 1 (buffer last read >= 2 steps ago by either half)
-    pp_barrier();
+    PPB(1);
     load_frags(s, 1);
-    if (dbg & 8) pp_barrier(); else pp_barrier_vm();        // own DMA pieces of stage s + 1 landed  (dbg 8: timing experiment, wrong results)
+    if (dbg & 8) PPB(2); else PPB_VM(2);                    // own DMA pieces of stage s + 1 landed  (dbg 8: timing experiment, wrong results)
     multiply(no_dma, 0, 0);
-    pp_barrier();
+    PPB(3);
   }
+#ifdef CTCN_GEMM_STATS
+  if (lane == 0 && (wave & 3) == 0 && (blockIdx.x == 0 || blockIdx.x == 1000) && g_gemm_stats) {
+    long long *o = g_gemm_stats + ((blockIdx.x ? 2 : 0) + (wave >> 2)) * 16;
+    for (int i = 0; i < 4; ++i) { o[i] = gs_work[i]; o[4 + i] = gs_wait[i]; }
+    o[8] = clock64() - gs_t0; o[9] = nst - 1;
+  }
+#endif
   load_frags(nst - 1, 0);
   pp_barrier();
   multiply(no_dma, 0, 0);
@@ -940,6 +975,11 @@ __device__ __forceinline__ void planes256pp_tile(unsigned char *qsm, int bid, in
         }
       }
     }
+#ifdef CTCN_GEMM_STATS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && (wave & 3) == 0 && (blockIdx.x == 0 || blockIdx.x == 1000) && g_gemm_stats)
+    g_gemm_stats[((blockIdx.x ? 2 : 0) + (wave >> 2)) * 16 + 10] = clock64() - gs_entry;
+#endif
 }
 
 template <int WNT>
@@ -1556,9 +1596,10 @@ static int launch_planes256(hipStream_t st, int M, int N, int Kp, const unsigned
                             const unsigned short *bl, float *C, int ldc, float beta) {
   const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 128 * WNT);
   const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 128 * WNT * 64);
+  const int dbg = ctcn_get_option("gemm_dbg");
   auto kern = ctcn_get_option("gemm_pingpong") ? gemm_planes_nt256pp_kernel<WNT> : gemm_planes_nt256_kernel<WNT>;
   CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, tiles_m, tiles_n, ctcn_get_option("gemm_dbg"));
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, ldc, beta, tiles_m, tiles_n, dbg);
   return CTCN_OK;
 }
 

@@ -1,4 +1,4 @@
-"""Where does the 256-row plane tile spend its time?  gemm_dbg bit 0 = no C stores, bit 1 = no DMA loads (results invalid).  Development aid."""
+"""Where does the 256-row plane tile spend its time?  gemm_dbg bit 0 = no C stores, bit 3 = no vmcnt wait in front of the stage barrier (results invalid).  Development aid."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,8 @@ for M, N, K in [(25600, 2560, 640), (76800, 3072, 1024), (25600, 1280, 640)]:
     A = torch.randn(M, K, device=dev)
     B = torch.randn(N, K, device=dev)
     C = torch.empty(M, N, device=dev)
-    for dbg in (0, 1, 2, 3):
+    ref = None
+    for dbg in (0, 1, 8, 9):
         ops.set_option("gemm_dbg", dbg)
         for _ in range(3):
             ops.gemm(0, 1, M, N, K, A, K, B, K, C, N)
@@ -21,6 +22,7 @@ for M, N, K in [(25600, 2560, 640), (76800, 3072, 1024), (25600, 1280, 640)]:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
+        if dbg == 0: ref = C.clone()
         print("%6d x %5d x %5d  gemm_dbg=%d (%s)  %8.1f us  %7.1f TFLOP/s algorithmic (incl. split passes)" % (
-            M, N, K, dbg, ["as shipped", "no C stores", "no DMA loads", "no stores, no loads"][dbg], us, 2.0 * M * N * K / us / 1e6))
+            M, N, K, dbg, {0: "as shipped", 1: "no C stores", 8: "no vmcnt wait before the barrier (wrong results)", 9: "8 + no C stores"}[dbg] + ("" if dbg & 1 else (" equal=%s" % bool(torch.equal(C, ref)) if ref is not None else "")), us, 2.0 * M * N * K / us / 1e6))
     ops.set_option("gemm_dbg", 0)

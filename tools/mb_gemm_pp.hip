@@ -1,0 +1,49 @@
+// tools/mb_gemm_pp.hip -- phase accounting of the 256 x 256 ping-pong plane tile (gemm_planes_nt256pp_kernel<2>): in-kernel clock64 sums of the
+// cycles waves 0 (half A) and 4 (half B) spend working before each of the four barriers of a stage and waiting inside it (development aid).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/mb_gemm_pp.bin tools/mb_gemm_pp.hip ctc_pytorch_amd/csrc/core.hip
+#define CTCN_GEMM_STATS 1
+#include "../ctc_pytorch_amd/csrc/gemm.hip"
+#include <vector>
+extern "C" int ctcn_device_xcds(void) { return 8; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 76800, N = argc > 2 ? atoi(argv[2]) : 3072, Kp = argc > 3 ? atoi(argv[3]) : 1024;
+  unsigned short *ah, *al, *bh, *bl; float *C; long long *stats, h[64];
+  CK(hipMalloc(&ah, (size_t)M * Kp * 2)); CK(hipMalloc(&al, (size_t)M * Kp * 2)); CK(hipMalloc(&bh, (size_t)N * Kp * 2)); CK(hipMalloc(&bl, (size_t)N * Kp * 2));
+  CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&stats, sizeof(h))); CK(hipMemset(stats, 0, sizeof(h)));
+  {   // random finite bf16 bit patterns (sign, exponent 120..127, random mantissa): the clocks depend on the data
+    std::vector<unsigned short> v((size_t)M * Kp);
+    unsigned x = 12345u;
+    auto fill = [&](unsigned short *d, size_t n) { for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; v[i] = (unsigned short)(((x >> 16) & 0x807f) | ((120 + ((x >> 8) & 7)) << 7)); } return hipMemcpy(d, v.data(), n * 2, hipMemcpyHostToDevice); };
+    CK(fill(ah, (size_t)M * Kp)); CK(fill(al, (size_t)M * Kp)); CK(fill(bh, (size_t)N * Kp)); CK(fill(bl, (size_t)N * Kp));
+  }
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stats), &stats, sizeof(stats)));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+  const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 256 * 64);
+  for (int dbg : {0, 1}) {
+    auto kern = gemm_planes_nt256pp_kernel<2>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int it = 0; it < 3; ++it) {
+      if (it == 2) CK(hipEventRecord(e0, st));
+      hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, N, 0.0f, tiles_m, tiles_n, dbg);
+    }
+    CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
+    printf("M %d N %d Kp %d dbg %d: %.1f us, %.0f TFLOP/s algorithmic (planes given), %d tiles on %d CUs\n", M, N, Kp, dbg, ms * 1e3, 2.0 * M * N * Kp / (ms * 1e-3) / 1e12,
+           tiles_m * tiles_n, ctcn_device_cus());
+    const char *who[4] = {"block 0 wave 0 (half A)", "block 0 wave 4 (half B)", "block 1000 wave 0 (half A)", "block 1000 wave 4 (half B)"};
+    const char *site[4] = {"read (s,0)      ", "multiply + DMA  ", "read (s,1) + vm ", "multiply        "};
+    for (int w = 0; w < 4; ++w) {
+      const long long *o = h + w * 16;
+      const double n = (double)o[9];
+      if (n <= 0) continue;
+      printf("  %s: %.0f cycles per stage over %d stages; whole tile %lld cycles\n", who[w], o[8] / n, (int)n, o[10]);
+      for (int i = 0; i < 4; ++i) printf("      %s work %7.0f   barrier wait %7.0f\n", site[i], o[i] / n, o[4 + i] / n);
+    }
+  }
+  return 0;
+}
