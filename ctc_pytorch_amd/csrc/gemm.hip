@@ -1212,32 +1212,54 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
   // select on the loaded value made the wave wait for every load where it is issued, i.e. inside the multiply phase.  K % 4 == 0: a
   // piece is inside the matrix or outside it as a whole, and the ones outside are zeroed when they are split.
   const int arow0 = tid >> 2, ach = tid & 3;
-  const float *aptr0 = A + (size_t)min(m0 + arow0, M - 1) * lda, *aptr1 = A + (size_t)min(m0 + 128 + arow0, M - 1) * lda;
-  f32x4 av[4];
+  // aw[2 * r + h]: row r (arow0 / 128 + arow0) of the tile, floats 4 h .. 4 h + 3 of the thread's eight.  The loads are issued by hand (uniform
+  // base = first row of the tile + k0 in SGPRs, this lane's row / column as a 32-bit offset: no address arithmetic per stage) and waited for
+  // by hand (WAIT_A): with loads of two stages in flight hipcc puts s_waitcnt vmcnt(0) in front of the first use of the older ones, i.e.
+  // waits for the loads it has just issued
+  u32x4 aw[4];
+  const float *atile = A + (size_t)m0 * lda;
+  const unsigned arel[2] = {(unsigned)min(arow0, M - 1 - m0) * (unsigned)lda, (unsigned)min(128 + arow0, M - 1 - m0) * (unsigned)lda};
   auto load_a_piece = [&](int q, int k0) {                     // q = 2 * row + half
-    av[q] = *reinterpret_cast<const f32x4 *>((q >> 1 ? aptr1 : aptr0) + min(k0 + 8 * ach + 4 * (q & 1), K - 4));
+    // ONE asm statement per piece (an if / else around two of them lets the compiler merge the two "results" with register copies behind the
+    // branch -- of registers whose load is still in flight).  The stage that holds the end of K is clamped per lane (the split zeroes what
+    // lies beyond K); every other stage adds k0 on the scalar side
+    const int c = 8 * ach + 4 * (q & 1);
+    const bool whole = k0 + 32 <= K;
+    const float *sbase = atile + (whole ? k0 : 0);
+    const unsigned voff = (arel[q >> 1] + (unsigned)(whole ? c : min(k0 + c, K - 4))) * 4u;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(aw[q]) : "v"(voff), "s"(sbase) : "memory");
   };
-  auto store_a = [&](int buf, int k0) {
-    unsigned char *sb = qsm + buf * STAGE;
-    if (k0 + 32 > K) {
+#ifdef CTCN_GEMM_NOVM      // (timing experiment of tools/mb_gemm_pp.hip: wrong results)
+#define WAIT_A(N, r) asm volatile("" : "+v"(aw[2 * (r)]), "+v"(aw[2 * (r) + 1])::"memory")
+#else
+#define WAIT_A(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(aw[2 * (r)]), "+v"(aw[2 * (r) + 1])::"memory")
+#endif
+  // two neighbours at a time: hi = bf16(x) of both in one v_cvt_pk_bf16_f32, lo = bf16(x - hi) likewise (the split_bf16 values)
+  auto split_pair = [](float a, float b, unsigned &hw, unsigned &lw) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+    const f32x2_t r = {a - __uint_as_float(hw << 16), b - __uint_as_float(hw & 0xffff0000u)};
+    lw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+  };
+  // half h of row r (four consecutive floats) of the stage that starts at k0, in place: {x0, x1, x2, x3} -> {hi01, hi23, lo01, lo23}
+  auto convert_half = [&](int r, int h, int k0) {
+    u32x4 w = aw[2 * r + h];
+    if (k0 + 32 > K && k0 + 8 * ach + 4 * h >= K) w = (u32x4){0u, 0u, 0u, 0u};          // (K % 4 == 0: a 16-B piece is inside or outside as a whole)
+    unsigned h0, l0, h1, l1;
+    split_pair(__uint_as_float(w[0]), __uint_as_float(w[1]), h0, l0);
+    split_pair(__uint_as_float(w[2]), __uint_as_float(w[3]), h1, l1);
+    aw[2 * r + h] = (u32x4){h0, h1, l0, l1};
+  };
+  // the converted row r -> its 16-B chunk of either plane, as two 8-B halves each (straight from the register pairs convert_half left; four
+  // lanes per row: a row's 64 B are contiguous)
+  auto store_a_row = [&](int r, int buf) {
+    unsigned char *sb = qsm + buf * STAGE + qswz(arow0 + 128 * r, ach);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (k0 + 8 * ach + 4 * (q & 1) >= K) av[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      unsigned hw[4], lw[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned short h0, l0, h1, l1;
-        split_bf16(av[2 * r + (e >> 1)][(e & 1) * 2], h0, l0);
-        split_bf16(av[2 * r + (e >> 1)][(e & 1) * 2 + 1], h1, l1);
-        hw[e] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lw[e] = (unsigned)l0 | ((unsigned)l1 << 16);
-      }
-      const int o = qswz(arow0 + 128 * r, ach);
-      *reinterpret_cast<u32x4 *>(sb + o) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
-      *reinterpret_cast<u32x4 *>(sb + A_BYTES + o) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<u32x2 *>(sb + 8 * h) = (u32x2){aw[2 * r + h][0], aw[2 * r + h][1]};
+      *reinterpret_cast<u32x2 *>(sb + A_BYTES + 8 * h) = (u32x2){aw[2 * r + h][2], aw[2 * r + h][3]};
     }
   };
   const int nst = Kp / 32;
@@ -1265,9 +1287,18 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
     }
   };
   constexpr int NMM = 4 * WNT;
-  // MODE 0: bare MFMAs; 1: + the wave's 2*IB DMA pieces of B for the next stage; 2: + this thread's four 16-B loads of A two stages ahead
-  auto multiply = [&](auto mode, int k0, int buf) {
-    constexpr int MODE = decltype(mode)::value;
+  // One multiply phase: 3 * NMM MFMAs with the wave's other work of the stage between them, one item behind an MFMA:
+  //   WHICH 1 (first multiply of stage s):  DMA pieces of B(s+1), the two loads of A(s+2) row 0 | split of A(s+1) row 1 (loaded two phases ago)
+  //   WHICH 2 (second multiply):            the two loads of A(s+2) row 1 | split of A(s+2) row 0 (loaded two phases ago)
+  // HAS1: stage s + 1 exists, HAS2: stage s + 2 exists.  The float32 -> hi / lo split (12 VALU instructions per four floats) sits in the
+  // shadow of the wave's OWN MFMAs, ~5 cycles per instruction: in the read phases, next to the other half's MFMAs, the same instructions cost
+  // 15-20 cycles each (as one block of both rows that phase was 1 100-1 400 cycles long against the 430-500 of the MFMAs it is meant to hide
+  // behind; one row per read phase: 800 -- tools/mb_gemm_pp.hip).  In flight, oldest first (loads and DMA pieces return in order), when the
+  // split starts: first multiply: A(s+1) row 1 (2 loads), this phase's 2 IB DMA pieces and (HAS2) 2 loads; second: A(s+2) row 0 (2), row 1 (2)
+  auto multiply = [&](auto which, auto has1, auto has2, int s) {
+    constexpr int WHICH = decltype(which)::value;
+    constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
+    constexpr int CV0 = 3 * NMM - 3;                           // the two splits go behind the third- and second-to-last MFMA (the loads have had the longest time)
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -1278,44 +1309,88 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
           else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           const int n = t * NMM + i * WNT + j;
-          if ((n & 1) && (n >> 1) < (MODE == 1 ? 2 * IB : 4)) {
+          if (n < 2 * IB + 2 || n == CV0 || n == CV0 + 1) {
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MODE == 1) issue_b_piece(n >> 1, k0, buf);
-            if constexpr (MODE == 2) load_a_piece(n >> 1, k0);
+            if constexpr (WHICH == 1) {
+              if (HAS1 && n < 2 * IB) issue_b_piece(n, (s + 1) * 32, (s + 1) & 1);
+              if (HAS2 && n >= 2 * IB && n < 2 * IB + 2) load_a_piece(n - 2 * IB, (s + 2) * 32);
+              if (HAS1 && n == CV0) {
+                if constexpr (HAS2) { if constexpr (IB == 1) WAIT_A(4, 1); else WAIT_A(6, 1); }
+                else { if constexpr (IB == 1) WAIT_A(2, 1); else WAIT_A(4, 1); }
+              }
+              if (HAS1 && n >= CV0) convert_half(1, n - CV0, (s + 1) * 32);
+            } else {
+              if (HAS2 && n < 2) load_a_piece(2 + n, (s + 2) * 32);
+              if (HAS2 && n == CV0) WAIT_A(2, 0);
+              if (HAS2 && n >= CV0) convert_half(0, n - CV0, (s + 2) * 32);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
   };
-  constexpr std::integral_constant<int, 0> bare{};
-  constexpr std::integral_constant<int, 1> with_b{};
-  constexpr std::integral_constant<int, 2> with_a{};
-  // prologue: stage 0 into buffer 0 (A through the registers, B by DMA), A of stage 1 into the registers
+  constexpr std::integral_constant<int, 1> first{};
+  constexpr std::integral_constant<int, 2> second{};
+  constexpr std::integral_constant<bool, true> yes{};
+  constexpr std::integral_constant<bool, false> no{};
+  // prologue: stage 0 into buffer 0 (A through the registers, B by DMA), all of A(1) into the registers
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aw[q] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
   for (int q = 0; q < 4; ++q) load_a_piece(q, 0);
 #pragma unroll
   for (int n = 0; n < 2 * IB; ++n) issue_b_piece(n, 0, 0);
-  store_a(0, 0);
+  WAIT_A(0, 0); WAIT_A(0, 1);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    convert_half(r, 0, 0); convert_half(r, 1, 0);
+    store_a_row(r, 0);
+  }
   if (nst > 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the ds_writes have read aw)
 #pragma unroll
     for (int q = 0; q < 4; ++q) load_a_piece(q, 32);
+    WAIT_A(2, 0);
+    convert_half(0, 0, 32); convert_half(0, 1, 32);           // row 0 of A(1): the first read phase stores it; row 1 is split in the first multiply
   }
   pp_barrier_vm();
   if (wm == 1) pp_barrier();
-  auto stage = [&](int s, auto c0, auto c1) {
+#ifdef CTCN_GEMM_STATS
+  long long gs_work[4] = {0, 0, 0, 0}, gs_wait[4] = {0, 0, 0, 0};
+  const long long gs_t0 = clock64();
+  long long gs_prev = gs_t0;
+#endif
+  auto stage = [&](int s, auto has1, auto has2) {
+    constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
     load_frags(s, 0);
-    pp_barrier();
-    multiply(c0, (s + 1) * 32, (s + 1) & 1);
-    pp_barrier();
+    if constexpr (HAS1) store_a_row(0, (s + 1) & 1);          // A(s+1) row 0 (split in the previous multiply phase) -> the other buffer (last read two phases ago)
+    PPB(0);
+    multiply(first, has1, has2, s);
+    PPB(1);
     load_frags(s, 1);
-    if constexpr (decltype(c0)::value == 1) store_a((s + 1) & 1, (s + 1) * 32);   // A of stage s + 1 (loaded three phases ago) -> the other buffer (last read two phases ago)
-    pp_barrier_vm();                           // own DMA pieces of B(s + 1) landed
-    multiply(c1, (s + 2) * 32, 0);
-    pp_barrier();
+    if constexpr (HAS1) store_a_row(1, (s + 1) & 1);          // A(s+1) row 1 (split in the multiply phase just before)
+    // this wave's DMA pieces of B(s+1) have landed (the two loads of A(s+2) row 0, issued behind them, may still be in flight)
+#ifdef CTCN_GEMM_STATS
+    PPB_VM(2);
+#else
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    multiply(second, has1, has2, s);
+    PPB(3);
   };
   int s = 0;
-  for (; s + 2 < nst; ++s) stage(s, with_b, with_a);
-  if (s + 1 < nst) { stage(s, with_b, bare); ++s; }
-  stage(s, bare, bare);
+  for (; s + 2 < nst; ++s) stage(s, yes, yes);
+#ifdef CTCN_GEMM_STATS
+  if (lane == 0 && (wave & 3) == 0 && (blockIdx.x == 0 || blockIdx.x == 1000) && g_gemm_stats) {
+    long long *o = g_gemm_stats + ((blockIdx.x ? 2 : 0) + (wave >> 2)) * 16;
+    for (int i = 0; i < 4; ++i) { o[i] = gs_work[i]; o[4 + i] = gs_wait[i]; }
+    o[8] = clock64() - gs_t0; o[9] = nst - 2; o[10] = 0;
+  }
+#endif
+  if (s + 1 < nst) { stage(s, yes, no); ++s; }
+  stage(s, no, no);
   if (wm == 0) pp_barrier();
 #pragma unroll
   for (int i = 0; i < 4; ++i)

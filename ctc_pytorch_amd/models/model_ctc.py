@@ -46,7 +46,7 @@ class BatchRNN(nn.Module):
                                self.batch_norm.running_var, T * B, C, 1, self.batch_norm.training,
                                0.1 if self.batch_norm.momentum is None else self.batch_norm.momentum, self.batch_norm.eps)
             if self.batch_norm.training:
-                self.batch_norm.num_batches_tracked += 1
+                self.batch_norm.count_batch()
         if isinstance(self.rnn, (nn.LSTM, nn.GRU, nn.RNN)):
             # the dropout rides along with the recurrent layer (same mask, same values as self.dropout(x); the recurrence stores the
             # dropped output itself where its tagged-gather kernel applies)

@@ -87,7 +87,30 @@ class RNN(_RecurrentMixin, _tnn.RNN):
             raise NotImplementedError("only nonlinearity='tanh' (the nn.RNN default the reference uses)")
 
 
-class BatchNorm1d(_tnn.BatchNorm1d):
+class _LazyBatchCount:
+    """`num_batches_tracked += 1` is a 5-us launch per BatchNorm layer and training step that nothing on the device reads (momentum is never
+    None in the reference, model_ctc.py:29,47): the increments are counted on the host and added to the buffer when somebody looks --
+    `state_dict()` (checkpoints, train_ctc.py:205-207), `load_state_dict`, `flush_batch_count()`."""
+
+    def count_batch(self):
+        self.__dict__["_nbt_pending"] = self.__dict__.get("_nbt_pending", 0) + 1
+
+    def flush_batch_count(self):
+        n = self.__dict__.get("_nbt_pending", 0)
+        if n and self.num_batches_tracked is not None:
+            self.num_batches_tracked += n
+        self.__dict__["_nbt_pending"] = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_batch_count()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__["_nbt_pending"] = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
+
+class BatchNorm1d(_LazyBatchCount, _tnn.BatchNorm1d):
     """(N,C) or (N,C,L) input, statistics per channel over N*L -- BatchRNN feeds (T,C,B) views (model_ctc.py:29-32)."""
 
     fuse_relu = False
@@ -99,7 +122,7 @@ class BatchNorm1d(_tnn.BatchNorm1d):
         training = self.training
         mom = 0.1 if self.momentum is None else self.momentum
         if training:
-            self.num_batches_tracked += 1
+            self.count_batch()
         if x.dim() == 2:
             return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], C, 1, training,
                                   mom, self.eps, self.fuse_relu)
@@ -116,7 +139,7 @@ class BatchNorm1d(_tnn.BatchNorm1d):
                               mom, self.eps, self.fuse_relu)
 
 
-class BatchNorm2d(_tnn.BatchNorm2d):
+class BatchNorm2d(_LazyBatchCount, _tnn.BatchNorm2d):
     """NCHW, statistics per channel over (B,T,F) (model_ctc.py:47,63)."""
 
     fuse_relu = False
@@ -127,7 +150,7 @@ class BatchNorm2d(_tnn.BatchNorm2d):
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError("BatchNorm2d expects (B,C,H,W)")
         if self.training:
-            self.num_batches_tracked += 1
+            self.count_batch()
         mom = 0.1 if self.momentum is None else self.momentum
         x = ops.contiguous(x)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], x.shape[1],

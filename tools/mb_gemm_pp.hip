@@ -21,23 +21,45 @@ int main(int argc, char **argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stats), &stats, sizeof(stats)));
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-  const size_t lds = (size_t)2 * (2 * 256 * 64 + 2 * 256 * 64);
+  const int tiles_m = (M + 255) / 256;
+  const int mode = argc > 4 ? atoi(argv[4]) : 0;        // 0: plane tile <2>; 1: float32-A tile <1>; 2: float32-A tile <2>
+  float *Af = nullptr;
+  if (mode) {
+    CK(hipMalloc(&Af, (size_t)M * Kp * 4));
+    std::vector<float> v((size_t)M * Kp);
+    unsigned x = 777u;
+    for (auto &f : v) { x = x * 1664525u + 1013904223u; f = ((int)(x >> 8) % 2001 - 1000) * 1e-3f; }
+    CK(hipMemcpy(Af, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  }
   for (int dbg : {0, 1}) {
-    auto kern = gemm_planes_nt256pp_kernel<2>;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (mode && dbg) break;
+    const int wnt = mode == 1 ? 1 : 2;
+    const int tiles_nn = (N + 128 * wnt - 1) / (128 * wnt);
+    const size_t ldsb = (size_t)2 * (2 * 256 * 64 + 2 * 128 * wnt * 64);
     for (int it = 0; it < 3; ++it) {
       if (it == 2) CK(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, M, N, Kp, ah, al, bh, bl, C, N, 0.0f, tiles_m, tiles_n, dbg);
+      if (mode == 0) {
+        auto kern = gemm_planes_nt256pp_kernel<2>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_nn), dim3(512), ldsb, st, M, N, Kp, ah, al, bh, bl, C, N, 0.0f, tiles_m, tiles_nn, dbg);
+      } else if (mode == 1) {
+        auto kern = gemm_planes_nt256pp_af32_kernel<1>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_nn), dim3(512), ldsb, st, M, N, Kp, Kp, (const float *)Af, Kp, bh, bl, C, N, 0.0f, tiles_m, tiles_nn);
+      } else {
+        auto kern = gemm_planes_nt256pp_af32_kernel<2>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_nn), dim3(512), ldsb, st, M, N, Kp, Kp, (const float *)Af, Kp, bh, bl, C, N, 0.0f, tiles_m, tiles_nn);
+      }
     }
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(h, stats, sizeof(h), hipMemcpyDeviceToHost));
-    printf("M %d N %d Kp %d dbg %d: %.1f us, %.0f TFLOP/s algorithmic (planes given), %d tiles on %d CUs\n", M, N, Kp, dbg, ms * 1e3, 2.0 * M * N * Kp / (ms * 1e-3) / 1e12,
-           tiles_m * tiles_n, ctcn_device_cus());
+    printf("mode %d M %d N %d Kp %d dbg %d: %.1f us, %.0f TFLOP/s algorithmic, %d tiles on %d CUs\n", mode, M, N, Kp, dbg, ms * 1e3, 2.0 * M * N * Kp / (ms * 1e-3) / 1e12,
+           tiles_m * tiles_nn, ctcn_device_cus());
     const char *who[4] = {"block 0 wave 0 (half A)", "block 0 wave 4 (half B)", "block 1000 wave 0 (half A)", "block 1000 wave 4 (half B)"};
-    const char *site[4] = {"read (s,0)      ", "multiply + DMA  ", "read (s,1) + vm ", "multiply        "};
-    for (int w = 0; w < 4; ++w) {
+    const char *site[4] = {"read (s,0)             ", "multiply + B DMA       ", "read (s,1) + A cvt + vm", "multiply (+ A loads)   "};
+    for (int w = 0; w < 2; ++w) {
       const long long *o = h + w * 16;
       const double n = (double)o[9];
       if (n <= 0) continue;

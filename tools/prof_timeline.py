@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Timeline of the last training step in a rocprofv3 rocpd database: per stream, every kernel with its start offset,
-duration and the idle gap before it; plus per-stream busy / gap totals.  usage: prof_timeline.py results.db [min_gap_us]"""
+duration and the idle gap before it; plus per-stream busy / gap totals.  usage: prof_timeline.py results.db [min_gap_us] [all]
+(`all`: list the side streams' kernels as well, offsets from the same origin)"""
 import sqlite3
 import sys
 
 db = sys.argv[1]
 min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+show_all = "all" in sys.argv[3:]
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, stream_id, start, end from kernels order by start"))
 adam = [i for i, r in enumerate(rows) if r[0].startswith("adam_kernel") or "adam_kernel" in r[0]]
@@ -28,7 +30,7 @@ for sid, ks in sorted(streams.items(), key=lambda kv: -len(kv[1])):
         gap = (k[2] - prev) / 1e3
         if sid == main and gap > 0:
             gaps += gap
-        if sid == main and (gap >= min_gap or (k[3] - k[2]) / 1e3 >= 100):
+        if (sid == main or show_all) and (gap >= min_gap or (k[3] - k[2]) / 1e3 >= 100):
             print("%10.1f  gap %7.1f  dur %8.1f  %s" % ((k[2] - t0) / 1e3, gap, (k[3] - k[2]) / 1e3, k[0].replace("(anonymous namespace)::", "")[:70]))
         prev = max(prev, k[3])
     if sid == main:
