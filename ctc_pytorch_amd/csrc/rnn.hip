@@ -2736,6 +2736,10 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   // last pair would be left for the ~320 us tail after the last recurrence -- loses as well: 16 x 7 small launches on a third stream
   // finish ~1 ms after the recurrence (which slows from 1.48 to 1.57 ms next to them): 13.8 -> 14.3 ms.  The write-through stores and
   // the counters themselves cost 12 us per layer.)
+  // (Round 3, after the TN tile left the idle XCDs empty for the last ~0.5 ms of every backward recurrence: a TIMING-ONLY experiment -- three
+  // quarters of the dx product on a third stream on the idle XCDs, started by a clock-bounded sleeper kernel 0.7-1.0 ms into the recurrence,
+  // the remaining quarter behind the recurrence -- bounds what the real thing (progress counters, L2 write-back per chunk, wait kernels) could
+  // give: 13.39 -> 13.20-13.25 ms per cfg2 step, 1.2-1.4 %.  Not built a third time.)
   // dx = [da_fwd | da_rev] [W_ih_fwd ; W_ih_rev]: the reserve already holds both directions side by side (row = dirs*GH floats),
   // so with the two weight matrices stacked in the workspace one K = 2*GH product replaces two K = GH products and the
   // read-modify-write of dx between them (65 MB each way at cfg2)
