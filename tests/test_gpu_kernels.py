@@ -173,7 +173,9 @@ def test_gemm_bf16x3_big_tiles_equal_small_tiles(dev, M, N, K, ta, tb):
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb,beta", [(25600, 1280, 640, 0, 1, 0.0), (25600, 640, 2560, 0, 0, 0.0), (16390, 1030, 200, 0, 1, 1.0),
-                                                  (8192, 2560, 136, 0, 1, 0.0), (12800, 96, 320, 0, 0, 1.0), (76800, 1536, 1024, 0, 1, 0.0)])
+                                                  (8192, 2560, 136, 0, 1, 0.0), (12800, 96, 320, 0, 0, 1.0), (76800, 1536, 1024, 0, 1, 0.0),
+                                                  # the float32-A tile (A split while it is staged) with a K tail inside its last stage, ragged M: 256 x 128 and 256 x 256
+                                                  (16390, 384, 1300, 0, 1, 1.0), (25001, 512, 204, 0, 0, 0.0), (25600, 640, 36, 0, 1, 0.0)])
 def test_gemm_bf16x3_tile256_equals_tile128(dev, M, N, K, ta, tb, beta):
     """precision 1: the 256 x 256 / 256 x 128 workgroup tiles (global_load_lds staging, `gemm_tile256`, the default for
     activation-sized products) accumulate every output element over k in the same order with the same operands as the
