@@ -1469,7 +1469,7 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
   for (;;) {
     if (tid == 0) s_item = (int)atomicAdd(queue, 1u);
     __syncthreads();
-    const int item = s_item;
+    const int item = __builtin_amdgcn_readfirstlane(s_item);   // (uniform: everything derived from it -- tile origin, k window, buffer resources -- stays scalar)
     if (item >= nt * splits) return;
     const int z = item / nt, tile = item - z * nt;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -1487,17 +1487,27 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
 
     const int acol = m0 + 32 * wave + c4, bcol = n0 + 32 * bsub + c4;
     const bool a_ok = acol < M, b_ok = bcol < N;                 // (M, N multiples of 4: a piece is inside or outside as a whole)
-    const float *aptr = A + acol, *bptr = B + bcol;
     // pw[q]: piece q of the stage in flight (0..3: A, 4..: B) -- first the four floats as loaded, then (convert_piece) the packed
     // words {hi01, hi23, lo01, lo23} in the same registers.  A piece beyond M / N / the k window is loaded from 16 zero bytes next to
     // the queue word instead: the select is on the ADDRESS, so nothing waits for the data inside the multiply phase the loads are
     // issued in, and the split needs no special case
     u32x4 pw[4 + NB];
-    const float *zero16 = reinterpret_cast<const float *>(queue + 16);
+    // Round 3: the eight rows of a piece through a buffer resource made on the SCALAR side per piece -- base = the piece's first row, extent =
+    // its rows inside the k window -- and ONE loop-invariant lane offset (row krow, this lane's columns; 0xfffffff0 for a lane whose columns lie
+    // beyond M / N): rows past the window and lanes past the edge read zeros from the range check, and the multiply phase that issues the
+    // loads loses the ~18 VALU instructions per load of 64-bit address arithmetic and selects it carried (1 320 -> ~1 000 cycles,
+    // tools/mb_gemm_pp.hip)
+    const unsigned voff_a = a_ok ? (unsigned)((krow * lda + acol) * 4) : 0xfffffff0u;
+    const unsigned voff_b = b_ok ? (unsigned)((krow * ldb + bcol) * 4) : 0xfffffff0u;
     auto load_piece = [&](int q, int k0) {                       // k0 = first k of the stage
-      const int k = q < 4 ? k0 + 8 * q + krow : k0 + bk0 + 8 * (q - 4) + krow;
-      const float *src = q < 4 ? aptr + (size_t)k * lda : bptr + (size_t)k * ldb;
-      pw[q] = *reinterpret_cast<const u32x4 *>((q < 4 ? a_ok : b_ok) && k < kend ? src : zero16);
+      const int kr = q < 4 ? k0 + 8 * q : k0 + bk0 + 8 * (q - 4);                      // first of the piece's eight rows (uniform)
+      const int ld = q < 4 ? lda : ldb;
+      const float *base = (q < 4 ? A : B) + (size_t)min(kr, K - 1) * ld;
+      int rows = min(8, kend - kr);
+      asm volatile("" : "+s"(rows));                             // (kept on the scalar side: as max(0, min(8, .)) it becomes a v_med3 and the resource a waterfall loop)
+      const int nrec = max(0, rows) * ld * 4;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, nrec, 0x00020000);
+      pw[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, q < 4 ? voff_a : voff_b, 0, 0);
     };
     // two neighbours at a time: hi = bf16(x) of both in one v_cvt_pk_bf16_f32, lo = bf16(x - hi) likewise (the split_bf16 values)
     auto split_pair = [](float a, float b, unsigned &hw, unsigned &lw) {
@@ -1582,20 +1592,32 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
     if (wm == 1) pp_barrier();
     // a stage = four phases: read (s, k-half 0) | multiply + split of the pieces of stage s + 1 (loaded two phases ago) |
     //                        read (s, 1) + LDS stores of stage s + 1 (buffer last read two phases ago) | multiply + loads of stage s + 2
+#ifdef CTCN_GEMM_STATS
+    long long gs_work[4] = {0, 0, 0, 0}, gs_wait[4] = {0, 0, 0, 0};
+    const long long gs_t0 = clock64();
+    long long gs_prev = gs_t0;
+#endif
     auto stage = [&](int s, auto do_store, auto c1) {
       load_frags(s, 0);
-      pp_barrier();
+      PPB(0);
       if constexpr (decltype(do_store)::value == 1) multiply(with_split, 0);
       else multiply(bare, 0);
-      pp_barrier();
+      PPB(1);
       load_frags(s, 1);
       if constexpr (decltype(do_store)::value == 1) store_ab((s + 1) & 1);
-      pp_barrier();
+      PPB(2);
       multiply(c1, kbeg + (s + 2) * 32);
-      pp_barrier();
+      PPB(3);
     };
     int s = 0;
     for (; s + 2 < nst; ++s) stage(s, with_loads, with_loads);
+#ifdef CTCN_GEMM_STATS
+    if (lane == 0 && (wave & 3) == 0 && item == 0 && g_gemm_stats) {
+      long long *o = g_gemm_stats + (wave >> 2) * 16;
+      for (int i = 0; i < 4; ++i) { o[i] = gs_work[i]; o[4 + i] = gs_wait[i]; }
+      o[8] = clock64() - gs_t0; o[9] = nst - 2; o[10] = 0;
+    }
+#endif
     if (s + 1 < nst) { stage(s, with_loads, bare); ++s; }
     stage(s, bare, bare);
     if (wm == 0) pp_barrier();
@@ -1760,7 +1782,8 @@ static thread_local int g_b_shift = 0;      // one-shot, set by ctcn_gemm_shift_
 static bool tn_eligible(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, int precision, const void *ws,
                         size_t ws_bytes) {
   return precision == 1 && transA && !transB && ws && ws_bytes >= 1024 && ctcn_get_option("gemm_tn") != 0 && M >= 128 && N >= 32 && K >= 1024 &&
-         M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+         M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
+         lda < (1 << 24) && ldb < (1 << 24);                     // (eight rows of a piece behind one 32-bit buffer offset)
 }
 // xcd_allow: 0 = whole device; otherwise (precision 1 plane path only) the XCDs the GEMM workgroups may run on
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,

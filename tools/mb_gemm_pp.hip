@@ -22,7 +22,7 @@ int main(int argc, char **argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int tiles_m = (M + 255) / 256;
-  const int mode = argc > 4 ? atoi(argv[4]) : 0;        // 0: plane tile <2>; 1: float32-A tile <1>; 2: float32-A tile <2>
+  const int mode = argc > 4 ? atoi(argv[4]) : 0;        // 0: plane tile <2>; 1: float32-A tile <1>; 2: float32-A tile <2>; 3: TN tile <2> (M, N = the output, Kp = the contraction)
   float *Af = nullptr;
   if (mode) {
     CK(hipMalloc(&Af, (size_t)M * Kp * 4));
@@ -31,6 +31,15 @@ int main(int argc, char **argv) {
     for (auto &f : v) { x = x * 1664525u + 1013904223u; f = ((int)(x >> 8) % 2001 - 1000) * 1e-3f; }
     CK(hipMemcpy(Af, v.data(), v.size() * 4, hipMemcpyHostToDevice));
   }
+  float *Bf = nullptr, *part = nullptr; unsigned *queue = nullptr;
+  if (mode == 3) {     // TN tile <2>: C (M x N) = A^T B, A: Kp x M, B: Kp x N float32 (contraction-major), split-K over the device
+    CK(hipMalloc(&Bf, (size_t)N * Kp * 4)); CK(hipMemset(Bf, 0, (size_t)N * Kp * 4));
+    std::vector<float> v((size_t)N * Kp);
+    unsigned x = 4242u;
+    for (auto &f : v) { x = x * 1664525u + 1013904223u; f = ((int)(x >> 8) % 2001 - 1000) * 1e-3f; }
+    CK(hipMemcpy(Bf, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&part, (size_t)64 * M * N * 4)); CK(hipMalloc(&queue, 256));
+  }
   for (int dbg : {0, 1}) {
     if (mode && dbg) break;
     const int wnt = mode == 1 ? 1 : 2;
@@ -38,7 +47,13 @@ int main(int argc, char **argv) {
     const size_t ldsb = (size_t)2 * (2 * 256 * 64 + 2 * 128 * wnt * 64);
     for (int it = 0; it < 3; ++it) {
       if (it == 2) CK(hipEventRecord(e0, st));
-      if (mode == 0) {
+      if (mode == 3) {
+        auto kern = gemm_tn_f32_pp_kernel<2>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        const int nt = tiles_m * tiles_nn, splits = std::max(1, 256 / nt), kchunk = ((Kp + splits - 1) / splits + 31) / 32 * 32;
+        CK(hipMemsetAsync(queue, 0, 128, st));
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), ldsb, st, M, N, Kp, (const float *)Af, M, (const float *)Bf, N, C, N, 0.0f, kchunk, (Kp + kchunk - 1) / kchunk, part, tiles_m, tiles_nn, 0xffu, queue);
+      } else if (mode == 0) {
         auto kern = gemm_planes_nt256pp_kernel<2>;
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_nn), dim3(512), ldsb, st, M, N, Kp, ah, al, bh, bl, C, N, 0.0f, tiles_m, tiles_nn, dbg);
@@ -58,7 +73,7 @@ int main(int argc, char **argv) {
     printf("mode %d M %d N %d Kp %d dbg %d: %.1f us, %.0f TFLOP/s algorithmic, %d tiles on %d CUs\n", mode, M, N, Kp, dbg, ms * 1e3, 2.0 * M * N * Kp / (ms * 1e-3) / 1e12,
            tiles_m * tiles_nn, ctcn_device_cus());
     const char *who[4] = {"block 0 wave 0 (half A)", "block 0 wave 4 (half B)", "block 1000 wave 0 (half A)", "block 1000 wave 4 (half B)"};
-    const char *site[4] = {"read (s,0)             ", "multiply + B DMA       ", "read (s,1) + A cvt + vm", "multiply (+ A loads)   "};
+    const char *site[4] = {"read (s,0)             ", "multiply 1 (+ DMA / split)", "read (s,1) (+ LDS stores)", "multiply 2 (+ loads)   "};
     for (int w = 0; w < 2; ++w) {
       const long long *o = h + w * 16;
       const double n = (double)o[9];
