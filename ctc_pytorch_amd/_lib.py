@@ -47,10 +47,10 @@ _SIGS = {
     "ctcn_rnn_bwd_dropout": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, P, P, Z, P, F, U, U, P]),
     "ctcn_rnn_bwd_weights": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, F, I, ctypes.c_uint, P, Z, P]),
     "ctcn_bn_ws_bytes": (Z, [I, I, I]),
-    "ctcn_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, Z, P]),
+    "ctcn_bn_fwd_train": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, Z, P, P]),
     "ctcn_bn_fwd_eval": (I, [P, P, P, P, P, P, I, I, I, F, I, P]),
     "ctcn_bn_fwd_sums": (I, [P, P, I, I, I, P, Z, P]),
-    "ctcn_bn_fwd_finish": (I, [P, P, P, P, P, P, P, P, P, D, I, I, I, F, F, I, P]),
+    "ctcn_bn_fwd_finish": (I, [P, P, P, P, P, P, P, P, P, D, I, I, I, F, F, I, P, P]),
     "ctcn_bn_bwd_sums": (I, [P, P, P, P, P, P, I, I, I, I, P, Z, P]),
     "ctcn_bn_bwd_finish": (I, [P, P, P, P, P, P, P, P, P, P, P, D, I, I, I, I, F, P, Z, P]),
     "ctcn_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P, Z, P]),

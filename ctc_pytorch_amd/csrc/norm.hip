@@ -144,9 +144,10 @@ __global__ __launch_bounds__(256) void colreduce_nchw_kernel(F f, int outer, int
 
 __global__ void bn_finalize_stats_kernel(const double *__restrict__ part, int nchunks, int C, double count, float eps,
                                          float momentum, float *__restrict__ mean_out, float *__restrict__ rstd_out,
-                                         float *__restrict__ rm, float *__restrict__ rv) {
+                                         float *__restrict__ rm, float *__restrict__ rv, long long *__restrict__ batches) {
   // one wave per channel: lanes take the chunk partials k = lane, lane+64, ... in order, then a fixed shuffle tree
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (batches && blockIdx.x == 0 && threadIdx.x == 0) *batches += 1;          // nn.BatchNorm's num_batches_tracked: no launch of its own
   if (c >= C) return;
   double s = 0.0, ss = 0.0;
   for (int k = lane; k < nchunks; k += 64) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
@@ -345,7 +346,7 @@ extern "C" size_t ctcn_bn_ws_bytes(int outer, int C, int inner) {
 
 extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                                  float *running_var, float *save_mean, float *save_rstd, int outer, int C, int inner,
-                                 float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream) {
+                                 float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream, long long *num_batches_tracked) {
   CTCN_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && ws, "ctcn_bn_fwd_train: null pointer");
   CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_fwd_train: bad dims");
   if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_fwd_train: workspace too small"); return CTCN_EWORKSPACE; }
@@ -356,7 +357,7 @@ extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, c
   CTCN_LAUNCH_CHECK();
   const double count = (double)outer * inner;
   hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, count, eps, momentum,
-                     save_mean, save_rstd, running_mean, running_var);
+                     save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
   launch_bn_apply(st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C, inner, relu);
@@ -382,12 +383,12 @@ extern "C" int ctcn_bn_fwd_sums(const float *x, double *sums, int outer, int C, 
 
 extern "C" int ctcn_bn_fwd_finish(const float *x, float *y, const float *gamma, const float *beta, float *running_mean, float *running_var,
                                   float *save_mean, float *save_rstd, const double *sums, double count_total, int outer, int C, int inner,
-                                  float eps, float momentum, int relu, void *stream) {
+                                  float eps, float momentum, int relu, void *stream, long long *num_batches_tracked) {
   CTCN_REQUIRE(x && y && gamma && beta && save_mean && save_rstd && sums, "ctcn_bn_fwd_finish: null pointer");
   CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0 && count_total >= (double)outer * inner, "ctcn_bn_fwd_finish: bad dims / count");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, sums, 1, C, count_total, eps, momentum, save_mean,
-                     save_rstd, running_mean, running_var);
+                     save_rstd, running_mean, running_var, num_batches_tracked);
   CTCN_LAUNCH_CHECK();
   const size_t total = (size_t)outer * C * inner;
   launch_bn_apply(st, x, y, gamma, beta, save_mean, save_rstd, eps, 0, total, C, inner, relu);

@@ -44,9 +44,8 @@ class BatchRNN(nn.Module):
             T, B, C = x.shape
             x = ops.batch_norm(ops.contiguous(x), self.batch_norm.weight, self.batch_norm.bias, self.batch_norm.running_mean,
                                self.batch_norm.running_var, T * B, C, 1, self.batch_norm.training,
-                               0.1 if self.batch_norm.momentum is None else self.batch_norm.momentum, self.batch_norm.eps)
-            if self.batch_norm.training:
-                self.batch_norm.count_batch()
+                               0.1 if self.batch_norm.momentum is None else self.batch_norm.momentum, self.batch_norm.eps,
+                               num_batches_tracked=self.batch_norm.num_batches_tracked)
         if isinstance(self.rnn, (nn.LSTM, nn.GRU, nn.RNN)):
             # the dropout rides along with the recurrent layer (same mask, same values as self.dropout(x); the recurrence stores the
             # dropped output itself where its tagged-gather kernel applies)

@@ -87,30 +87,7 @@ class RNN(_RecurrentMixin, _tnn.RNN):
             raise NotImplementedError("only nonlinearity='tanh' (the nn.RNN default the reference uses)")
 
 
-class _LazyBatchCount:
-    """`num_batches_tracked += 1` is a 5-us launch per BatchNorm layer and training step that nothing on the device reads (momentum is never
-    None in the reference, model_ctc.py:29,47): the increments are counted on the host and added to the buffer when somebody looks --
-    `state_dict()` (checkpoints, train_ctc.py:205-207), `load_state_dict`, `flush_batch_count()`."""
-
-    def count_batch(self):
-        self.__dict__["_nbt_pending"] = self.__dict__.get("_nbt_pending", 0) + 1
-
-    def flush_batch_count(self):
-        n = self.__dict__.get("_nbt_pending", 0)
-        if n and self.num_batches_tracked is not None:
-            self.num_batches_tracked += n
-        self.__dict__["_nbt_pending"] = 0
-
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        self.flush_batch_count()
-        super()._save_to_state_dict(destination, prefix, keep_vars)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self.__dict__["_nbt_pending"] = 0
-        super()._load_from_state_dict(*args, **kwargs)
-
-
-class BatchNorm1d(_LazyBatchCount, _tnn.BatchNorm1d):
+class BatchNorm1d(_tnn.BatchNorm1d):
     """(N,C) or (N,C,L) input, statistics per channel over N*L -- BatchRNN feeds (T,C,B) views (model_ctc.py:29-32)."""
 
     fuse_relu = False
@@ -121,25 +98,24 @@ class BatchNorm1d(_LazyBatchCount, _tnn.BatchNorm1d):
         C = self.num_features
         training = self.training
         mom = 0.1 if self.momentum is None else self.momentum
-        if training:
-            self.count_batch()
+        nbt = self.num_batches_tracked              # (+= 1 by the statistics kernel in training: no launch of its own)
         if x.dim() == 2:
             return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], C, 1, training,
-                                  mom, self.eps, self.fuse_relu)
+                                  mom, self.eps, self.fuse_relu, nbt)
         if x.dim() != 3 or x.shape[1] != C:
             raise ValueError("BatchNorm1d expects (N,C) or (N,C,L)")
         xt = x.transpose(1, 2)                     # (N,L,C)
         if xt.is_contiguous():                     # the reference's x.transpose(-1,-2) of a (T,B,C) tensor
             N, Lq = xt.shape[0], xt.shape[1]
             y = ops.batch_norm(xt, self.weight, self.bias, self.running_mean, self.running_var, N * Lq, C, 1, training, mom,
-                               self.eps, self.fuse_relu)
+                               self.eps, self.fuse_relu, nbt)
             return y.view(N, Lq, C).transpose(1, 2)
         x = ops.contiguous(x)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], C, x.shape[2], training,
-                              mom, self.eps, self.fuse_relu)
+                              mom, self.eps, self.fuse_relu, nbt)
 
 
-class BatchNorm2d(_LazyBatchCount, _tnn.BatchNorm2d):
+class BatchNorm2d(_tnn.BatchNorm2d):
     """NCHW, statistics per channel over (B,T,F) (model_ctc.py:47,63)."""
 
     fuse_relu = False
@@ -149,12 +125,10 @@ class BatchNorm2d(_LazyBatchCount, _tnn.BatchNorm2d):
             raise NotImplementedError("affine=True, track_running_stats=True only")
         if x.dim() != 4 or x.shape[1] != self.num_features:
             raise ValueError("BatchNorm2d expects (B,C,H,W)")
-        if self.training:
-            self.count_batch()
         mom = 0.1 if self.momentum is None else self.momentum
         x = ops.contiguous(x)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], x.shape[1],
-                              x.shape[2] * x.shape[3], self.training, mom, self.eps, self.fuse_relu)
+                              x.shape[2] * x.shape[3], self.training, mom, self.eps, self.fuse_relu, self.num_batches_tracked)
 
 
 class Linear(_tnn.Linear):

@@ -512,7 +512,7 @@ def set_sync_bn(reducer):
 
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, outer, C, inner, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, rm, rv, outer, C, inner, training, momentum, eps, relu, nbt=None):
         _need_gpu(x, gamma, beta)
         ctx.gviews = (_gview(gamma), _gview(beta))
         x = _f32c(x)
@@ -529,7 +529,7 @@ class _BatchNorm(torch.autograd.Function):
             total = float(_sync_bn["reduce"](sums, outer * inner))
             _lib.check(L.ctcn_bn_fwd_finish(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(mean), _ptr(rstd),
                                             _ptr(sums), total, outer, C, inner, float(eps), float(momentum), int(relu),
-                                            _lib.stream_ptr()), "bn_fwd_finish")
+                                            _lib.stream_ptr(), _ptr(nbt)), "bn_fwd_finish")
             ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
             ctx.train_mode = True
             ctx.sync = (_sync_bn["reduce"], total)
@@ -538,7 +538,7 @@ class _BatchNorm(torch.autograd.Function):
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
             w, wp, wn = _ws(x)
             _lib.check(L.ctcn_bn_fwd_train(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(mean), _ptr(rstd),
-                                           outer, C, inner, float(eps), float(momentum), int(relu), wp, wn, _lib.stream_ptr()),
+                                           outer, C, inner, float(eps), float(momentum), int(relu), wp, wn, _lib.stream_ptr(), _ptr(nbt)),
                        "bn_fwd_train")
             ctx.save_for_backward(x, y if relu else None, gamma, mean, rstd)
             ctx.train_mode = True
@@ -584,11 +584,17 @@ class _BatchNorm(torch.autograd.Function):
                                               _lib.stream_ptr()), "bn_bwd")
         if into_flat:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum=0.1, eps=1e-5, relu=False):
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum, eps, relu)
+def batch_norm(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum=0.1, eps=1e-5, relu=False, num_batches_tracked=None):
+    """num_batches_tracked: nn.BatchNorm's int64 counter (device tensor) or None -- in training the statistics kernel adds 1 to it (no launch
+    of its own)."""
+    if num_batches_tracked is not None and (not training or num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        if training:
+            num_batches_tracked += 1
+        num_batches_tracked = None
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum, eps, relu, num_batches_tracked)
 
 
 class _ReLU(torch.autograd.Function):

@@ -205,7 +205,8 @@ int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int dirs, const f
 size_t ctcn_bn_ws_bytes(int outer, int C, int inner);
 int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                       float *running_var, float *save_mean, float *save_rstd, int outer, int C, int inner,
-                      float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream);
+                      float eps, float momentum, int relu, void *ws, size_t ws_bytes, void *stream,
+                      long long *num_batches_tracked /* device int64 or NULL: += 1 by the statistics kernel (nn.BatchNorm's counter, no launch of its own) */);
 /* Synchronised BatchNorm for data-parallel training (statistics over the global batch): every rank calls
  * _sums (per-channel fp64 [C][2]: sum x, sum x^2 / sum dy', sum dy'*xhat), the host all-reduces the 2*C doubles, and
  * _finish normalises with count_total = global number of elements per channel.  In the backward finish local_sums feed
@@ -213,7 +214,8 @@ int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float 
 int ctcn_bn_fwd_sums(const float *x, double *sums, int outer, int C, int inner, void *ws, size_t ws_bytes, void *stream);
 int ctcn_bn_fwd_finish(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                        float *running_var, float *save_mean, float *save_rstd, const double *sums, double count_total,
-                       int outer, int C, int inner, float eps, float momentum, int relu, void *stream);
+                       int outer, int C, int inner, float eps, float momentum, int relu, void *stream,
+                       long long *num_batches_tracked /* as in ctcn_bn_fwd_train */);
 int ctcn_bn_bwd_sums(const float *x, const float *y, const float *dy, const float *save_mean, const float *save_rstd,
                      double *sums, int outer, int C, int inner, int relu, void *ws, size_t ws_bytes, void *stream);
 int ctcn_bn_bwd_finish(const float *x, const float *y, const float *dy, const float *gamma, const float *save_mean,

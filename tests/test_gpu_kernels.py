@@ -559,7 +559,7 @@ def test_sync_batchnorm_two_shards_equal_full_batch(dev, rows, C, inner, relu):
         yy, mean, rstd = torch.empty_like(xs), torch.empty(C, device=dev), torch.empty(C, device=dev)
         rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         _lib.check(L.ctcn_bn_fwd_finish(ptr(xs), ptr(yy), ptr(g), ptr(b), ptr(rm2), ptr(rv2), ptr(mean), ptr(rstd), ptr(glob), total,
-                                        xs.shape[0], C, inner, 1e-5, 0.1, int(relu), st), "finish")
+                                        xs.shape[0], C, inner, 1e-5, 0.1, int(relu), st, None), "finish")
         ys.append(yy); means.append(mean); rstds.append(rstd); rms.append(rm2); rvs.append(rv2)
     assert maxabs(torch.cat(ys), y) < 2e-6
     assert maxabs(rms[0], rm) < 1e-7 and maxabs(rvs[1], rv) < 1e-6 and maxabs(rms[0], rms[1]) == 0

@@ -488,25 +488,3 @@ def test_decode_driver_picks_the_decoder_from_the_yaml_keys(tmp_path):
         TE.main({"use_gpu": False})
 
 
-
-def test_batchnorm_batch_count_is_lazy_but_exact_in_the_state_dict():
-    """num_batches_tracked is counted on the host and lands in the buffer whenever a state dict is taken (nn._LazyBatchCount): the
-    checkpoint of train_ctc.py:205-207 carries the same count torch.nn.BatchNorm writes, without a launch per layer and step."""
-    import torch
-    from ctc_pytorch_amd import nn
-    for cls in (nn.BatchNorm1d, nn.BatchNorm2d):
-        bn = cls(3)
-        for _ in range(4):
-            bn.count_batch()
-        assert int(bn.num_batches_tracked) == 0
-        sd = bn.state_dict()
-        assert int(sd["num_batches_tracked"]) == 4 and int(bn.num_batches_tracked) == 4
-        bn.count_batch()
-        assert int(bn.state_dict()["num_batches_tracked"]) == 5
-        bn.count_batch()
-        sd["num_batches_tracked"] = torch.tensor(9)
-        bn.load_state_dict(sd)                        # loading replaces the count, pending increments included
-        assert int(bn.state_dict()["num_batches_tracked"]) == 9
-        wrapped = torch.nn.Sequential(bn)
-        bn.count_batch()
-        assert int(wrapped.state_dict()["0.num_batches_tracked"]) == 10
