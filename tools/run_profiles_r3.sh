@@ -23,6 +23,12 @@ timeout 400 python bench.py --workload cfg2 --precision 0 --steps 10 --warmup 3 
 timeout 600 python bench.py --steps 20 --warmup 3 > $O/r03_bench_default.json 2> $O/bench_default.err
 ( timeout 200 ./tools/mb_bwd2.bin 320 32 800 > $O/r03_mb_bwd2_cfg2.txt 2>&1 ); ( timeout 100 ./tools/mb_bwd2.bin 384 8 400 > $O/r03_mb_bwd2_ref_yaml.txt 2>&1 ); ( timeout 100 ./tools/mb_bwd2.bin 512 64 1200 > $O/r03_mb_bwd2_h512.txt 2>&1 )
 ( timeout 60 ./tools/mb_mfma16.bin > $O/r03_mb_mfma16.txt 2>&1 ); ( timeout 60 ./tools/mb_store.bin > $O/r03_mb_store.txt 2>&1 )
+{ echo "# tools/mb_gemm_pp.bin: cycles per barrier site (work before the barrier | wait inside it), waves 0 and 4 of block 0, instrumented build"
+  echo "## plane tile 256 x 256 (gemm_planes_nt256pp_kernel<2>)"; timeout 60 ./tools/mb_gemm_pp.bin 76800 3072 1024 0
+  echo "## float32-A tile 256 x 128 (dx GEMM of cfg2)"; timeout 60 ./tools/mb_gemm_pp.bin 25600 640 2560 1
+  echo "## float32-A tile 256 x 256 (the bench probe shape)"; timeout 60 ./tools/mb_gemm_pp.bin 25600 1280 640 2
+  echo "## TN tile 256 x 256 (dW_ih of cfg4)"; timeout 100 ./tools/mb_gemm_pp.bin 3072 1024 76800 3
+  echo "## bare MFMA issue rate (tools/mb_mfma.bin)"; timeout 60 ./tools/mb_mfma.bin; } > $O/r03_mb_gemm_pp.txt 2>&1
 rm -rf $O/stats/*/*.db $O/fetch $O/write $O/fetch2 $O/write2 2>/dev/null
 ls -la $O
 for f in r03_bench_default r03_bench_cfg1 r03_bench_cfg3 r03_bench_cfg4 r03_bench_ref_yaml r03_bench_cfg2_f32; do python - "$O/$f.json" <<'PY'
