@@ -82,6 +82,7 @@ _SIGS = {
     "ctcn_rnn_last_kernel": (ctypes.c_char_p, [I]),
     "ctcn_beam_ws_bytes": (Z, [I, I, I, I]),
     "ctcn_beam_decode": (I, [P, I, P, P, D, I, I, P, P, P, P, I, I, I, P, Z, P]),
+    "ctcn_beam_decode_nbest": (I, [P, I, P, P, D, I, I, I, P, P, P, P, P, I, I, I, P, Z, P]),
 }
 
 

@@ -59,6 +59,7 @@ struct BeamState {   // one copy of the beam (BHat) in LDS
 struct BeamArgs {
   const float *x; int input_is_prob; const int32_t *lens; const double *lm; double alpha; int W, blank;
   int32_t *out_ids, *out_len; double *out_score; int32_t *status; int T, B, V;
+  int nbest; int32_t *out_count;        // ctcn_beam_decode_nbest: the `nbest` best labellings per utterance (outputs [B][nbest]...), their number in out_count
   unsigned long long *ht_keys; int *ht_ids; int *node_par; int *node_sym; double *cand_global;
   int ht_size, max_nodes, cand_in_lds;
 };
@@ -232,23 +233,40 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
     int st = 0;
     for (int r = 0; r < nb; ++r) if (L.len[r] == 0) st = 1;          // classes[y[-1]] on () -> IndexError
     if (s_nodes > a.max_nodes) st = 3;
-    int best = -1; double bestv = 0.0;
+    const int NB = a.nbest;
     if (st == 0) {
+      // normalised scores (BeamSearch.py:147: prTotal / labelling length), then `last.sort()[0:nbest]` (:150, the reference keeps [0]): a stable
+      // descending sort -- among equal scores the earlier entry (the order of BHat) comes first.  L.pT is reused for the scores, L.par as "taken"
       for (int r = 0; r < nb; ++r) {
         const double pr = L.pT[r] + a.lm[(size_t)L.last[r] * (V + 1) + V] * a.alpha;
         const double tot = log_add_prob(LOG_ZERO, pr);
         const int ln = L.len[r];
-        const double nv = tot * (1.0 / (ln ? ln : 1));
-        if (best < 0 || nv > bestv) { best = r; bestv = nv; }
+        L.pT[r] = tot * (1.0 / (ln ? ln : 1));
+        L.par[r] = 0;
       }
-      const int ln = L.len[best];
-      a.out_len[b] = ln; a.out_score[b] = bestv;
-      int n = L.node[best];
-      for (int i = ln - 1; i >= 0; --i) { a.out_ids[(size_t)b * T + i] = nsym[n]; n = npar[n]; }
-    } else { a.out_len[b] = 0; a.out_score[b] = 0.0; }
+      const int nout = min(NB, nb);
+      for (int k = 0; k < nout; ++k) {
+        int best = -1; double bestv = 0.0;
+        for (int r = 0; r < nb; ++r)
+          if (!L.par[r] && (best < 0 || L.pT[r] > bestv)) { best = r; bestv = L.pT[r]; }
+        L.par[best] = 1;
+        const int ln = L.len[best];
+        const size_t o = (size_t)b * NB + k;
+        a.out_len[o] = ln; a.out_score[o] = bestv;
+        int n = L.node[best];
+        for (int i = ln - 1; i >= 0; --i) { a.out_ids[o * T + i] = nsym[n]; n = npar[n]; }
+      }
+      for (int k = nout; k < NB; ++k) { a.out_len[(size_t)b * NB + k] = 0; a.out_score[(size_t)b * NB + k] = 0.0; }
+      if (a.out_count) a.out_count[b] = nout;
+    } else {
+      for (int k = 0; k < NB; ++k) { a.out_len[(size_t)b * NB + k] = 0; a.out_score[(size_t)b * NB + k] = 0.0; }
+      if (a.out_count) a.out_count[b] = 0;
+    }
     a.status[b] = st;
   } else if (tid == 0) {
-    a.out_len[b] = 0; a.out_score[b] = 0.0; a.status[b] = status;
+    for (int k = 0; k < a.nbest; ++k) { a.out_len[(size_t)b * a.nbest + k] = 0; a.out_score[(size_t)b * a.nbest + k] = 0.0; }
+    if (a.out_count) a.out_count[b] = 0;
+    a.status[b] = status;
   }
 }
 
@@ -282,6 +300,7 @@ struct FastArgs {
   const double *lgd; const float *pb; const unsigned char *zf;
   const int32_t *lens; const double *lm; double alpha; int W, blank;
   int32_t *out_ids, *out_len; double *out_score; int32_t *status; int T, B, V;
+  int nbest; int32_t *out_count;
   unsigned long long *ht; int *node_par; int *node_sym; int ht_size, max_nodes;
   int trie_slots;       // LDS trie slots (power of two)
 #ifdef CTCN_BEAM_STATS
@@ -793,26 +812,42 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     int st = 0;
     for (int r = 0; r < nb; ++r) if (f_len[r] == 0) st = 1;          // classes[y[-1]] on () -> IndexError
     if (s_gnodes > a.max_nodes) st = 3;
-    int best = -1; double bestv = 0.0;
+    const int NB = a.nbest;
     if (st == 0) {
+      // as in beam_kernel: normalised scores, then the first `nbest` of a stable descending sort (f_pT is reused for the scores, f_last as "taken")
       for (int r = 0; r < nb; ++r) {
         const double pr = f_pT[r] + a.lm[(size_t)f_last[r] * V1 + V] * a.alpha;
         const double tot = log_add_prob(LOG_ZERO, pr);
         const int ln = f_len[r];
-        const double nv = tot * (1.0 / (ln ? ln : 1));
-        if (best < 0 || nv > bestv) { best = r; bestv = nv; }
+        f_pT[r] = tot * (1.0 / (ln ? ln : 1));
+        f_last[r] = 0;
       }
-      const int ln = f_len[best];
-      a.out_len[b] = ln; a.out_score[b] = bestv;
-      int n = f_node[best];
-      for (int i = ln - 1; i >= 0; --i) {
-        if (n <= TS) { const unsigned e = trie[n - 1]; a.out_ids[(size_t)b * T + i] = (int)(e & 0x1FFFFu); n = (int)(e >> 17) - 1; }
-        else { const int gq = n - TS - 1; a.out_ids[(size_t)b * T + i] = nsym[gq]; n = npar[gq]; }
+      const int nout = min(NB, nb);
+      for (int k = 0; k < nout; ++k) {
+        int best = -1; double bestv = 0.0;
+        for (int r = 0; r < nb; ++r)
+          if (!f_last[r] && (best < 0 || f_pT[r] > bestv)) { best = r; bestv = f_pT[r]; }
+        f_last[best] = 1;
+        const int ln = f_len[best];
+        const size_t o = (size_t)b * NB + k;
+        a.out_len[o] = ln; a.out_score[o] = bestv;
+        int n = f_node[best];
+        for (int i = ln - 1; i >= 0; --i) {
+          if (n <= TS) { const unsigned e = trie[n - 1]; a.out_ids[o * T + i] = (int)(e & 0x1FFFFu); n = (int)(e >> 17) - 1; }
+          else { const int gq = n - TS - 1; a.out_ids[o * T + i] = nsym[gq]; n = npar[gq]; }
+        }
       }
-    } else { a.out_len[b] = 0; a.out_score[b] = 0.0; }
+      for (int k = nout; k < NB; ++k) { a.out_len[(size_t)b * NB + k] = 0; a.out_score[(size_t)b * NB + k] = 0.0; }
+      if (a.out_count) a.out_count[b] = nout;
+    } else {
+      for (int k = 0; k < NB; ++k) { a.out_len[(size_t)b * NB + k] = 0; a.out_score[(size_t)b * NB + k] = 0.0; }
+      if (a.out_count) a.out_count[b] = 0;
+    }
     a.status[b] = st;
   } else if (tid == 0) {
-    a.out_len[b] = 0; a.out_score[b] = 0.0; a.status[b] = status;
+    for (int k = 0; k < a.nbest; ++k) { a.out_len[(size_t)b * a.nbest + k] = 0; a.out_score[(size_t)b * a.nbest + k] = 0.0; }
+    if (a.out_count) a.out_count[b] = 0;
+    a.status[b] = status;
   }
 }
 
@@ -887,12 +922,13 @@ extern "C" size_t ctcn_beam_ws_bytes(int T, int B, int V, int W) {
   return std::max(beam_layout(T, B, V, W).total, fast_layout(T, B, V, W).total);
 }
 
-extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha, int W,
-                                int blank, int32_t *out_ids, int32_t *out_len, double *out_score, int32_t *status, int T, int B,
-                                int V, void *ws, size_t ws_bytes, void *stream) {
+extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha, int W,
+                                      int blank, int nbest, int32_t *out_ids, int32_t *out_len, double *out_score, int32_t *out_count,
+                                      int32_t *status, int T, int B, int V, void *ws, size_t ws_bytes, void *stream) {
   CTCN_REQUIRE(x && lens && lm && out_ids && out_len && out_score && status && ws, "ctcn_beam_decode: null pointer");
   CTCN_REQUIRE(T > 0 && B > 0 && V > 1 && blank >= 0 && blank < V, "ctcn_beam_decode: bad dims");
   if (W < 1 || W > BEAM_WMAX) { ctcn_set_error("ctcn_beam_decode: beam width %d outside [1,%d]", W, BEAM_WMAX); return CTCN_EUNSUPPORTED; }
+  CTCN_REQUIRE(nbest >= 1 && nbest <= W, "ctcn_beam_decode_nbest: nbest %d outside [1, beam width %d]", nbest, W);
   hipStream_t st = (hipStream_t)stream;
   char *base = (char *)ws;
   const FastLayout fl = fast_layout(T, B, V, W);
@@ -903,6 +939,7 @@ extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t
     a.lgd = (const double *)(base + fl.lgd); a.pb = (const float *)(base + fl.pb); a.zf = (const unsigned char *)(base + fl.zf);
     a.lens = lens; a.lm = lm; a.alpha = alpha; a.W = W; a.blank = blank;
     a.out_ids = out_ids; a.out_len = out_len; a.out_score = out_score; a.status = status; a.T = T; a.B = B; a.V = V;
+    a.nbest = nbest; a.out_count = out_count;
     a.ht = (unsigned long long *)(base + fl.ht); a.node_par = (int *)(base + fl.npar); a.node_sym = (int *)(base + fl.nsym);
     a.ht_size = fl.ht_size; a.max_nodes = fl.max_nodes; a.trie_slots = fl.trie_slots;
 #ifdef CTCN_BEAM_STATS
@@ -933,6 +970,7 @@ extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t
   BeamArgs a;
   a.x = x; a.input_is_prob = input_is_prob; a.lens = lens; a.lm = lm; a.alpha = alpha; a.W = W; a.blank = blank;
   a.out_ids = out_ids; a.out_len = out_len; a.out_score = out_score; a.status = status; a.T = T; a.B = B; a.V = V;
+    a.nbest = nbest; a.out_count = out_count;
   a.ht_keys = (unsigned long long *)(base + l.keys); a.ht_ids = (int *)(base + l.ids);
   a.node_par = (int *)(base + l.npar); a.node_sym = (int *)(base + l.nsym); a.cand_global = (double *)(base + l.cand);
   a.ht_size = l.ht_size; a.max_nodes = l.max_nodes;
@@ -942,6 +980,12 @@ extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t
   hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(256), sm, st, a);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
+}
+
+extern "C" int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha, int W,
+                                int blank, int32_t *out_ids, int32_t *out_len, double *out_score, int32_t *status, int T, int B,
+                                int V, void *ws, size_t ws_bytes, void *stream) {
+  return ctcn_beam_decode_nbest(x, input_is_prob, lens, lm, alpha, W, blank, 1, out_ids, out_len, out_score, nullptr, status, T, B, V, ws, ws_bytes, stream);
 }
 
 #ifdef CTCN_BEAM_STATS

@@ -972,6 +972,36 @@ def beam_decode(x_tbv, lens, lm_table, alpha, beam_width, blank=0, input_is_prob
     return [list(map(int, ids_c[b, : len_c[b]])) for b in range(B)], score.cpu().numpy(), status.cpu().numpy()
 
 
+def beam_decode_nbest(x_tbv, lens, lm_table, alpha, beam_width, nbest, blank=0, input_is_prob=False):
+    """The `nbest` best labellings of every utterance (ctcn_beam_decode_nbest: the first nbest entries of the reference's final `last.sort()`,
+    BeamSearch.py:150 keeps [0]).  Returns CPU (ids: per utterance a list of up to nbest label lists, best first; scores (B, nbest) float64,
+    0 past the labellings returned; status (B,) int32).  Synchronises."""
+    _need_gpu(x_tbv)
+    x = _f32c(x_tbv.detach())
+    T, B, V = x.shape
+    dev = x.device
+    nbest = int(nbest)
+    if not 1 <= nbest <= int(beam_width):
+        raise ValueError("nbest must lie in [1, beam_width]")
+    lens_t = lens.to(device=dev, dtype=torch.int32).contiguous() if torch.is_tensor(lens) else torch.as_tensor(lens, dtype=torch.int32).to(dev)
+    lm = torch.as_tensor(lm_table, dtype=torch.float64, device=dev).contiguous()
+    if lm.numel() != (V + 1) * (V + 1):
+        raise ValueError("lm table must be (V+1)x(V+1)")
+    L = _lib.lib()
+    ws = torch.empty(max(L.ctcn_beam_ws_bytes(T, B, V, int(beam_width)), 1), dtype=torch.uint8, device=dev)
+    out_ids = torch.zeros((B, nbest, T), dtype=torch.int32, device=dev)
+    out_len = torch.zeros((B, nbest), dtype=torch.int32, device=dev)
+    score = torch.zeros((B, nbest), dtype=torch.float64, device=dev)
+    count = torch.zeros(B, dtype=torch.int32, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    _lib.check(L.ctcn_beam_decode_nbest(_ptr(x), int(bool(input_is_prob)), _ptr(lens_t), _ptr(lm), float(alpha), int(beam_width), int(blank), nbest,
+                                        _ptr(out_ids), _ptr(out_len), _ptr(score), _ptr(count), _ptr(status), T, B, V, _ptr(ws), ws.numel(),
+                                        _lib.stream_ptr()), "beam_decode_nbest")
+    ids_c, len_c, cnt = out_ids.cpu().numpy(), out_len.cpu().numpy(), count.cpu().numpy()
+    ids = [[list(map(int, ids_c[b, k, : len_c[b, k]])) for k in range(cnt[b])] for b in range(B)]
+    return ids, score.cpu().numpy(), status.cpu().numpy()
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     _need_gpu(p, g, m, v)
     _lib.check(_lib.lib().ctcn_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2),

@@ -66,3 +66,15 @@ class ctcBeamSearch(object):
             x = x.to("cuda")
         ids, _ = self.decode_ids(x, inputs_list, input_is_prob=True)
         return [" ".join(self.classes[k] for k in seq) for seq in ids]
+
+    def decode_nbest(self, inputs, inputs_list, nbest):
+        """The `nbest` best labellings per utterance, best first, as strings -- `last.sort()[0:nbest]` where the reference's decode keeps
+        element [0] (BeamSearch.py:150; SURVEY section 8f-4, the optional n-best output).  Returns (strings: B lists of up to nbest
+        strings, scores: (B, nbest) float64 length-normalised log-probabilities)."""
+        x = inputs.transpose(0, 1)
+        if not x.is_cuda:
+            x = x.to("cuda")
+        ids, score, status = ops.beam_decode_nbest(x, inputs_list, self._lm_table(), self.lm_alpha, self.beamWidth, nbest, self.blank_index,
+                                                   input_is_prob=True)
+        self._checked(ids, score, status)
+        return [[" ".join(self.classes[k] for k in seq) for seq in utt] for utt in ids], score

@@ -330,6 +330,14 @@ size_t ctcn_beam_ws_bytes(int T, int B, int V, int W);
 int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha,
                      int W, int blank, int32_t *out_ids, int32_t *out_len, double *out_score, int32_t *status,
                      int T, int B, int V, void *ws, size_t ws_bytes, void *stream);
+/* The same search returning the `nbest` (1 <= nbest <= W) best labellings of every utterance: the first nbest entries of the final
+ * `last.sort()` of BeamSearch.py:150, of which the reference keeps element [0] ("optional n-best output") -- a stable
+ * descending sort by the length-normalised score, entry 0 = what ctcn_beam_decode returns.
+ *   out_ids (B,nbest,T) int32, out_len (B,nbest) int32, out_score (B,nbest) float64; out_count (B) int32 or NULL: labellings actually
+ *   returned for the utterance (the final beam can hold fewer than nbest; the remaining entries have length 0 and score 0) */
+int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha,
+                           int W, int blank, int nbest, int32_t *out_ids, int32_t *out_len, double *out_score,
+                           int32_t *out_count, int32_t *status, int T, int B, int V, void *ws, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Diagnostics (not on the compute path).

@@ -129,14 +129,16 @@ static int top_w(const State *s, int W, int *out) {
 }
 
 /* status: 0 ok, 1 IndexError (best labelling empty at the end, :135), 2 ValueError (math.log(<=0)) */
-int beam_ref_decode(const float *probs /* [B][T][V] = exp(lp), float32 */, int B, int T, int V,
+/* nbest >= 1: the first `nbest` labellings of the final `last.sort()` (:150; the reference keeps element [0]); outputs [B][nbest]...,
+   out_count[B] (may be NULL) = labellings returned (the final beam can hold fewer), the rest have length 0 / score 0 */
+int beam_ref_decode_nbest(const float *probs /* [B][T][V] = exp(lp), float32 */, int B, int T, int V,
                     const int *lens, const double *lm /* [(V+1)][(V+1)] ln-probs; row V = <s>, col V = </s> */,
-                    double alpha, int W, int blank, int *out_ids /* [B][T] */, int *out_len /* [B] */,
-                    double *out_score /* [B] */, int *status /* [B] */) {
+                    double alpha, int W, int blank, int nbest, int *out_ids /* [B][nbest][T] */, int *out_len /* [B][nbest] */,
+                    double *out_score /* [B][nbest] */, int *out_count /* [B] or NULL */, int *status /* [B] */) {
   Trie trie; State a, b; State *last = &a, *curr = &b;
   int cap = W * V + W + 8;
   state_init(&a, cap); state_init(&b, cap);
-  int *bhat = (int *)malloc(sizeof(int) * (W > 0 ? W : 1));
+  int *bhat = (int *)malloc(sizeof(int) * ((W > nbest ? W : nbest) > 0 ? (W > nbest ? W : nbest) : 1));
   double *lg = (double *)malloc(sizeof(double) * V);
   for (int bi = 0; bi < B; ++bi) {
     const float *mat = probs + (size_t)bi * T * V;
@@ -188,7 +190,8 @@ int beam_ref_decode(const float *probs /* [B][T][V] = exp(lp), float32 */, int B
       }
       State *tmp = last; last = curr; curr = tmp;                    /* :128 */
     }
-    out_len[bi] = 0; out_score[bi] = 0.0;
+    for (int k = 0; k < nbest; ++k) { out_len[(size_t)bi * nbest + k] = 0; out_score[(size_t)bi * nbest + k] = 0.0; }
+    if (out_count) out_count[bi] = 0;
     if (!st) {
       int m = top_w(last, W, bhat);                                  /* :130 */
       state_clear(curr);
@@ -206,11 +209,15 @@ int beam_ref_decode(const float *probs /* [B][T][V] = exp(lp), float32 */, int B
           int len = trie.nodes[curr->y[i]].depth;
           curr->prT[i] = curr->prT[i] * (1.0 / (len ? len : 1));
         }
-        int best;
-        top_w(curr, 1, &best);                                       /* :148 */
-        int y = curr->y[best]; int len = trie.nodes[y].depth;
-        out_len[bi] = len; out_score[bi] = curr->prT[best];
-        for (int i = len - 1, n = y; i >= 0; --i, n = trie.nodes[n].parent) out_ids[(size_t)bi * T + i] = trie.nodes[n].sym;
+        int nout = top_w(curr, nbest, bhat);                         /* :148-150: last.sort()[0] -- here [0:nbest] */
+        for (int k = 0; k < nout; ++k) {
+          int best = bhat[k];
+          int y = curr->y[best]; int len = trie.nodes[y].depth;
+          size_t o = (size_t)bi * nbest + k;
+          out_len[o] = len; out_score[o] = curr->prT[best];
+          for (int i = len - 1, n = y; i >= 0; --i, n = trie.nodes[n].parent) out_ids[o * T + i] = trie.nodes[n].sym;
+        }
+        if (out_count) out_count[bi] = nout;
       }
     }
     status[bi] = st;
@@ -218,4 +225,9 @@ int beam_ref_decode(const float *probs /* [B][T][V] = exp(lp), float32 */, int B
   }
   free(bhat); free(lg); state_free(&a); state_free(&b);
   return 0;
+}
+
+int beam_ref_decode(const float *probs, int B, int T, int V, const int *lens, const double *lm, double alpha, int W, int blank,
+                    int *out_ids /* [B][T] */, int *out_len /* [B] */, double *out_score /* [B] */, int *status /* [B] */) {
+  return beam_ref_decode_nbest(probs, B, T, V, lens, lm, alpha, W, blank, 1, out_ids, out_len, out_score, 0, status);
 }

@@ -31,6 +31,7 @@ def lib():
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.beam_ref_decode.restype = ctypes.c_int
+        _lib.beam_ref_decode_nbest.restype = ctypes.c_int
     return _lib
 
 
@@ -102,6 +103,24 @@ def decode_ids(probs_btv, lens, lm_table, alpha, W, blank=0):
                           ctypes.c_double(alpha), W, blank, P(out_ids.ctypes.data), P(out_len.ctypes.data),
                           P(score.ctypes.data), P(status.ctypes.data))
     return [list(out_ids[b, : out_len[b]]) for b in range(B)], score, status
+
+
+def decode_ids_nbest(probs_btv, lens, lm_table, alpha, W, nbest, blank=0):
+    """The first `nbest` labellings of the final `last.sort()` (BeamSearch.py:150 keeps [0]).  Returns (ids: per utterance a list of up to
+    nbest label lists, scores (B, nbest) float64, status (B))."""
+    probs = np.ascontiguousarray(probs_btv, dtype=np.float32)
+    B, T, V = probs.shape
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    lm = np.ascontiguousarray(lm_table, dtype=np.float64)
+    out_ids = np.zeros((B, nbest, T), dtype=np.int32)
+    out_len = np.zeros((B, nbest), dtype=np.int32)
+    score = np.zeros((B, nbest), dtype=np.float64)
+    count = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    P = ctypes.c_void_p
+    lib().beam_ref_decode_nbest(P(probs.ctypes.data), B, T, V, P(lens.ctypes.data), P(lm.ctypes.data), ctypes.c_double(alpha), W, blank, nbest,
+                                P(out_ids.ctypes.data), P(out_len.ctypes.data), P(score.ctypes.data), P(count.ctypes.data), P(status.ctypes.data))
+    return [[list(map(int, out_ids[b, k, : out_len[b, k]])) for k in range(count[b])] for b in range(B)], score, status
 
 
 def decode_strings(probs_btv, lens, lm_table, alpha, W, int2char, blank=0):

@@ -429,6 +429,44 @@ def gen_decoders():
     print("beam   peaky[0]:", meta["beam_peaky_W5_a0.1"][0][:60])
 
 
+def gen_nbest():
+    """n-best labellings of the reference search (optional): the reference's decode returns `last.sort()[0]`
+    (BeamSearch.py:150); the whole sorted list is captured here by wrapping BeamState.sort -- its last call for an utterance IS that final
+    sort -- while the reference decodes the utterances of decoders.npz one at a time.  tests/golden/decoders_nbest.json: per (regime, W, alpha)
+    the first min(W, 5) labellings of every utterance as class-index lists."""
+    import utils.BeamSearch as refbs
+    V = 62
+    i2c = synth.int2char(V)
+    arpa = os.path.join(GOLD, "lm_phone_bg.arpa")
+    z = np.load(os.path.join(GOLD, "decoders.npz"))
+    lens = json.load(open(os.path.join(GOLD, "decoders.json")))["lens"]
+    calls = []
+    orig = refbs.BeamState.sort
+
+    def recording_sort(self):
+        r = orig(self)
+        calls.append(r)
+        return r
+
+    refbs.BeamState.sort = recording_sort
+    out = {}
+    try:
+        for regime, W, alpha in (("peaky", 5, 0.1), ("peaky", 20, 0.1), ("peaky", 5, 0.0), ("flat", 5, 0.1)):
+            lpt = torch.from_numpy(z["lp_" + regime])
+            bd = BeamDecoder(i2c, beam_width=W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=alpha)
+            per_utt, best = [], []
+            for b in range(lpt.shape[1]):
+                del calls[:]
+                best.append(bd.decode(lpt[:, b:b + 1], [lens[b]])[0])
+                per_utt.append([[int(k) for k in y] for y in calls[-1][:min(W, 5)]])
+            out["nbest_%s_W%d_a%g" % (regime, W, alpha)] = dict(labellings=per_utt, best_string=best)
+            print("nbest", regime, W, alpha, "done")
+    finally:
+        refbs.BeamState.sort = orig
+    with open(os.path.join(GOLD, "decoders_nbest.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def gen_lm():
     """get_bi_prob over every (prev,next) class pair from the reference's own LanguageModel (NgramLM.py:65-78)."""
     import utils.NgramLM as uNgram
@@ -567,7 +605,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
-                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml)
+                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml, nbest=gen_nbest)
     if a.large:
         gen_large()
     else:

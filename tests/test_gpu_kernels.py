@@ -1709,6 +1709,52 @@ def test_beam_vs_c_oracle_random(dev, regime, W):
     assert got2 == got
 
 
+@pytest.mark.parametrize("fast", [1, 0])
+def test_beam_nbest_golden_and_oracle(dev, fast):
+    """ctcn_beam_decode_nbest (the optional n-best output): the labellings equal the reference's whole final `last.sort()`
+    (decoders_nbest.json, captured from the reference by oracle/gen_golden.py), ids and float64 scores equal the C oracle's on random
+    batches for nbest = 1, 3 and W (the final beam can hold fewer than nbest entries), entry 0 equals ctcn_beam_decode; both kernels."""
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder
+    z = load("decoders")
+    meta = json.load(open(os.path.join(G, "decoders.json")))
+    nb = json.load(open(os.path.join(G, "decoders_nbest.json")))
+    V = 62
+    i2c = synth.int2char(V)
+    arpa = os.path.join(G, "lm_phone_bg.arpa")
+    tab = LanguageModel(arpa).table([i2c[i] for i in range(V)])
+    ops.set_option("beam_fast", fast)
+    try:
+        for key, rec in nb.items():
+            _, regime, w, a = key.split("_")
+            W, alpha = int(w[1:]), float(a[1:])
+            N = min(W, 5)
+            lpt = torch.from_numpy(z["lp_" + regime])
+            ids, score, st = ops.beam_decode_nbest(torch.exp(lpt).to(dev), meta["lens"], tab, alpha, W, N, 0, input_is_prob=True)
+            assert not st.any() and ids == rec["labellings"], key
+            bd = BeamDecoder(i2c, beam_width=W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=alpha)
+            strings, sc2 = bd._decoder.decode_nbest(torch.exp(lpt).transpose(0, 1), meta["lens"], N)
+            assert [u[0] for u in strings] == rec["best_string"] and np.array_equal(sc2, score)
+        T, B = 160, 12
+        for regime, W in (("peaky", 20), ("flat", 8), ("peaky", 3)):
+            lp = synth.make_logprobs(seed=101 + W, T=T, B=B, V=V, regime=regime)
+            lens = list(np.random.RandomState(5).randint(T // 2, T + 1, size=B))
+            probs = torch.exp(torch.from_numpy(lp))
+            one, s1, st1 = ops.beam_decode(probs.to(dev), lens, tab, 0.1, W, 0, input_is_prob=True)
+            for N in (1, 3, W):
+                N = min(N, W)
+                want, wscore, wst = beam_ref.decode_ids_nbest(probs.numpy().transpose(1, 0, 2), lens, tab, 0.1, W, N)
+                got, score, st = ops.beam_decode_nbest(probs.to(dev), lens, tab, 0.1, W, N, 0, input_is_prob=True)
+                assert list(st) == list(wst) and got == want, (regime, W, N)
+                assert np.allclose(score, wscore, rtol=1e-12, atol=1e-12)
+                assert [u[0] for u in got] == one and np.array_equal(score[:, 0], s1)
+        with pytest.raises(Exception):
+            ops.beam_decode_nbest(probs.to(dev), lens, tab, 0.1, 3, 4, 0, input_is_prob=True)          # nbest > beam width
+    finally:
+        ops.set_option("beam_fast", 1)
+
+
 def test_beam_error_paths(dev):
     from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder
     i2c = synth.int2char(62)

@@ -177,6 +177,30 @@ def test_beam_search_strings():
     assert n >= 10
 
 
+def test_beam_search_nbest_pins_the_oracle_to_the_reference():
+    """n-best: oracle/beam_ref.c's first `nbest` labellings == the reference's whole final `last.sort()` captured by
+    oracle/gen_golden.py (decoders_nbest.json), entry 0 == the string the reference's decode returns."""
+    z = load("decoders")
+    meta = json.load(open(os.path.join(G, "decoders.json")))
+    nb = json.load(open(os.path.join(G, "decoders_nbest.json")))
+    i2c = synth.int2char(62)
+    tab = beam_ref.arpa_table(os.path.join(G, "lm_phone_bg.arpa"), i2c)
+    assert len(nb) >= 4
+    for key, rec in nb.items():
+        _, regime, w, a = key.split("_")
+        W = int(w[1:])
+        probs = np.exp(z["lp_" + regime].astype(np.float32)).transpose(1, 0, 2)
+        N = min(W, 5)
+        ids, score, st = beam_ref.decode_ids_nbest(probs, meta["lens"], tab, float(a[1:]), W, N)
+        assert not st.any()
+        assert ids == rec["labellings"], key
+        for b, utt in enumerate(ids):
+            assert " ".join(i2c[k] for k in utt[0]) == rec["best_string"][b] == meta["beam_%s_W%d_a%g" % (regime, W, float(a[1:]))][b]
+            assert all(score[b, k] >= score[b, k + 1] for k in range(len(utt) - 1))          # sorted, best first
+        one, s1, _ = beam_ref.decode_ids(probs, meta["lens"], tab, float(a[1:]), W)
+        assert [u[0] for u in ids] == [list(map(int, u)) for u in one] and np.array_equal(s1, score[:, 0])
+
+
 def test_beam_error_paths():
     i2c = synth.int2char(62)
     tab = beam_ref.arpa_table(os.path.join(G, "lm_phone_bg.arpa"), i2c)
