@@ -12,6 +12,7 @@ Rank 0 prints ONE JSON line; `value` = acoustic frames/s of the whole job.  `--m
 (beam W=20 + bigram LM over 128 utterances x 800 frames; utterances/s).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -175,19 +176,29 @@ def recurrence_probe(dev, c):
     gy = torch.ones(T, B, 2 * H, device=dev)
 
     def timed(reps):
-        f = b = 0.0
-        for _ in range(reps + 1):                      # first pass warms up
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            ev[0].record()
-            y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
-            ev[1].record()
-            y.backward(gy)
-            ev[2].record()
-            torch.cuda.synchronize()
-            f, b = f + ev[0].elapsed_time(ev[1]), b + ev[1].elapsed_time(ev[2])
-            if _ == 0:
-                f = b = 0.0
-        return f * 1e3 / reps, b * 1e3 / reps          # us per layer pass
+        # median of the passes behind a warm-up pass, the interpreter's collector off (as in the timed steps: a collection of the heap the
+        # training loop left behind is tens of milliseconds of host time in the middle of an enqueue -- the device then waits for its kernels)
+        fs, bs = [], []
+        gc_was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            for i in range(reps + 1):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                y = ops.rnn_layer(x, w[0], w[1], w[2], w[3], cell)
+                ev[1].record()
+                y.backward(gy)
+                ev[2].record()
+                torch.cuda.synchronize()
+                if i:
+                    fs.append(ev[0].elapsed_time(ev[1]))
+                    bs.append(ev[1].elapsed_time(ev[2]))
+        finally:
+            if gc_was:
+                gc.enable()
+        fs.sort(); bs.sort()
+        return fs[len(fs) // 2] * 1e3, bs[len(bs) // 2] * 1e3          # us per layer pass
 
     lf, lb = timed(3)
     ops.set_option("rnn_recurrence_only", 1)
