@@ -12,12 +12,19 @@ void ctcn_set_error(const char *fmt, ...);
 int *ctcn_status_word(void);      // device int registered with ctcn_set_status_buffer (may be null)
 int ctcn_opt_rnn_persistent(void);
 int ctcn_transpose01_pair(const float *in0, const float *in1, float *out0, float *out1, int A, int B, int C, void *stream);   // two ctcn_transpose01 in one launch
-void ctcn_gemm_hint_same_b(void);   // ... the same, unmodified B (its planes are reused if A has the same size as well)
-void ctcn_gemm_hint_same_a(void);   // next ctcn_gemm on this thread has the same, unmodified A as the previous one
+// What a sequence of internal bf16x3 GEMM calls left in ITS workspace, owned by the function that makes the sequence (on its stack: no state
+// outlives an ABI call or is shared between threads -- round 3): a call records which operand planes it wrote, and a call
+// made with `same_a` / `same_b` set (one-shot requests: "the operand is the one of my previous call, unmodified") skips that split pass
+// when pointer / shape / layout / workspace / stream match.
+struct GemmPlanes {
+  const float *A = nullptr; int lda = 0, M = 0, Ka = 0, transA = 0; void *ws_a = nullptr, *st_a = nullptr; bool a_valid = false;
+  const float *B = nullptr; int ldb = 0, N = 0, Kb = 0, transB = 0, shift = 0; void *ws_b = nullptr, *st_b = nullptr; const void *bh = nullptr; bool b_valid = false;
+  bool same_a = false, same_b = false;
+};
 int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
-                      int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow);
+                      int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, GemmPlanes *planes = nullptr);
 int ctcn_gemm_shift_b(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float beta, int precision,
-                      void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, int shift);
+                      void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, int shift, GemmPlanes *planes = nullptr);
 int ctcn_opt_handoff(void);
 int ctcn_opt_poll_depth(void);
 int ctcn_opt_bwd_scatter(void);

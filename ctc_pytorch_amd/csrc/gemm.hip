@@ -1766,17 +1766,6 @@ __global__ void transpose01_kernel(const float *__restrict__ in, float *__restri
 
 }  // namespace
 
-// Hint from a caller that issues consecutive GEMMs with the SAME, unmodified A operand on the same stream and workspace
-// (the two directions of a recurrent layer's input projection): the A planes of the previous call are still in the
-// workspace, so the next call skips its split pass when pointer / shape / layout match.  One-shot, per host thread.
-static thread_local struct { const float *A; int lda, M, K, transA; void *ws; hipStream_t st; bool valid, armed; } g_last_a = {};
-void ctcn_gemm_hint_same_a(void) { g_last_a.armed = true; }
-// ... and the same for B (the chunk GEMMs of a pipelined input projection multiply by the same W_ih six times): its planes of the
-// previous call are reused when they sit at the same place in the same workspace (i.e. the A operand has the same size too)
-static thread_local struct { const float *B; int ldb, N, K, transB, shift; void *ws; hipStream_t st; const unsigned short *bh; bool valid, armed; } g_last_b = {};
-void ctcn_gemm_hint_same_b(void) { g_last_b.armed = true; }
-
-static thread_local int g_b_shift = 0;      // one-shot, set by ctcn_gemm_shift_b for the plane path's B split
 // the TN tile (gemm_tn_f32_pp_kernel) takes C = A^T B with 16-B aligned rows of whole float4 pieces, large K, and a workspace for its
 // queue word (+ the split-K partials)
 static bool tn_eligible(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, int precision, const void *ws,
@@ -1786,8 +1775,13 @@ static bool tn_eligible(int transA, int transB, int M, int N, int K, const float
          lda < (1 << 24) && ldb < (1 << 24);                     // (eight rows of a piece behind one 32-bit buffer offset)
 }
 // xcd_allow: 0 = whole device; otherwise (precision 1 plane path only) the XCDs the GEMM workgroups may run on
-int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
-                      int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow) {
+// b_shift: ctcn_gemm_shift_b's shift of B along k, applied while B is split (plane path only)
+static int gemm_core(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
+                     int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, GemmPlanes *planes, int b_shift) {
+  GemmPlanes scratch_planes;                  // a caller without a sequence: nothing to reuse, nothing remembered
+  GemmPlanes &pl = planes ? *planes : scratch_planes;
+  const bool want_same_a = pl.same_a, want_same_b = pl.same_b;
+  pl.same_a = pl.same_b = false;              // one-shot
   CTCN_REQUIRE(precision == 0 || precision == 1, "ctcn_gemm: precision %d (0 = f32 MFMA, 1 = bf16x3 split MFMA)", precision);
   CTCN_REQUIRE(M > 0 && N > 0 && K >= 0, "ctcn_gemm: bad dims M=%d N=%d K=%d", M, N, K);
   CTCN_REQUIRE(A && B && C, "ctcn_gemm: null pointer");
@@ -1807,10 +1801,9 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
     kchunk = ceil_div(ceil_div(K, splits), XBK) * XBK;
     splits = ceil_div(K, kchunk);
   }
-  if (tn_eligible(transA, transB, M, N, K, A, lda, B, ldb, precision, ws, ws_bytes) && g_b_shift == 0) {
+  if (tn_eligible(transA, transB, M, N, K, A, lda, B, ldb, precision, ws, ws_bytes) && b_shift == 0) {
     // both operands contraction-major (weight gradients): the TN tile reads the float32 rows as they are -- no plane pass
-    g_last_a.valid = false; g_last_a.armed = false;
-    g_last_b.valid = false; g_last_b.armed = false;
+    pl.a_valid = false; pl.b_valid = false;
     const int wnt = ceil_div(N, 256) * 256 == ceil_div(N, 128) * 128 ? 2 : 1;     // (N = 640 as 3 x 256 or 5 x 128: the same time)
     unsigned *queue = (unsigned *)((char *)ws + ((ws_bytes - 256) & ~(size_t)255));
     const int tsplits = tn_splits(M, N, K, wnt, ws_bytes - 512);
@@ -1842,14 +1835,12 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
             hipLaunchKernelGGL(split_transpose_kernel, dim3(ceil_div(rows, 64), ceil_div(Kp, 64)), dim3(256), 0, st, src, ld, K, rows, Kp, hi, lo, shift);
         }
       };
-      const bool same_a = g_last_a.armed && g_last_a.valid && g_last_a.A == A && g_last_a.lda == lda && g_last_a.M == M && g_last_a.K == K &&
-                          g_last_a.transA == transA && g_last_a.ws == ws && g_last_a.st == st;
-      g_last_a.armed = false;
-      const bool same_b = g_last_b.armed && g_last_b.valid && g_last_b.B == B && g_last_b.ldb == ldb && g_last_b.N == N && g_last_b.K == K &&
-                          g_last_b.transB == transB && g_last_b.shift == g_b_shift && g_last_b.ws == ws && g_last_b.st == st && g_last_b.bh == bh;
-      g_last_b.armed = false;
-      g_last_b.B = B; g_last_b.ldb = ldb; g_last_b.N = N; g_last_b.K = K; g_last_b.transB = transB; g_last_b.shift = g_b_shift; g_last_b.ws = ws;
-      g_last_b.st = st; g_last_b.bh = bh; g_last_b.valid = true;            // (every branch below leaves B's planes at bh / bl)
+      const bool same_a = want_same_a && pl.a_valid && pl.A == A && pl.lda == lda && pl.M == M && pl.Ka == K && pl.transA == transA && pl.ws_a == ws &&
+                          pl.st_a == (void *)st;
+      const bool same_b = want_same_b && pl.b_valid && pl.B == B && pl.ldb == ldb && pl.N == N && pl.Kb == K && pl.transB == transB && pl.shift == b_shift &&
+                          pl.ws_b == ws && pl.st_b == (void *)st && pl.bh == (const void *)bh;
+      pl.B = B; pl.ldb = ldb; pl.N = N; pl.Kb = K; pl.transB = transB; pl.shift = b_shift; pl.ws_b = ws;
+      pl.st_b = (void *)st; pl.bh = (const void *)bh; pl.b_valid = true;     // (every branch below leaves B's planes at bh / bl)
       // activation-sized products (M = T*B): the 256-row tiles, when they give the device at least ~0.75 workgroups per CU; a
       // row-major A (k contiguous) is then split while it is staged, without a plane pass of its own
       const int wnt256 = (N % 256 == 0 || (N > 512 && ceil_div(N, 256) * 256 - N <= N / 8)) ? 2 : 1;
@@ -1862,10 +1853,8 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       const bool a_inline = use256 && !same_a && !transA && ctcn_get_option("gemm_a_inline") != 0 && K >= 32 && K % 4 == 0 && lda % 4 == 0 &&
                             ((uintptr_t)A & 15) == 0 && ceil_div(N, 128 * wnt256) <= 5;
       if (a_inline) {
-        g_last_a.valid = false;                     // no A planes in the workspace after this call
-        const int bshift0 = g_b_shift;
-        g_b_shift = 0;
-        if (!same_b) split(B, ldb, transB == 0, N, bh, bl, bshift0);
+        pl.a_valid = false;                         // no A planes in the workspace after this call
+        if (!same_b) split(B, ldb, transB == 0, N, bh, bl, b_shift);
         CTCN_LAUNCH_CHECK();
         const int lrc = wnt256 == 2 ? launch_planes256_af32<2>(st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta)
                                     : launch_planes256_af32<1>(st, M, N, K, Kp, A, lda, bh, bl, C, ldc, beta);
@@ -1874,11 +1863,9 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
         return CTCN_OK;
       }
       if (!same_a) split(A, lda, transA != 0, M, ah, al, 0);
-      g_last_a.A = A; g_last_a.lda = lda; g_last_a.M = M; g_last_a.K = K; g_last_a.transA = transA; g_last_a.ws = ws; g_last_a.st = st;
-      g_last_a.valid = true;
-      const int bshift = g_b_shift;
-      g_b_shift = 0;
-      if (!same_b) split(B, ldb, transB == 0, N, bh, bl, bshift);
+      pl.A = A; pl.lda = lda; pl.M = M; pl.Ka = K; pl.transA = transA; pl.ws_a = ws; pl.st_a = (void *)st;
+      pl.a_valid = true;
+      if (!same_b) split(B, ldb, transB == 0, N, bh, bl, b_shift);
       CTCN_LAUNCH_CHECK();
       // tile shape: 128x128 (two workgroups per CU).  Option gemm_big_tiles: 256x128 / 128x256 tiles (one per CU, 96 KB of LDS)
       // when they fill the device at least once without more padding -- 25 % fewer LDS fragment reads per MFMA, yet measured
@@ -1942,8 +1929,7 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
       return CTCN_OK;
     }
   }
-  g_last_a.valid = false; g_last_a.armed = false;               // not the plane path: nothing to reuse
-  g_last_b.valid = false; g_last_b.armed = false;
+  pl.a_valid = false; pl.b_valid = false;                        // not the plane path: nothing to reuse
   const bool vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   const bool vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
   float *wsp = splits > 1 ? (float *)ws : nullptr;
@@ -1983,9 +1969,14 @@ int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *
 // C = A^T * shift_k(B) for contraction-major A (K x M) and B (K x N): B_eff[k] = B[k - shift] when 0 <= k - shift < K, else 0 --
 // the recurrent weight gradient dW_hh = da^T h_prev with h_prev = y delayed (forward direction) or advanced (reverse) by one
 // timestep.  On the bf16x3 plane path the shift is applied while B is split, so that A = da^T keeps the SAME K window as in
-// dW_ih = da^T x and its planes can be reused (ctcn_gemm_hint_same_a); elsewhere the window is narrowed instead.
+// dW_ih = da^T x and its planes can be reused (GemmPlanes::same_a); elsewhere the window is narrowed instead.
+int ctcn_gemm_on_xcds(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
+                      int ldc, float beta, int precision, void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, GemmPlanes *planes) {
+  return gemm_core(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow, planes, 0);
+}
+
 int ctcn_gemm_shift_b(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, float beta, int precision,
-                      void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, int shift) {
+                      void *ws, size_t ws_bytes, void *stream, unsigned xcd_allow, int shift, GemmPlanes *planes) {
   const int as = shift < 0 ? -shift : shift;
   CTCN_REQUIRE(as < K, "ctcn_gemm_shift_b: |shift| %d >= K %d", as, K);
   const int Kp = ceil_div(K, PBK) * PBK;
@@ -1993,20 +1984,17 @@ int ctcn_gemm_shift_b(int M, int N, int K, const float *A, int lda, const float 
   const bool plane = precision == 1 && K >= 64 && ws && ws_bytes >= plane_bytes + 1024 &&
                      !tn_eligible(1, 0, M, N, K - as, A, lda, B, ldb, precision, ws, ws_bytes);   // (the TN tile narrows the window: no planes to share)
   if (!plane) {
-    g_last_a.armed = false;
+    if (planes) planes->same_a = false;
     const float *A2 = shift > 0 ? A + (size_t)as * lda : A, *B2 = shift < 0 ? B + (size_t)as * ldb : B;
-    return ctcn_gemm_on_xcds(1, 0, M, N, K - as, A2, lda, B2, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow);
+    return gemm_core(1, 0, M, N, K - as, A2, lda, B2, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow, planes, 0);
   }
-  g_b_shift = shift;
-  const int rc = ctcn_gemm_on_xcds(1, 0, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow);
-  g_b_shift = 0;
-  return rc;
+  return gemm_core(1, 0, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, xcd_allow, planes, shift);
 }
 
 extern "C" int ctcn_gemm(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B,
                          int ldb, float *C, int ldc, float beta, int precision, void *ws, size_t ws_bytes,
                          void *stream) {
-  return ctcn_gemm_on_xcds(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, 0u);
+  return gemm_core(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, precision, ws, ws_bytes, stream, 0u, nullptr, 0);
 }
 
 // the same transposition of two equally shaped tensors in ONE launch (W_hh of the two directions before a backward recurrence)

@@ -2512,15 +2512,16 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
                      // 1024-thread workgroups of the recurrence leave no room on their own CUs, so some CUs of the XCD must stay free --
                      // otherwise the GEMM cannot finish before the recurrence does, which is waiting for it (H = 512: 32 of 32 CUs)
                      ceil_div(dirs * ceil_div(B, 16), nxd_p) * (H / 16) + 4 <= ctcn_device_cus() / nxd_p;
-  auto project_chunk = [&](int c, void *wsp, size_t wsb, void *strm, unsigned allow) -> int {
+  GemmPlanes pl_main, pl_side;                           // what this call's GEMMs left in the main / the side workspace (operand planes reused within the call)
+  auto project_chunk = [&](int c, void *wsp, size_t wsb, void *strm, unsigned allow, GemmPlanes &pl) -> int {
     const int t0 = c * chunk_T, t1 = std::min(T, t0 + chunk_T);
     return ctcn_gemm_on_xcds(0, 1, (t1 - t0) * B, 2 * GH, I, x + (size_t)t0 * B * I, I, w_ih0, I, gates + (size_t)t0 * B * 2 * GH, 2 * GH, 0.0f, precision,
-                             wsp, wsb, strm, allow);
+                             wsp, wsb, strm, allow, &pl);
   };
   if (piped) {
-    int rc = project_chunk(0, ws, ws_bytes, stream, 0);
-    ctcn_gemm_hint_same_b();                              // W_ih: split into planes once per stream (reused when the chunk has the same size)
-    if (!rc) rc = project_chunk(NCHUNK - 1, ws, ws_bytes, stream, 0);
+    int rc = project_chunk(0, ws, ws_bytes, stream, 0, pl_main);
+    pl_main.same_b = true;                                // W_ih: split into planes once per stream (reused when the chunk has the same size)
+    if (!rc) rc = project_chunk(NCHUNK - 1, ws, ws_bytes, stream, 0, pl_main);
     if (rc) return rc;
     proj_done = true;
   }
@@ -2540,9 +2541,9 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
     }
   }
   for (int d = 0; d < dirs && !proj_done; ++d) {
-    if (d > 0) ctcn_gemm_hint_same_a();                 // split x into planes once
-    int rc = ctcn_gemm(0, 1, T * B, GH, I, x, I, w_ih[d], I, gates + (size_t)d * GH, dirs * GH, 0.0f, precision, ws,
-                       ws_bytes, stream);
+    if (d > 0) pl_main.same_a = true;                   // split x into planes once
+    int rc = ctcn_gemm_on_xcds(0, 1, T * B, GH, I, x, I, w_ih[d], I, gates + (size_t)d * GH, dirs * GH, 0.0f, precision, ws,
+                               ws_bytes, stream, 0u, &pl_main);
     if (rc) return rc;
   }
   RnnArgs a;
@@ -2623,10 +2624,10 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
             for (int pr = 1; pr < NCHUNK / 2; ++pr) {
               // (W_ih is split into planes by the first of these calls only; splitting x of all six side chunks in that call as well --
               // one pass instead of six -- delays the first pair and measured 35 us per step slower)
-              if (pr > 1) ctcn_gemm_hint_same_b();
-              int rc = project_chunk(pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
-              ctcn_gemm_hint_same_b();
-              if (!rc) rc = project_chunk(NCHUNK - 1 - pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow);
+              if (pr > 1) pl_side.same_b = true;
+              int rc = project_chunk(pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow, pl_side);
+              pl_side.same_b = true;
+              if (!rc) rc = project_chunk(NCHUNK - 1 - pr, ov.ws, ov.ws_bytes, ov.stream, ov.xcd_allow, pl_side);
               if (rc) {         // the recurrence is already queued and will wait for this counter: release it (its output is invalid, the
                                 // caller sees rc) instead of letting it spin to the hand-off timeout and poison the status word
                 hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(1), 0, sd, pa.chunk_ready, (unsigned)NCHUNK);
@@ -2639,7 +2640,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
           return CTCN_OK;
         }
         if (piped)              // not co-resident after all: finish the projection here, then the other kernels take over
-          for (int c = 1; c < NCHUNK - 1; ++c) { const int rc = project_chunk(c, ws, ws_bytes, stream, 0); if (rc) return rc; }
+          for (int c = 1; c < NCHUNK - 1; ++c) { const int rc = project_chunk(c, ws, ws_bytes, stream, 0, pl_main); if (rc) return rc; }
       }
     }
     for (int ci = 0; ci < nc && kq <= 8; ++ci) {
@@ -2743,6 +2744,7 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
   // dx = [da_fwd | da_rev] [W_ih_fwd ; W_ih_rev]: the reserve already holds both directions side by side (row = dirs*GH floats),
   // so with the two weight matrices stacked in the workspace one K = 2*GH product replaces two K = GH products and the
   // read-modify-write of dx between them (65 MB each way at cfg2)
+  GemmPlanes pl;                               // operand planes this call's GEMMs leave in the workspace (da^T is shared by dW_ih and dW_hh)
   bool dx_done = false;
   if (dx && dirs == 2) {
     const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
@@ -2769,7 +2771,7 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
       if (rc) return rc;
     }
     if (!weights || !dw_ih[d]) continue;
-    rc = ctcn_gemm_on_xcds(1, 0, GH, I, TB, da, ldg, x, I, dw_ih[d], I, beta_w, precision, ws, ws_bytes, stream, xcd_allow);
+    rc = ctcn_gemm_on_xcds(1, 0, GH, I, TB, da, ldg, x, I, dw_ih[d], I, beta_w, precision, ws, ws_bytes, stream, xcd_allow, &pl);
     if (rc) return rc;
     // dW_hh = sum_t dgh_t^T h_prev(t);  h_prev(t) = y[t-1] (fwd) / y[t+1] (reverse), zero at the sequence start
     const int Kh = (T - 1) * B;
@@ -2787,9 +2789,9 @@ static int rnn_bwd_gemms(int cell, int T, int B, int I, int H, int dirs, const f
       if (rc) return rc;
     } else {
       // same A = da^T over the same K = T*B window as dW_ih above (its bf16 planes are reused); h_prev = y shifted by one timestep
-      ctcn_gemm_hint_same_a();
+      pl.same_a = true;
       rc = ctcn_gemm_shift_b(GH, H, TB, da, ldg, y + (size_t)d * H, dirs * H, dw_hh[d], H, beta_w, precision, ws, ws_bytes, stream, xcd_allow,
-                             d == 0 ? B : -B);
+                             d == 0 ? B : -B, &pl);
       if (rc) return rc;
     }
   }

@@ -8,10 +8,8 @@ extern "C" int ctcn_gemm(int, int, int, int, int, const float *, int, const floa
 extern "C" int ctcn_transpose01(const float *, float *, int, int, int, void *) { return 0; }
 int ctcn_transpose01_pair(const float *, const float *, float *, float *, int, int, int, void *) { return 0; }
 extern "C" int ctcn_dropout(const float *, float *, size_t, float, uint64_t, uint64_t, void *) { return 0; }
-void ctcn_gemm_hint_same_a(void) {}
-void ctcn_gemm_hint_same_b(void) {}
-int ctcn_gemm_on_xcds(int, int, int, int, int, const float *, int, const float *, int, float *, int, float, int, void *, size_t, void *, unsigned) { return 0; }
-int ctcn_gemm_shift_b(int, int, int, const float *, int, const float *, int, float *, int, float, int, void *, size_t, void *, unsigned, int) { return 0; }
+int ctcn_gemm_on_xcds(int, int, int, int, int, const float *, int, const float *, int, float *, int, float, int, void *, size_t, void *, unsigned, GemmPlanes *) { return 0; }
+int ctcn_gemm_shift_b(int, int, int, const float *, int, const float *, int, float *, int, float, int, void *, size_t, void *, unsigned, int, GemmPlanes *) { return 0; }
 
 namespace {
 __global__ void empty_kernel(RnnArgs p) { if (p.T < 0) p.y[0] = 1.f; }
