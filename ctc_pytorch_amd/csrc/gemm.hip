@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
             else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             const int n = t * NMM + i * WNT + j;
-            if (MODE != 0 && (n & 1) && (n >> 1) < 4 + NB) {
+            if (MODE != 0 && (n & 1) && (n >> 1) < (MODE == 1 ? 4 : 4 + NB)) {       // (MODE 1: the A pieces only -- B's are loaded in the read phase after)
               __builtin_amdgcn_sched_barrier(0);
               if constexpr (MODE == 1) load_piece(n >> 1, k0);
               if constexpr (MODE == 2) convert_piece(n >> 1);
@@ -1586,12 +1586,15 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
     store_ab(0);
     if (nst > 1) {
 #pragma unroll
-      for (int q = 0; q < 4 + NB; ++q) load_piece(q, kbeg + 32);
+      for (int q = 0; q < 4; ++q) load_piece(q, kbeg + 32);
     }
     pp_barrier();
     if (wm == 1) pp_barrier();
-    // a stage = four phases: read (s, k-half 0) | multiply + split of the pieces of stage s + 1 (loaded two phases ago) |
-    //                        read (s, 1) + LDS stores of stage s + 1 (buffer last read two phases ago) | multiply + loads of stage s + 2
+    // a stage = four phases: read (s, k-half 0) + loads of B(s+1) | multiply + split of the pieces of stage s + 1 (A loaded two phases ago) |
+    //                        read (s, 1) + LDS stores of stage s + 1 (buffer last read two phases ago) | multiply + loads of A(s+2)
+    // (round 3: all 4 + NB loads in the second multiply phase made it the longest of the four -- 1 000 cycles against a first read phase of
+    // 400 whose half then waits 600 for the other half's multiply; B's NB loads moved into that read phase.  The compiler's counted vmcnt
+    // waits in the split keep the order: A's pieces, the older loads, are split first)
 #ifdef CTCN_GEMM_STATS
     long long gs_work[4] = {0, 0, 0, 0}, gs_wait[4] = {0, 0, 0, 0};
     const long long gs_t0 = clock64();
@@ -1599,6 +1602,11 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
 #endif
     auto stage = [&](int s, auto do_store, auto c1) {
       load_frags(s, 0);
+      if constexpr (decltype(do_store)::value == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 4; q < 4 + NB; ++q) load_piece(q, kbeg + (s + 1) * 32);       // (their registers were stored to LDS two phases ago)
+      }
       PPB(0);
       if constexpr (decltype(do_store)::value == 1) multiply(with_split, 0);
       else multiply(bare, 0);
