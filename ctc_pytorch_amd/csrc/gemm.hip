@@ -1288,13 +1288,15 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
   };
   constexpr int NMM = 4 * WNT;
   // One multiply phase: 3 * NMM MFMAs with the wave's other work of the stage between them, one item behind an MFMA:
-  //   WHICH 1 (first multiply of stage s):  DMA pieces of B(s+1), the two loads of A(s+2) row 0 | split of A(s+1) row 1 (loaded two phases ago)
-  //   WHICH 2 (second multiply):            the two loads of A(s+2) row 1 | split of A(s+2) row 0 (loaded two phases ago)
+  //   WHICH 1 (first multiply of stage s):  DMA pieces of B(s+1) | split of A(s+1) row 1 (loaded three phases ago)
+  //   WHICH 2 (second multiply):            split of A(s+2) row 0 (loaded three phases ago)
   // HAS1: stage s + 1 exists, HAS2: stage s + 2 exists.  The float32 -> hi / lo split (12 VALU instructions per four floats) sits in the
   // shadow of the wave's OWN MFMAs, ~5 cycles per instruction: in the read phases, next to the other half's MFMAs, the same instructions cost
   // 15-20 cycles each (as one block of both rows that phase was 1 100-1 400 cycles long against the 430-500 of the MFMAs it is meant to hide
-  // behind; one row per read phase: 800 -- tools/mb_gemm_pp.hip).  In flight, oldest first (loads and DMA pieces return in order), when the
-  // split starts: first multiply: A(s+1) row 1 (2 loads), this phase's 2 IB DMA pieces and (HAS2) 2 loads; second: A(s+2) row 0 (2), row 1 (2)
+  // behind; one row per read phase: 800 -- tools/mb_gemm_pp.hip).  The A loads leave from the READ phases (row 0 of A(s+2) in the first one of
+  // stage s, row 1 in the second, each right behind the ds_write that freed its registers).  In flight, oldest first (loads and DMA pieces
+  // return in order), when the split starts: first multiply: A(s+1) row 1 (2 loads), A(s+2) row 0 (2, HAS2), this phase's 2 IB DMA pieces;
+  // second multiply: A(s+2) row 1 (2) -- row 0 and the DMA pieces were waited for in front of the barrier before it
   auto multiply = [&](auto which, auto has1, auto has2, int s) {
     constexpr int WHICH = decltype(which)::value;
     constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
@@ -1309,18 +1311,16 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
           else if (t == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           const int n = t * NMM + i * WNT + j;
-          if (n < 2 * IB + 2 || n == CV0 || n == CV0 + 1) {
+          if (n < 2 * IB || n == CV0 || n == CV0 + 1) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (WHICH == 1) {
               if (HAS1 && n < 2 * IB) issue_b_piece(n, (s + 1) * 32, (s + 1) & 1);
-              if (HAS2 && n >= 2 * IB && n < 2 * IB + 2) load_a_piece(n - 2 * IB, (s + 2) * 32);
               if (HAS1 && n == CV0) {
                 if constexpr (HAS2) { if constexpr (IB == 1) WAIT_A(4, 1); else WAIT_A(6, 1); }
                 else { if constexpr (IB == 1) WAIT_A(2, 1); else WAIT_A(4, 1); }
               }
               if (HAS1 && n >= CV0) convert_half(1, n - CV0, (s + 1) * 32);
             } else {
-              if (HAS2 && n < 2) load_a_piece(2 + n, (s + 2) * 32);
               if (HAS2 && n == CV0) WAIT_A(2, 0);
               if (HAS2 && n >= CV0) convert_half(0, n - CV0, (s + 2) * 32);
             }
@@ -1363,12 +1363,20 @@ __global__ __launch_bounds__(512) void gemm_planes_nt256pp_af32_kernel(int M, in
     constexpr bool HAS1 = decltype(has1)::value, HAS2 = decltype(has2)::value;
     load_frags(s, 0);
     if constexpr (HAS1) store_a_row(0, (s + 1) & 1);          // A(s+1) row 0 (split in the previous multiply phase) -> the other buffer (last read two phases ago)
+    if constexpr (HAS2) {                                     // its registers take A(s+2) row 0 (the ds_write above has read them at issue; the load returns hundreds of cycles later)
+      __builtin_amdgcn_sched_barrier(0);
+      load_a_piece(0, (s + 2) * 32); load_a_piece(1, (s + 2) * 32);
+    }
     PPB(0);
     multiply(first, has1, has2, s);
     PPB(1);
     load_frags(s, 1);
     if constexpr (HAS1) store_a_row(1, (s + 1) & 1);          // A(s+1) row 1 (split in the multiply phase just before)
-    // this wave's DMA pieces of B(s+1) have landed (the two loads of A(s+2) row 0, issued behind them, may still be in flight)
+    if constexpr (HAS2) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_a_piece(2, (s + 2) * 32); load_a_piece(3, (s + 2) * 32);
+    }
+    // this wave's DMA pieces of B(s+1) have landed (and A(s+2) row 0, older; the two loads of row 1, just issued, stay in flight)
 #ifdef CTCN_GEMM_STATS
     PPB_VM(2);
 #else
