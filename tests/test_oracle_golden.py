@@ -201,6 +201,27 @@ def test_beam_search_nbest_pins_the_oracle_to_the_reference():
         assert [u[0] for u in ids] == [list(map(int, u)) for u in one] and np.array_equal(s1, score[:, 0])
 
 
+def test_beam_search_nbest_short_final_beam():
+    """n-best when the final beam holds fewer labellings than asked for: every returned list is a prefix of the longer request's list, entries
+    past the final beam are absent (count < nbest), and scores are sorted; two-class input where the search can only ever build a handful
+    of distinct labellings."""
+    rs = np.random.RandomState(3)
+    T, V = 6, 3
+    p = rs.dirichlet(np.ones(V) * 0.7, size=(2, T)).astype(np.float32)             # (B=2, T, V) probabilities
+    tab = np.zeros((V + 1, V + 1), dtype=np.float64)
+    full, fs, st = beam_ref.decode_ids_nbest(p, [T, T - 2], tab, 0.0, 8, 8)
+    assert not st.any()
+    for b in range(2):
+        assert 1 <= len(full[b]) <= 8
+        assert len({tuple(y) for y in full[b]}) == len(full[b])                        # distinct labellings
+        assert all(fs[b, k] >= fs[b, k + 1] for k in range(len(full[b]) - 1))
+        assert (fs[b, len(full[b]):] == 0).all()
+    for N in (1, 2, 5):
+        part, ps, _ = beam_ref.decode_ids_nbest(p, [T, T - 2], tab, 0.0, 8, N)
+        for b in range(2):
+            assert part[b] == full[b][:N] and np.array_equal(ps[b, :len(part[b])], fs[b, :len(part[b])])
+
+
 def test_beam_error_paths():
     i2c = synth.int2char(62)
     tab = beam_ref.arpa_table(os.path.join(G, "lm_phone_bg.arpa"), i2c)
