@@ -2428,7 +2428,7 @@ int gates_of(int cell) { return cell == CTCN_CELL_LSTM ? 4 : (cell == CTCN_CELL_
 
 // which recurrent kernel the last forward / backward call of this process launched (diagnostics: ctcn_rnn_last_kernel; bench.py names
 // the kernel its roofline object describes from this, not from what the host expects)
-const char *g_last_kernel[2] = {"", ""};
+thread_local const char *g_last_kernel[2] = {"", ""};   // diagnostic only (ctcn_rnn_last_kernel): per calling thread, string literals
 
 // One line on stderr (per distinct reason, per process) when a layer that asked for the persistent recurrence runs one launch
 // per timestep instead: that path is 4x slower and nothing else would tell the user.  CTCN_QUIET=1 silences it.
@@ -2507,6 +2507,10 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
   const bool piped = !proj_done && ov.stream && ov.event && ov.ws && ov.xcd_allow != 0 && dirs == 2 && w_ih1 == w_ih0 + (size_t)GH * I &&
                      ctcn_opt_rnn_persistent() && ctcn_get_option("rnn_fwd_tagged") && precision == 1 && cell != CTCN_CELL_TANH && H % 32 == 0 &&
                      H / 32 <= 24 && nxd_p > 1 && T >= 4 * NCHUNK && chunk_T * (NCHUNK - 1) < T &&
+                     // the LAST chunk holds at least two frames: the RSV prologue fetches the pre-activations of steps 0 and 1 without looking
+                     // at the chunk counter, and step 1 of the reverse direction is frame T - 2 -- with a one-frame last chunk (8 chunks:
+                     // T = 36 / 43 / 50 / 57) that frame belongs to pair 1, which the side stream writes after the launch
+                     T - chunk_T * (NCHUNK - 1) >= 2 &&
                      (size_t)T * B * dirs * GH * sizeof(float) < ((size_t)1 << 32) &&
                      // the side GEMMs' workgroups that land on a recurrence XCD must be able to START there (to exit at once): the
                      // 1024-thread workgroups of the recurrence leave no room on their own CUs, so some CUs of the XCD must stay free --
@@ -2855,11 +2859,13 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
     // scatter formulation (default): partial dh tiles travel, 1 KB per (owner, source) pair; gather formulation: the da tile
     // measured: scatter wins at H = 320 (2.46 vs 2.68 us per step), ties at H = 128, loses at H = 512 (nsl^2 KB of partial tiles
     // per group and step) and at precision 0 (f32 MFMA: 32 cycles x 16 per tile on 4 waves per SIMD)
-    // item-wave gather (rnn_bwd_scatter2, option "bwd_item_gather"): tagged hand-off only, up to 36 slices (H <= 576), 16-B aligned reserves
+    // item-wave gather (rnn_bwd_scatter2, option "bwd_item_gather"): tagged hand-off only, up to 40 slices (H <= 640), 16-B aligned reserves
+    // (gates / aux are checked above; dy, y and -- when the unfused dropout pass feeds the kernel -- dy_tmp here: 16-B LDS DMA and f32x4 stores)
     // "bwd_item_gather": 0 never, 1 (default) where it measured faster -- more than 20 slices, i.e. H > 320 (tools/mb_bwd2.hip: H = 384 1.58 vs
     // 1.63 us per step, H = 512 2.44 vs 3.38 for the gather formulation, the only other kernel there; H = 320 1.90 vs 1.88, H = 128 1.25 vs 1.19) --, 2 always
     const int ig = ctcn_get_option("bwd_item_gather");
-    const bool gather2 = (ig == 2 || (ig >= 1 && (nsl > 20 || !fits32))) && nsl <= 40 && ctcn_opt_handoff_tags() && H % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)y % 16 == 0;
+    const bool gather2 = (ig == 2 || (ig >= 1 && (nsl > 20 || !fits32))) && nsl <= 40 && ctcn_opt_handoff_tags() && H % 4 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)y % 16 == 0 &&
+                         (!call.dy_tmp || (uintptr_t)call.dy_tmp % 16 == 0);
     const bool scatter = ctcn_opt_bwd_scatter() && prec && nsl <= (gather2 ? 40 : 24);
     const int ntw = nsl <= 12 ? 1 : 2;                        // rnn_bwd_scatter: output tiles per scattering wave (12 of them; nsl <= 24)
     const size_t hx_bytes = scatter ? align_up((size_t)2 * dirs * nbt * nsl * nsl * 1024, 256)

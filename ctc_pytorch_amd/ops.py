@@ -415,7 +415,10 @@ class _RNNLayer(torch.autograd.Function):
             side = False
         # small layers (below min_items: weight GEMMs inline): the two directions' weight gradients are independent chains of small launches
         # that do not fill the device one at a time -- one direction per stream, joined at once (nothing runs next to a recurrence)
-        small_split = (not side and not split_dirs and into_flat and _side["enabled"] and _side["small_split"] and dirs == 2 and T > 1)
+        # (not when the layer ABOVE has parked side work: the join below waits for the whole side stream, which would then hold that layer's
+        # deferred weight GEMMs -- and its early all-reduce -- in front of the main stream; a mixed large / small stack keeps this layer inline)
+        small_split = (not side and not split_dirs and into_flat and _side["enabled"] and _side["small_split"] and dirs == 2 and T > 1
+                       and key not in _side["deferred"])
         if small_split:
             split_dirs = True
         # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right

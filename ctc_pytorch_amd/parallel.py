@@ -240,7 +240,14 @@ def sync_bn_buffers(model):
     """Per-shard BatchNorm (the default, sync_bn off) leaves every rank with running_mean / running_var of its OWN shards; evaluation and
     the checkpoint (written by rank 0) would then depend on the rank.  Called at the end of a training epoch: the floating-point buffers
     are averaged over the ranks (num_batches_tracked is identical everywhere).  A no-op without collectives or with sync_bn on (the
-    statistics are already global there, averaging identical values changes nothing but rounding -- skipped)."""
+    statistics are already global there, averaging identical values changes nothing but rounding -- skipped).
+
+    An APPROXIMATION of the single-process buffers, by construction of per-shard statistics: running_mean is exact for equal shards (the
+    moving average is linear in the per-step means); running_var becomes the rank average of the per-shard variances, i.e. the global
+    batch variance MINUS the between-shard variance of the means, E_k[Var_r(mu_{r,k})] -- about 1 / (rows per shard) of the variance for
+    i.i.d. shards (1 / 25 600 at cfg2), and not recoverable from the averaged buffers: the moving average of a variance of means is not
+    the variance of the moving averages.  Uneven shards (the last batch of an epoch) are weighted equally.  `enable_sync_bn()` is the
+    exact mode."""
     if not _collectives_on() or world_size() == 1:
         return 0
     from . import ops

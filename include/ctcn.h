@@ -344,8 +344,10 @@ int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const int32_t *len
  * ctcn_diag_squat: `wgs_per_xcd` workgroups of `threads` threads (+ `lds_bytes` of LDS each) on every XCD that only hold their CU
  * slots for `usec` microseconds (clock-bounded, <= 5 s) -- what an RCCL kernel waiting for a slow peer looks like to the rest of the
  * chip.  The data-parallel co-residency contract of the persistent recurrences is tested against it.
- * ctcn_rnn_last_kernel: name of the recurrent kernel the most recent ctcn_rnn_fwd (which = 0) / ctcn_rnn_bwd (which = 1) of this
- * process launched ("rnn_fwd_tagged", "rnn_fwd_persist", "rnn_fwd_step", "rnn_bwd_scatter", "rnn_bwd_persist", "rnn_bwd_step"). */
+ * ctcn_rnn_last_kernel: name of the recurrent kernel the most recent ctcn_rnn_fwd (which = 0) / ctcn_rnn_bwd (which = 1) of the CALLING
+ * THREAD launched ("rnn_fwd_tagged", "rnn_fwd_persist", "rnn_fwd_step", "rnn_bwd_scatter", "rnn_bwd_scatter2", "rnn_bwd_persist",
+ * "rnn_bwd_step"; "" before the thread's first call).  The one piece of state the library keeps between compute calls: a thread-local
+ * pointer to a string literal, read by nothing on the compute path. */
 int ctcn_diag_squat(int wgs_per_xcd, int threads, int lds_bytes, unsigned usec, void *stream);
 const char *ctcn_rnn_last_kernel(int which);
 

@@ -1000,6 +1000,48 @@ def test_forward_projection_overlap_equals_inline(dev, rnn, H, B, T):
     assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
 
 
+@pytest.mark.parametrize("T", [57, 50, 43, 36, 58, 64])
+@pytest.mark.parametrize("rsv", [1, 0])
+def test_forward_projection_overlap_short_last_chunk(dev, T, rsv):
+    """with 8 time chunks and T = 36 / 43 / 50 / 57 the last chunk holds ONE frame, so step 1 of the reverse direction
+    (frame T - 2) lies in chunk pair 1, which the side stream projects after the recurrence was launched -- and the prologue of the
+    reserve-through-LDS variant (`fwd_rsv_lds = 1`) fetches the pre-activations of steps 0 and 1 without looking at the chunk counter.
+    The host now keeps such a T off the pipeline; with the side-stream threshold lowered so that the pipeline WOULD apply, output,
+    reserves-derived gradients and weight gradients equal the inline order bit for bit, six runs in a row."""
+    from ctc_pytorch_amd import nn, ops
+    ops.set_precision(1)
+    H, B = 320, 32
+    rs = np.random.RandomState(T)
+    layer = nn.LSTM(40, H, bidirectional=True, bias=False).to(dev)
+    x = torch.from_numpy(rs.standard_normal((T, B, 40)).astype(np.float32)).to(dev)
+    gy = torch.from_numpy(rs.standard_normal((T, B, 2 * H)).astype(np.float32)).to(dev)
+    outs = {}
+    old_min = ops._side["min_items"]
+    try:
+        ops.set_side_stream(True, min_items=1)
+        ops.set_option("fwd_rsv_lds", rsv)
+        for mode in (False, True, True, True, True, True, True):
+            ops.set_fwd_overlap(mode)
+            xin = x.clone().requires_grad_()
+            for p_ in layer.parameters():
+                p_.grad = None
+            y, _ = layer(xin)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            ops.check_health()
+            assert ops.rnn_last_kernels()[0] == "rnn_fwd_tagged"
+            got = [y.detach().clone(), xin.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()]
+            if mode not in outs:
+                outs[mode] = got
+            else:
+                assert all(torch.equal(a, b_) for a, b_ in zip(got, outs[mode]))
+    finally:
+        ops.set_fwd_overlap(True)
+        ops.set_option("fwd_rsv_lds", 2)
+        ops.set_side_stream(True, min_items=old_min)
+    assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
+
+
 @pytest.mark.parametrize("rnn,H,B,T,I,bidir", [("LSTM", 320, 32, 100, 640, True), ("GRU", 256, 20, 77, 40, True), ("LSTM", 64, 5, 33, 24, False),
                                                ("LSTM", 24, 3, 9, 8, True), ("RNN", 32, 4, 12, 8, True), ("LSTM", 30, 2, 7, 6, True)])
 def test_rnn_layer_with_fused_dropout_equals_layer_then_dropout(dev, rnn, H, B, T, I, bidir):
