@@ -376,39 +376,45 @@ __device__ __forceinline__ double lane_gather(double v, int src_lane) {
 struct __attribute__((aligned(16))) Survivor { unsigned long long k; int idx; int pad; };
 constexpr int SURV_MAX = 256;
 
+constexpr int FAST_NCT = 1024 - 192;                           // candidate threads: waves 3..15
 constexpr int FAST_NTH = 1024, FAST_NWV = FAST_NTH / 64;      // 16 waves: the parallel phases are instruction-issue bound (~10 cycles per
                                                                // dependent instruction and wave), so more waves per SIMD is what shortens them
 template <int NPT, bool LM_LDS>
 __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   constexpr int NTH = FAST_NTH, NWV = FAST_NWV;
-  // dynamic LDS: [alpha*LM (V+1)^2 doubles] | cand[W*V] doubles | lg[V] doubles | mslot[W*V] ints | flist[T] ints | trie[slots] uints
+  // dynamic LDS: [alpha*LM (V+1)^2 doubles] | cand[W*V] doubles | lg[2][V] doubles (by frame parity) | mslot[W*V] ints | flist[T] ints | trie[slots] uints
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   __shared__ Survivor surv[SURV_MAX];                                 // candidates above the pruning bound (order-preserving key, index)
   __shared__ double red_v[NWV];
   __shared__ int red_i[NWV + 1];
   __shared__ unsigned gmax[64];                                        // per 16-lane row: largest candidate key (high word)
   __shared__ double bm_pB[FAST_WMAX], bm_pT[FAST_WMAX], selv[FAST_WMAX];
-  __shared__ int bm_c1[FAST_WMAX], sel[FAST_WMAX];
+  __shared__ int bm_c1[2][FAST_WMAX], sel[FAST_WMAX];                 // context class of every slot, by frame parity
   __shared__ int f_node[FAST_WMAX], f_len[FAST_WMAX], f_last[FAST_WMAX];   // final beam (dumped once, after the last frame)
   __shared__ double f_pT[FAST_WMAX];
   __shared__ int woff[NWV];
   __shared__ double stayv[FAST_WMAX], homev[FAST_WMAX];
   __shared__ int ns[FAST_WMAX];
+  __shared__ double enbv[FAST_WMAX], totv[FAST_WMAX];                // this frame's e.nb of every slot (e.t is homev) | log_add(prBlank', prNonBlank') of the next frame (wave 2)
+  __shared__ int nid[2][FAST_WMAX];                                   // node id of every beam slot, double-buffered by frame parity (wave 1)
+  __shared__ int s_totflag, s_beamflag, s_decflag;                    // frame number + 1 whose totv[] | beam record (bm_*) | wave 1's decode of the selection is complete
+  __shared__ int s_fault;                                             // a bounded wait inside the workgroup ran out (status 4)
   __shared__ int s_cnt;
   __shared__ unsigned s_theta;
-  __shared__ int s_nfl, s_gnodes, s_lnodes;      // processed frames | 0 while the LDS trie takes inserts, else 1 + global nodes | LDS trie nodes
+  __shared__ int s_nfl, s_gnodes;                // processed frames | 0 while the LDS trie takes inserts, else 1 + global nodes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, V = a.V, W = a.W, B = a.B, T = a.T, blank = a.blank;
   const int V1 = V + 1;
   double *lmA = reinterpret_cast<double *>(fsm);
   double *cand = lmA + (LM_LDS ? V1 * V1 : 0);
-  double *lg = cand + W * V;
-  int *mslot = reinterpret_cast<int *>(lg + V);
+  double *lg2 = cand + W * V;
+  int *mslot = reinterpret_cast<int *>(lg2 + 2 * V);
   int *flist = mslot + W * V;
   unsigned *trie = reinterpret_cast<unsigned *>(flist + T);
   const int TS = a.trie_slots;
   const unsigned tmask = (unsigned)TS - 1u;
+  const int tshift = 32 - (31 - __builtin_clz((unsigned)TS));      // top log2(TS) bits of a 32-bit hash
   unsigned long long *ht = a.ht + (size_t)b * a.ht_size;
   int *npar = a.node_par + (size_t)b * a.max_nodes;
   int *nsym = a.node_sym + (size_t)b * a.max_nodes;
@@ -421,9 +427,10 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   for (int i = tid; i < TS; i += NTH) trie[i] = 0u;
   const int nframes = min(max(a.lens[b], 0), T);
   if (tid == 0) {
-    bm_c1[0] = V; bm_pB[0] = 0.0; bm_pT[0] = 0.0;                                // the empty labelling: prBlank = prTotal = 0 (BeamSearch.py:83-87)
-    s_nfl = 0; s_gnodes = 0; s_lnodes = 0;
+    bm_c1[0][0] = V; bm_pB[0] = 0.0; bm_pT[0] = 0.0;                             // the empty labelling: prBlank = prTotal = 0 (BeamSearch.py:83-87)
+    s_nfl = 0; s_gnodes = 0; s_totflag = 0; s_beamflag = 0; s_decflag = 0; s_fault = 0;
   }
+  if (tid < 2 * FAST_WMAX) nid[0][tid] = 0;                                       // (both parities: node 0 = the empty labelling)
   __syncthreads();
   // frames the search processes, in order (BeamSearch.py:93-94: skip when 1 - p_blank < 0.1, a float32 compare), each with its
   // "p_blank of the previous frame < 0.9" bit (:63) and its "log(0)" bit
@@ -449,32 +456,41 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   }
   const int nfl = s_nfl;
 
-  // Wave 0 owns the beam (lane = slot) and the serial work; waves 1..15 (960 threads) own the candidates: slot i of thread u = tid - 64
-  // is c = ((37 * u) mod 960) + 960 * i -> (beam ci, class ck; ck < 0: the stay slot).  Any bijection works (the selection ranks
-  // by explicit (score, index)); the multiplier spreads neighbouring candidates -- the classes of one beam -- over different
-  // 16-lane rows, which keeps the pruning bound of the selection tight.
-  constexpr int NCT = NTH - 64;
+  // Wave 0 owns the beam (lane = slot) and the serial chain, wave 1 the prefix trie (node ids are only needed a frame later), wave 2 the
+  // log-add of every slot's stay entry that needs no parent slot (round 4); waves 3..15 (832 threads) own the candidates: slot i of
+  // thread u = tid - 192 is c = ((37 * u) mod 832) + 832 * i -> (beam ci, class ck; ck < 0: the stay slot).  Any bijection works (the
+  // selection ranks by explicit (score, index)); the multiplier spreads neighbouring candidates -- the classes of one beam -- over
+  // different 16-lane rows, which keeps the pruning bound of the selection tight.
+  constexpr int NCT = FAST_NCT;
   int cc[NPT], ci[NPT], ck[NPT];
 #pragma unroll
   for (int i = 0; i < NPT; ++i) {
-    const int c = wave == 0 ? W * V : ((37 * (tid - 64)) % NCT) + i * NCT;
+    const int c = wave < 3 ? W * V : ((37 * (tid - 192)) % NCT) + i * NCT;
     cc[i] = min(c, W * V - 1);
     ci[i] = c < W * V ? c / V : FAST_WMAX;                        // beyond the table / wave 0: never valid (nb <= W <= FAST_WMAX)
     const int kk = c - (c / V) * V;
     ck[i] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
   }
   // ln p row of the next frame, one frame ahead (threads < V; handed to everybody through LDS)
+  // (held by threads 128 .. 128 + V - 1: wave 0's instruction stream is the critical chain; lg[p] = row of the frames of parity p, written
+  // at the top of the frame BEFORE the one that uses it, so that every reader finds it behind the selection's barriers)
   double nlg = 0.0;
+  const int lgk = tid - 128;
   auto fetch_lg = [&](int fword) {
-    if (tid < V) nlg = a.lgd[((size_t)(fword & TMASK) * B + b) * V + tid];
+    if (lgk >= 0 && lgk < V) nlg = a.lgd[((size_t)(fword & TMASK) * B + b) * V + lgk];
   };
   if (nfl > 0) fetch_lg(flist[0]);
-  if (tid < V) lg[tid] = nlg;
+  if (lgk >= 0 && lgk < V) lg2[lgk] = nlg;
   if (nfl > 1) fetch_lg(flist[1]);
 
   // the beam: lane r of wave 0 holds slot r.  node ids: 0 = the empty labelling, s + 1 = LDS trie slot s, TS + 1 + g = entry g of the
-  // global table.  z_mf = the slot that holds this slot's parent labelling (-1: none) -- its extension by z_last IS this labelling
-  int z_node = 0, z_len = 0, z_last = -1, z_par = -1, z_mf = -1;
+  // global table.  z_mf = the slot that holds this slot's parent labelling (-1: none) -- its extension by z_last IS this labelling.
+  // Wave 0 never waits for the trie: the id of a slot's OWN labelling lives with wave 1 (y_node; handed over through nid[] a frame later,
+  // when a child needs it as its z_par).  What wave 0 carries instead is the parent labelling's key, (z_gpar, z_plast) = (id of the
+  // grandparent labelling, last class of the parent labelling): a labelling created in this frame as (parent id p, class k) IS the parent
+  // of slot r exactly when p == z_gpar[r] and k == z_plast[r] (ids are unique per (parent, class)), which needs old ids only.
+  int z_len = 0, z_last = -1, z_par = -1, z_mf = -1, z_gpar = -2, z_plast = -1;
+  int y_node = 0, y_lnodes = 0;                                    // wave 1: node id of slot `lane`; LDS trie nodes so far (wave-uniform)
   double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;
   double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;          // this frame's stay / merged entry of the slot (BeamSearch.py:99-113)
   int nb = 1, status = 0;
@@ -487,10 +503,11 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   // ---- scoring of frame jf, two parties side by side -------------------------------------------------------------------------
   // waves 1..15: extension scores (calcExtPr) into cand[]: two LDS hops (the slot's context class, then LM / prBlank / prTotal),
   // every read of a hop issued before the first use (clamped addresses, selects afterwards)
-  auto score_extensions = [&](bool rep_ok) {
+  auto score_extensions = [&](bool rep_ok, int jf) {
+    const double *lg = lg2 + (jf & 1) * V;
     int c1[NPT];
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[min(ci[i], FAST_WMAX - 1)];
+    for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[jf & 1][min(ci[i], FAST_WMAX - 1)];
     double lmv[NPT], pbv[NPT], ptv[NPT], lk[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
@@ -515,6 +532,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   // mslot[extension candidate] = {frame tag, 1: holds slot ip's merged entry | 0: removed (merged into the stay candidate), ip}
   auto stay_and_merge = [&](bool rep_ok, int jf) {
     const int ip = lane;
+    const double *lg = lg2 + (jf & 1) * V;
     const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
     const int mi = ip < nb ? z_mf : -1;
     const int src = max(mi, 0);
@@ -529,29 +547,37 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     const double s_b = z_pT + lgb;                                // :106
     const bool ext_first = mi >= 0 && mi < ip;                    // the reference meets the extension before the stay entry
     BSTAMP(6);
-    double r_nb, r_t;
-    if (nb <= 32) {
-      // lanes 0..31: tot = log_add(s_b, s_nb) of slot lane; lanes 32..63: e.nb of slot lane - 32 when merged -- side by side
-      const int q = lane & 31;
-      const double q_snb = lane_gather(s_nb, q), q_pr = lane_gather(pr, q);
-      const int q_mi = lane_gather(mi, q);
-      const bool q_first = q_mi >= 0 && q_mi < q;
-      double x = lane < 32 ? s_b : (q_first ? q_pr : q_snb), y = lane < 32 ? s_nb : (q_first ? q_snb : q_pr);
-      const bool need = lane < 32 ? true : q_mi >= 0;
-      const double r1 = need ? log_add_prob(x, y) : LOG_ZERO;
-      const double a_nb = lane_gather(r1, (lane & 31) + 32);
-      const double tot = r1;                                       // (lanes < 32)
-      r_nb = mi >= 0 ? a_nb : s_nb;
-      r_t = mi >= 0 ? (ext_first ? log_add_prob(pr, tot) : log_add_prob(tot, pr)) : tot;
-    } else {
-      const double tot = log_add_prob(s_b, s_nb);
-      r_nb = mi >= 0 ? (ext_first ? log_add_prob(pr, s_nb) : log_add_prob(s_nb, pr)) : s_nb;
-      r_t = mi >= 0 ? (ext_first ? log_add_prob(pr, tot) : log_add_prob(tot, pr)) : tot;
+    // tot = log_add(s_b, s_nb) of every slot comes from wave 2 (it needs no parent slot, so it is computed next to the lines above)
+    // (bounded: wave 2 reaches its store whenever this wave gets here -- both follow the wave-uniform `more` -- so the bound only turns a
+    // programming error into status 4 instead of a hung workgroup)
+    // -- and mslot[] below is rewritten only once wave 1, too, has decoded this frame's selection (s_decflag; set thousands of cycles ago)
+    for (int spins = 0; __hip_atomic_load(&s_totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != jf + 1 ||
+                        __hip_atomic_load(&s_decflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != jf; ++spins) {
+      if (spins > (1 << 20)) { s_fault = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const double tot = totv[ip];
+    double r_nb = s_nb, r_t = tot;
+    if (__any(mi >= 0)) {                                          // some slot merges with its parent's extension: ONE level of log-adds
+      // lanes 0..31: e.t of slot q, lanes 32..63: e.nb of slot q, q = (lane & 31) + 32 * pass -- side by side (one pass when nb <= 32)
+#pragma nounroll
+      for (int q0 = 0; q0 < nb; q0 += 32) {
+        const int q = (lane & 31) + q0;
+        const double q_snb = lane_gather(s_nb, q), q_pr = lane_gather(pr, q), q_tot = lane_gather(tot, q);
+        const int q_mi = lane_gather(mi, q);
+        const bool q_first = q_mi >= 0 && q_mi < q;
+        const double other = lane < 32 ? q_tot : q_snb;
+        const double ax = q_first ? q_pr : other, ay = q_first ? other : q_pr;      // the reference's argument order (extension met first or second)
+        const double r1 = q_mi >= 0 ? log_add_prob(ax, ay) : LOG_ZERO;
+        const int from = (lane & 31);                              // slot ip = q0 + from reads lanes from (e.t) and from + 32 (e.nb)
+        const double a_t = lane_gather(r1, from), a_nb = lane_gather(r1, from + 32);
+        if (mi >= 0 && (ip >> 5) == (q0 >> 5)) { r_nb = a_nb; r_t = a_t; }
+      }
     }
     BSTAMP(7);
     if (ip < nb) {
       e_nb = r_nb; e_b = s_b; e_t = r_t;
-      homev[ip] = r_t;
+      homev[ip] = r_t; enbv[ip] = r_nb;
       stayv[ip] = ext_first ? -INFINITY : r_t;
       if (mi >= 0) {
         const int kkl = (z_last < blank) ? z_last + 1 : z_last;
@@ -560,16 +586,33 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     }
     if (lane == 0) { s_theta = 0u; s_cnt = 0; }
   };
+  // wave 2: tot = log_add(prBlank', prNonBlank') (BeamSearch.py:112) of the stay entry of every slot for frame jf, from the slot's
+  // (context class, prNonBlank, prTotal) -- the same expressions on the same operands as wave 0 forms for s_nb / s_b -- then the flag
+  // wave 0 waits for.  It needs no parent slot, so it runs next to wave 0's P4a / parent-slot work instead of in front of its log-add
+  auto stay_totals = [&](int jf, bool on, int c1, double pNB, double pT) {
+    const double *lg = lg2 + (jf & 1) * V;
+    const double lgl = lg[c1 < V ? c1 : 0], lgb = lg[blank];
+    double s_nb = LOG_ZERO;
+    if (c1 < V) s_nb = pNB + lgl;
+    const double s_b = pT + lgb;
+    const double tot = on ? log_add_prob(s_b, s_nb) : LOG_ZERO;
+    totv[lane] = tot;
+    __hip_atomic_store(&s_totflag, jf + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
 
   if (nfl > 0 && !(flist[0] & (1 << 29))) {
     const bool rep0 = (flist[0] >> 30) & 1;
-    if (wave == 0) stay_and_merge(rep0, 0); else score_extensions(rep0);
+    if (wave == 0) stay_and_merge(rep0, 0);
+    else if (wave == 2) stay_totals(0, lane == 0, V, LOG_ZERO, 0.0);       // the empty labelling
+    else if (wave >= 3) score_extensions(rep0, 0);
   }
   lds_barrier();
 
   for (int j = 0; j < nfl; ++j) {
     const int fw = flist[j];
     if (fw & (1 << 29)) { status = 2; break; }                     // math.log(0) in the reference: ValueError
+    if (lgk >= 0 && lgk < V && j + 1 < nfl) lg2[((j + 1) & 1) * V + lgk] = nlg;    // the next frame's ln p row (its last readers were frame j - 1's)
+    if (j + 2 < nfl) fetch_lg(flist[j + 2]);
     BSTAMP(0);
     // P3: BHat = top-W by (prTotal desc, candidate index asc), without sorting.
     //  1. splitter: every 16-lane row reduces the largest key (high word) of its ~16 * NPT candidates on the DPP network; the W-th
@@ -638,6 +681,8 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     if (S <= SURV_MAX) {
       // rank counting: P threads per survivor, thread part p compares it with survivors p, p + P, ...; DPP butterfly sum
       const int P = S <= 64 ? 16 : (S <= 128 ? 8 : 4);
+      if ((tid & ~63) < S * P) {                                 // (waves whose 64 / P survivors do not exist go straight to the barrier: the
+                                                                 // phase is issue-bound, fewer waves per SIMD finish it sooner)
       const int e = tid / P, part = tid - e * P;
       const Survivor me = surv[min(e, SURV_MAX - 1)];
       int cnt = 0;
@@ -654,6 +699,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       if (P >= 8) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
       if (P >= 16) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
       if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
+      }
     } else {
       // more than SURV_MAX candidates above the bound (never seen on the synthetic regimes): W block-wide arg-max rounds over the
       // candidate table (patched first so that it holds this frame's stay / merged entries), exactly as the generic kernel does
@@ -694,11 +740,16 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     lds_barrier();
     const int m = min(W, total);
     BSTAMP(4);
-    // P4a (wave 0): the new beam in rank order -- everything the next frame's extension scores need (context class, prBlank, prTotal)
+    // P4a: the new beam in rank order.  Waves 0, 1 and 2 decode the selection side by side, each for its own job, and meet the others
+    // again at the frame's last barrier only: wave 0 forms the beam (lane = slot) and publishes what the next frame's extension scores need
+    // (context class, prBlank, prTotal; the scoring waves wait for s_beamflag, not for a barrier -- wave 0 does not stop), wave 1 gives every
+    // new labelling its trie node, wave 2 computes the stay totals of the next frame.
+    const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
+    const bool rep_next = (flist[min(j + 1, nfl - 1)] >> 30) & 1;
     bool fresh = false, act = false;
-    int n_node = 0, n_len = 0, n_last = -1, n_par = -1, n_mf = -1, g_mf = -1, src = 0, sym = 0;
+    int n_len = 0, n_last = -1, n_par = -1, n_mf = -1, n_gpar = -2, n_plast = -1, g_mf = -1, src = 0, sym = 0;
     double n_pNB = LOG_ZERO, n_pB = LOG_ZERO, n_pT = LOG_ZERO;
-    if (wave == 0) {
+    if (wave < 3) {
       const int rr = min(lane, FAST_WMAX - 1);
       const int c = sel[rr];
       const double sv = selv[rr];
@@ -710,40 +761,87 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       const bool merged = act && kk != 0 && ms >= 0 && (ms >> 8) == j && (ms & 128);   // this candidate holds the merged entry of slot ms & 63
       fresh = act && kk != 0 && !merged;
       src = merged ? (ms & 63) : i;
-      ns[lane] = -1;
-      const int g_node = lane_gather(z_node, src), g_len = lane_gather(z_len, src), g_last = lane_gather(z_last, src), g_par = lane_gather(z_par, src);
-      g_mf = lane_gather(z_mf, src);
-      const double g_nb = lane_gather(e_nb, src), g_b = lane_gather(e_b, src), g_t = lane_gather(e_t, src);
-      n_node = g_node; n_len = g_len; n_last = g_last; n_par = g_par;
-      n_pNB = g_nb; n_pB = g_b; n_pT = g_t;
-      if (fresh) { n_len = g_len + 1; n_last = sym; n_par = g_node; n_pNB = sv; n_pB = LOG_ZERO; n_pT = sv; }
-      if (act) { bm_c1[lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
-      if (act && !fresh) ns[src] = lane;                           // where the old slot's labelling went
+      if (wave == 0) {
+        ns[lane] = -1;
+        const int g_len = lane_gather(z_len, src), g_last = lane_gather(z_last, src), g_par = lane_gather(z_par, src);
+        const int g_gpar = lane_gather(z_gpar, src), g_plast = lane_gather(z_plast, src);
+        const int g_nid = nid[j & 1][src];                         // id of the old slot's labelling (wave 1, previous frame)
+        g_mf = lane_gather(z_mf, src);
+        const double g_nb = lane_gather(e_nb, src), g_b = lane_gather(e_b, src), g_t = lane_gather(e_t, src);
+        n_len = g_len; n_last = g_last; n_par = g_par; n_gpar = g_gpar; n_plast = g_plast;
+        n_pNB = g_nb; n_pB = g_b; n_pT = g_t;
+        if (fresh) {
+          n_len = g_len + 1; n_last = sym; n_par = g_nid; n_gpar = g_len > 0 ? g_par : -2; n_plast = g_last;
+          n_pNB = sv; n_pB = LOG_ZERO; n_pT = sv;
+        }
+        if (act) { bm_c1[(j + 1) & 1][lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
+        if (act && !fresh) ns[src] = lane;                           // where the old slot's labelling went
+        __hip_atomic_store(&s_beamflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (wave == 1) {
+        __hip_atomic_store(&s_decflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (the reads above have returned: `src` is formed)
+      } else if (wave == 2 && more) {
+        // the new slot's (context class, prNonBlank, prTotal) without wave 0: a fresh labelling carries its candidate's score, a copy the
+        // stay / merged entry of the slot it comes from (enbv / homev, written by wave 0 before the last barrier; bm_c1 of the old parity)
+        const int o_c1 = bm_c1[j & 1][src];
+        const double o_nb = enbv[src], o_t = homev[src];
+        stay_totals(j + 1, act, fresh ? sym : o_c1, fresh ? sv : o_nb, fresh ? sv : o_t);
+      }
     }
-    if (tid < V) lg[tid] = nlg;                                    // the next frame's ln p row (lg is not read during the selection)
-    if (j + 2 < nfl) fetch_lg(flist[j + 2]);
-    lds_barrier();
     BSTAMP(5);
-    const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
-    const bool rep_next = (flist[min(j + 1, nfl - 1)] >> 30) & 1;
-    const int nb_old = nb;
     nb = m;
     if (wave == 0) {
-      // P4b: trie node of every fresh labelling, parent slots of the new beam; then the stay / merge entries of the NEXT frame,
-      // while waves 1..15 score its extensions
+      // P4b (wave 0): parent slot of every new slot, then the stay / merge entries of the NEXT frame.  A fresh labelling's parent is the
+      // old slot it extends; a copy's parent is the old slot's parent, wherever that went -- or, when the parent was NOT in the old beam,
+      // possibly a labelling created just now: fresh lane f holds labelling (parent id n_par[f], class n_last[f]), which is slot r's
+      // parent exactly when that pair equals (n_gpar[r], n_plast[r]).  The loop walks the shorter of the two lane sets.
+      {
+        const int pm = fresh ? src : g_mf;
+        n_mf = (act && pm >= 0 && n_len > 0) ? ns[pm] : -1;
+        const bool scan = act && !fresh && n_len > 1 && g_mf < 0;   // (a labelling of length 1 has the empty labelling as parent: never fresh)
+        unsigned long long fmask = __ballot(fresh), smask = __ballot(scan);
+        if (smask != 0ull && fmask != 0ull) {
+          if (__popcll(fmask) <= __popcll(smask)) {
+            while (fmask) {
+              const int fl = __ffsll((long long)fmask) - 1;
+              fmask &= fmask - 1;
+              const int fp = __builtin_amdgcn_readlane(n_par, fl), fk = __builtin_amdgcn_readlane(n_last, fl);
+              if (scan && fp == n_gpar && fk == n_plast) n_mf = fl;
+            }
+          } else {
+            while (smask) {
+              const int sl = __ffsll((long long)smask) - 1;
+              smask &= smask - 1;
+              const int gp = __builtin_amdgcn_readlane(n_gpar, sl), pk = __builtin_amdgcn_readlane(n_plast, sl);
+              const unsigned long long hit = __ballot(fresh && n_par == gp && n_last == pk);
+              if (hit != 0ull && lane == sl) n_mf = __ffsll((long long)hit) - 1;
+            }
+          }
+        }
+      }
+      z_len = n_len; z_last = n_last; z_par = n_par; z_gpar = n_gpar; z_plast = n_plast; z_mf = n_mf; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
+      if (more) stay_and_merge(rep_next, j + 1);
+    } else if (wave == 1) {
+      // P4b (wave 1): trie node of every fresh labelling; copies keep the id of the slot they come from
+      const int p_id = lane_gather(y_node, src);
+      int id = p_id;
       if (fresh) {
-        const int parent = n_par;
-        int id = -1;
+        const int parent = p_id;
+        id = -1;
         const bool lds_ok = parent <= TS;                           // a child of a global node was created after the overflow
         if (lds_ok) {
           const unsigned entry = ((unsigned)(parent + 1) << 17) | (unsigned)sym;
-          unsigned h = (unsigned)mix64(((unsigned long long)(unsigned)parent << 20) | (unsigned)sym) & tmask;
+          // double hashing on the (unique) 32-bit entry: the probe sequence of a key is h, h + step, h + 2 step, ... with an odd step, which
+          // visits every slot of the power-of-two table; at 3/4 occupancy the longest of a frame's ~20 probe chains -- what the wave waits
+          // for -- is a fraction of what linear probing's clusters gave (round 4; ids are slot numbers, nothing else depends on the order)
+          // (multiplicative hashing: the HIGH bits of the products -- the low ones depend on the class and a few parent bits only)
+          unsigned h = (entry * 0x9E3779B1u) >> tshift;
+          const unsigned step = ((entry * 0x85EBCA6Bu) >> tshift) | 1u;
           const bool may_insert = s_gnodes == 0;
           for (int probe = 0; probe < TS; ++probe) {
             unsigned prev = may_insert ? atomicCAS(&trie[h], 0u, entry) : trie[h];
             if (prev == entry) { id = (int)h + 1; break; }
             if (prev == 0u) { if (may_insert) id = (int)h + 1; break; }
-            h = (h + 1) & tmask;
+            h = (h + step) & tmask;
           }
         }
         if (id < 0) {                                               // global table: {parent : 24 | symbol : 16 | id : 24}
@@ -764,37 +862,22 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
             h = (h + 1) & htmask;
           }
         }
-        n_node = id;
       }
       {   // LDS trie occupancy: count this frame's fresh lanes; past 3/4 the table is closed for inserts
-        const unsigned long long fm = __ballot(fresh && n_node <= TS);
-        if (lane == 0 && s_gnodes == 0) {
-          s_lnodes += __popcll(fm);
-          if (s_lnodes * 4 > TS * 3) s_gnodes = 1;
-        }
+        const unsigned long long fm = __ballot(fresh && id <= TS);
+        y_lnodes += __popcll(fm);
+        if (lane == 0 && y_lnodes * 4 > TS * 3 && s_gnodes == 0) s_gnodes = 1;
       }
-      // parent slot of every new slot: a fresh labelling's parent is the old slot it extends; a copy's parent is the old slot's
-      // parent, wherever that went -- or, when the parent was NOT in the old beam, possibly a labelling created just now
-      {
-        const int pm = fresh ? src : g_mf;
-        n_mf = (act && pm >= 0 && n_len > 0) ? ns[pm] : -1;
-        const bool scan = act && !fresh && n_len > 0 && g_mf < 0;
-        unsigned long long fmask = __ballot(fresh);
-        if (__any(scan)) {
-          while (fmask) {
-            const int fl = __ffsll((long long)fmask) - 1;
-            fmask &= fmask - 1;
-            const int fid = __builtin_amdgcn_readlane(n_node, fl);
-            if (scan && fid == n_par) n_mf = fl;
-          }
-        }
+      y_node = act ? id : 0;
+      nid[(j + 1) & 1][lane] = y_node;
+      BSTAMP(6);
+    } else if (wave >= 3 && more) {
+      for (int spins = 0; __hip_atomic_load(&s_beamflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1; ++spins) {
+        if (spins > (1 << 20)) { s_fault = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
       }
-      z_node = n_node; z_len = n_len; z_last = n_last; z_par = n_par; z_mf = n_mf; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
-      if (more) stay_and_merge(rep_next, j + 1);
-    } else if (more) {
-      score_extensions(rep_next);
+      score_extensions(rep_next, j + 1);
     }
-    (void)nb_old;
     lds_barrier();
     BSTAMP(2);
   }
@@ -805,8 +888,9 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     o[12] = zrounds; o[13] = ziters; o[14] = nfl; o[15] = clock64() - zt0;
   }
 #endif
-  if (wave == 0) { f_node[lane] = z_node; f_len[lane] = z_len; f_last[lane] = z_last; f_pT[lane] = z_pT; }
+  if (wave == 0) { f_node[lane] = nid[nfl & 1][lane]; f_len[lane] = z_len; f_last[lane] = z_last; f_pT[lane] = z_pT; }
   __syncthreads();
+  if (status == 0 && s_fault) status = 4;
   // final LM step, length normalisation and best labelling (BeamSearch.py:130-151)
   if (status == 0 && tid == 0) {
     int st = 0;
@@ -817,7 +901,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       // as in beam_kernel: normalised scores, then the first `nbest` of a stable descending sort (f_pT is reused for the scores, f_last as "taken")
       for (int r = 0; r < nb; ++r) {
         const double pr = f_pT[r] + a.lm[(size_t)f_last[r] * V1 + V] * a.alpha;
-        const double tot = log_add_prob(LOG_ZERO, pr);
+        const double tot = pr;                      // == log_add_prob(LOG_ZERO, pr): its first test returns the second argument (BeamSearch.py:44-45)
         const int ln = f_len[r];
         f_pT[r] = tot * (1.0 / (ln ? ln : 1));
         f_last[r] = 0;
@@ -884,9 +968,9 @@ FastLayout fast_layout(int T, int B, int V, int W) {
   l.pb = off;   off += align_up((size_t)T * B * sizeof(float), 256);
   l.zf = off;   off += align_up((size_t)T * B, 256);
   l.total = off;
-  l.npt = ceil_div(W * V, FAST_NTH - 64);                // candidate slots per thread of waves 1..15 (1..4)
+  l.npt = ceil_div(W * V, FAST_NCT);                     // candidate slots per thread of waves 3..15 (1..4: W * V <= 3 328)
   if (l.npt > 4) l.npt = 0;
-  const size_t core = ((size_t)W * V + V) * sizeof(double) + ((size_t)W * V + T) * sizeof(int);   // cand, lg | mslot, flist
+  const size_t core = ((size_t)W * V + 2 * V) * sizeof(double) + ((size_t)W * V + T) * sizeof(int);   // cand, lg[2] | mslot, flist
   const size_t lm = (size_t)(V + 1) * (V + 1) * sizeof(double);
   const size_t budget = 144 * 1024;                     // of the CU's 160 KB (the kernel also has ~8 KB of static LDS)
   // LDS trie: as many slots as fit, at most 16 K (node ids of the LDS table must fit 14 bits); then the LM if it still fits

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 #include <type_traits>
 
@@ -2428,7 +2430,10 @@ int gates_of(int cell) { return cell == CTCN_CELL_LSTM ? 4 : (cell == CTCN_CELL_
 
 // which recurrent kernel the last forward / backward call of this process launched (diagnostics: ctcn_rnn_last_kernel; bench.py names
 // the kernel its roofline object describes from this, not from what the host expects)
-thread_local const char *g_last_kernel[2] = {"", ""};   // diagnostic only (ctcn_rnn_last_kernel): per calling thread, string literals
+// diagnostic only (ctcn_rnn_last_kernel): pointers to string literals, relaxed atomics -- process-wide, the last call of ANY thread wins (the
+// backward pass runs on the autograd thread, the reader is the main thread: a thread-local would hide it)
+struct LastKernel { std::atomic<const char *> v{""}; void operator=(const char *s) { v.store(s, std::memory_order_relaxed); } operator const char *() const { return v.load(std::memory_order_relaxed); } };
+LastKernel g_last_kernel[2];
 
 // One line on stderr (per distinct reason, per process) when a layer that asked for the persistent recurrence runs one launch
 // per timestep instead: that path is 4x slower and nothing else would tell the user.  CTCN_QUIET=1 silences it.

@@ -324,7 +324,8 @@ int ctcn_step_stats(const float *loss, const int32_t *dist, const int64_t *tgt_l
  *   x (T,B,V) float32: log-probs (input_is_prob==0, exp taken on device) or probabilities exp(lp)
  *   lens (B) int32; lm ((V+1)*(V+1)) float64 ln-probs, row V = '<s>', column V = '</s>'
  *   out_ids (B,T) int32, out_len (B) int32, out_score (B) float64 (length-normalised prTotal)
- *   status (B) int32: 0 ok, 1 best labelling empty (reference raises IndexError), 2 log(0) (ValueError)
+ *   status (B) int32: 0 ok, 1 best labelling empty (reference raises IndexError), 2 log(0) (ValueError), 3 node table of the workspace
+ *   exhausted, 4 internal hand-over between the waves of the search timed out (a bug, never seen; outputs zeroed for 2..4)
  *   ws: >= ctcn_beam_ws_bytes(T,B,V,W) */
 size_t ctcn_beam_ws_bytes(int T, int B, int V, int W);
 int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha,
@@ -344,10 +345,11 @@ int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const int32_t *len
  * ctcn_diag_squat: `wgs_per_xcd` workgroups of `threads` threads (+ `lds_bytes` of LDS each) on every XCD that only hold their CU
  * slots for `usec` microseconds (clock-bounded, <= 5 s) -- what an RCCL kernel waiting for a slow peer looks like to the rest of the
  * chip.  The data-parallel co-residency contract of the persistent recurrences is tested against it.
- * ctcn_rnn_last_kernel: name of the recurrent kernel the most recent ctcn_rnn_fwd (which = 0) / ctcn_rnn_bwd (which = 1) of the CALLING
- * THREAD launched ("rnn_fwd_tagged", "rnn_fwd_persist", "rnn_fwd_step", "rnn_bwd_scatter", "rnn_bwd_scatter2", "rnn_bwd_persist",
- * "rnn_bwd_step"; "" before the thread's first call).  The one piece of state the library keeps between compute calls: a thread-local
- * pointer to a string literal, read by nothing on the compute path. */
+ * ctcn_rnn_last_kernel: name of the recurrent kernel the most recent ctcn_rnn_fwd (which = 0) / ctcn_rnn_bwd (which = 1) of this
+ * PROCESS launched ("rnn_fwd_tagged", "rnn_fwd_persist", "rnn_fwd_step", "rnn_bwd_scatter", "rnn_bwd_scatter2", "rnn_bwd_persist",
+ * "rnn_bwd_step"; "" before the first call).  The one piece of state the library keeps between compute calls: two atomic pointers to
+ * string literals (relaxed; with several calling threads the last writer wins -- the backward pass of autograd runs on another thread
+ * than the reader, which is why it is not thread-local), read by nothing on the compute path. */
 int ctcn_diag_squat(int wgs_per_xcd, int threads, int lds_bytes, unsigned usec, void *stream);
 const char *ctcn_rnn_last_kernel(int which);
 

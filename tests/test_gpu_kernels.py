@@ -1731,7 +1731,7 @@ def test_beam_decoder_golden(dev):
     assert sum(bd.cer(a, b) for a, b in zip(dec, meta["labels"])) == sc["total_cer"]
 
 
-@pytest.mark.parametrize("regime,W", [("peaky", 20), ("flat", 8), ("peaky", 3)])
+@pytest.mark.parametrize("regime,W", [("peaky", 20), ("flat", 8), ("peaky", 3), ("peaky", 40), ("flat", 33), ("flat", 20), ("peaky", 57)])
 def test_beam_vs_c_oracle_random(dev, regime, W):
     from ctc_pytorch_amd import ops
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
