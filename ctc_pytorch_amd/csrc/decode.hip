@@ -494,6 +494,14 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;
   double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;          // this frame's stay / merged entry of the slot (BeamSearch.py:99-113)
   int nb = 1, status = 0;
+  // the serial chain (wave 0) and its two helpers win the issue arbitration of their SIMDs against the scoring waves they share them with (0.3-0.9 %)
+  if (wave == 0) __builtin_amdgcn_s_setprio(3); else if (wave == 2) __builtin_amdgcn_s_setprio(2); else if (wave == 1) __builtin_amdgcn_s_setprio(1);
+  // (round 4, measured on one box against this build -- cfg5 batch 1 098 us peaky / 2 796 us flat -- and NOT kept: the pruning bound formed by
+  // the scoring waves in the shadow of wave 0's chain, with a barrier of their own or ranked by the last wave to arrive: 1 167-1 230 / 2 804-2 903
+  // (13 waves x the extra instructions are issue-bound and end up BEHIND wave 0); candidate state packed into one word + opaque indices so
+  // that nothing spills: 1 158 / 2 929 (the unpacking costs the parallel phases more than the scratch re-loads did); the bound ranked by waves
+  // 0..3 only: 1 192 / 2 987; waves 0..2 skipping the candidate phases of the selection: 1 196 / 3 000.  The parallel phases cost
+  // (instructions per wave) x (waves per SIMD) x ~4.5 cycles whatever their dependences are; the build is sensitive to register allocation.)
   __syncthreads();
 #ifdef CTCN_BEAM_STATS
   long long zst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zlast = clock64(), zrounds = 0, ziters = 0;
