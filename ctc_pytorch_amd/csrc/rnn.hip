@@ -1066,6 +1066,9 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   int have_chunks = 0;                                         // chunk pairs known to be complete (pair 0 is computed before the launch)
   int pset = 0;                                                // RSV: ring set of the current step (s % 3)
+  // (round 4, measured and not kept: issue priorities -- s_setprio 2 for the exchange waves, and / or 3 for the item waves from the barrier
+  // to their publish and 0 for their reserve traffic, here and in rnn_bwd_scatter: 13.36 ms per cfg2 step without, 13.38-13.43 with; the
+  // phases of the two wave kinds barely overlap, so there is nothing to arbitrate)
   __syncthreads();
 #ifdef CTCN_PERSIST_STATS
   long long zx[4] = {0, 0, 0, 0}, zi[6] = {0, 0, 0, 0, 0, 0}, zt0 = clock64(), z_prev = zt0, zq = 0;
