@@ -1751,6 +1751,32 @@ def test_beam_vs_c_oracle_random(dev, regime, W):
     assert got2 == got
 
 
+@pytest.mark.parametrize("V,W,regime,alpha", [(3, 2, "flat", 0.0), (4, 5, "flat", 0.5), (4, 20, "flat", 0.1), (8, 33, "flat", 0.3), (8, 52, "peaky", 0.1),
+                                                 (5, 52, "flat", 1.0), (30, 10, "flat", 0.1), (200, 10, "peaky", 0.1), (200, 16, "flat", 0.2), (62, 1, "flat", 0.1)])
+def test_beam_fuzz_small_alphabets_vs_c_oracle(dev, V, W, regime, alpha):
+    """Round 4 moved the prefix trie to a wave of its own: wave 0 recognises "this labelling's parent was created in this very frame" from
+    (grandparent id, parent's last class) keys instead of node ids.  Small alphabets are what stresses that logic -- labellings leave the beam
+    and come back, parents are re-created next to their children, nearly every slot merges -- so: V = 3 .. 8 with beams wider than the
+    alphabet, one and two log-add passes (W <= 32 / > 32), the widest beam of the fast kernel (52), a 200-class alphabet (cfg4's), W = 1,
+    zero-length and one-frame utterances, random LM tables.  Labellings and status equal the C restatement, float64 scores to the last places."""
+    from ctc_pytorch_amd import ops
+    T, B = 70, 14
+    rs = np.random.RandomState(1000 * V + W)
+    lp = synth.make_logprobs(seed=V * 7 + W, T=T, B=B, V=V, regime=regime)
+    lens = list(rs.randint(T // 3, T + 1, size=B))
+    lens[0], lens[1], lens[2] = 0, 1, T
+    tab = -3.0 * rs.random_sample((V + 1, V + 1))
+    probs = torch.exp(torch.from_numpy(lp))
+    want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, alpha, W)
+    got, score, st = ops.beam_decode(probs.to(dev), lens, tab, alpha, W, 0, input_is_prob=True)
+    assert list(st) == list(wst)
+    assert got == [list(map(int, s_)) for s_ in want]
+    # float64 scores: the device's exp / log (ocml) and glibc's differ in the last place on some arguments -- 0-2 ulp of the final score on
+    # these batches, the same with the round-3 kernel (tools/beam_fuzz_ab.py runs both: bit-equal to each other); the golden sets are bit-equal
+    score, wscore = np.asarray(score), np.asarray(wscore)
+    assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
+
+
 @pytest.mark.parametrize("fast", [1, 0])
 def test_beam_nbest_golden_and_oracle(dev, fast):
     """ctcn_beam_decode_nbest (the optional n-best output): the labellings equal the reference's whole final `last.sort()`
