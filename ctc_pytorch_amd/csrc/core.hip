@@ -45,7 +45,7 @@ static int g_opt_edit_wave = 1;         // 1: edit distance on one wavefront per
 static int g_opt_bwd_item_gather = 1;   // backward scatter recurrence with item-wave gather + exchange-wave reserve traffic (rnn_bwd_scatter2): 0 never, 1 for H > 320, 2 always
 static int g_opt_bwd_poll_delay = -1;   // rnn_bwd_scatter2: 64-cycle sleeps before an item wave's first poll of a step; -1 = auto (16 up to 24 slices, 24 beyond)
 static int g_opt_fwd_rsv_lds = 2;       // rnn_fwd_tagged: reserve traffic through LDS (16-B stores by the exchange waves, LDS-DMA pre-activation loads): 0 off, 1 on, 2 for H > 384
-static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 64, W*V <= 4096); 0: the generic kernel always
+static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
 static int *g_status_dev = nullptr;
 
 extern "C" int ctcn_set_option(const char *name, int value) {

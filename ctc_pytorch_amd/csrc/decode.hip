@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
 
 
 // =====================================================================================================================
-// Fast path (W <= 64, W*V <= 4096, V <= 256): the same search, restructured around the per-frame latency chain.
+// Fast path (W <= 60, W*V <= 3328, V <= 256): the same search, restructured around the per-frame latency chain.
 // The generic kernel above spends ~39 us per processed frame (cfg5): W block-wide arg-max rounds (two __syncthreads + a
 // serial 4-way compare each), the double-precision log of the frame, LM gathers from global memory, trie CAS round trips
 // to L2 (~1.9 us each), and -- everywhere -- chains of dependent LDS reads (~100 cycles per hop).  Here:
@@ -281,18 +281,21 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
 //   * the workgroup compacts its list of processed frames once (the skip rule 1 - p_blank < 0.1 needs no beam state), keeps
 //     alpha * LM (31.7 KB at V = 62) in LDS, and every thread prefetches the next frame's ln p of ITS candidate classes;
 //   * the beam lives in the registers of wave 0 (lane = beam slot); cross-slot reads are v_readlane / ds_bpermute, not LDS
-//     round trips; the per-slot values the candidate scoring needs are mirrored into a 24-byte LDS record;
-//   * top-W: candidate c lives in registers of wave c % 4, lane (c / 4) / NPT (so that lane order == candidate order inside a
-//     wave).  Each wave extracts ITS best candidates with wave-local rounds: the doubles are mapped to order-preserving
-//     64-bit keys and reduced as two 32-bit DPP max-reductions (high word, then low word among the lanes that hold the
-//     high maximum) -- exact, no barrier, no LDS; the first lane holding the maximum wins (== lowest candidate index on
-//     ties).  The four sorted lists are merged by rank counting (a few parallel compares per lane + a quad reduction).  A wave
-//     extracts ceil(W/4) + 4 candidates at first and continues only while its last extracted candidate still ranks inside
-//     the top W of the union (if it does not, the rest of its candidates cannot either: exact);
-//   * trie: a 16K-slot open-addressing table IN LDS (node id = slot + 1, entry = {parent id + 1 : 15 | symbol : 17}), one
-//     ds_cmpst per probe; only when it fills beyond 3/4 do new labellings go to the global-memory table of the generic kernel
-//     (64-bit entries {parent : 24 | symbol : 16 | id : 24}).
-// Every score is computed by the same expressions on the same operands as in beam_kernel: bit-identical results.
+//     round trips; the per-slot values the candidate scoring needs are mirrored into a small LDS record;
+//   * top-W without sorting: waves 3..15 hold the <= W*V candidates (<= 4 per thread); every 16-lane row reduces its largest
+//     order-preserving key (high word) on the DPP network, the W-th largest row maximum is a lower bound of the W-th best candidate
+//     (exact pruning), the survivors (typically W + a few) are compacted into LDS and ranked by counting with the explicit
+//     (score desc, index asc) order of BeamState.sort; more than 256 survivors fall back to block-wide arg-max rounds;
+//   * trie: a 16K-slot table IN LDS (node id = slot + 1, entry = {parent id + 1 : 15 | symbol : 17}, double hashing, one ds_cmpst
+//     per probe); only when it fills beyond 3/4 do new labellings go to the global-memory table of the generic kernel (64-bit
+//     entries {parent : 24 | symbol : 16 | id : 24});
+//   * round 4: the per-frame serial chain is split over three waves.  Wave 1 owns the trie (a node id is needed a frame later, as
+//     the parent id of the labelling's children); wave 0 recognises "this slot's parent labelling was created in this frame" from
+//     (grandparent id, parent's last class) keys, which need old ids only.  Wave 2 computes the first level of the stay entries'
+//     log-adds (it needs no parent slot) next to wave 0's new-beam work; wave 0 publishes the beam record through an LDS flag, not a
+//     barrier.  cfg5 batch 1 300 -> 1 098 us (peaky), 3 949 -> 2 796 us (flat), labellings and scores bit-equal to the round-3 kernel.
+// Every score is computed by the same expressions on the same operands as in beam_kernel: bit-identical results.  (Against the
+// C oracle: identical labellings; float64 scores bit-equal on the golden sets and within 2 ulp elsewhere -- ocml's exp / log vs glibc's.)
 // =====================================================================================================================
 constexpr int FAST_WMAX = 64;
 

@@ -1751,6 +1751,28 @@ def test_beam_vs_c_oracle_random(dev, regime, W):
     assert got2 == got
 
 
+@pytest.mark.parametrize("regime", ["peaky", "flat"])
+def test_beam_cfg5_full_batch_vs_c_oracle(dev, regime):
+    """BASELINE config 5 at full size -- 128 utterances x 800 frames x 62 classes, W = 20, bigram LM, lens U{400..800}, the batch bench.py
+    times -- every utterance against the C restatement of BeamSearch.py (bench.py checks 16 + 4 of them).  The flat regime creates up to
+    ~15 000 labellings per utterance: past 12 288 the LDS trie is closed and wave 1 goes to the global table, which no smaller test
+    reaches.  Labellings and status equal; float64 scores to the last places (ocml vs glibc exp / log)."""
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    V, T, B, W = 62, 800, 128, 20
+    i2c = synth.int2char(V)
+    tab = LanguageModel(os.path.join(G, "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    lp = synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)
+    lens = list(np.random.RandomState(2).randint(400, 801, size=B))
+    probs = torch.exp(torch.from_numpy(lp))
+    want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, 0.1, W)
+    got, score, st = ops.beam_decode(probs.to(dev), lens, tab, 0.1, W, 0, input_is_prob=True)      # the same float32 probabilities as the oracle
+    assert list(st) == list(wst) and not any(st)
+    assert got == [list(map(int, s_)) for s_ in want]
+    score, wscore = np.asarray(score), np.asarray(wscore)
+    assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
+
+
 @pytest.mark.parametrize("V,W,regime,alpha", [(3, 2, "flat", 0.0), (4, 5, "flat", 0.5), (4, 20, "flat", 0.1), (8, 33, "flat", 0.3), (8, 52, "peaky", 0.1),
                                                  (5, 52, "flat", 1.0), (30, 10, "flat", 0.1), (200, 10, "peaky", 0.1), (200, 16, "flat", 0.2), (62, 1, "flat", 0.1)])
 def test_beam_fuzz_small_alphabets_vs_c_oracle(dev, V, W, regime, alpha):
