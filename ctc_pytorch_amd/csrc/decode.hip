@@ -433,6 +433,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     bm_c1[0][0] = V; bm_pB[0] = 0.0; bm_pT[0] = 0.0;                             // the empty labelling: prBlank = prTotal = 0 (BeamSearch.py:83-87)
     s_nfl = 0; s_gnodes = 0; s_totflag = 0; s_beamflag = 0; s_decflag = 0; s_fault = 0;
   }
+  if (tid < 64) gmax[tid] = 0u;                                                  // (rows 52..63 belong to no candidate wave: they stay 0)
   if (tid < 2 * FAST_WMAX) nid[0][tid] = 0;                                       // (both parities: node 0 = the empty labelling)
   __syncthreads();
   // frames the search processes, in order (BeamSearch.py:93-94: skip when 1 - p_blank < 0.1, a float32 compare), each with its
@@ -460,23 +461,14 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   const int nfl = s_nfl;
 
   // Wave 0 owns the beam (lane = slot) and the serial chain, wave 1 the prefix trie (node ids are only needed a frame later), wave 2 the
-  // log-add of every slot's stay entry that needs no parent slot (round 4); waves 3..15 (832 threads) own the candidates: slot i of
-  // thread u = tid - 192 is c = ((37 * u) mod 832) + 832 * i -> (beam ci, class ck; ck < 0: the stay slot).  Any bijection works (the
-  // selection ranks by explicit (score, index)); the multiplier spreads neighbouring candidates -- the classes of one beam -- over
-  // different 16-lane rows, which keeps the pruning bound of the selection tight.
+  // log-add of every slot's stay entry that needs no parent slot (round 4); waves 3..15 (832 threads) own the candidates.
+  // Every role runs ITS OWN frame loop below (same barriers, in the same order): the kernel sits at its register limit, and with the roles
+  // interleaved phase by phase in one loop every role's state was live everywhere -- the allocator spilled loop-invariant addresses to
+  // scratch and re-loaded them inside the frame's critical path.  In separate branches the live ranges do not overlap.
   constexpr int NCT = FAST_NCT;
-  int cc[NPT], ci[NPT], ck[NPT];
-#pragma unroll
-  for (int i = 0; i < NPT; ++i) {
-    const int c = wave < 3 ? W * V : ((37 * (tid - 192)) % NCT) + i * NCT;
-    cc[i] = min(c, W * V - 1);
-    ci[i] = c < W * V ? c / V : FAST_WMAX;                        // beyond the table / wave 0: never valid (nb <= W <= FAST_WMAX)
-    const int kk = c - (c / V) * V;
-    ck[i] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
-  }
-  // ln p row of the next frame, one frame ahead (threads < V; handed to everybody through LDS)
-  // (held by threads 128 .. 128 + V - 1: wave 0's instruction stream is the critical chain; lg[p] = row of the frames of parity p, written
-  // at the top of the frame BEFORE the one that uses it, so that every reader finds it behind the selection's barriers)
+  // ln p row of the next frame, one frame ahead, held by threads 128 .. 128 + V - 1 (waves 2..5: wave 0's instruction stream is the
+  // critical chain); lg[p] = row of the frames of parity p, written at the top of the frame BEFORE the one that uses it, so that every
+  // reader finds it behind the selection's barriers
   double nlg = 0.0;
   const int lgk = tid - 128;
   auto fetch_lg = [&](int fword) {
@@ -485,326 +477,351 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   if (nfl > 0) fetch_lg(flist[0]);
   if (lgk >= 0 && lgk < V) lg2[lgk] = nlg;
   if (nfl > 1) fetch_lg(flist[1]);
-
-  // the beam: lane r of wave 0 holds slot r.  node ids: 0 = the empty labelling, s + 1 = LDS trie slot s, TS + 1 + g = entry g of the
-  // global table.  z_mf = the slot that holds this slot's parent labelling (-1: none) -- its extension by z_last IS this labelling.
-  // Wave 0 never waits for the trie: the id of a slot's OWN labelling lives with wave 1 (y_node; handed over through nid[] a frame later,
-  // when a child needs it as its z_par).  What wave 0 carries instead is the parent labelling's key, (z_gpar, z_plast) = (id of the
-  // grandparent labelling, last class of the parent labelling): a labelling created in this frame as (parent id p, class k) IS the parent
-  // of slot r exactly when p == z_gpar[r] and k == z_plast[r] (ids are unique per (parent, class)), which needs old ids only.
-  int z_len = 0, z_last = -1, z_par = -1, z_mf = -1, z_gpar = -2, z_plast = -1;
-  int y_node = 0, y_lnodes = 0;                                    // wave 1: node id of slot `lane`; LDS trie nodes so far (wave-uniform)
-  double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;
-  double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;          // this frame's stay / merged entry of the slot (BeamSearch.py:99-113)
+  auto frame_top = [&](int j) {                                  // (holders only) the next frame's ln p row: its last readers were frame j - 1's
+    if (lgk >= 0 && lgk < V && j + 1 < nfl) lg2[((j + 1) & 1) * V + lgk] = nlg;
+    if (j + 2 < nfl) fetch_lg(flist[j + 2]);
+  };
   int nb = 1, status = 0;
   // the serial chain (wave 0) and its two helpers win the issue arbitration of their SIMDs against the scoring waves they share them with (0.3-0.9 %)
   if (wave == 0) __builtin_amdgcn_s_setprio(3); else if (wave == 2) __builtin_amdgcn_s_setprio(2); else if (wave == 1) __builtin_amdgcn_s_setprio(1);
-  // (round 4, measured on one box against this build -- cfg5 batch 1 098 us peaky / 2 796 us flat -- and NOT kept: the pruning bound formed by
-  // the scoring waves in the shadow of wave 0's chain, with a barrier of their own or ranked by the last wave to arrive: 1 167-1 230 / 2 804-2 903
-  // (13 waves x the extra instructions are issue-bound and end up BEHIND wave 0); candidate state packed into one word + opaque indices so
-  // that nothing spills: 1 158 / 2 929 (the unpacking costs the parallel phases more than the scratch re-loads did); the bound ranked by waves
-  // 0..3 only: 1 192 / 2 987; waves 0..2 skipping the candidate phases of the selection: 1 196 / 3 000.  The parallel phases cost
-  // (instructions per wave) x (waves per SIMD) x ~4.5 cycles whatever their dependences are; the build is sensitive to register allocation.)
+  // (round 4, measured on one box against the interleaved build -- cfg5 batch 1 098 us peaky / 2 796 us flat -- and NOT kept: the pruning bound
+  // formed by the scoring waves in the shadow of wave 0's chain, with a barrier of their own or ranked by the last wave to arrive: 1 167-1 230 /
+  // 2 804-2 903 (13 waves x the extra instructions are issue-bound and end up BEHIND wave 0); candidate state packed into one word + opaque
+  // indices so that nothing spills: 1 158 / 2 929 (the unpacking costs the parallel phases more than the scratch re-loads did); the bound ranked
+  // by waves 0..3 only: 1 192 / 2 987.  The parallel phases cost (instructions per wave) x (waves per SIMD) x ~4.5 cycles whatever their
+  // dependences are.)
   __syncthreads();
 #ifdef CTCN_BEAM_STATS
   long long zst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zlast = clock64(), zrounds = 0, ziters = 0;
   const long long zt0 = zlast;
 #endif
-
-  // ---- scoring of frame jf, two parties side by side -------------------------------------------------------------------------
-  // waves 1..15: extension scores (calcExtPr) into cand[]: two LDS hops (the slot's context class, then LM / prBlank / prTotal),
-  // every read of a hop issued before the first use (clamped addresses, selects afterwards)
-  auto score_extensions = [&](bool rep_ok, int jf) {
-    const double *lg = lg2 + (jf & 1) * V;
-    int c1[NPT];
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[jf & 1][min(ci[i], FAST_WMAX - 1)];
-    double lmv[NPT], pbv[NPT], ptv[NPT], lk[NPT];
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int bi = min(ci[i], FAST_WMAX - 1), k = max(ck[i], 0);
-      const int c1c = min(max(c1[i], 0), V);
-      lmv[i] = LM_LDS ? lmA[c1c * V1 + k] : a.lm[(size_t)c1c * V1 + k] * a.alpha;
-      lk[i] = lg[k];
-      pbv[i] = bm_pB[bi];
-      ptv[i] = bm_pT[bi];
-    }
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      if (ci[i] < nb && ck[i] >= 0) {
-        const double base = (c1[i] == ck[i] && rep_ok) ? pbv[i] : ptv[i];     // c1 == k <=> non-empty labelling ending in k
-        cand[cc[i]] = lk[i] + lmv[i] + base;
+  // more than SURV_MAX candidates above the bound (never seen on the synthetic regimes): W block-wide arg-max rounds over the candidate
+  // table (wave 0 patches it first so that it holds this frame's stay / merged entries), exactly as the generic kernel does.  All threads.
+  auto arg_max_rounds = [&]() -> int {
+    const int ncand = nb * V;
+    int got = 0;
+    for (int r = 0; r < W; ++r) {
+      double bv = -INFINITY; int bi = 0x7fffffff;
+      for (int c = tid; c < ncand; c += NTH) {
+        const double v = cand[c];
+        if (v != -INFINITY && cand_better(v, c, bv, bi)) { bv = v; bi = c; }
       }
-    }
-  };
-  // wave 0: stay entries of every slot, merged with the extension of the parent slot that equals the labelling (same expression,
-  // same operands as score_extensions writes for that candidate).  Results: e_nb / e_b / e_t in the slot's lane; for the selection:
-  // stayv[ip] = value of the stay candidate (or -inf when the entry lives in the extension's place), homev[ip] = e_t, and
-  // mslot[extension candidate] = {frame tag, 1: holds slot ip's merged entry | 0: removed (merged into the stay candidate), ip}
-  auto stay_and_merge = [&](bool rep_ok, int jf) {
-    const int ip = lane;
-    const double *lg = lg2 + (jf & 1) * V;
-    const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
-    const int mi = ip < nb ? z_mf : -1;
-    const int src = max(mi, 0);
-    const int p_len = lane_gather(z_len, src), p_last = lane_gather(z_last, src);
-    const double p_pB = lane_gather(z_pB, src), p_pT = lane_gather(z_pT, src);
-    const int c1 = p_len > 0 ? p_last : V, k = max(z_last, 0);
-    const double lmv = LM_LDS ? lmA[c1 * V1 + k] : a.lm[(size_t)c1 * V1 + k] * a.alpha;
-    const double base = (c1 == k && rep_ok) ? p_pB : p_pT;
-    const double pr = lgl + lmv + base;                           // == cand[mi * V + kk(z_last)]
-    double s_nb = LOG_ZERO;
-    if (z_len > 0) s_nb = z_pNB + lgl;                            // BeamSearch.py:102-103
-    const double s_b = z_pT + lgb;                                // :106
-    const bool ext_first = mi >= 0 && mi < ip;                    // the reference meets the extension before the stay entry
-    BSTAMP(6);
-    // tot = log_add(s_b, s_nb) of every slot comes from wave 2 (it needs no parent slot, so it is computed next to the lines above)
-    // (bounded: wave 2 reaches its store whenever this wave gets here -- both follow the wave-uniform `more` -- so the bound only turns a
-    // programming error into status 4 instead of a hung workgroup)
-    // -- and mslot[] below is rewritten only once wave 1, too, has decoded this frame's selection (s_decflag; set thousands of cycles ago)
-    for (int spins = 0; __hip_atomic_load(&s_totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != jf + 1 ||
-                        __hip_atomic_load(&s_decflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != jf; ++spins) {
-      if (spins > (1 << 20)) { s_fault = 1; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    const double tot = totv[ip];
-    double r_nb = s_nb, r_t = tot;
-    if (__any(mi >= 0)) {                                          // some slot merges with its parent's extension: ONE level of log-adds
-      // lanes 0..31: e.t of slot q, lanes 32..63: e.nb of slot q, q = (lane & 31) + 32 * pass -- side by side (one pass when nb <= 32)
-#pragma nounroll
-      for (int q0 = 0; q0 < nb; q0 += 32) {
-        const int q = (lane & 31) + q0;
-        const double q_snb = lane_gather(s_nb, q), q_pr = lane_gather(pr, q), q_tot = lane_gather(tot, q);
-        const int q_mi = lane_gather(mi, q);
-        const bool q_first = q_mi >= 0 && q_mi < q;
-        const double other = lane < 32 ? q_tot : q_snb;
-        const double ax = q_first ? q_pr : other, ay = q_first ? other : q_pr;      // the reference's argument order (extension met first or second)
-        const double r1 = q_mi >= 0 ? log_add_prob(ax, ay) : LOG_ZERO;
-        const int from = (lane & 31);                              // slot ip = q0 + from reads lanes from (e.t) and from + 32 (e.nb)
-        const double a_t = lane_gather(r1, from), a_nb = lane_gather(r1, from + 32);
-        if (mi >= 0 && (ip >> 5) == (q0 >> 5)) { r_nb = a_nb; r_t = a_t; }
-      }
-    }
-    BSTAMP(7);
-    if (ip < nb) {
-      e_nb = r_nb; e_b = s_b; e_t = r_t;
-      homev[ip] = r_t; enbv[ip] = r_nb;
-      stayv[ip] = ext_first ? -INFINITY : r_t;
-      if (mi >= 0) {
-        const int kkl = (z_last < blank) ? z_last + 1 : z_last;
-        mslot[mi * V + kkl] = (jf << 8) | (ext_first ? 128 : 0) | ip;
-      }
-    }
-    if (lane == 0) { s_theta = 0u; s_cnt = 0; }
-  };
-  // wave 2: tot = log_add(prBlank', prNonBlank') (BeamSearch.py:112) of the stay entry of every slot for frame jf, from the slot's
-  // (context class, prNonBlank, prTotal) -- the same expressions on the same operands as wave 0 forms for s_nb / s_b -- then the flag
-  // wave 0 waits for.  It needs no parent slot, so it runs next to wave 0's P4a / parent-slot work instead of in front of its log-add
-  auto stay_totals = [&](int jf, bool on, int c1, double pNB, double pT) {
-    const double *lg = lg2 + (jf & 1) * V;
-    const double lgl = lg[c1 < V ? c1 : 0], lgb = lg[blank];
-    double s_nb = LOG_ZERO;
-    if (c1 < V) s_nb = pNB + lgl;
-    const double s_b = pT + lgb;
-    const double tot = on ? log_add_prob(s_b, s_nb) : LOG_ZERO;
-    totv[lane] = tot;
-    __hip_atomic_store(&s_totflag, jf + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-
-  if (nfl > 0 && !(flist[0] & (1 << 29))) {
-    const bool rep0 = (flist[0] >> 30) & 1;
-    if (wave == 0) stay_and_merge(rep0, 0);
-    else if (wave == 2) stay_totals(0, lane == 0, V, LOG_ZERO, 0.0);       // the empty labelling
-    else if (wave >= 3) score_extensions(rep0, 0);
-  }
-  lds_barrier();
-
-  for (int j = 0; j < nfl; ++j) {
-    const int fw = flist[j];
-    if (fw & (1 << 29)) { status = 2; break; }                     // math.log(0) in the reference: ValueError
-    if (lgk >= 0 && lgk < V && j + 1 < nfl) lg2[((j + 1) & 1) * V + lgk] = nlg;    // the next frame's ln p row (its last readers were frame j - 1's)
-    if (j + 2 < nfl) fetch_lg(flist[j + 2]);
-    BSTAMP(0);
-    // P3: BHat = top-W by (prTotal desc, candidate index asc), without sorting.
-    //  1. splitter: every 16-lane row reduces the largest key (high word) of its ~16 * NPT candidates on the DPP network; the W-th
-    //     largest of the 60 row maxima is a lower bound of the W-th best candidate (W distinct candidates reach it): exact pruning;
-    //  2. the survivors (typically W + a few) are compacted into LDS and ranked by counting, all threads sharing the compares.
-    unsigned long long key[NPT];
-    bool val[NPT];
-    unsigned mhi = 0u;
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) {
-      const int bi = min(ci[i], FAST_WMAX - 1);
-      double v = ck[i] < 0 ? stayv[bi] : cand[cc[i]];
-      const int ms = mslot[cc[i]];
-      if (ck[i] >= 0 && ms >= 0 && (ms >> 8) == j) v = (ms & 128) ? homev[ms & 63] : -INFINITY;
-      key[i] = f64_key(v);
-      val[i] = ci[i] < nb && v != -INFINITY;
-      mhi = max(mhi, val[i] ? (unsigned)(key[i] >> 32) : 0u);
-    }
-    mhi = dpp_umax_step<0x111, 0xf>(mhi);
-    mhi = dpp_umax_step<0x112, 0xf>(mhi);
-    mhi = dpp_umax_step<0x114, 0xf>(mhi);
-    mhi = dpp_umax_step<0x118, 0xf>(mhi);
-    if ((lane & 15) == 15) gmax[tid >> 4] = mhi;
-    BSTAMP(8);
-    lds_barrier();
-    {
-      // rank of row maximum e among the 64 (ties broken by the row number: a strict order); 16 threads per row maximum
-      const int e = tid >> 4, part = tid & 15;
-      const unsigned mine = gmax[e];
-      int cnt = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = part * 4 + u;
-        const unsigned o = gmax[q];
-        cnt += (o > mine || (o == mine && q < e)) ? 1 : 0;
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || cand_better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
       }
-      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);    // row_half_mirror
-      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
-      if (part == 0 && cnt == W - 1) s_theta = mine;                        // (no such row when fewer than W rows hold a candidate: 0)
-    }
-    lds_barrier();
-    {
-      const unsigned theta = s_theta;
-      bool keep[NPT];
-      int wtot = 0, pos[NPT];
-#pragma unroll
-      for (int i = 0; i < NPT; ++i) {
-        keep[i] = val[i] && (unsigned)(key[i] >> 32) >= theta;
-        const unsigned long long bal = __ballot(keep[i]);
-        pos[i] = wtot + __popcll(bal & ((1ull << lane) - 1ull));
-        wtot += __popcll(bal);
-      }
-      int wbase = 0;
-      if (lane == 0 && wtot > 0) wbase = atomicAdd(&s_cnt, wtot);
-      wbase = __builtin_amdgcn_readfirstlane(wbase);
-#pragma unroll
-      for (int i = 0; i < NPT; ++i)
-        if (keep[i] && wbase + pos[i] < SURV_MAX) { surv[wbase + pos[i]].k = key[i]; surv[wbase + pos[i]].idx = ci[i] * V + (ck[i] < 0 ? 0 : (ck[i] < blank ? ck[i] + 1 : ck[i])); }
-    }
-    BSTAMP(3);
-    lds_barrier();
-    const int S = s_cnt;
-    int total = S;
-    if (S <= SURV_MAX) {
-      // rank counting: P threads per survivor, thread part p compares it with survivors p, p + P, ...; DPP butterfly sum
-      const int P = S <= 64 ? 16 : (S <= 128 ? 8 : 4);
-      if ((tid & ~63) < S * P) {                                 // (waves whose 64 / P survivors do not exist go straight to the barrier: the
-                                                                 // phase is issue-bound, fewer waves per SIMD finish it sooner)
-      const int e = tid / P, part = tid - e * P;
-      const Survivor me = surv[min(e, SURV_MAX - 1)];
-      int cnt = 0;
-      for (int q0 = part; q0 < S; q0 += 4 * P) {
-        Survivor oe[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) oe[u] = surv[min(q0 + u * P, SURV_MAX - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          cnt += (q0 + u * P < S && (oe[u].k > me.k || (oe[u].k == me.k && oe[u].idx < me.idx))) ? 1 : 0;
-      }
-      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
-      cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);                  // quad_perm [2,3,0,1]
-      if (P >= 8) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
-      if (P >= 16) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
-      if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
-      }
-    } else {
-      // more than SURV_MAX candidates above the bound (never seen on the synthetic regimes): W block-wide arg-max rounds over the
-      // candidate table (patched first so that it holds this frame's stay / merged entries), exactly as the generic kernel does
-      if (wave == 0 && lane < nb) {
-        cand[lane * V] = stayv[lane];
-        if (z_mf >= 0) { const int kkl = (z_last < blank) ? z_last + 1 : z_last; cand[z_mf * V + kkl] = (z_mf < lane) ? homev[lane] : -INFINITY; }
+      if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+      lds_barrier();
+      if (tid == 0) {
+        double v = red_v[0]; int ix = red_i[0];
+        for (int w = 1; w < NWV; ++w)
+          if (red_i[w] != 0x7fffffff && (ix == 0x7fffffff || cand_better(red_v[w], red_i[w], v, ix))) { v = red_v[w]; ix = red_i[w]; }
+        red_i[NWV] = ix;
+        if (ix != 0x7fffffff) { sel[r] = ix; selv[r] = v; cand[ix] = -INFINITY; }
       }
       lds_barrier();
-      const int ncand = nb * V;
-      int got = 0;
-      for (int r = 0; r < W; ++r) {
-        double bv = -INFINITY; int bi = 0x7fffffff;
-        for (int c = tid; c < ncand; c += NTH) {
-          const double v = cand[c];
-          if (v != -INFINITY && cand_better(v, c, bv, bi)) { bv = v; bi = c; }
-        }
+      if (red_i[NWV] == 0x7fffffff) break;
+      ++got;
+    }
+    return got;
+  };
+  // waves 0..2: decode of the selection -- new slot `lane` <- candidate sel[lane]: which old slot it comes from, fresh labelling or copy
+  struct Dec { bool act, fresh; int src, sym; double sv; };
+  auto decode_sel = [&](int j, int m) -> Dec {
+    Dec d;
+    const int rr = min(lane, FAST_WMAX - 1);
+    const int c = sel[rr];
+    d.sv = selv[rr];
+    d.act = lane < m;
+    const int i = d.act ? (int)(((float)c + 0.5f) * (1.0f / (float)V)) : 0;       // c / V (exact for c < 2^20)
+    const int kk = c - i * V;
+    d.sym = (kk - 1 < blank) ? kk - 1 : kk;
+    const int ms = mslot[d.act ? c : 0];
+    const bool merged = d.act && kk != 0 && ms >= 0 && (ms >> 8) == j && (ms & 128);   // this candidate holds the merged entry of slot ms & 63
+    d.fresh = d.act && kk != 0 && !merged;
+    d.src = merged ? (ms & 63) : i;
+    return d;
+  };
+  const bool first_ok = nfl > 0 && !(flist[0] & (1 << 29));
+  const bool rep0 = nfl > 0 && ((flist[0] >> 30) & 1);
+
+  if (wave >= 3) {
+    // ======================================= waves 3..15: the candidates =======================================================
+    // slot i of thread u = tid - 192 is c = ((37 * u) mod 832) + 832 * i -> (beam ci, class ck; ck < 0: the stay slot).  Any bijection works
+    // (the selection ranks by explicit (score, index)); the multiplier spreads neighbouring candidates -- the classes of one beam -- over
+    // different 16-lane rows, which keeps the pruning bound of the selection tight.
+    const int u = tid - 192;
+    int cc[NPT], ci[NPT], ck[NPT];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const double ov = __shfl_xor(bv, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (oi != 0x7fffffff && (bi == 0x7fffffff || cand_better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
-        lds_barrier();
-        if (tid == 0) {
-          double v = red_v[0]; int ix = red_i[0];
-          for (int w = 1; w < NWV; ++w)
-            if (red_i[w] != 0x7fffffff && (ix == 0x7fffffff || cand_better(red_v[w], red_i[w], v, ix))) { v = red_v[w]; ix = red_i[w]; }
-          red_i[NWV] = ix;
-          if (ix != 0x7fffffff) { sel[r] = ix; selv[r] = v; cand[ix] = -INFINITY; }
-        }
-        lds_barrier();
-        if (red_i[NWV] == 0x7fffffff) break;
-        ++got;
-      }
-      total = got;
+    for (int i = 0; i < NPT; ++i) {
+      const int c = ((37 * u) % NCT) + i * NCT;
+      cc[i] = min(c, W * V - 1);
+      ci[i] = c < W * V ? c / V : FAST_WMAX;                      // beyond the table: never valid (nb <= W <= FAST_WMAX)
+      const int kk = c - (c / V) * V;
+      ck[i] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
     }
+    // extension scores (calcExtPr) of frame jf into cand[]: two LDS hops (the slot's context class, then LM / prBlank / prTotal), every
+    // read of a hop issued before the first use (clamped addresses, selects afterwards)
+    auto score_extensions = [&](bool rep_ok, int jf) {
+      const double *lg = lg2 + (jf & 1) * V;
+      int c1[NPT];
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) c1[i] = bm_c1[jf & 1][min(ci[i], FAST_WMAX - 1)];
+      double lmv[NPT], pbv[NPT], ptv[NPT], lk[NPT];
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        const int bi = min(ci[i], FAST_WMAX - 1), k = max(ck[i], 0);
+        const int c1c = min(max(c1[i], 0), V);
+        lmv[i] = LM_LDS ? lmA[c1c * V1 + k] : a.lm[(size_t)c1c * V1 + k] * a.alpha;
+        lk[i] = lg[k];
+        pbv[i] = bm_pB[bi];
+        ptv[i] = bm_pT[bi];
+      }
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        if (ci[i] < nb && ck[i] >= 0) {
+          const double base = (c1[i] == ck[i] && rep_ok) ? pbv[i] : ptv[i];     // c1 == k <=> non-empty labelling ending in k
+          cand[cc[i]] = lk[i] + lmv[i] + base;
+        }
+      }
+    };
+    if (first_ok) score_extensions(rep0, 0);
     lds_barrier();
-    const int m = min(W, total);
-    BSTAMP(4);
-    // P4a: the new beam in rank order.  Waves 0, 1 and 2 decode the selection side by side, each for its own job, and meet the others
-    // again at the frame's last barrier only: wave 0 forms the beam (lane = slot) and publishes what the next frame's extension scores need
-    // (context class, prBlank, prTotal; the scoring waves wait for s_beamflag, not for a barrier -- wave 0 does not stop), wave 1 gives every
-    // new labelling its trie node, wave 2 computes the stay totals of the next frame.
-    const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
-    const bool rep_next = (flist[min(j + 1, nfl - 1)] >> 30) & 1;
-    bool fresh = false, act = false;
-    int n_len = 0, n_last = -1, n_par = -1, n_mf = -1, n_gpar = -2, n_plast = -1, g_mf = -1, src = 0, sym = 0;
-    double n_pNB = LOG_ZERO, n_pB = LOG_ZERO, n_pT = LOG_ZERO;
-    if (wave < 3) {
-      const int rr = min(lane, FAST_WMAX - 1);
-      const int c = sel[rr];
-      const double sv = selv[rr];
-      act = lane < m;
-      const int i = act ? (int)(((float)c + 0.5f) * (1.0f / (float)V)) : 0;       // c / V (exact for c < 2^20)
-      const int kk = c - i * V;
-      sym = (kk - 1 < blank) ? kk - 1 : kk;
-      const int ms = mslot[act ? c : 0];
-      const bool merged = act && kk != 0 && ms >= 0 && (ms >> 8) == j && (ms & 128);   // this candidate holds the merged entry of slot ms & 63
-      fresh = act && kk != 0 && !merged;
-      src = merged ? (ms & 63) : i;
-      if (wave == 0) {
-        ns[lane] = -1;
-        const int g_len = lane_gather(z_len, src), g_last = lane_gather(z_last, src), g_par = lane_gather(z_par, src);
-        const int g_gpar = lane_gather(z_gpar, src), g_plast = lane_gather(z_plast, src);
-        const int g_nid = nid[j & 1][src];                         // id of the old slot's labelling (wave 1, previous frame)
-        g_mf = lane_gather(z_mf, src);
-        const double g_nb = lane_gather(e_nb, src), g_b = lane_gather(e_b, src), g_t = lane_gather(e_t, src);
-        n_len = g_len; n_last = g_last; n_par = g_par; n_gpar = g_gpar; n_plast = g_plast;
-        n_pNB = g_nb; n_pB = g_b; n_pT = g_t;
-        if (fresh) {
-          n_len = g_len + 1; n_last = sym; n_par = g_nid; n_gpar = g_len > 0 ? g_par : -2; n_plast = g_last;
-          n_pNB = sv; n_pB = LOG_ZERO; n_pT = sv;
-        }
-        if (act) { bm_c1[(j + 1) & 1][lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
-        if (act && !fresh) ns[src] = lane;                           // where the old slot's labelling went
-        __hip_atomic_store(&s_beamflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (wave == 1) {
-        __hip_atomic_store(&s_decflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (the reads above have returned: `src` is formed)
-      } else if (wave == 2 && more) {
-        // the new slot's (context class, prNonBlank, prTotal) without wave 0: a fresh labelling carries its candidate's score, a copy the
-        // stay / merged entry of the slot it comes from (enbv / homev, written by wave 0 before the last barrier; bm_c1 of the old parity)
-        const int o_c1 = bm_c1[j & 1][src];
-        const double o_nb = enbv[src], o_t = homev[src];
-        stay_totals(j + 1, act, fresh ? sym : o_c1, fresh ? sv : o_nb, fresh ? sv : o_t);
+    for (int j = 0; j < nfl; ++j) {
+      const int fw = flist[j];
+      if (fw & (1 << 29)) { status = 2; break; }                   // math.log(0) in the reference: ValueError
+      frame_top(j);
+      BSTAMP(0);
+      // P3: BHat = top-W by (prTotal desc, candidate index asc), without sorting.
+      //  1. splitter: every 16-lane row reduces the largest key (high word) of its 16 * NPT candidates on the DPP network; the W-th largest
+      //     of the 52 row maxima is a lower bound of the W-th best candidate (W distinct candidates reach it): exact pruning;
+      //  2. the survivors (typically W + a few) are compacted into LDS and ranked by counting, the candidate threads sharing the compares.
+      unsigned long long key[NPT];
+      bool val[NPT];
+      unsigned mhi = 0u;
+#pragma unroll
+      for (int i = 0; i < NPT; ++i) {
+        const int bi = min(ci[i], FAST_WMAX - 1);
+        double v = ck[i] < 0 ? stayv[bi] : cand[cc[i]];
+        const int ms = mslot[cc[i]];
+        if (ck[i] >= 0 && ms >= 0 && (ms >> 8) == j) v = (ms & 128) ? homev[ms & 63] : -INFINITY;
+        key[i] = f64_key(v);
+        val[i] = ci[i] < nb && v != -INFINITY;
+        mhi = max(mhi, val[i] ? (unsigned)(key[i] >> 32) : 0u);
       }
+      mhi = dpp_umax_step<0x111, 0xf>(mhi);
+      mhi = dpp_umax_step<0x112, 0xf>(mhi);
+      mhi = dpp_umax_step<0x114, 0xf>(mhi);
+      mhi = dpp_umax_step<0x118, 0xf>(mhi);
+      if ((lane & 15) == 15) gmax[u >> 4] = mhi;
+      BSTAMP(8);
+      lds_barrier();
+      {
+        // rank of row maximum e among the 52 (ties broken by the row number: a strict order); 16 threads per row maximum (gmax[52..63] stay 0)
+        const int e = u >> 4, part = u & 15;
+        const unsigned mine = gmax[e];
+        int cnt = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int q = part * 4 + q4;
+          const unsigned o = gmax[q];
+          cnt += (o > mine || (o == mine && q < e)) ? 1 : 0;
+        }
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);    // row_half_mirror
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
+        if (part == 0 && cnt == W - 1) s_theta = mine;                        // (no such row when fewer than W rows hold a candidate: 0)
+      }
+      lds_barrier();
+      {
+        const unsigned theta = s_theta;
+        bool keep[NPT];
+        int wtot = 0, pos[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+          keep[i] = val[i] && (unsigned)(key[i] >> 32) >= theta;
+          const unsigned long long bal = __ballot(keep[i]);
+          pos[i] = wtot + __popcll(bal & ((1ull << lane) - 1ull));
+          wtot += __popcll(bal);
+        }
+        int wbase = 0;
+        if (lane == 0 && wtot > 0) wbase = atomicAdd(&s_cnt, wtot);
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+          if (keep[i] && wbase + pos[i] < SURV_MAX) { surv[wbase + pos[i]].k = key[i]; surv[wbase + pos[i]].idx = ci[i] * V + (ck[i] < 0 ? 0 : (ck[i] < blank ? ck[i] + 1 : ck[i])); }
+      }
+      BSTAMP(3);
+      lds_barrier();
+      const int S = s_cnt;
+      int total = S;
+      if (S <= SURV_MAX) {
+        // rank counting: P of the 832 candidate threads per survivor, thread part p compares it with survivors p, p + P, ...; DPP butterfly sum
+        const int P = S <= 52 ? 16 : (S <= 104 ? 8 : (S <= 208 ? 4 : 2));
+        if ((u & ~63) < S * P) {                                 // (waves whose 64 / P survivors do not exist go straight to the barrier: the
+                                                                 // phase is issue-bound, fewer waves per SIMD finish it sooner)
+          const int e = u / P, part = u - e * P;
+          const Survivor me = surv[min(e, SURV_MAX - 1)];
+          int cnt = 0;
+          for (int q0 = part; q0 < S; q0 += 4 * P) {
+            Survivor oe[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) oe[q4] = surv[min(q0 + q4 * P, SURV_MAX - 1)];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+              cnt += (q0 + q4 * P < S && (oe[q4].k > me.k || (oe[q4].k == me.k && oe[q4].idx < me.idx))) ? 1 : 0;
+          }
+          cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
+          if (P >= 4) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+          if (P >= 8) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
+          if (P >= 16) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
+          if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
+        }
+      } else {
+        lds_barrier();                                             // (wave 0 has patched the candidate table)
+        total = arg_max_rounds();
+      }
+      lds_barrier();
+      BSTAMP(4);
+      nb = min(W, total);
+      const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
+      if (more) {
+        // the new beam's record (context class, prBlank, prTotal of every slot) comes from wave 0 through a flag, not a barrier
+        for (int spins = 0; __hip_atomic_load(&s_beamflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1; ++spins) {
+          if (spins > (1 << 20)) { s_fault = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        BSTAMP(6);
+        score_extensions((flist[j + 1] >> 30) & 1, j + 1);
+        BSTAMP(9);
+      }
+      lds_barrier();
+      BSTAMP(2);
     }
-    BSTAMP(5);
-    nb = m;
-    if (wave == 0) {
-      // P4b (wave 0): parent slot of every new slot, then the stay / merge entries of the NEXT frame.  A fresh labelling's parent is the
-      // old slot it extends; a copy's parent is the old slot's parent, wherever that went -- or, when the parent was NOT in the old beam,
-      // possibly a labelling created just now: fresh lane f holds labelling (parent id n_par[f], class n_last[f]), which is slot r's
-      // parent exactly when that pair equals (n_gpar[r], n_plast[r]).  The loop walks the shorter of the two lane sets.
+  } else if (wave == 0) {
+    // ======================================= wave 0: the beam and the serial chain =============================================
+    // lane r holds slot r.  node ids: 0 = the empty labelling, s + 1 = LDS trie slot s, TS + 1 + g = entry g of the global table.
+    // z_mf = the slot that holds this slot's parent labelling (-1: none) -- its extension by z_last IS this labelling.
+    // Wave 0 never waits for the trie: the id of a slot's OWN labelling lives with wave 1 (handed over through nid[] a frame later, when
+    // a child needs it as its z_par).  What wave 0 carries instead is the parent labelling's key, (z_gpar, z_plast) = (id of the
+    // grandparent labelling, last class of the parent labelling): a labelling created in this frame as (parent id p, class k) IS the
+    // parent of slot r exactly when p == z_gpar[r] and k == z_plast[r] (ids are unique per (parent, class)), which needs old ids only.
+    int z_len = 0, z_last = -1, z_par = -1, z_mf = -1, z_gpar = -2, z_plast = -1;
+    double z_pB = 0.0, z_pNB = LOG_ZERO, z_pT = 0.0;
+    double e_nb = LOG_ZERO, e_b = LOG_ZERO, e_t = LOG_ZERO;        // this frame's stay / merged entry of the slot (BeamSearch.py:99-113)
+    // stay entries of every slot, merged with the extension of the parent slot that equals the labelling (same expression, same operands
+    // as score_extensions writes for that candidate).  Results: e_nb / e_b / e_t in the slot's lane; for the selection: stayv[ip] = value
+    // of the stay candidate (or -inf when the entry lives in the extension's place), homev[ip] = e_t, and mslot[extension candidate] =
+    // {frame tag, 1: holds slot ip's merged entry | 0: removed (merged into the stay candidate), ip}
+    auto stay_and_merge = [&](bool rep_ok, int jf) {
+      const int ip = lane;
+      const double *lg = lg2 + (jf & 1) * V;
+      const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
+      const int mi = ip < nb ? z_mf : -1;
+      const int src = max(mi, 0);
+      const int p_len = lane_gather(z_len, src), p_last = lane_gather(z_last, src);
+      const double p_pB = lane_gather(z_pB, src), p_pT = lane_gather(z_pT, src);
+      const int c1 = p_len > 0 ? p_last : V, k = max(z_last, 0);
+      const double lmv = LM_LDS ? lmA[c1 * V1 + k] : a.lm[(size_t)c1 * V1 + k] * a.alpha;
+      const double base = (c1 == k && rep_ok) ? p_pB : p_pT;
+      const double pr = lgl + lmv + base;                           // == cand[mi * V + kk(z_last)]
+      double s_nb = LOG_ZERO;
+      if (z_len > 0) s_nb = z_pNB + lgl;                            // BeamSearch.py:102-103
+      const double s_b = z_pT + lgb;                                // :106
+      const bool ext_first = mi >= 0 && mi < ip;                    // the reference meets the extension before the stay entry
+      BSTAMP(6);
+      // tot = log_add(s_b, s_nb) of every slot comes from wave 2 (it needs no parent slot, so it is computed next to the lines above)
+      // (bounded: wave 2 reaches its store whenever this wave gets here -- both follow the wave-uniform `more` -- so the bound only turns a
+      // programming error into status 4 instead of a hung workgroup)
+      // -- and mslot[] below is rewritten only once wave 1, too, has decoded this frame's selection (s_decflag; set thousands of cycles ago)
+      for (int spins = 0; __hip_atomic_load(&s_totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != jf + 1 ||
+                          __hip_atomic_load(&s_decflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != jf; ++spins) {
+        if (spins > (1 << 20)) { s_fault = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const double tot = totv[ip];
+      double r_nb = s_nb, r_t = tot;
+      if (__any(mi >= 0)) {                                          // some slot merges with its parent's extension: ONE level of log-adds
+        // lanes 0..31: e.t of slot q, lanes 32..63: e.nb of slot q, q = (lane & 31) + 32 * pass -- side by side (one pass when nb <= 32)
+#pragma nounroll
+        for (int q0 = 0; q0 < nb; q0 += 32) {
+          const int q = (lane & 31) + q0;
+          const double q_snb = lane_gather(s_nb, q), q_pr = lane_gather(pr, q), q_tot = lane_gather(tot, q);
+          const int q_mi = lane_gather(mi, q);
+          const bool q_first = q_mi >= 0 && q_mi < q;
+          const double other = lane < 32 ? q_tot : q_snb;
+          const double ax = q_first ? q_pr : other, ay = q_first ? other : q_pr;      // the reference's argument order (extension met first or second)
+          const double r1 = q_mi >= 0 ? log_add_prob(ax, ay) : LOG_ZERO;
+          const int from = (lane & 31);                              // slot ip = q0 + from reads lanes from (e.t) and from + 32 (e.nb)
+          const double a_t = lane_gather(r1, from), a_nb = lane_gather(r1, from + 32);
+          if (mi >= 0 && (ip >> 5) == (q0 >> 5)) { r_nb = a_nb; r_t = a_t; }
+        }
+      }
+      BSTAMP(7);
+      if (ip < nb) {
+        e_nb = r_nb; e_b = s_b; e_t = r_t;
+        homev[ip] = r_t; enbv[ip] = r_nb;
+        stayv[ip] = ext_first ? -INFINITY : r_t;
+        if (mi >= 0) {
+          const int kkl = (z_last < blank) ? z_last + 1 : z_last;
+          mslot[mi * V + kkl] = (jf << 8) | (ext_first ? 128 : 0) | ip;
+        }
+      }
+      if (lane == 0) { s_theta = 0u; s_cnt = 0; }
+    };
+    if (first_ok) stay_and_merge(rep0, 0);
+    lds_barrier();
+    for (int j = 0; j < nfl; ++j) {
+      const int fw = flist[j];
+      if (fw & (1 << 29)) { status = 2; break; }
+      BSTAMP(0);
+      lds_barrier();                                               // (row maxima)
+      lds_barrier();                                               // (pruning bound)
+      BSTAMP(3);
+      lds_barrier();                                               // (survivors compacted)
+      const int S = s_cnt;
+      int total = S;
+      if (S > SURV_MAX) {
+        if (lane < nb) {
+          cand[lane * V] = stayv[lane];
+          if (z_mf >= 0) { const int kkl = (z_last < blank) ? z_last + 1 : z_last; cand[z_mf * V + kkl] = (z_mf < lane) ? homev[lane] : -INFINITY; }
+        }
+        lds_barrier();
+        total = arg_max_rounds();
+      }
+      lds_barrier();                                               // (selection ranked)
+      BSTAMP(4);
+      const int m = min(W, total);
+      const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
+      const bool rep_next = (flist[min(j + 1, nfl - 1)] >> 30) & 1;
+      // P4a: the new beam in rank order; the record the next frame's extension scores need goes out through s_beamflag (wave 0 does not stop)
+      const Dec d = decode_sel(j, m);
+      const bool act = d.act, fresh = d.fresh;
+      const int src = d.src, sym = d.sym;
+      ns[lane] = -1;
+      const int g_len = lane_gather(z_len, src), g_last = lane_gather(z_last, src), g_par = lane_gather(z_par, src);
+      const int g_gpar = lane_gather(z_gpar, src), g_plast = lane_gather(z_plast, src);
+      const int g_nid = nid[j & 1][src];                           // id of the old slot's labelling (wave 1, previous frame)
+      const int g_mf = lane_gather(z_mf, src);
+      const double g_nb = lane_gather(e_nb, src), g_b = lane_gather(e_b, src), g_t = lane_gather(e_t, src);
+      int n_len = g_len, n_last = g_last, n_par = g_par, n_gpar = g_gpar, n_plast = g_plast, n_mf = -1;
+      double n_pNB = g_nb, n_pB = g_b, n_pT = g_t;
+      if (fresh) {
+        n_len = g_len + 1; n_last = sym; n_par = g_nid; n_gpar = g_len > 0 ? g_par : -2; n_plast = g_last;
+        n_pNB = d.sv; n_pB = LOG_ZERO; n_pT = d.sv;
+      }
+      if (act) { bm_c1[(j + 1) & 1][lane] = n_len > 0 ? n_last : V; bm_pB[lane] = n_pB; bm_pT[lane] = n_pT; }
+      if (act && !fresh) ns[src] = lane;                           // where the old slot's labelling went
+      __hip_atomic_store(&s_beamflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      BSTAMP(5);
+      nb = m;
+      // P4b: parent slot of every new slot, then the stay / merge entries of the NEXT frame.  A fresh labelling's parent is the old slot it
+      // extends; a copy's parent is the old slot's parent, wherever that went -- or, when the parent was NOT in the old beam, possibly a
+      // labelling created just now: fresh lane f holds labelling (parent id n_par[f], class n_last[f]), which is slot r's parent exactly
+      // when that pair equals (n_gpar[r], n_plast[r]).  The loop walks the shorter of the two lane sets.
       {
         const int pm = fresh ? src : g_mf;
         n_mf = (act && pm >= 0 && n_len > 0) ? ns[pm] : -1;
@@ -831,75 +848,117 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       }
       z_len = n_len; z_last = n_last; z_par = n_par; z_gpar = n_gpar; z_plast = n_plast; z_mf = n_mf; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
       if (more) stay_and_merge(rep_next, j + 1);
-    } else if (wave == 1) {
-      // P4b (wave 1): trie node of every fresh labelling; copies keep the id of the slot they come from
-      const int p_id = lane_gather(y_node, src);
-      int id = p_id;
-      if (fresh) {
-        const int parent = p_id;
-        id = -1;
-        const bool lds_ok = parent <= TS;                           // a child of a global node was created after the overflow
-        if (lds_ok) {
-          const unsigned entry = ((unsigned)(parent + 1) << 17) | (unsigned)sym;
-          // double hashing on the (unique) 32-bit entry: the probe sequence of a key is h, h + step, h + 2 step, ... with an odd step, which
-          // visits every slot of the power-of-two table; at 3/4 occupancy the longest of a frame's ~20 probe chains -- what the wave waits
-          // for -- is a fraction of what linear probing's clusters gave (round 4; ids are slot numbers, nothing else depends on the order)
-          // (multiplicative hashing: the HIGH bits of the products -- the low ones depend on the class and a few parent bits only)
-          unsigned h = (entry * 0x9E3779B1u) >> tshift;
-          const unsigned step = ((entry * 0x85EBCA6Bu) >> tshift) | 1u;
-          const bool may_insert = s_gnodes == 0;
-          for (int probe = 0; probe < TS; ++probe) {
-            unsigned prev = may_insert ? atomicCAS(&trie[h], 0u, entry) : trie[h];
-            if (prev == entry) { id = (int)h + 1; break; }
-            if (prev == 0u) { if (may_insert) id = (int)h + 1; break; }
-            h = (h + step) & tmask;
-          }
-        }
-        if (id < 0) {                                               // global table: {parent : 24 | symbol : 16 | id : 24}
-          const unsigned long long key40 = ((unsigned long long)(unsigned)parent << 16) | (unsigned)sym;
-          unsigned h = (unsigned)mix64(key40) & htmask;
-          int gid = -1;
-          for (int probe = 0; probe <= (int)htmask; ++probe) {
-            const unsigned long long seen = __hip_atomic_load(&ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen != HT_EMPTY) {
-              if ((seen >> 24) == key40) { id = TS + 1 + (int)(seen & 0xFFFFFFull); break; }
-              h = (h + 1) & htmask;
-              continue;
-            }
-            if (gid < 0) gid = atomicAdd(&s_gnodes, 1) - 1;         // s_gnodes = 1 + number of global nodes once overflowed
-            const unsigned long long prev = atomicCAS(&ht[h], HT_EMPTY, (key40 << 24) | (unsigned long long)(unsigned)gid);
-            if (prev == HT_EMPTY) { id = TS + 1 + gid; if (gid < a.max_nodes) { npar[gid] = parent; nsym[gid] = sym; } break; }
-            if ((prev >> 24) == key40) { id = TS + 1 + (int)(prev & 0xFFFFFFull); break; }   // (cannot happen: keys of a frame are distinct)
-            h = (h + 1) & htmask;
-          }
-        }
-      }
-      {   // LDS trie occupancy: count this frame's fresh lanes; past 3/4 the table is closed for inserts
-        const unsigned long long fm = __ballot(fresh && id <= TS);
-        y_lnodes += __popcll(fm);
-        if (lane == 0 && y_lnodes * 4 > TS * 3 && s_gnodes == 0) s_gnodes = 1;
-      }
-      y_node = act ? id : 0;
-      nid[(j + 1) & 1][lane] = y_node;
-      BSTAMP(6);
-    } else if (wave >= 3 && more) {
-      for (int spins = 0; __hip_atomic_load(&s_beamflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1; ++spins) {
-        if (spins > (1 << 20)) { s_fault = 1; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      score_extensions(rep_next, j + 1);
+      lds_barrier();
+      BSTAMP(2);
     }
+    f_len[lane] = z_len; f_last[lane] = z_last; f_pT[lane] = z_pT;
+  } else {
+    // ======================================= waves 1 and 2: the trie | the stay totals ==========================================
+    int y_node = 0, y_lnodes = 0;                                  // wave 1: node id of slot `lane`; LDS trie nodes so far (wave-uniform)
+    // wave 2: tot = log_add(prBlank', prNonBlank') (BeamSearch.py:112) of the stay entry of every slot for frame jf, from the slot's (context
+    // class, prNonBlank, prTotal) -- the same expressions on the same operands as wave 0 forms for s_nb / s_b -- then the flag wave 0 waits
+    // for.  It needs no parent slot, so it runs next to wave 0's new-beam / parent-slot work instead of in front of its log-add
+    auto stay_totals = [&](int jf, bool on, int c1, double pNB, double pT) {
+      const double *lg = lg2 + (jf & 1) * V;
+      const double lgl = lg[c1 < V ? c1 : 0], lgb = lg[blank];
+      double s_nb = LOG_ZERO;
+      if (c1 < V) s_nb = pNB + lgl;
+      const double s_b = pT + lgb;
+      const double tot = on ? log_add_prob(s_b, s_nb) : LOG_ZERO;
+      totv[lane] = tot;
+      __hip_atomic_store(&s_totflag, jf + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (first_ok && wave == 2) stay_totals(0, lane == 0, V, LOG_ZERO, 0.0);       // the empty labelling
     lds_barrier();
-    BSTAMP(2);
+    for (int j = 0; j < nfl; ++j) {
+      const int fw = flist[j];
+      if (fw & (1 << 29)) { status = 2; break; }
+      frame_top(j);
+      BSTAMP(0);
+      lds_barrier();
+      lds_barrier();
+      lds_barrier();
+      const int S = s_cnt;
+      int total = S;
+      if (S > SURV_MAX) { lds_barrier(); total = arg_max_rounds(); }
+      lds_barrier();
+      BSTAMP(4);
+      const int m = min(W, total);
+      const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
+      const Dec d = decode_sel(j, m);
+      nb = m;
+      if (wave == 1) {
+        __hip_atomic_store(&s_decflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (the decode's reads have returned: d.src is formed)
+        BSTAMP(5);
+        // trie node of every fresh labelling; copies keep the id of the slot they come from
+        const int p_id = lane_gather(y_node, d.src);
+        int id = p_id;
+        if (d.fresh) {
+          const int parent = p_id, sym = d.sym;
+          id = -1;
+          const bool lds_ok = parent <= TS;                           // a child of a global node was created after the overflow
+          if (lds_ok) {
+            const unsigned entry = ((unsigned)(parent + 1) << 17) | (unsigned)sym;
+            // double hashing on the (unique) 32-bit entry: the probe sequence of a key is h, h + step, h + 2 step, ... with an odd step,
+            // which visits every slot of the power-of-two table; at 3/4 occupancy the longest of a frame's ~20 probe chains -- what the
+            // wave waits for -- is a fraction of what linear probing's clusters gave (ids are slot numbers, nothing else depends on the
+            // order).  Multiplicative hashing: the HIGH bits of the products -- the low ones depend on the class and a few parent bits only
+            unsigned h = (entry * 0x9E3779B1u) >> tshift;
+            const unsigned step = ((entry * 0x85EBCA6Bu) >> tshift) | 1u;
+            const bool may_insert = s_gnodes == 0;
+            for (int probe = 0; probe < TS; ++probe) {
+              unsigned prev = may_insert ? atomicCAS(&trie[h], 0u, entry) : trie[h];
+              if (prev == entry) { id = (int)h + 1; break; }
+              if (prev == 0u) { if (may_insert) id = (int)h + 1; break; }
+              h = (h + step) & tmask;
+            }
+          }
+          if (id < 0) {                                               // global table: {parent : 24 | symbol : 16 | id : 24}
+            const unsigned long long key40 = ((unsigned long long)(unsigned)parent << 16) | (unsigned)sym;
+            unsigned h = (unsigned)mix64(key40) & htmask;
+            int gid = -1;
+            for (int probe = 0; probe <= (int)htmask; ++probe) {
+              const unsigned long long seen = __hip_atomic_load(&ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (seen != HT_EMPTY) {
+                if ((seen >> 24) == key40) { id = TS + 1 + (int)(seen & 0xFFFFFFull); break; }
+                h = (h + 1) & htmask;
+                continue;
+              }
+              if (gid < 0) gid = atomicAdd(&s_gnodes, 1) - 1;         // s_gnodes = 1 + number of global nodes once overflowed
+              const unsigned long long prev = atomicCAS(&ht[h], HT_EMPTY, (key40 << 24) | (unsigned long long)(unsigned)gid);
+              if (prev == HT_EMPTY) { id = TS + 1 + gid; if (gid < a.max_nodes) { npar[gid] = parent; nsym[gid] = sym; } break; }
+              if ((prev >> 24) == key40) { id = TS + 1 + (int)(prev & 0xFFFFFFull); break; }   // (cannot happen: keys of a frame are distinct)
+              h = (h + 1) & htmask;
+            }
+          }
+        }
+        {   // LDS trie occupancy: count this frame's fresh lanes; past 3/4 the table is closed for inserts
+          const unsigned long long fm = __ballot(d.fresh && id <= TS);
+          y_lnodes += __popcll(fm);
+          if (lane == 0 && y_lnodes * 4 > TS * 3 && s_gnodes == 0) s_gnodes = 1;
+        }
+        y_node = d.act ? id : 0;
+        nid[(j + 1) & 1][lane] = y_node;
+        BSTAMP(6);
+      } else if (more) {
+        // the new slot's (context class, prNonBlank, prTotal) without wave 0: a fresh labelling carries its candidate's score, a copy the
+        // stay / merged entry of the slot it comes from (enbv / homev, written by wave 0 before the last barrier; bm_c1 of the old parity)
+        const int o_c1 = bm_c1[j & 1][d.src];
+        const double o_nb = enbv[d.src], o_t = homev[d.src];
+        stay_totals(j + 1, d.act, d.fresh ? d.sym : o_c1, d.fresh ? d.sv : o_nb, d.fresh ? d.sv : o_t);
+      }
+      lds_barrier();
+      BSTAMP(2);
+    }
   }
 #ifdef CTCN_BEAM_STATS
-  if (a.stats && b == 0 && (tid == 0 || tid == 64)) {
+  if (a.stats && b == 0 && (tid == 0 || tid == 192)) {
     long long *o = a.stats + (tid == 0 ? 0 : 16);
     for (int i = 0; i < 12; ++i) o[i] = zst[i];
     o[12] = zrounds; o[13] = ziters; o[14] = nfl; o[15] = clock64() - zt0;
   }
 #endif
-  if (wave == 0) { f_node[lane] = nid[nfl & 1][lane]; f_len[lane] = z_len; f_last[lane] = z_last; f_pT[lane] = z_pT; }
+  if (wave == 0) f_node[lane] = nid[nfl & 1][lane];
   __syncthreads();
   if (status == 0 && s_fault) status = 4;
   // final LM step, length normalisation and best labelling (BeamSearch.py:130-151)
