@@ -36,11 +36,13 @@ def decode_and_score(model, loader, decoder, index2word, device, verbose=False, 
             decoder.num_word += len(labels[x].split())
             decoder.num_char += len(labels[x])
 
-    # the beam search of a batch runs on one of two extra streams (the model forward stays on the current one: it owns the library
-    # workspace) and its strings are collected one batch later: two searches in flight fill the device (a batch is one workgroup per
-    # utterance) and the host-side scoring of batch i overlaps with the search of batch i + 1.  Same order of batches, same results.
+    # the beam search of a batch runs on one of three extra streams (the model forward stays on the current one: it owns the library
+    # workspace) and its strings are collected later: two searches fill the device (a batch is one workgroup per utterance, <= 128 of 256
+    # CUs) but each lasts as long as its LONGEST utterance -- the third one's workgroups take the CUs the shorter utterances have left
+    # (cfg5: 206 k -> 246 k utt/s) -- and the host-side scoring of batch i overlaps with the searches behind it.  Same order, same results.
+    NS = 3
     pipelined = hasattr(decoder, "decode_async") and torch.device(device).type == "cuda"
-    streams = [torch.cuda.Stream(device=device) for _ in range(2)] if pipelined else []
+    streams = [torch.cuda.Stream(device=device) for _ in range(NS)] if pipelined else []
     pending = []
     with torch.no_grad():
         for i, (inputs, input_sizes, targets, target_sizes, utt_list) in enumerate(loader):
@@ -49,13 +51,13 @@ def decode_and_score(model, loader, decoder, index2word, device, verbose=False, 
             if not pipelined:
                 score(decoder.decode(probs, lens), targets, target_sizes)
                 continue
-            st = streams[i % 2]
+            st = streams[i % NS]
             st.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(st):
                 wait = decoder.decode_async(probs, lens)
             probs.record_stream(st)
             pending.append((wait, targets, target_sizes))
-            if len(pending) == 3:                # two searches running, one queued behind them
+            if len(pending) == NS + 1:           # NS searches running, one queued behind them
                 w, t, ts = pending.pop(0)
                 score(w(), t, ts)
         for w, t, ts in pending:

@@ -138,8 +138,9 @@ class BeamDecoder(Decoder):
 
     def decode_async(self, prob_tensor, frame_seq_len=None):
         """decode() enqueued on the current stream: returns a callable that waits for this batch alone and returns its strings
-        (steps/test_ctc.decode_and_score keeps two batches in flight on two streams: a batch of <= 128 utterances occupies at most
-        half of the device, and the host-side string assembly and scoring of one batch overlaps with the search of the next)."""
+        (steps/test_ctc.decode_and_score keeps three batches in flight on three streams: a batch of <= 128 utterances occupies at most
+        half of the device for as long as its longest utterance lasts, and the host-side string assembly and scoring of one batch overlaps
+        with the search of the next)."""
         lp = _to_device(prob_tensor)
         if frame_seq_len is None:
             frame_seq_len = [lp.shape[0]] * lp.shape[1]
