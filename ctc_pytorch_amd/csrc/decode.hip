@@ -489,7 +489,9 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   // 2 804-2 903 (13 waves x the extra instructions are issue-bound and end up BEHIND wave 0); candidate state packed into one word + opaque
   // indices so that nothing spills: 1 158 / 2 929 (the unpacking costs the parallel phases more than the scratch re-loads did); the bound ranked
   // by waves 0..3 only: 1 192 / 2 987.  The parallel phases cost (instructions per wave) x (waves per SIMD) x ~4.5 cycles whatever their
-  // dependences are.)
+  // dependences are.  The bound in the scoring phase again ON this role-split build (995 / 2 552): 991 / 2 402, with wave 2 publishing the beam
+  // record early 998 / 2 410, with a second bound from the stay totals 979 / 2 434 -- the scoring waves' own barrier waits for the slowest of
+  // thirteen issue-bound waves, 1.6 k cycles in the very phase the bound was meant to hide in; not kept for 5 % of the flat regime.)
   __syncthreads();
 #ifdef CTCN_BEAM_STATS
   long long zst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, zlast = clock64(), zrounds = 0, ziters = 0;
