@@ -3,7 +3,7 @@
 recurrence, weight-gradient side stream, gradient-slice hook), `check_health` EVERY step, loss finite, and the whole loss trajectory
 BIT-REPRODUCIBLE across two runs from the same seed (everything in the step rests on L2-visibility timing; nothing may depend on it).
 
-    python tools/soak.py [--cfg2 5000] [--cfg4 2000] [--ref-yaml 2000] [--decode 1000] [--out profiles/r03_soak.json]
+    python tools/soak.py [--cfg2 5000] [--cfg4 2000] [--ref-yaml 2000] [--decode 1000] [--out profiles/r04_soak.json]
 """
 import argparse
 import hashlib
