@@ -123,16 +123,27 @@ def set_grad_ready_hook(fn):
     _grad_ready["hook"] = fn
 
 
-_side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": int(os.environ.get("CTCN_SIDE_MIN_ITEMS", str(1 << 21))),
+_side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": int(os.environ.get("CTCN_SIDE_MIN_ITEMS", str(1 << 21))), "min_items_bwd": int(os.environ.get("CTCN_SIDE_MIN_ITEMS_BWD", os.environ.get("CTCN_SIDE_MIN_ITEMS", str(1 << 18)))),
          "small_split": os.environ.get("CTCN_SMALL_SPLIT", "1") != "0"}
 
 
-def set_side_stream(flag, min_items=None):
-    """Enable / disable the weight-gradient side stream (default on; env CTCN_SIDE_STREAM=0 disables).  min_items: smallest
-    T*B*H of a recurrent layer whose weight GEMMs go to the side stream (default 2^21; smaller layers stay inline)."""
+SIDE_MIN_ITEMS_FWD, SIDE_MIN_ITEMS_BWD = 1 << 21, 1 << 18
+
+
+def set_side_stream(flag, min_items=None, min_items_bwd=None):
+    """Enable / disable the side stream (default on; env CTCN_SIDE_STREAM=0 disables).  Two size thresholds on T*B*H of a recurrent layer:
+    `min_items` (default 2^21, env CTCN_SIDE_MIN_ITEMS) for the input projection pipelined with the forward recurrence, `min_items_bwd`
+    (default 2^18, env CTCN_SIDE_MIN_ITEMS_BWD) for the weight-gradient GEMMs next to the recurrence of the layer below.  Passing
+    `min_items` alone sets BOTH (what the tests that force everything onto / off the side stream do).  Round 4: the two used to share
+    2^21, which kept the shipped-YAML shape (4 x 384, B = 8, 200 steps: 614 k items) inline -- 110 us of launch-bound weight GEMMs per
+    layer in front of a 350-us recurrence that leaves six XCDs idle: 4.69 -> 4.36 ms per step with the lower threshold (cfg1 2.02 -> 1.95),
+    while the forward pipeline at that size costs more than it hides (5.74 ms)."""
     _side["enabled"] = bool(flag)
     if min_items is not None:
         _side["min_items"] = int(min_items)
+        _side["min_items_bwd"] = int(min_items)
+    if min_items_bwd is not None:
+        _side["min_items_bwd"] = int(min_items_bwd)
 
 
 def set_fwd_overlap(flag):
@@ -399,10 +410,10 @@ class _RNNLayer(torch.autograd.Function):
         # XCDs a persistent recurrence of this shape leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
         nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
         allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
-        # small layers stay inline: below ~2 M (frame, row, unit) items the weight GEMMs are launch-bound and the XCD-filtered
-        # launches of the side stream (thousands of workgroups that exit at once) only disturb the main stream (cfg1: 2.27 ms
-        # per step inline, 2.8-4.5 ms with the side stream)
-        side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items"]
+        # very small layers stay inline (below min_items_bwd = 2^18 (frame, row, unit) items: the test fixtures).  Round 1 measured cfg1 slower
+        # with the side stream (2.27 ms inline, 2.8-4.5 with it) and set the threshold at 2^21; with the queue-form GEMMs and the deferred issue
+        # of rounds 2-3 the picture is the opposite (round 4: cfg1 2.02 -> 1.95 ms, the shipped-YAML shape 4.69 -> 4.36): set_side_stream
+        side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items_bwd"]
         null = ctypes.c_void_p(None)
         key = (dev.type, dev.index)
         if ctx.counted:

@@ -1016,7 +1016,7 @@ def test_forward_projection_overlap_short_last_chunk(dev, T, rsv):
     x = torch.from_numpy(rs.standard_normal((T, B, 40)).astype(np.float32)).to(dev)
     gy = torch.from_numpy(rs.standard_normal((T, B, 2 * H)).astype(np.float32)).to(dev)
     outs = {}
-    old_min = ops._side["min_items"]
+    old_min, old_min_bwd = ops._side["min_items"], ops._side["min_items_bwd"]
     try:
         ops.set_side_stream(True, min_items=1)
         ops.set_option("fwd_rsv_lds", rsv)
@@ -1038,7 +1038,7 @@ def test_forward_projection_overlap_short_last_chunk(dev, T, rsv):
     finally:
         ops.set_fwd_overlap(True)
         ops.set_option("fwd_rsv_lds", 2)
-        ops.set_side_stream(True, min_items=old_min)
+        ops.set_side_stream(True, min_items=old_min, min_items_bwd=old_min_bwd)
     assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
 
 
@@ -1190,7 +1190,7 @@ def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
             grads[side] = torch.cat([p._ctcn_grad.reshape(-1) for p in m.parameters()]).clone()
     finally:
         ops.set_precision(0)
-        ops.set_side_stream(True, min_items=1 << 21)
+        ops.set_side_stream(True, min_items=ops.SIDE_MIN_ITEMS_FWD, min_items_bwd=ops.SIDE_MIN_ITEMS_BWD)
     ops.check_health()
     assert base is not None and torch.isfinite(grads[True]).all()
     assert float(grads[True].abs().max()) > 0
