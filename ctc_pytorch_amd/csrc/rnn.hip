@@ -2502,19 +2502,26 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
   // H = 320): 10 chunks of 2 560 rows = 10 x 10 tiles on 128 CUs -- a pair then takes less time than the recurrence needs for a chunk,
   // which with 8 chunks of 3 200 rows on the 128 x 128 tiles it did not (the recurrence waited ~50 us per layer for its pre-activations)
   int NCHUNK = 8;
+  bool chunking_fits = false;                            // a chunk count whose pair the side stream digests in one round was found
   if (ov.xcd_allow && nxd_p > 1) {
     const int cus_side = ctcn_device_cus() / nxd_p * __builtin_popcount(ov.xcd_allow), N2 = 2 * GH;
     const int wnt = (N2 % 256 == 0 || (N2 > 512 && ceil_div(N2, 256) * 256 - N2 <= N2 / 8)) ? 2 : 1, tiles_n = ceil_div(N2, 128 * wnt);
     for (int n : {8, 10, 12, 14, 16, 20, 24}) {
       const int ct = ceil_div(T, n);
       const long rows = (long)ct * B, tiles = rows / 256 * tiles_n;
-      if (rows % 256 == 0 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; break; }
+      if (rows % 256 == 0 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; chunking_fits = true; break; }
     }
   }
   const int chunk_T = ceil_div(T, NCHUNK);
   const bool piped = !proj_done && ov.stream && ov.event && ov.ws && ov.xcd_allow != 0 && dirs == 2 && w_ih1 == w_ih0 + (size_t)GH * I &&
                      ctcn_opt_rnn_persistent() && ctcn_get_option("rnn_fwd_tagged") && precision == 1 && cell != CTCN_CELL_TANH && H % 32 == 0 &&
                      H / 32 <= 24 && nxd_p > 1 && T >= 4 * NCHUNK && chunk_T * (NCHUNK - 1) < T &&
+                     // only with such a chunking (round 4): the pipeline runs neck and neck with the recurrence where it fits (cfg2: a pair of
+                     // 2 x 2 560 rows takes the side stream ~130 us, the recurrence consumes it in 128: 13.64 -> 13.21 ms per step), and
+                     // falls behind where it does not -- cfg3 (400 recurrent steps: 8 chunks of 1 600 rows on the 128-row tiles, the fixed cost
+                     // of a pair spread over 50 steps instead of 80) ran 8.51 ms per step with it and 7.87 without.  Option
+                     // "fwd_pipe_any_chunking" = 1 lifts the restriction (the tests that hold the pipeline to the inline order use it)
+                     (chunking_fits || ctcn_get_option("fwd_pipe_any_chunking") != 0) &&
                      // the LAST chunk holds at least two frames: the RSV prologue fetches the pre-activations of steps 0 and 1 without looking
                      // at the chunk counter, and step 1 of the reverse direction is frame T - 2 -- with a one-frame last chunk (8 chunks:
                      // T = 36 / 43 / 50 / 57) that frame belongs to pair 1, which the side stream writes after the launch

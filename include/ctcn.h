@@ -73,6 +73,9 @@ int ctcn_device_xcds(void);
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
+ * "fwd_pipe_any_chunking" = 0 (default): the input projection is pipelined with the forward recurrence (ctcn_rnn_call.side_stream) only
+ * when a time-chunk count exists whose chunk pair the side stream digests in one round of 256-row tiles (cfg2: 10 chunks of 2 560 rows);
+ * 1: with the default 8 chunks otherwise too (slower where measured: cfg3 8.51 vs 7.87 ms per step; the parity tests of the pipeline use it).
  * "fwd_rsv_lds" = 2 (default): rnn_fwd_tagged moves its reserve traffic through LDS (the items park their values, exchange waves store
  * them with 16-B stores in the pause before their first poll, pre-activations arrive by LDS DMA two steps ahead) for H > 384; 1: wherever the
  * reserves are 16-B aligned; 0: never (scattered dword stores / loads from the item waves).  Same values either way.

@@ -981,6 +981,7 @@ def test_forward_projection_overlap_equals_inline(dev, rnn, H, B, T):
     gy = torch.from_numpy(rs.standard_normal((T, B, 2 * H)).astype(np.float32)).to(dev)
     outs = {}
     try:
+        ops.set_option("fwd_pipe_any_chunking", 1)                 # (these shapes have no chunk count that fits the side stream's one-round rule)
         for mode in (False, True, True, True, True, True):
             ops.set_fwd_overlap(mode)
             xin = x.clone().requires_grad_()
@@ -997,6 +998,7 @@ def test_forward_projection_overlap_equals_inline(dev, rnn, H, B, T):
                 assert all(torch.equal(a, b_) for a, b_ in zip(got, outs[mode]))
     finally:
         ops.set_fwd_overlap(True)
+        ops.set_option("fwd_pipe_any_chunking", 0)
     assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
 
 
@@ -1019,6 +1021,7 @@ def test_forward_projection_overlap_short_last_chunk(dev, T, rsv):
     old_min, old_min_bwd = ops._side["min_items"], ops._side["min_items_bwd"]
     try:
         ops.set_side_stream(True, min_items=1)
+        ops.set_option("fwd_pipe_any_chunking", 1)
         ops.set_option("fwd_rsv_lds", rsv)
         for mode in (False, True, True, True, True, True, True):
             ops.set_fwd_overlap(mode)
@@ -1037,6 +1040,7 @@ def test_forward_projection_overlap_short_last_chunk(dev, T, rsv):
                 assert all(torch.equal(a, b_) for a, b_ in zip(got, outs[mode]))
     finally:
         ops.set_fwd_overlap(True)
+        ops.set_option("fwd_pipe_any_chunking", 0)
         ops.set_option("fwd_rsv_lds", 2)
         ops.set_side_stream(True, min_items=old_min, min_items_bwd=old_min_bwd)
     assert all(torch.equal(a, b_) for a, b_ in zip(outs[True], outs[False]))
