@@ -420,7 +420,9 @@ int make_geom(ConvGeom &g, int B, int Ci, int Hi, int Wi, int Co, int kh, int kw
 }
 
 // ---- MFMA path: tile plans ---------------------------------------------------------------------------------------------------------
-constexpr size_t CONV_LDS_MAX = 158 * 1024;
+constexpr size_t CONV_LDS_MAX = 158 * 1024;   // (round 4: capping the image at 79 / 52 KB so that two / three workgroups share a CU -- the kernels use 61 VGPRs --
+                                               // measured no gain at cfg3 (8.02 / 8.02 / 8.31 ms per step) and a loss at the shipped-YAML shape (4.36 / 4.73 / 5.19):
+                                               // the smaller tiles re-read more halo and waste MFMA rows)
 inline int round4(int k) { return (k + 3) & ~3; }
 inline int log2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
