@@ -420,6 +420,10 @@ int make_geom(ConvGeom &g, int B, int Ci, int Hi, int Wi, int Co, int kh, int kw
 }
 
 // ---- MFMA path: tile plans ---------------------------------------------------------------------------------------------------------
+// (round 4, the forward / dgrad kernel at cfg3's layer 2 is 116-140 us against ~16 us of HBM and MFMA floor; three things measured and not kept:
+// (1) eight k-steps per trip with every LDS read issued before the first MFMA: 141 -> 136 us, within noise -- the k loop is not the chain;
+// (2) the next tile's window prefetched into registers before the MFMA loop and committed to LDS after the stores: 139 -> 142 us forward,
+// 283 -> 352 us backward (243 VGPRs, and most workgroups own one or two tiles); (3) smaller LDS images for 2-3 workgroups per CU, below.)
 constexpr size_t CONV_LDS_MAX = 158 * 1024;   // (round 4: capping the image at 79 / 52 KB so that two / three workgroups share a CU -- the kernels use 61 VGPRs --
                                                // measured no gain at cfg3 (8.02 / 8.02 / 8.31 ms per step) and a loss at the shipped-YAML shape (4.36 / 4.73 / 5.19):
                                                // the smaller tiles re-read more halo and waste MFMA rows)
