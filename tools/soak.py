@@ -3,7 +3,7 @@
 recurrence, weight-gradient side stream, gradient-slice hook), `check_health` EVERY step, loss finite, and the whole loss trajectory
 BIT-REPRODUCIBLE across two runs from the same seed (everything in the step rests on L2-visibility timing; nothing may depend on it).
 
-    python tools/soak.py [--cfg2 5000] [--cfg4 2000] [--ref-yaml 2000] [--decode 1000] [--out profiles/r04_soak.json]
+    python tools/soak.py [--cfg2 5000] [--cfg4 2000] [--ref-yaml 2000] [--cfg1 0] [--cfg3 0] [--decode 1000] [--out profiles/r04_soak.json]
 """
 import argparse
 import hashlib
@@ -75,7 +75,8 @@ def decode_run(batches, dev):
     i2c = synth.int2char(V)
     tab = LanguageModel(os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
     tab_dev = torch.as_tensor(tab, dtype=torch.float64).to(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    NS = 3                                              # searches in flight, as steps/test_ctc.decode_and_score runs them
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     h = hashlib.sha256()
     bad = 0
     t0 = time.perf_counter()
@@ -88,9 +89,9 @@ def decode_run(batches, dev):
     first = {}
     for i in range(batches):
         x, lens = xs[i % 4]
-        with torch.cuda.stream(streams[i % 2]):
+        with torch.cuda.stream(streams[i % NS]):
             pend.append((i % 4, ops.beam_decode_async(x, lens, tab_dev, 0.1, W)))
-        if len(pend) == 4:
+        if len(pend) == 2 * NS:
             k, res = pend.pop(0)
             ids, score, st = res.result()
             key = (tuple(map(tuple, ids)), score.tobytes())
@@ -113,12 +114,14 @@ if __name__ == "__main__":
     ap.add_argument("--cfg4", type=int, default=2000)
     ap.add_argument("--ref-yaml", type=int, default=2000)
     ap.add_argument("--decode", type=int, default=1000)
+    ap.add_argument("--cfg1", type=int, default=0)
+    ap.add_argument("--cfg3", type=int, default=0)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     res = {"precision": 1, "note": "two runs per workload from the same seed; `bit_reproducible` compares the sha256 of the float32 loss trajectories"}
     ok = True
-    for name, steps in (("cfg2", a.cfg2), ("cfg4", a.cfg4), ("ref_yaml", a.ref_yaml)):
+    for name, steps in (("cfg2", a.cfg2), ("cfg4", a.cfg4), ("ref_yaml", a.ref_yaml), ("cfg1", a.cfg1), ("cfg3", a.cfg3)):
         if steps <= 0:
             continue
         r1 = train_run(name, steps, dev)
