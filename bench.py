@@ -228,7 +228,10 @@ def run_train(args):
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    c = WORKLOADS[args.workload]
+    c = dict(WORKLOADS[args.workload])
+    if os.environ.get("CTCN_BENCH_T") or os.environ.get("CTCN_BENCH_B"):     # experiment aid (tools/ab_env.sh): the named workload at another T / B --
+        c["T"] = int(os.environ.get("CTCN_BENCH_T", c["T"]))                 # the config string of the line reports them; never a headline number
+        c["B"] = int(os.environ.get("CTCN_BENCH_B", c["B"]))
     from ctc_pytorch_amd import ops as _ops
     _ops.set_precision(args.precision)
     torch.manual_seed(1)
