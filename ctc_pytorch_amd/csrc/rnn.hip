@@ -2511,6 +2511,8 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
       // (round 4: ragged chunks count too -- the queue tile clamps its last rows -- so that the rule is not an accident of T * B: T = 1 000 finds
       // 12 chunks of 2 688 rows (17.21 -> 16.6 ms per step with the pipeline), T = 600 / 700 eight of 2 400 / 2 816; T = 400 finds none)
       const long rows = (long)ct * B, tiles = (rows + 255) / 256 * tiles_n;
+      // (also accepting chunks that fill less than 3/4 of the side CUs when they hold >= 72 steps was measured: B = 16 gains 1.6 %, B = 20 at
+      // T = 650 loses 1.7 % -- not a rule)
       if (rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; chunking_fits = true; break; }
     }
   }
