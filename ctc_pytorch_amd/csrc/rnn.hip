@@ -2513,7 +2513,10 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
       const long rows = (long)ct * B, tiles = (rows + 255) / 256 * tiles_n;
       // (also accepting chunks that fill less than 3/4 of the side CUs when they hold >= 72 steps was measured: B = 16 gains 1.6 %, B = 20 at
       // T = 650 loses 1.7 % -- not a rule)
-      if (rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; chunking_fits = true; break; }
+      // and a chunk holds at least 72 steps: a pair costs the side stream ~130-150 us whatever its size (two one-round GEMMs, their splits, the
+      // counter), which the recurrence must take at least as long to consume -- measured: 75-100 steps per chunk gain 1-4 %, 50 lose 7.5 %
+      // (T = 400), and B = 40 -- two idle XCDs, where only 24 chunks of 34 steps pass the one-round test -- lost 14 % (18.8 vs 16.2 ms per step)
+      if (ct >= 72 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; chunking_fits = true; break; }
     }
   }
   const int chunk_T = ceil_div(T, NCHUNK);

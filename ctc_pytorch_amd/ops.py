@@ -414,6 +414,14 @@ class _RNNLayer(torch.autograd.Function):
         # with the side stream (2.27 ms inline, 2.8-4.5 with it) and set the threshold at 2^21; with the queue-form GEMMs and the deferred issue
         # of rounds 2-3 the picture is the opposite (round 4: cfg1 2.02 -> 1.95 ms, the shipped-YAML shape 4.69 -> 4.36): set_side_stream
         side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items_bwd"]
+        if side:
+            # ... and only when the idle XCDs can digest the layer's weight GEMMs within the recurrence they run next to (round 4): at ~300
+            # TFLOP/s of the whole chip, scaled to the idle share, against T steps of ~1.7 us.  With 3 batch tiles (B = 33..48: 6 of 8 XCDs
+            # taken) the side stream fell further behind with every layer and the step waited for it at the end: cfg2's model at B = 40
+            # 18.5 ms per step with it, 16.2 without (B = 48: 17.9 / 17.2); B = 16 / 32 keep it (12.0 / 12.6 and 13.2 / 14.4 without)
+            nidle = bin(allow).count("1")
+            side_us = 2.0 * T * B * (dirs * GATES[cell] * H) * (I + H) / (300e6 * nidle / nx)
+            side = side_us <= 0.9 * T * 1.7
         null = ctypes.c_void_p(None)
         key = (dev.type, dev.index)
         if ctx.counted:
