@@ -229,9 +229,11 @@ def run_train(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     c = dict(WORKLOADS[args.workload])
-    if os.environ.get("CTCN_BENCH_T") or os.environ.get("CTCN_BENCH_B"):     # experiment aid (tools/ab_env.sh): the named workload at another T / B --
-        c["T"] = int(os.environ.get("CTCN_BENCH_T", c["T"]))                 # the config string of the line reports them; never a headline number
-        c["B"] = int(os.environ.get("CTCN_BENCH_B", c["B"]))
+    for key in ("T", "B", "H", "L"):                                           # experiment aid (tools/ab_env.sh): the named workload at another T / B / H / L --
+        if os.environ.get("CTCN_BENCH_" + key):                                # the config string of the line reports them; never a headline number
+            c[key] = int(os.environ["CTCN_BENCH_" + key])
+    if os.environ.get("CTCN_BENCH_RNN"):
+        c["rnn"] = os.environ["CTCN_BENCH_RNN"]
     from ctc_pytorch_amd import ops as _ops
     _ops.set_precision(args.precision)
     torch.manual_seed(1)

@@ -2516,7 +2516,12 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
       // and a chunk holds at least 72 steps: a pair costs the side stream ~130-150 us whatever its size (two one-round GEMMs, their splits, the
       // counter), which the recurrence must take at least as long to consume -- measured: 75-100 steps per chunk gain 1-4 %, 50 lose 7.5 %
       // (T = 400), and B = 40 -- two idle XCDs, where only 24 chunks of 34 steps pass the one-round test -- lost 14 % (18.8 vs 16.2 ms per step)
-      if (ct >= 72 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3) { NCHUNK = n; chunking_fits = true; break; }
+      // and the side stream keeps up: a pair's flops at ~32.5 TFLOP/s per idle XCD (what the queue tiles reach next to a recurrence: cfg2's
+      // pair of 16.8 GFLOP takes 129 us on four) within the time the recurrence needs for the chunk's steps (1.2 + H / 800 us each, measured
+      // 1.36 .. 1.7 for H = 128 .. 384), 8 % slack -- the pair's flops grow with H^2: at H = 384 (B = 32, T = 800) the pipeline lost 2.7 %
+      const double pair_us = 2.0 * (2.0 * ct * B) * N2 * (double)I / (32.5e6 * __builtin_popcount(ov.xcd_allow));
+      const double rec_us = ct * (1.2 + H / 800.0);
+      if (I >= ctcn_get_option("fwd_pipe_min_input") && ct >= 72 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3 && pair_us <= 1.08 * rec_us) { NCHUNK = n; chunking_fits = true; break; }
     }
   }
   const int chunk_T = ceil_div(T, NCHUNK);
@@ -2537,13 +2542,17 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
                      // the side GEMMs' workgroups that land on a recurrence XCD must be able to START there (to exit at once): the
                      // 1024-thread workgroups of the recurrence leave no room on their own CUs, so some CUs of the XCD must stay free --
                      // otherwise the GEMM cannot finish before the recurrence does, which is waiting for it (H = 512: 32 of 32 CUs)
-                     ceil_div(dirs * ceil_div(B, 16), nxd_p) * (H / 16) + 4 <= ctcn_device_cus() / nxd_p;
+                     // (round 4: EIGHT free CUs, counting the spare workgroups of the launch -- H = 384: 24 + 3 workgroups per XCD leave five, and even
+                     // the bottom layer's tiny projection (I = 40, ten chunk GEMMs of a few microseconds) cost 4 % of the step when pipelined:
+                     // 16.4 vs 15.7 ms; H = 320 / 352 leave ten / eight and gain)
+                     [&] { const int wpx_ = ceil_div(dirs * ceil_div(B, 16), nxd_p) * (H / 16); return wpx_ + std::max(2, wpx_ / 8) + 8 <= ctcn_device_cus() / nxd_p; }();
   GemmPlanes pl_main, pl_side;                           // what this call's GEMMs left in the main / the side workspace (operand planes reused within the call)
   auto project_chunk = [&](int c, void *wsp, size_t wsb, void *strm, unsigned allow, GemmPlanes &pl) -> int {
     const int t0 = c * chunk_T, t1 = std::min(T, t0 + chunk_T);
     return ctcn_gemm_on_xcds(0, 1, (t1 - t0) * B, 2 * GH, I, x + (size_t)t0 * B * I, I, w_ih0, I, gates + (size_t)t0 * B * 2 * GH, 2 * GH, 0.0f, precision,
                              wsp, wsb, strm, allow, &pl);
   };
+  if (getenv("CTCN_LOG_PIPE")) fprintf(stderr, "libctcn: rnn_fwd T=%d B=%d I=%d H=%d: projection pipeline %s (chunks %d x %d steps, fits=%d)\n", T, B, I, H, piped ? "ON" : "off", NCHUNK, chunk_T, (int)chunking_fits);
   if (piped) {
     int rc = project_chunk(0, ws, ws_bytes, stream, 0, pl_main);
     pl_main.same_b = true;                                // W_ih: split into planes once per stream (reused when the chunk has the same size)

@@ -74,8 +74,11 @@ int ctcn_device_xcds(void);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
  * "fwd_pipe_any_chunking" = 0 (default): the input projection is pipelined with the forward recurrence (ctcn_rnn_call.side_stream) only
- * when a time-chunk count exists whose chunk pair the side stream digests in one round of 256-row tiles (cfg2: 10 chunks of 2 560 rows);
- * 1: with the default 8 chunks otherwise too (slower where measured: cfg3 8.51 vs 7.87 ms per step; the parity tests of the pipeline use it).
+ * when a time-chunk count exists whose chunk pair the side stream digests in one round of 256-row tiles on the idle XCDs (cfg2: 10 chunks
+ * of 2 560 rows), with at least 72 steps per chunk, at a flop rate the idle XCDs sustain within the recurrence's time for the chunk, and with
+ * eight CUs of every recurrence XCD left free; 1: with the default 8 chunks otherwise too (slower where measured: cfg3 8.51 vs 7.87 ms per
+ * step; the parity tests of the pipeline use it).  "fwd_pipe_min_input" = 0: smallest layer input width that is pipelined (experiments).
+ * Environment CTCN_LOG_PIPE=1 prints the decision of every ctcn_rnn_fwd_ex call to stderr.
  * "fwd_rsv_lds" = 2 (default): rnn_fwd_tagged moves its reserve traffic through LDS (the items park their values, exchange waves store
  * them with 16-B stores in the pause before their first poll, pre-activations arrive by LDS DMA two steps ahead) for H > 384; 1: wherever the
  * reserves are 16-B aligned; 0: never (scattered dword stores / loads from the item waves).  Same values either way.
