@@ -124,7 +124,8 @@ def set_grad_ready_hook(fn):
 
 
 _side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled": os.environ.get("CTCN_SIDE_STREAM", "1") != "0", "streams": {}, "pending": {}, "deferred": {}, "live": {}, "events": {}, "min_items": int(os.environ.get("CTCN_SIDE_MIN_ITEMS", str(1 << 21))), "min_items_bwd": int(os.environ.get("CTCN_SIDE_MIN_ITEMS_BWD", os.environ.get("CTCN_SIDE_MIN_ITEMS", str(1 << 18)))),
-         "small_split": os.environ.get("CTCN_SMALL_SPLIT", "1") != "0"}
+         "small_split": os.environ.get("CTCN_SMALL_SPLIT", "1") != "0",
+         "capacity_slack": float(os.environ.get("CTCN_SIDE_CAPACITY_SLACK", "1.0"))}      # > 1: the weight-gradient side stream also where the rule says it cannot keep up (experiments)
 
 
 SIDE_MIN_ITEMS_FWD, SIDE_MIN_ITEMS_BWD = 1 << 21, 1 << 18
@@ -416,12 +417,17 @@ class _RNNLayer(torch.autograd.Function):
         side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items_bwd"]
         if side:
             # ... and only when the idle XCDs can digest the layer's weight GEMMs within the recurrence they run next to (round 4): at ~300
-            # TFLOP/s of the whole chip, scaled to the idle share, against T steps of ~1.7 us.  With 3 batch tiles (B = 33..48: 6 of 8 XCDs
+            # TFLOP/s of the whole chip, scaled to the idle share, against T backward steps of 1.2 + H / 400 us.  With 3 batch tiles (B = 33..48: 6 of 8 XCDs
             # taken) the side stream fell further behind with every layer and the step waited for it at the end: cfg2's model at B = 40
             # 18.5 ms per step with it, 16.2 without (B = 48: 17.9 / 17.2); B = 16 / 32 keep it (12.0 / 12.6 and 13.2 / 14.4 without)
             nidle = bin(allow).count("1")
             side_us = 2.0 * T * B * (dirs * GATES[cell] * H) * (I + H) / (300e6 * nidle / nx)
-            side = side_us <= 0.9 * T * 1.7
+            side = side_us <= 0.9 * T * (1.2 + H / 400.0) * _side["capacity_slack"]        # (backward step: ~1.5 / 2.0 / 2.5 us at H = 128 / 320 / 512)
+            # ... and the recurrence leaves CUs free on ITS XCDs: the side GEMMs' workgroups that the dispatcher deals to a recurrence XCD must
+            # start there to find out that they are on the wrong XCD and leave; with every CU taken (H = 512: 32 slices) they wait for the
+            # recurrence to end, and the in-order dispatcher with them (cfg4's model at B = 32: 41.2 ms per step with the side stream, 40.0 without)
+            wpx = ((groups + nx - 1) // nx) * ((H + 15) // 16)
+            side = side and wpx + max(2, wpx // 8) + 2 <= L.ctcn_device_cus() // nx
         null = ctypes.c_void_p(None)
         key = (dev.type, dev.index)
         if ctx.counted:
