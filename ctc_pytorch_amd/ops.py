@@ -153,6 +153,27 @@ def set_fwd_overlap(flag):
     _side["fwd_overlap"] = bool(flag)
 
 
+def side_stream_fits(cell, T, B, I, H, dirs, nx, cus, slack=1.0):
+    """Can the XCDs a persistent recurrence of this shape leaves idle digest the layer's weight-gradient GEMMs (dW_ih, dW_hh) within the
+    recurrence of the layer below, which they run next to?  Pure arithmetic (round 4; every constant from a measured loss):
+    * capacity: the GEMMs' flops at ~300 TFLOP/s of the whole chip, scaled to the idle share of the XCDs, against 0.9 x T backward steps of
+      1.2 + H / 400 us (~1.5 / 2.0 / 2.5 us at H = 128 / 320 / 512).  With 3 batch tiles (B = 33..48: 6 of 8 XCDs taken) the side stream
+      fell further behind with every layer and the step waited for it at the end: cfg2's model at B = 48 17.9 ms per step with it, 17.2
+      without; B = 16 / 32 keep it (12.0 / 12.6 and 13.2 / 15.0 without);
+    * free CUs on the recurrence's OWN XCDs: the side GEMMs' workgroups that the dispatcher deals to a recurrence XCD must start there to find
+      out that they are on the wrong XCD and leave; with every CU taken (H = 512: 32 slices) they wait for the recurrence to end, and the
+      in-order dispatcher with them (cfg4's model at B = 32: 41.2 ms per step with the side stream, 40.2 without)."""
+    groups = dirs * ((B + 15) // 16)
+    nidle = nx - groups
+    if nx <= 1 or nidle <= 0:
+        return False
+    side_us = 2.0 * T * B * (dirs * GATES[cell] * H) * (I + H) / (300e6 * nidle / nx)
+    if side_us > 0.9 * T * (1.2 + H / 400.0) * slack:
+        return False
+    wpx = ((groups + nx - 1) // nx) * ((H + 15) // 16)
+    return wpx + max(2, wpx // 8) + 2 <= cus // nx
+
+
 def _side_stream(dev):
     key = (dev.type, dev.index)
     st = _side["streams"].get(key)
@@ -415,19 +436,7 @@ class _RNNLayer(torch.autograd.Function):
         # with the side stream (2.27 ms inline, 2.8-4.5 with it) and set the threshold at 2^21; with the queue-form GEMMs and the deferred issue
         # of rounds 2-3 the picture is the opposite (round 4: cfg1 2.02 -> 1.95 ms, the shipped-YAML shape 4.69 -> 4.36): set_side_stream
         side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items_bwd"]
-        if side:
-            # ... and only when the idle XCDs can digest the layer's weight GEMMs within the recurrence they run next to (round 4): at ~300
-            # TFLOP/s of the whole chip, scaled to the idle share, against T backward steps of 1.2 + H / 400 us.  With 3 batch tiles (B = 33..48: 6 of 8 XCDs
-            # taken) the side stream fell further behind with every layer and the step waited for it at the end: cfg2's model at B = 40
-            # 18.5 ms per step with it, 16.2 without (B = 48: 17.9 / 17.2); B = 16 / 32 keep it (12.0 / 12.6 and 13.2 / 14.4 without)
-            nidle = bin(allow).count("1")
-            side_us = 2.0 * T * B * (dirs * GATES[cell] * H) * (I + H) / (300e6 * nidle / nx)
-            side = side_us <= 0.9 * T * (1.2 + H / 400.0) * _side["capacity_slack"]        # (backward step: ~1.5 / 2.0 / 2.5 us at H = 128 / 320 / 512)
-            # ... and the recurrence leaves CUs free on ITS XCDs: the side GEMMs' workgroups that the dispatcher deals to a recurrence XCD must
-            # start there to find out that they are on the wrong XCD and leave; with every CU taken (H = 512: 32 slices) they wait for the
-            # recurrence to end, and the in-order dispatcher with them (cfg4's model at B = 32: 41.2 ms per step with the side stream, 40.0 without)
-            wpx = ((groups + nx - 1) // nx) * ((H + 15) // 16)
-            side = side and wpx + max(2, wpx // 8) + 2 <= L.ctcn_device_cus() // nx
+        side = side and side_stream_fits(cell, T, B, I, H, dirs, nx, L.ctcn_device_cus(), _side["capacity_slack"])
         null = ctypes.c_void_p(None)
         key = (dev.type, dev.index)
         if ctx.counted:

@@ -488,3 +488,23 @@ def test_decode_driver_picks_the_decoder_from_the_yaml_keys(tmp_path):
         TE.main({"use_gpu": False})
 
 
+
+
+def test_side_stream_capacity_rule_on_the_measured_shapes():
+    """ops.side_stream_fits (round 4): the weight-gradient side stream is used where the idle XCDs can digest a layer's GEMMs within the
+    recurrence beside them and the recurrence leaves CUs free on its own XCDs -- the decisions at the shapes whose A/B runs set the constants
+    (8 XCDs x 32 CUs; LSTM = cell 0, GRU = cell 1)."""
+    from ctc_pytorch_amd import ops
+    fits = lambda cell, T, B, I, H: ops.side_stream_fits(cell, T, B, I, H, 2, 8, 256)
+    assert fits(0, 800, 32, 640, 320)            # cfg2: 4 idle XCDs, 13.2 ms with / 15.0 without
+    assert fits(0, 800, 16, 640, 320)            # one batch tile: 6 idle XCDs
+    assert fits(0, 800, 24, 640, 320)
+    assert not fits(0, 800, 48, 640, 320)        # 3 batch tiles: 2 idle XCDs cannot keep up (17.9 with / 17.2 without)
+    assert not fits(0, 800, 40, 640, 320)
+    assert not fits(0, 800, 64, 640, 320)        # no idle XCD at all
+    assert fits(0, 200, 8, 768, 384)             # the shipped YAML shape: 4.69 -> 4.36 ms once its weight GEMMs left the main stream
+    assert fits(0, 300, 8, 256, 128)             # cfg1
+    assert fits(0, 800, 32, 768, 384)            # 27 of 32 CUs per recurrence XCD: still room to start and leave
+    assert not fits(1, 1200, 32, 1024, 512)      # H = 512: every CU of the recurrence XCDs taken (41.2 with / 40.2 without)
+    assert not fits(1, 1200, 64, 1024, 512)      # cfg4
+    assert not ops.side_stream_fits(0, 800, 32, 640, 320, 2, 1, 256)     # a device without XCDs to split
