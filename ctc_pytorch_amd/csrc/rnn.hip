@@ -2472,6 +2472,41 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
 // (round 3: the ABI keeps no state between calls any more.  What used to be armed by ctcn_set_fwd_overlap / ctcn_set_prelaunch_event and
 // handed over in thread-locals by the _dropout entry points travels in the caller's `ctcn_rnn_call` (include/ctcn.h); a NULL pointer or a
 // zeroed struct is the plain call.)
+// ---- the projection pipeline's plan (pure arithmetic; ctcn_diag_pipeline_chunks exposes it to the CPU tests) ---------------------------------
+// Returns the number of time chunks (even, 8..24) with which the input projection of a bidirectional layer is pipelined with its forward
+// recurrence -- the first pair of chunks in front of the launch, the others by XCD-filtered GEMMs on the side stream while the recurrence
+// runs, a counter per pair -- or 0 when no chunking pays.  Every condition below comes from a measured loss (round 4, `tools/ab_shapes.sh`:
+// cfg2's model over T, B, H; ms per training step with the pipeline | without):
+//  * one round: a chunk's GEMM ((T / n) * B rows x 2 * G * H columns; ragged last tile allowed) is one round of 256-row tiles on the idle
+//    XCDs' CUs, at least 3/4 of them busy -- cfg2 (T = 800, B = 32, H = 320): 10 chunks of 2 560 rows = 10 x 10 tiles on 128 CUs: 13.21 | 13.64;
+//    T = 1 000: 12 chunks of 2 688 rows: 16.69 | 17.28; T = 600 / 700: eight chunks: 10.34 | 10.45, 11.76 | 12.10; B = 24: 12.54 | 13.09;
+//  * at least 72 steps per chunk: a pair costs the side stream ~130-150 us whatever its size (two one-round GEMMs, their splits, the counter),
+//    which the recurrence must take at least as long to consume -- T = 400 (cfg3; 50 steps per chunk): 8.51 | 7.88; B = 40 (two idle XCDs: only
+//    24 chunks of 34 steps pass the one-round test): 18.8 | 16.2;
+//  * throughput: a pair's flops at ~32.5 TFLOP/s per idle XCD (cfg2's pair of 16.8 GFLOP takes 129 us on four) within the time the recurrence
+//    needs for the chunk's steps (1.2 + H / 800 us each; measured 1.36 .. 1.7 for H = 128 .. 384), 8 % slack -- H = 384: 16.09 | 15.66;
+//  * eight CUs of every recurrence XCD stay free, counting the launch's spare workgroups: the side GEMMs' workgroups dealt to a recurrence XCD
+//    must start there to leave -- H = 384 (24 + 3 workgroups per XCD) with only its bottom layer's tiny projection pipelined: 16.4 | 15.7.
+// (Measured and not a rule: chunks that fill less than 3/4 of the side CUs but hold >= 72 steps -- B = 16 gains 1.6 %, B = 20 at T = 650 loses 1.7 %.)
+static int plan_projection_pipeline(int T, int B, int I, int H, int dirs, int G, int nxd, int cus, unsigned xcd_allow, int min_input) {
+  if (nxd <= 1 || !xcd_allow || dirs != 2 || I < min_input) return 0;
+  const int GH = G * H, N2 = 2 * GH, nidle = __builtin_popcount(xcd_allow), cus_side = cus / nxd * nidle;
+  const int wpx = ceil_div(dirs * ceil_div(B, 16), nxd) * (H / 16);
+  if (wpx + std::max(2, wpx / 8) + 8 > cus / nxd) return 0;
+  const int wnt = (N2 % 256 == 0 || (N2 > 512 && ceil_div(N2, 256) * 256 - N2 <= N2 / 8)) ? 2 : 1, tiles_n = ceil_div(N2, 128 * wnt);
+  for (int n : {8, 10, 12, 14, 16, 20, 24}) {
+    const int ct = ceil_div(T, n);
+    const long rows = (long)ct * B, tiles = (rows + 255) / 256 * tiles_n;
+    const double pair_us = 2.0 * (2.0 * ct * B) * N2 * (double)I / (32.5e6 * nidle), rec_us = ct * (1.2 + H / 800.0);
+    if (ct >= 72 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3 && pair_us <= 1.08 * rec_us) return n;
+  }
+  return 0;
+}
+extern "C" int ctcn_diag_pipeline_chunks(int cell, int T, int B, int I, int H, int dirs, int xcds, int cus, unsigned xcd_allow) {
+  if (cell < 0 || cell > 2 || T <= 0 || B <= 0 || I <= 0 || H <= 0 || xcds <= 0 || cus <= 0) return -1;
+  return plan_projection_pipeline(T, B, I, H, dirs, gates_of(cell), xcds, cus, xcd_allow, 0);
+}
+
 static const ctcn_rnn_call k_plain_call = {};
 __global__ void set_counter_kernel(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -2497,33 +2532,11 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
   int *const status_word = call.status ? call.status : ctcn_status_word();
   // pipelined projection: needs the tagged-gather kernel (the only one that checks the chunk counter), both W_ih stacked, idle XCDs
   const int nxd_p = ctcn_opt_handoff() ? ctcn_device_xcds() : 1;
-  // time chunks: 8, or the first even count whose chunk GEMM ((T / n) * B rows x 2*GH columns) the side stream's 256-row tile queue
-  // (gemm_planes_nt256pp_queue_kernel) digests in ONE round on the allowed XCDs' CUs, at least 3/4 of them busy: cfg2 (T = 800, B = 32,
-  // H = 320): 10 chunks of 2 560 rows = 10 x 10 tiles on 128 CUs -- a pair then takes less time than the recurrence needs for a chunk,
-  // which with 8 chunks of 3 200 rows on the 128 x 128 tiles it did not (the recurrence waited ~50 us per layer for its pre-activations)
-  int NCHUNK = 8;
-  bool chunking_fits = false;                            // a chunk count whose pair the side stream digests in one round was found
-  if (ov.xcd_allow && nxd_p > 1) {
-    const int cus_side = ctcn_device_cus() / nxd_p * __builtin_popcount(ov.xcd_allow), N2 = 2 * GH;
-    const int wnt = (N2 % 256 == 0 || (N2 > 512 && ceil_div(N2, 256) * 256 - N2 <= N2 / 8)) ? 2 : 1, tiles_n = ceil_div(N2, 128 * wnt);
-    for (int n : {8, 10, 12, 14, 16, 20, 24}) {
-      const int ct = ceil_div(T, n);
-      // (round 4: ragged chunks count too -- the queue tile clamps its last rows -- so that the rule is not an accident of T * B: T = 1 000 finds
-      // 12 chunks of 2 688 rows (17.21 -> 16.6 ms per step with the pipeline), T = 600 / 700 eight of 2 400 / 2 816; T = 400 finds none)
-      const long rows = (long)ct * B, tiles = (rows + 255) / 256 * tiles_n;
-      // (also accepting chunks that fill less than 3/4 of the side CUs when they hold >= 72 steps was measured: B = 16 gains 1.6 %, B = 20 at
-      // T = 650 loses 1.7 % -- not a rule)
-      // and a chunk holds at least 72 steps: a pair costs the side stream ~130-150 us whatever its size (two one-round GEMMs, their splits, the
-      // counter), which the recurrence must take at least as long to consume -- measured: 75-100 steps per chunk gain 1-4 %, 50 lose 7.5 %
-      // (T = 400), and B = 40 -- two idle XCDs, where only 24 chunks of 34 steps pass the one-round test -- lost 14 % (18.8 vs 16.2 ms per step)
-      // and the side stream keeps up: a pair's flops at ~32.5 TFLOP/s per idle XCD (what the queue tiles reach next to a recurrence: cfg2's
-      // pair of 16.8 GFLOP takes 129 us on four) within the time the recurrence needs for the chunk's steps (1.2 + H / 800 us each, measured
-      // 1.36 .. 1.7 for H = 128 .. 384), 8 % slack -- the pair's flops grow with H^2: at H = 384 (B = 32, T = 800) the pipeline lost 2.7 %
-      const double pair_us = 2.0 * (2.0 * ct * B) * N2 * (double)I / (32.5e6 * __builtin_popcount(ov.xcd_allow));
-      const double rec_us = ct * (1.2 + H / 800.0);
-      if (I >= ctcn_get_option("fwd_pipe_min_input") && ct >= 72 && rows >= 1024 && T >= 4 * n && ct * (n - 1) < T && tiles <= cus_side && tiles * 4 >= (long)cus_side * 3 && pair_us <= 1.08 * rec_us) { NCHUNK = n; chunking_fits = true; break; }
-    }
-  }
+  // time chunks of the pipelined projection (plan_projection_pipeline, above): a fitting even count, or 8 when none fits (then the pipeline
+  // is used only with option "fwd_pipe_any_chunking")
+  int NCHUNK = ov.xcd_allow && nxd_p > 1 ? plan_projection_pipeline(T, B, I, H, dirs, G, nxd_p, ctcn_device_cus(), ov.xcd_allow, ctcn_get_option("fwd_pipe_min_input")) : 0;
+  const bool chunking_fits = NCHUNK > 0;
+  if (!chunking_fits) NCHUNK = 8;
   const int chunk_T = ceil_div(T, NCHUNK);
   const bool piped = !proj_done && ov.stream && ov.event && ov.ws && ov.xcd_allow != 0 && dirs == 2 && w_ih1 == w_ih0 + (size_t)GH * I &&
                      ctcn_opt_rnn_persistent() && ctcn_get_option("rnn_fwd_tagged") && precision == 1 && cell != CTCN_CELL_TANH && H % 32 == 0 &&
@@ -2541,11 +2554,9 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
                      (size_t)T * B * dirs * GH * sizeof(float) < ((size_t)1 << 32) &&
                      // the side GEMMs' workgroups that land on a recurrence XCD must be able to START there (to exit at once): the
                      // 1024-thread workgroups of the recurrence leave no room on their own CUs, so some CUs of the XCD must stay free --
-                     // otherwise the GEMM cannot finish before the recurrence does, which is waiting for it (H = 512: 32 of 32 CUs)
-                     // (round 4: EIGHT free CUs, counting the spare workgroups of the launch -- H = 384: 24 + 3 workgroups per XCD leave five, and even
-                     // the bottom layer's tiny projection (I = 40, ten chunk GEMMs of a few microseconds) cost 4 % of the step when pipelined:
-                     // 16.4 vs 15.7 ms; H = 320 / 352 leave ten / eight and gain)
-                     [&] { const int wpx_ = ceil_div(dirs * ceil_div(B, 16), nxd_p) * (H / 16); return wpx_ + std::max(2, wpx_ / 8) + 8 <= ctcn_device_cus() / nxd_p; }();
+                     // otherwise the GEMM cannot finish before the recurrence does, which is waiting for it (H = 512: 32 of 32 CUs).
+                     // (Four is the deadlock guard, for any chunking; the plan asks for eight.)
+                     ceil_div(dirs * ceil_div(B, 16), nxd_p) * (H / 16) + 4 <= ctcn_device_cus() / nxd_p;
   GemmPlanes pl_main, pl_side;                           // what this call's GEMMs left in the main / the side workspace (operand planes reused within the call)
   auto project_chunk = [&](int c, void *wsp, size_t wsb, void *strm, unsigned allow, GemmPlanes &pl) -> int {
     const int t0 = c * chunk_T, t1 = std::min(T, t0 + chunk_T);

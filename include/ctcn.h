@@ -357,6 +357,10 @@ int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const int32_t *len
  * string literals (relaxed; with several calling threads the last writer wins -- the backward pass of autograd runs on another thread
  * than the reader, which is why it is not thread-local), read by nothing on the compute path. */
 int ctcn_diag_squat(int wgs_per_xcd, int threads, int lds_bytes, unsigned usec, void *stream);
+/* ctcn_diag_pipeline_chunks: the plan of the projection pipeline (ctcn_rnn_call.side_stream of ctcn_rnn_fwd_ex) for a layer shape on a device
+ * of `xcds` XCDs and `cus` CUs with the idle XCDs `xcd_allow`: the number of time chunks (even, 8..24) it would be pipelined with, 0 = not
+ * pipelined (the one-round / 72-steps / throughput / free-CU rules of rnn.hip), -1 = bad arguments.  Pure arithmetic, no device needed. */
+int ctcn_diag_pipeline_chunks(int cell, int T, int B, int I, int H, int dirs, int xcds, int cus, unsigned xcd_allow);
 const char *ctcn_rnn_last_kernel(int which);
 
 #ifdef __cplusplus

@@ -508,3 +508,31 @@ def test_side_stream_capacity_rule_on_the_measured_shapes():
     assert not fits(1, 1200, 32, 1024, 512)      # H = 512: every CU of the recurrence XCDs taken (41.2 with / 40.2 without)
     assert not fits(1, 1200, 64, 1024, 512)      # cfg4
     assert not ops.side_stream_fits(0, 800, 32, 640, 320, 2, 1, 256)     # a device without XCDs to split
+
+
+def test_projection_pipeline_plan_on_the_measured_shapes():
+    """ctcn_diag_pipeline_chunks = the pure plan behind ctcn_rnn_fwd_ex's projection pipeline (rnn.hip, round 4): chunk counts at the shapes
+    whose A/B runs set its rules (8 XCDs x 32 CUs; `allow` = the XCDs a bidirectional recurrence of B rows leaves idle)."""
+    from ctc_pytorch_amd import _lib
+    L = _lib.lib()
+    def chunks(cell, T, B, I, H):
+        groups = 2 * ((B + 15) // 16)
+        allow = 0xFF & ~((1 << groups) - 1)
+        return L.ctcn_diag_pipeline_chunks(cell, T, B, I, H, 2, 8, 256, allow)
+    assert chunks(0, 800, 32, 640, 320) == 10        # cfg2: 10 chunks of 2 560 rows, 13.21 | 13.64 ms per step with | without
+    assert chunks(0, 1000, 32, 640, 320) == 12       # ragged chunks of 2 688 rows: 16.69 | 17.28
+    assert chunks(0, 600, 32, 640, 320) == 8
+    assert chunks(0, 700, 32, 640, 320) == 8
+    assert chunks(0, 400, 32, 640, 320) == 0         # cfg3's recurrent length: 50 steps per chunk lost 7.5 %
+    assert chunks(0, 800, 40, 640, 320) == 0         # two idle XCDs: 24 chunks of 34 steps had passed the one-round test and lost 14 %
+    assert chunks(0, 800, 48, 640, 320) == 0
+    assert chunks(0, 800, 24, 640, 320) == 8
+    assert chunks(0, 800, 16, 640, 320) == 0         # 70 tiles on 192 side CUs: below 3/4 of a round
+    assert chunks(0, 800, 32, 768, 384) == 0         # H = 384: a pair's flops outrun the idle XCDs (-2.7 %) ...
+    assert chunks(0, 800, 32, 40, 384) == 0          # ... and five free CUs per recurrence XCD are too few even for its bottom layer (-4 %)
+    assert chunks(0, 800, 32, 40, 320) == 10         # cfg2's bottom layer (ten free CUs): pipelined, +0.6 %
+    assert chunks(0, 800, 32, 512, 256) == 8          # H = 256: 12.05 | 12.61
+    assert chunks(1, 1200, 64, 1024, 512) == 0       # cfg4: no idle XCD
+    assert chunks(1, 1200, 32, 1024, 512) == 0       # H = 512: every CU of the recurrence XCDs taken
+    assert chunks(0, 200, 8, 768, 384) == 0          # the shipped YAML shape
+    assert L.ctcn_diag_pipeline_chunks(0, 800, 32, 640, 320, 2, 1, 256, 0) == 0 and L.ctcn_diag_pipeline_chunks(7, 800, 32, 640, 320, 2, 8, 256, 0xF0) == -1
