@@ -378,6 +378,8 @@ class _RNNLayer(torch.autograd.Function):
             call.y_drop, call.drop_p, call.drop_seed, call.drop_offset = y_drop.data_ptr(), float(drop_p), seed, off
         _lib.check(L.ctcn_rnn_fwd_ex(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
                                      _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr(), ctypes.byref(call)), "rnn_fwd_ex")
+        if T > 1 and B > 16 and (L.ctcn_rnn_last_kernel(0) or b"") == b"rnn_fwd_step" and get_option("rnn_persistent"):
+            _fallback_shapes.add((cell, H, dirs, B))       # (rnn_layer chunks this shape's batch from the next call on)
         if piped:
             # by the time the recurrence ends the side stream's GEMMs have long finished (the kernel waited for their counter); the join
             # only tells the allocator and the following kernels so
@@ -386,6 +388,7 @@ class _RNNLayer(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(st)
         ctx.cell, ctx.dims, ctx.has_aux = cell, (T, B, I, H, dirs), aux is not None
+        ctx.early_ok = not _chunking[0]        # a batch chunk's weight gradients are partial sums: no early all-reduce of the layer's slice (parallel._slice_ready)
         ctx.consumed = False
         # recurrent layers of this device whose backward is still to come (the deferral of the side work needs to know
         # whether another recurrence will follow in the backward pass)
@@ -478,6 +481,8 @@ class _RNNLayer(torch.autograd.Function):
             if above is not None:                       # keep the parked work for the join
                 _side["deferred"][key] = above
             raise
+        if T > 1 and B > 16 and (L.ctcn_rnn_last_kernel(1) or b"") == b"rnn_bwd_step" and get_option("rnn_persistent"):
+            _fallback_shapes.add((cell, H, dirs, B))           # (rnn_layer chunks this shape's batch from the next call on)
         if above is not None:
             above(ev)
         if split_dirs:
@@ -513,7 +518,7 @@ class _RNNLayer(torch.autograd.Function):
                     _lib.check(L.ctcn_rnn_bwd_weights(cell, T, B, I, H, dirs, _ptr(x), _ptr(y), _ptr(gates), _ptr(aux), _ptr(d_ih0),
                                                       _ptr(d_hh0), _ptr(d_ih1), _ptr(d_hh1), 1.0, prec, allow, wp2, wn2,
                                                       st.cuda_stream), "rnn_bwd_weights")
-                    if _grad_ready["hook"] is not None:          # this layer's weight gradients are final once `st` gets here
+                    if _grad_ready["hook"] is not None and ctx.early_ok:      # this layer's weight gradients are final once `st` gets here (not so for one of several batch chunks)
                         _grad_ready["hook"]([t for t in (d_ih0, d_hh0, d_ih1, d_hh1) if t is not None])
                 for t in (x, y, gates, aux):
                     if t is not None:
@@ -528,10 +533,50 @@ class _RNNLayer(torch.autograd.Function):
         return dx, d_ih0, d_hh0, d_ih1, d_hh1, None, None, None
 
 
+def persistent_batch_limit(H, dirs, nx, cus):
+    """Rows one launch of the persistent recurrences can hold: a (direction, 16-row batch tile) group is ceil(H / 16) workgroups on ONE XCD,
+    one workgroup per CU, so an XCD of cus / nx CUs takes floor((cus / nx) / ceil(H / 16)) groups -- bidirectional on 8 x 32 CUs: 64 rows for
+    256 < H <= 512, 128 for H <= 256, 256 at H = 128.  0: the shape has no persistent launch at all."""
+    nsl = (H + 15) // 16
+    per_xcd = (cus // max(nx, 1)) // nsl if nsl else 0
+    return 16 * ((per_xcd * max(nx, 1)) // dirs) if nx > 1 else 0
+
+
 def rnn_layer(x, w_ih0, w_hh0, w_ih1, w_hh1, cell, training=True, drop_p=0.0):
     """x (T,B,I) -> y (T,B,dirs*H); cell in {'lstm','gru','tanh'} (nn.LSTM/GRU/RNN, bias=False, model_ctc.py:24-25).
-    drop_p > 0 (training only): returns dropout(y, drop_p) instead -- the dropout that follows the layer in BatchRNN (model_ctc.py:34)."""
-    return _RNNLayer.apply(x, w_ih0, w_hh0, w_ih1, w_hh1, CELL[cell] if isinstance(cell, str) else cell, training, float(drop_p))
+    drop_p > 0 (training only): returns dropout(y, drop_p) instead -- the dropout that follows the layer in BatchRNN (model_ctc.py:34).
+
+    A batch that no persistent launch holds runs as BATCH CHUNKS, one persistent launch each, instead of the per-timestep kernels (round 4):
+    the utterances of a batch are independent, a chunk of 64 rows costs ~1.6-1.8 us per timestep and the per-timestep kernels 7-8 us whatever
+    B -- cfg2's model at B = 128: 75.7 -> 41.1 ms per step.  WHICH shapes those are is learnt, not computed: the library tries several
+    geometries per shape (cfg2's model at B = 96 still runs persistently, on the 256-thread flag kernel), so a shape is chunked from its SECOND
+    call on, after its first call was seen to fall back to rnn_fwd_step / rnn_bwd_step (`_fallback_shapes`); the chunk size is
+    persistent_batch_limit, which every geometry supports.  The chunks are separate layer calls on the strided x[:, b0:b1] (weight gradients
+    accumulate across them as across backward passes); the layer's dropout is then the separate pass over the concatenated output (the same
+    mask as layer-then-dropout).  CTCN_BATCH_CHUNKS=0 disables."""
+    cellc = CELL[cell] if isinstance(cell, str) else cell
+    T, B = int(x.shape[0]), int(x.shape[1])
+    H, dirs = int(w_hh0.shape[1]), 2 if w_ih1 is not None else 1
+    if x.is_cuda and T > 1 and _chunks_on[0] and (cellc, H, dirs, B) in _fallback_shapes and get_option("rnn_persistent"):
+        L = _lib.lib()
+        bmax = persistent_batch_limit(H, dirs, L.ctcn_device_xcds(), L.ctcn_device_cus())
+        if 0 < bmax < B:
+            _chunking[0] = True
+            try:
+                ys = [_RNNLayer.apply(xc, w_ih0, w_hh0, w_ih1, w_hh1, cellc, training, 0.0) for xc in x.split(bmax, dim=1)]   # (_f32c gathers the strided chunk)
+            finally:
+                _chunking[0] = False
+            return dropout(torch.cat(ys, dim=1), float(drop_p), training)
+    return _RNNLayer.apply(x, w_ih0, w_hh0, w_ih1, w_hh1, cellc, training, float(drop_p))
+
+
+_chunks_on = [os.environ.get("CTCN_BATCH_CHUNKS", "1") != "0"]
+_chunking = [False]           # set while rnn_layer issues the chunk calls of one layer (read by _RNNLayer.forward)
+_fallback_shapes = set()      # (cell, H, dirs, B) whose unchunked call ran the per-timestep kernels although rnn_persistent was on
+
+
+def set_batch_chunks(flag):
+    _chunks_on[0] = bool(flag)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -309,6 +309,48 @@ def test_rnn_persistent_equals_per_step_launches(dev, kind, T, B, I, H, bi):
         assert rel_l2(g1, g0) < 2e-6
 
 
+@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 40, 144, 48, 320, True), ("gru", 33, 300, 24, 256, True), ("lstm", 25, 600, 16, 64, False), ("lstm", 30, 140, 40, 512, True)])
+def test_rnn_batch_chunks_equal_one_launch_per_timestep(dev, kind, T, B, I, H, bi):
+    """A batch that no persistent launch holds runs as batch chunks of ops.persistent_batch_limit rows, one persistent launch each (round 4),
+    from the shape's second call on -- the first call is seen to fall back to the per-timestep kernels and marks the shape.  Output, input
+    gradient and weight gradients agree with the unchunked layer (the per-timestep kernels) to the rounding the two kernel families differ by;
+    the layer's dropout is the separate pass over the concatenated output (same mask as layer-then-dropout, bit for bit)."""
+    from ctc_pytorch_amd import ops
+    ops.set_precision(1)
+    G = {"lstm": 4, "gru": 3}[kind]
+    torch.manual_seed(3)
+    x = torch.randn(T, B, I, device=dev)
+    w = [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)]
+    w += [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)] if bi else [None, None]
+    dy = torch.randn(T, B, (2 if bi else 1) * H, device=dev)
+    key = ({"lstm": 0, "gru": 1}[kind], H, 2 if bi else 1, B)
+    ops._fallback_shapes.discard(key)
+    runs = {}
+    try:
+        for mode in ("first", "chunks", "chunks_drop", "whole"):
+            ops.set_batch_chunks(mode != "whole")
+            ops._drop_counter[0] = 77
+            xs = x.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) if t is not None else None for t in w]
+            y = ops.rnn_layer(xs, ws[0], ws[1], ws[2], ws[3], kind, True, 0.3 if mode == "chunks_drop" else 0.0)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            ops.check_health(dev)
+            runs[mode] = (y.detach().clone(), [xs.grad.clone()] + [t.grad.clone() for t in ws if t is not None], ops.rnn_last_kernels())
+            if mode == "first" and key not in ops._fallback_shapes:
+                pytest.skip("this shape runs persistently in one launch on this device: %s" % (runs[mode][2],))
+    finally:
+        ops.set_batch_chunks(True)
+        ops._fallback_shapes.discard(key)
+    assert "step" in runs["first"][2][0] + runs["first"][2][1] and "step" not in runs["chunks"][2][0] + runs["chunks"][2][1], (runs["first"][2], runs["chunks"][2])
+    assert "step" in runs["whole"][2][0] + runs["whole"][2][1]
+    assert maxabs(runs["whole"][0], runs["chunks"][0]) < 5e-5
+    for g0, g1 in zip(runs["whole"][1], runs["chunks"][1]):
+        assert torch.isfinite(g1).all() and rel_l2(g1, g0) < 5e-5
+    ops._drop_counter[0] = 77
+    assert torch.equal(runs["chunks_drop"][0], ops.dropout(runs["chunks"][0], 0.3, True))
+
+
 @pytest.mark.parametrize("kind,T,B,I,H,bi,drop", [("lstm", 50, 32, 40, 320, True, 0.0), ("lstm", 40, 8, 64, 384, True, 0.2), ("gru", 30, 64, 24, 512, True, 0.0),
                                                  ("lstm", 21, 9, 16, 640, True, 0.1), ("rnn", 31, 20, 8, 48, False, 0.0), ("gru", 25, 9, 16, 128, True, 0.3),
                                                  ("lstm", 19, 33, 12, 448, False, 0.0), ("lstm", 23, 16, 32, 72, True, 0.0)])
