@@ -153,25 +153,39 @@ def set_fwd_overlap(flag):
     _side["fwd_overlap"] = bool(flag)
 
 
-def side_stream_fits(cell, T, B, I, H, dirs, nx, cus, slack=1.0):
-    """Can the XCDs a persistent recurrence of this shape leaves idle digest the layer's weight-gradient GEMMs (dW_ih, dW_hh) within the
-    recurrence of the layer below, which they run next to?  Pure arithmetic (round 4; every constant from a measured loss):
-    * capacity: the GEMMs' flops at ~300 TFLOP/s of the whole chip, scaled to the idle share of the XCDs, against 0.9 x T backward steps of
-      1.2 + H / 400 us (~1.5 / 2.0 / 2.5 us at H = 128 / 320 / 512).  With 3 batch tiles (B = 33..48: 6 of 8 XCDs taken) the side stream
-      fell further behind with every layer and the step waited for it at the end: cfg2's model at B = 48 17.9 ms per step with it, 17.2
-      without; B = 16 / 32 keep it (12.0 / 12.6 and 13.2 / 15.0 without);
-    * free CUs on the recurrence's OWN XCDs: the side GEMMs' workgroups that the dispatcher deals to a recurrence XCD must start there to find
-      out that they are on the wrong XCD and leave; with every CU taken (H = 512: 32 slices) they wait for the recurrence to end, and the
-      in-order dispatcher with them (cfg4's model at B = 32: 41.2 ms per step with the side stream, 40.2 without)."""
+def side_stream_plan(cell, T, B, I, H, dirs, nx, cus, slack=1.0):
+    """Where can the weight-gradient GEMMs (dW_ih, dW_hh) of a layer run while the recurrence of the layer below occupies its XCDs?  Returns
+    the XCD mask for ctcn_rnn_bwd_weights' xcd_allow, 0 = nowhere (inline on the main stream).  Pure arithmetic (round 4; every constant from a
+    measured loss or gain, ms per training step of cfg2's model with | without the side stream):
+    * idle XCDs (groups = dirs x batch tiles < XCDs): the mask of the idle ones, if they can digest the GEMMs within the recurrence -- the
+      flops at ~300 TFLOP/s of the whole chip, scaled to the idle share, against 0.9 x T backward steps of 1.2 + H / 400 us (~1.5 / 2.0 / 2.5
+      us at H = 128 / 320 / 512): B = 32: 13.2 | 15.0, B = 16: 12.0 | 12.6; with 3 batch tiles (two idle XCDs) the side stream fell further
+      behind with every layer and the step waited for it at the end: B = 48: 17.9 | 17.2 -> inline -- and if the recurrence leaves CUs free
+      on ITS XCDs: the GEMMs' workgroups dealt to a recurrence XCD must start there to find out that they are on the wrong XCD and leave; with
+      every CU taken (H = 512: 32 slices) they wait for the recurrence to end, and the in-order dispatcher with them (B = 32: 41.2 | 40.2);
+    * NO idle XCD, but at least eight free CUs next to the recurrence on every XCD (B = 64 with H <= 256: 16 + 2 of 32 CUs taken): all XCDs,
+      unfiltered -- the GEMMs share the recurrence's XCDs and L2s -- with the same capacity test on the free CUs' share of the chip:
+      B = 64 at H = 256: 14.97 | 16.36, at H = 128: 11.39 | 11.92."""
     groups = dirs * ((B + 15) // 16)
-    nidle = nx - groups
-    if nx <= 1 or nidle <= 0:
-        return False
-    side_us = 2.0 * T * B * (dirs * GATES[cell] * H) * (I + H) / (300e6 * nidle / nx)
-    if side_us > 0.9 * T * (1.2 + H / 400.0) * slack:
-        return False
+    if nx <= 1:
+        return 0
+    per = cus // nx
     wpx = ((groups + nx - 1) // nx) * ((H + 15) // 16)
-    return wpx + max(2, wpx // 8) + 2 <= cus // nx
+    used = wpx + max(2, wpx // 8)
+    if groups < nx:
+        if used + 2 > per:
+            return 0
+        share, allow = (nx - groups) / float(nx), ((1 << nx) - 1) & ~((1 << groups) - 1)
+    else:
+        if per - used < 8:
+            return 0
+        share, allow = (per - used) / float(per), (1 << nx) - 1
+    side_us = 2.0 * T * B * (dirs * GATES[cell] * H) * (I + H) / (300e6 * share)
+    return allow if side_us <= 0.9 * T * (1.2 + H / 400.0) * slack else 0
+
+
+def side_stream_fits(cell, T, B, I, H, dirs, nx, cus, slack=1.0):
+    return side_stream_plan(cell, T, B, I, H, dirs, nx, cus, slack) != 0
 
 
 def _side_stream(dev):
@@ -438,8 +452,10 @@ class _RNNLayer(torch.autograd.Function):
         # very small layers stay inline (below min_items_bwd = 2^18 (frame, row, unit) items: the test fixtures).  Round 1 measured cfg1 slower
         # with the side stream (2.27 ms inline, 2.8-4.5 with it) and set the threshold at 2^21; with the queue-form GEMMs and the deferred issue
         # of rounds 2-3 the picture is the opposite (round 4: cfg1 2.02 -> 1.95 ms, the shipped-YAML shape 4.69 -> 4.36): set_side_stream
-        side = into_flat and _side["enabled"] and allow != 0 and T > 1 and T * B * H >= _side["min_items_bwd"]
-        side = side and side_stream_fits(cell, T, B, I, H, dirs, nx, L.ctcn_device_cus(), _side["capacity_slack"])
+        side = into_flat and _side["enabled"] and nx > 1 and T > 1 and T * B * H >= _side["min_items_bwd"]
+        if side:                    # where the weight GEMMs can run next to the recurrence of the layer below: idle XCDs, or free CUs on every XCD
+            allow = side_stream_plan(cell, T, B, I, H, dirs, nx, L.ctcn_device_cus(), _side["capacity_slack"])
+            side = allow != 0
         null = ctypes.c_void_p(None)
         key = (dev.type, dev.index)
         if ctx.counted:

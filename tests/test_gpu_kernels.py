@@ -1202,7 +1202,7 @@ def test_rnn_abi_is_stateless_two_layers_two_streams_two_threads(dev):
 
 
 @pytest.mark.parametrize("prec", [1, 0])
-@pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 128, 8, 60), ("GRU", 192, 40, 25)])
+@pytest.mark.parametrize("rnn,H,B,T", [("LSTM", 128, 8, 60), ("GRU", 192, 40, 25), ("LSTM", 96, 64, 30)])      # (B = 64: no idle XCD -- the free CUs next to the recurrence, every XCD)
 def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
     """FlatAdam, both matmul precisions: the weight-gradient GEMMs run on the second stream, restricted to the XCDs the next
     layer's persistent recurrence leaves idle (queue kernels), and are joined when backward ends.  Same flat gradient,

@@ -508,6 +508,12 @@ def test_side_stream_capacity_rule_on_the_measured_shapes():
     assert not fits(1, 1200, 32, 1024, 512)      # H = 512: every CU of the recurrence XCDs taken (41.2 with / 40.2 without)
     assert not fits(1, 1200, 64, 1024, 512)      # cfg4
     assert not ops.side_stream_fits(0, 800, 32, 640, 320, 2, 1, 256)     # a device without XCDs to split
+    plan = lambda cell, T, B, I, H: ops.side_stream_plan(cell, T, B, I, H, 2, 8, 256)
+    assert plan(0, 800, 32, 640, 320) == 0xF0                            # the idle XCDs' mask
+    assert plan(0, 800, 16, 640, 320) == 0xFC
+    assert plan(0, 800, 64, 512, 256) == 0xFF                            # no idle XCD, 14 free CUs per XCD: everywhere (14.97 | 16.36)
+    assert plan(0, 800, 64, 256, 128) == 0xFF                            # (11.39 | 11.92)
+    assert plan(0, 800, 64, 640, 320) == 0 and plan(1, 1200, 64, 1024, 512) == 0
 
 
 def test_projection_pipeline_plan_on_the_measured_shapes():
