@@ -165,7 +165,8 @@ def side_stream_plan(cell, T, B, I, H, dirs, nx, cus, slack=1.0):
       every CU taken (H = 512: 32 slices) they wait for the recurrence to end, and the in-order dispatcher with them (B = 32: 41.2 | 40.2);
     * NO idle XCD, but at least eight free CUs next to the recurrence on every XCD (B = 64 with H <= 256: 16 + 2 of 32 CUs taken): all XCDs,
       unfiltered -- the GEMMs share the recurrence's XCDs and L2s -- with the same capacity test on the free CUs' share of the chip:
-      B = 64 at H = 256: 14.97 | 16.36, at H = 128: 11.39 | 11.92."""
+      B = 64 at H = 256: 14.97 | 16.36, at H = 128: 11.39 | 11.92.  (Unfiltered although XCDs ARE idle -- more CUs, shared L2s -- measured
+      worse: cfg2 13.31 | filtered 13.22, the shipped-YAML shape 4.37 | 4.35.)"""
     groups = dirs * ((B + 15) // 16)
     if nx <= 1:
         return 0
