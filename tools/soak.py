@@ -25,8 +25,12 @@ def train_run(workload, steps, dev):
     from ctc_pytorch_amd import nn, ops, parallel
     from ctc_pytorch_amd.optim import FlatAdam
     from oracle import synth
-    c = bench.WORKLOADS[workload]
+    c = dict(bench.WORKLOADS[workload])
+    for key in ("T", "B", "H", "L"):                # the same shape overrides as bench.py (CTCN_BENCH_T / B / H / L)
+        if os.environ.get("CTCN_BENCH_" + key):
+            c[key] = int(os.environ["CTCN_BENCH_" + key])
     ops.set_precision(1)
+    ops._fallback_shapes.clear()            # (batch chunks are learnt from a shape's first call: both runs of a workload must learn at the same step)
     parallel.enable_overlap(True)
     torch.manual_seed(1)
     ops._drop_counter[0] = 0
