@@ -542,3 +542,13 @@ def test_projection_pipeline_plan_on_the_measured_shapes():
     assert chunks(1, 1200, 32, 1024, 512) == 0       # H = 512: every CU of the recurrence XCDs taken
     assert chunks(0, 200, 8, 768, 384) == 0          # the shipped YAML shape
     assert L.ctcn_diag_pipeline_chunks(0, 800, 32, 640, 320, 2, 1, 256, 0) == 0 and L.ctcn_diag_pipeline_chunks(7, 800, 32, 640, 320, 2, 8, 256, 0xF0) == -1
+
+
+def test_persistent_batch_limit_matches_the_documented_limits():
+    """ops.persistent_batch_limit = the chunk size of ops.rnn_layer's batch chunks (bidirectional on 8 XCDs x 32 CUs, 64 rows for
+    256 < H <= 512, 128 for H <= 256, 256 at H = 128; nothing beyond H = 512 or without XCDs)."""
+    from ctc_pytorch_amd import ops
+    lim = lambda H, dirs: ops.persistent_batch_limit(H, dirs, 8, 256)
+    assert [lim(H, 2) for H in (128, 256, 320, 384, 512)] == [256, 128, 64, 64, 64]
+    assert lim(320, 1) == 128 and lim(128, 1) == 512
+    assert lim(640, 2) == 0 and ops.persistent_batch_limit(320, 2, 1, 256) == 0
