@@ -596,6 +596,13 @@ def set_batch_chunks(flag):
     _chunks_on[0] = bool(flag)
 
 
+def mark_batch_chunks(cell, H, dirs, B):
+    """Chunk the batch of this layer shape from its FIRST call on (rnn_layer otherwise learns it from the first call's fallback to the
+    per-timestep kernels, so a process's first step differs in rounding from its later ones): for runs that must be reproducible step for
+    step across restarts.  cell: 'lstm' | 'gru' | 'tanh' or its code."""
+    _fallback_shapes.add((CELL[cell] if isinstance(cell, str) else int(cell), int(H), int(dirs), int(B)))
+
+
 # --------------------------------------------------------------------------------------------------
 # batch norm (+ fused ReLU)
 # --------------------------------------------------------------------------------------------------
