@@ -658,11 +658,30 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       }
       BSTAMP(3);
       lds_barrier();
+      // (the reads of the common case -- up to 52 survivors, 16 threads each -- are issued before the survivor count is known: one LDS round trip
+      // instead of three in a row)
+      const Survivor me16 = surv[u >> 4];
+      Survivor oe16[4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) oe16[q4] = surv[(u & 15) + 16 * q4];
       const int S = s_cnt;
       int total = S;
-      if (S <= SURV_MAX) {
+      if (S <= 52) {
+        if ((u & ~63) < S * 16) {
+          const int e = u >> 4, part = u & 15;
+          int cnt = 0;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            cnt += (part + 16 * q4 < S && (oe16[q4].k > me16.k || (oe16[q4].k == me16.k && oe16[q4].idx < me16.idx))) ? 1 : 0;
+          cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
+          cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);                  // quad_perm [2,3,0,1]
+          cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);                 // row_half_mirror
+          cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);                 // row_mirror
+          if (e < S && part == 0 && cnt < W) { sel[cnt] = me16.idx; selv[cnt] = key_f64(me16.k); }
+        }
+      } else if (S <= SURV_MAX) {
         // rank counting: P of the 832 candidate threads per survivor, thread part p compares it with survivors p, p + P, ...; DPP butterfly sum
-        const int P = S <= 52 ? 16 : (S <= 104 ? 8 : (S <= 208 ? 4 : 2));
+        const int P = S <= 104 ? 8 : (S <= 208 ? 4 : 2);
         if ((u & ~63) < S * P) {                                 // (waves whose 64 / P survivors do not exist go straight to the barrier: the
                                                                  // phase is issue-bound, fewer waves per SIMD finish it sooner)
           const int e = u / P, part = u - e * P;
@@ -679,7 +698,6 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
           cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
           if (P >= 4) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
           if (P >= 8) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
-          if (P >= 16) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);    // row_mirror
           if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
         }
       } else {
