@@ -392,6 +392,9 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   __shared__ int red_i[NWV + 1];
   __shared__ unsigned gmax[64];                                        // per 16-lane row: largest candidate key (high word)
   __shared__ double bm_pB[FAST_WMAX], bm_pT[FAST_WMAX], selv[FAST_WMAX];
+  __shared__ int selp[FAST_WMAX];                                     // per selected candidate: its position in surv[] (the speculative stay totals are stored by it)
+  __shared__ double tots[64];                                         // per survivor: log_add(prBlank', prNonBlank') of the next frame if it is selected (wave 2)
+  __shared__ int selm[FAST_WMAX];                                     // per selected candidate: 128 | slot whose merged entry it holds, 0: none, -1: see mslot[]
   __shared__ int bm_c1[2][FAST_WMAX], sel[FAST_WMAX];                 // context class of every slot, by frame parity
   __shared__ int f_node[FAST_WMAX], f_len[FAST_WMAX], f_last[FAST_WMAX];   // final beam (dumped once, after the last frame)
   __shared__ double f_pT[FAST_WMAX];
@@ -462,6 +465,11 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
 
   // Wave 0 owns the beam (lane = slot) and the serial chain, wave 1 the prefix trie (node ids are only needed a frame later), wave 2 the
   // log-add of every slot's stay entry that needs no parent slot (round 4); waves 3..15 (832 threads) own the candidates.
+  // That log-add -- exp and log in f64, ~1.8 k cycles of one wave -- is the longest link of the frame.  Wave 2 forms it for every SURVIVOR of
+  // the pruning bound (at most 64, one per lane) while the candidate waves still rank them: up to 1 + exp(.) before the barrier that ends the
+  // rank count, the logarithm behind it; wave 0 picks the totals of the selected survivors up by their position (selp[] -> tots[]).  With
+  // more than 64 survivors the total is formed behind the decode of the selection as before (totv[]).  (Measured and not kept: a counter
+  // instead of that barrier so that wave 2 need not hold it up -- thirteen LDS atomics and two polling waves cost more than the barrier.)
   // Every role runs ITS OWN frame loop below (same barriers, in the same order): the kernel sits at its register limit, and with the roles
   // interleaved phase by phase in one loop every role's state was live everywhere -- the allocator spilled loop-invariant addresses to
   // scratch and re-loaded them inside the frame's critical path.  In separate branches the live ranges do not overlap.
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
         for (int w = 1; w < NWV; ++w)
           if (red_i[w] != 0x7fffffff && (ix == 0x7fffffff || cand_better(red_v[w], red_i[w], v, ix))) { v = red_v[w]; ix = red_i[w]; }
         red_i[NWV] = ix;
-        if (ix != 0x7fffffff) { sel[r] = ix; selv[r] = v; cand[ix] = -INFINITY; }
+        if (ix != 0x7fffffff) { sel[r] = ix; selv[r] = v; selm[r] = -1; cand[ix] = -INFINITY; }
       }
       lds_barrier();
       if (red_i[NWV] == 0x7fffffff) break;
@@ -540,10 +548,13 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     const int i = d.act ? (int)(((float)c + 0.5f) * (1.0f / (float)V)) : 0;       // c / V (exact for c < 2^20)
     const int kk = c - i * V;
     d.sym = (kk - 1 < blank) ? kk - 1 : kk;
-    const int ms = mslot[d.act ? c : 0];
-    const bool merged = d.act && kk != 0 && ms >= 0 && (ms >> 8) == j && (ms & 128);   // this candidate holds the merged entry of slot ms & 63
+    // does this candidate hold the merged entry of a slot?  The candidate's thread looked that up when it loaded the value (selm[]: one LDS
+    // round trip less on the serial chain); -1: the selection came from the arg-max rounds, mslot[] has it
+    int sm = selm[rr];
+    if (sm < 0) { const int ms = mslot[d.act ? c : 0]; sm = (kk != 0 && ms >= 0 && (ms >> 8) == j && (ms & 128)) ? (128 | (ms & 63)) : 0; }
+    const bool merged = d.act && (sm & 128);
     d.fresh = d.act && kk != 0 && !merged;
-    d.src = merged ? (ms & 63) : i;
+    d.src = merged ? (sm & 63) : i;
     return d;
   };
   const bool first_ok = nfl > 0 && !(flist[0] & (1 << 29));
@@ -591,8 +602,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     };
     if (first_ok) score_extensions(rep0, 0);
     lds_barrier();
-    for (int j = 0; j < nfl; ++j) {
-      const int fw = flist[j];
+    for (int j = 0, fw = nfl > 0 ? flist[0] : 0; j < nfl; ++j) {  // (fw: the frame's word, read one frame ahead)
       if (fw & (1 << 29)) { status = 2; break; }                   // math.log(0) in the reference: ValueError
       frame_top(j);
       BSTAMP(0);
@@ -602,13 +612,16 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       //  2. the survivors (typically W + a few) are compacted into LDS and ranked by counting, the candidate threads sharing the compares.
       unsigned long long key[NPT];
       bool val[NPT];
-      unsigned mhi = 0u;
+      unsigned mhi = 0u, mpack = 0u;                                // mpack: byte i = 128 | slot when candidate i holds that slot's merged entry
 #pragma unroll
       for (int i = 0; i < NPT; ++i) {
         const int bi = min(ci[i], FAST_WMAX - 1);
         double v = ck[i] < 0 ? stayv[bi] : cand[cc[i]];
         const int ms = mslot[cc[i]];
-        if (ck[i] >= 0 && ms >= 0 && (ms >> 8) == j) v = (ms & 128) ? homev[ms & 63] : -INFINITY;
+        if (ck[i] >= 0 && ms >= 0 && (ms >> 8) == j) {
+          v = (ms & 128) ? homev[ms & 63] : -INFINITY;
+          if (ms & 128) mpack |= (unsigned)(128 | (ms & 63)) << (8 * i);
+        }
         key[i] = f64_key(v);
         val[i] = ci[i] < nb && v != -INFINITY;
         mhi = max(mhi, val[i] ? (unsigned)(key[i] >> 32) : 0u);
@@ -654,21 +667,29 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
         wbase = __builtin_amdgcn_readfirstlane(wbase);
 #pragma unroll
         for (int i = 0; i < NPT; ++i)
-          if (keep[i] && wbase + pos[i] < SURV_MAX) { surv[wbase + pos[i]].k = key[i]; surv[wbase + pos[i]].idx = ci[i] * V + (ck[i] < 0 ? 0 : (ck[i] < blank ? ck[i] + 1 : ck[i])); }
+          if (keep[i] && wbase + pos[i] < SURV_MAX) {
+            Survivor sv;
+            sv.k = key[i]; sv.idx = ci[i] * V + (ck[i] < 0 ? 0 : (ck[i] < blank ? ck[i] + 1 : ck[i])); sv.pad = (int)((mpack >> (8 * i)) & 255u);
+            surv[wbase + pos[i]] = sv;
+          }
       }
       BSTAMP(3);
       lds_barrier();
       // (the reads of the common case -- up to 52 survivors, 16 threads each -- are issued before the survivor count is known: one LDS round trip
       // instead of three in a row)
-      const Survivor me16 = surv[u >> 4];
+      // (thread index of the rank count: the candidate waves that share wave 2's SIMD -- 6, 10, 14 -- take the last survivors, which rarely
+      // exist, so that wave 2's log-add has that SIMD to itself)
+      const int cw = wave - 3;
+      const int ur = (((cw & 3) == 3) ? 10 + (cw >> 2) : cw - (cw >> 2)) * 64 + lane;
+      const Survivor me16 = surv[ur >> 4];
       Survivor oe16[4];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) oe16[q4] = surv[(u & 15) + 16 * q4];
+      for (int q4 = 0; q4 < 4; ++q4) oe16[q4] = surv[(ur & 15) + 16 * q4];
       const int S = s_cnt;
       int total = S;
       if (S <= 52) {
-        if ((u & ~63) < S * 16) {
-          const int e = u >> 4, part = u & 15;
+        if ((ur & ~63) < S * 16) {
+          const int e = ur >> 4, part = ur & 15;
           int cnt = 0;
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4)
@@ -677,14 +698,14 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
           cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);                  // quad_perm [2,3,0,1]
           cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);                 // row_half_mirror
           cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xf, 0xf, true);                 // row_mirror
-          if (e < S && part == 0 && cnt < W) { sel[cnt] = me16.idx; selv[cnt] = key_f64(me16.k); }
+          if (e < S && part == 0 && cnt < W) { sel[cnt] = me16.idx; selv[cnt] = key_f64(me16.k); selm[cnt] = me16.pad; selp[cnt] = e; }
         }
       } else if (S <= SURV_MAX) {
         // rank counting: P of the 832 candidate threads per survivor, thread part p compares it with survivors p, p + P, ...; DPP butterfly sum
         const int P = S <= 104 ? 8 : (S <= 208 ? 4 : 2);
-        if ((u & ~63) < S * P) {                                 // (waves whose 64 / P survivors do not exist go straight to the barrier: the
+        if ((ur & ~63) < S * P) {                                 // (waves whose 64 / P survivors do not exist go straight to the barrier: the
                                                                  // phase is issue-bound, fewer waves per SIMD finish it sooner)
-          const int e = u / P, part = u - e * P;
+          const int e = ur / P, part = ur - e * P;
           const Survivor me = surv[min(e, SURV_MAX - 1)];
           int cnt = 0;
           for (int q0 = part; q0 < S; q0 += 4 * P) {
@@ -698,7 +719,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
           cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);                  // quad_perm [1,0,3,2]
           if (P >= 4) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
           if (P >= 8) cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror
-          if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); }
+          if (e < S && part == 0 && cnt < W) { sel[cnt] = me.idx; selv[cnt] = key_f64(me.k); selm[cnt] = me.pad; selp[cnt] = e; }
         }
       } else {
         lds_barrier();                                             // (wave 0 has patched the candidate table)
@@ -707,7 +728,8 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       lds_barrier();
       BSTAMP(4);
       nb = min(W, total);
-      const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
+      const int fwn = flist[min(j + 1, nfl - 1)];
+      const bool more = j + 1 < nfl && !(fwn & (1 << 29));
       if (more) {
         // the new beam's record (context class, prBlank, prTotal of every slot) comes from wave 0 through a flag, not a barrier
         for (int spins = 0; __hip_atomic_load(&s_beamflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != j + 1; ++spins) {
@@ -715,9 +737,10 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
           __builtin_amdgcn_s_sleep(2);
         }
         BSTAMP(6);
-        score_extensions((flist[j + 1] >> 30) & 1, j + 1);
+        score_extensions((fwn >> 30) & 1, j + 1);
         BSTAMP(9);
       }
+      fw = fwn;
       lds_barrier();
       BSTAMP(2);
     }
@@ -736,15 +759,16 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     // as score_extensions writes for that candidate).  Results: e_nb / e_b / e_t in the slot's lane; for the selection: stayv[ip] = value
     // of the stay candidate (or -inf when the entry lives in the extension's place), homev[ip] = e_t, and mslot[extension candidate] =
     // {frame tag, 1: holds slot ip's merged entry | 0: removed (merged into the stay candidate), ip}
-    auto stay_and_merge = [&](bool rep_ok, int jf) {
+    auto stay_and_merge = [&](bool rep_ok, int jf, int tsrc) {
       const int ip = lane;
       const double *lg = lg2 + (jf & 1) * V;
       const double lgl = lg[max(z_last, 0)], lgb = lg[blank];
       const int mi = ip < nb ? z_mf : -1;
       const int src = max(mi, 0);
-      const int p_len = lane_gather(z_len, src), p_last = lane_gather(z_last, src);
       const double p_pB = lane_gather(z_pB, src), p_pT = lane_gather(z_pT, src);
-      const int c1 = p_len > 0 ? p_last : V, k = max(z_last, 0);
+      // (context class of the parent labelling: its last class travels with the slot -- z_plast -- and its length is this one's minus one:
+      // the LM term is read next to the ln p terms, not behind the parent slot)
+      const int c1 = z_len > 1 ? max(z_plast, 0) : V, k = max(z_last, 0);
       const double lmv = LM_LDS ? lmA[c1 * V1 + k] : a.lm[(size_t)c1 * V1 + k] * a.alpha;
       const double base = (c1 == k && rep_ok) ? p_pB : p_pT;
       const double pr = lgl + lmv + base;                           // == cand[mi * V + kk(z_last)]
@@ -762,7 +786,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
         if (spins > (1 << 20)) { s_fault = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
-      const double tot = totv[ip];
+      const double tot = tsrc >= 0 ? tots[tsrc] : totv[ip];
       double r_nb = s_nb, r_t = tot;
       if (__any(mi >= 0)) {                                          // some slot merges with its parent's extension: ONE level of log-adds
         // lanes 0..31: e.t of slot q, lanes 32..63: e.nb of slot q, q = (lane & 31) + 32 * pass -- side by side (one pass when nb <= 32)
@@ -792,10 +816,9 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       }
       if (lane == 0) { s_theta = 0u; s_cnt = 0; }
     };
-    if (first_ok) stay_and_merge(rep0, 0);
+    if (first_ok) stay_and_merge(rep0, 0, -1);
     lds_barrier();
-    for (int j = 0; j < nfl; ++j) {
-      const int fw = flist[j];
+    for (int j = 0, fw = nfl > 0 ? flist[0] : 0; j < nfl; ++j) {
       if (fw & (1 << 29)) { status = 2; break; }
       BSTAMP(0);
       lds_barrier();                                               // (row maxima)
@@ -815,10 +838,12 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       lds_barrier();                                               // (selection ranked)
       BSTAMP(4);
       const int m = min(W, total);
-      const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
-      const bool rep_next = (flist[min(j + 1, nfl - 1)] >> 30) & 1;
+      const int fwn = flist[min(j + 1, nfl - 1)];
+      const bool more = j + 1 < nfl && !(fwn & (1 << 29));
+      const bool rep_next = (fwn >> 30) & 1;
       // P4a: the new beam in rank order; the record the next frame's extension scores need goes out through s_beamflag (wave 0 does not stop)
       const Dec d = decode_sel(j, m);
+      const int tsrc = (more && S <= 64) ? (selp[min(lane, FAST_WMAX - 1)] & 63) : -1;   // where wave 2 leaves this slot's stay total (tots[]; -1: totv[])
       const bool act = d.act, fresh = d.fresh;
       const int src = d.src, sym = d.sym;
       ns[lane] = -1;
@@ -867,7 +892,8 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
         }
       }
       z_len = n_len; z_last = n_last; z_par = n_par; z_gpar = n_gpar; z_plast = n_plast; z_mf = n_mf; z_pNB = n_pNB; z_pB = n_pB; z_pT = n_pT;
-      if (more) stay_and_merge(rep_next, j + 1);
+      if (more) stay_and_merge(rep_next, j + 1, tsrc);
+      fw = fwn;
       lds_barrier();
       BSTAMP(2);
     }
@@ -878,20 +904,21 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
     // wave 2: tot = log_add(prBlank', prNonBlank') (BeamSearch.py:112) of the stay entry of every slot for frame jf, from the slot's (context
     // class, prNonBlank, prTotal) -- the same expressions on the same operands as wave 0 forms for s_nb / s_b -- then the flag wave 0 waits
     // for.  It needs no parent slot, so it runs next to wave 0's new-beam / parent-slot work instead of in front of its log-add
-    auto stay_totals = [&](int jf, bool on, int c1, double pNB, double pT) {
+    auto stay_total = [&](int jf, bool on, int c1, double pNB, double pT) -> double {
       const double *lg = lg2 + (jf & 1) * V;
       const double lgl = lg[c1 < V ? c1 : 0], lgb = lg[blank];
       double s_nb = LOG_ZERO;
       if (c1 < V) s_nb = pNB + lgl;
       const double s_b = pT + lgb;
-      const double tot = on ? log_add_prob(s_b, s_nb) : LOG_ZERO;
-      totv[lane] = tot;
+      return on ? log_add_prob(s_b, s_nb) : LOG_ZERO;
+    };
+    auto stay_totals = [&](int jf, bool on, int c1, double pNB, double pT) {
+      totv[lane] = stay_total(jf, on, c1, pNB, pT);
       __hip_atomic_store(&s_totflag, jf + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     if (first_ok && wave == 2) stay_totals(0, lane == 0, V, LOG_ZERO, 0.0);       // the empty labelling
     lds_barrier();
-    for (int j = 0; j < nfl; ++j) {
-      const int fw = flist[j];
+    for (int j = 0, fw = nfl > 0 ? flist[0] : 0; j < nfl; ++j) {
       if (fw & (1 << 29)) { status = 2; break; }
       frame_top(j);
       BSTAMP(0);
@@ -900,12 +927,51 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
       lds_barrier();
       const int S = s_cnt;
       int total = S;
+      const int fwn = flist[min(j + 1, nfl - 1)];
+      const bool more = j + 1 < nfl && !(fwn & (1 << 29));
+      // wave 2, while the candidate waves rank the survivors: the next frame's stay total of EVERY survivor (at most 64: one per lane), from
+      // what its new slot would carry -- a fresh labelling its candidate's score, a copy the stay / merged entry of the slot it comes from --
+      // so that the log-add is over when wave 0 asks for it, instead of starting behind the decode of the selection
+      const bool spec = wave == 2 && more && S <= 64;
+      double sp_x = LOG_ZERO, sp_s = 1.0;
+      bool sp_half = false;
+      if (spec) {
+        const Survivor sv = surv[lane];
+        const bool on = lane < S;
+        const int c = on ? sv.idx : 0;
+        const int i = (int)(((float)c + 0.5f) * (1.0f / (float)V));
+        const int kk = c - i * V;
+        const int sym = (kk - 1 < blank) ? kk - 1 : kk;
+        const bool merged = on && (sv.pad & 128);
+        const bool fresh = on && kk != 0 && !merged;
+        const int src = merged ? (sv.pad & 63) : i;
+        const double v = key_f64(sv.k);
+        const int o_c1 = bm_c1[j & 1][src];
+        const double o_nb = enbv[src], o_t = homev[src];
+        // log_add_prob(prBlank', prNonBlank') in two halves: up to 1 + exp(.) before the barrier the candidate waves' rank count ends with, the
+        // logarithm behind it (the whole chain, ~1.8 k cycles, would hold that barrier up; the store keeps the first half on this side of it)
+        const int c1 = fresh ? sym : o_c1;
+        const double pNB = fresh ? v : o_nb, pT = fresh ? v : o_t;
+        const double *lg = lg2 + ((j + 1) & 1) * V;
+        const double lgl = lg[c1 < V ? c1 : 0], lgb = lg[blank];
+        const double s_nb = c1 < V ? pNB + lgl : LOG_ZERO, s_b = pT + lgb;
+        sp_half = false;
+        if (!on) sp_x = LOG_ZERO;
+        else if (s_b <= LOG_ZERO) sp_x = s_nb;
+        else if (s_nb <= LOG_ZERO) sp_x = s_b;
+        else {
+          double x = s_b, y = s_nb;
+          if ((y - x) > 0.0) { x = s_nb; y = s_b; }
+          sp_x = x; sp_s = 1 + exp(y - x); sp_half = true;
+        }
+        tots[lane] = sp_s;
+      }
       if (S > SURV_MAX) { lds_barrier(); total = arg_max_rounds(); }
       lds_barrier();
       BSTAMP(4);
       const int m = min(W, total);
-      const bool more = j + 1 < nfl && !(flist[min(j + 1, nfl - 1)] & (1 << 29));
-      const Dec d = decode_sel(j, m);
+      Dec d = {false, false, 0, 0, 0.0};
+      if (!spec) d = decode_sel(j, m);
       nb = m;
       if (wave == 1) {
         __hip_atomic_store(&s_decflag, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // (the decode's reads have returned: d.src is formed)
@@ -960,6 +1026,9 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
         y_node = d.act ? id : 0;
         nid[(j + 1) & 1][lane] = y_node;
         BSTAMP(6);
+      } else if (spec) {
+        tots[lane] = sp_half ? sp_x + log(sp_s) : sp_x;
+        __hip_atomic_store(&s_totflag, j + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (more) {
         // the new slot's (context class, prNonBlank, prTotal) without wave 0: a fresh labelling carries its candidate's score, a copy the
         // stay / merged entry of the slot it comes from (enbv / homev, written by wave 0 before the last barrier; bm_c1 of the old parity)
@@ -967,6 +1036,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
         const double o_nb = enbv[d.src], o_t = homev[d.src];
         stay_totals(j + 1, d.act, d.fresh ? d.sym : o_c1, d.fresh ? d.sv : o_nb, d.fresh ? d.sv : o_t);
       }
+      fw = fwn;
       lds_barrier();
       BSTAMP(2);
     }

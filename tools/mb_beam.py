@@ -52,7 +52,7 @@ def run(regime):
     assert L.ctcn_beam_stats(st) == 0
     names = ["(loop top)", "-", "until the frame's last barrier (wave 0: publish + waiting; wave 3: waiting)", "wave 0: idle at the selection's barriers 1-3 | wave 3: pruning bound + prune / compact",
              "barrier + rank count + barrier", "wave 0: new beam (P4a) + publish", "wave 0: parent slots + gathers + pr | wave 3: waiting for the beam flag", "wave 0: waiting for the stay totals + log-adds",
-             "wave 3: candidate load + row max", "wave 3: extension scores of the next frame"]
+             "wave 3: candidate load + row max", "wave 3: extension scores of the next frame", "(scratch stamp 10)", "(scratch stamp 11)"]
     for base, who in ((0, "wave 0"), (16, "wave 3")):
         nfl = max(st[base + 14], 1)
         print("%s  %s: frames %d, total %.0f cycles/frame, rounds/frame %.2f, merge iterations/frame %.2f" % (regime, who, nfl, st[base + 15] / nfl, st[base + 12] / nfl, st[base + 13] / nfl))
