@@ -1845,6 +1845,38 @@ def test_beam_fuzz_small_alphabets_vs_c_oracle(dev, V, W, regime, alpha):
     assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
 
 
+@pytest.mark.parametrize("kind,V,W,alpha", [("uniform", 62, 20, 0.0), ("uniform", 62, 20, 0.1), ("uniform", 16, 52, 0.0), ("quantised", 62, 20, 0.0),
+                                             ("quantised", 30, 40, 0.3)])
+def test_beam_exact_ties_vs_c_oracle(dev, kind, V, W, alpha):
+    """Collisions, as this domain has them: EXACT ties of prTotal.  Uniform posteriors (every class 1 / V) make all extensions of a slot --
+    and, from the second frame on, of all slots -- tie to the last bit; posteriors quantised to powers of two make most of them tie.  The
+    reference ranks with a stable descending sort (BeamSearch.py:29-33), so ties resolve by insertion order, which the kernel restates as
+    (prTotal desc, candidate index asc); hundreds of candidates then sit AT the pruning bound: more than the 256 survivors the rank count
+    holds, i.e. the block-wide arg-max rounds that no random batch reaches (and, below 64, wave 2's per-survivor stay totals with tied keys).
+    Labellings and status equal the C restatement; scores to the last places."""
+    from ctc_pytorch_amd import ops
+    T, B = 14, 6
+    rs = np.random.RandomState(5 * V + W)
+    if kind == "uniform":
+        probs = np.full((T, B, V), 1.0 / V, dtype=np.float32)
+    else:
+        e = rs.randint(1, 4, size=(T, B, V))                 # 1/2, 1/4, 1/8 (not normalised: the search takes the probabilities as they are)
+        probs = (0.5 ** e).astype(np.float32)
+    lens = [T, T - 1, 1, 0, T // 2, T]
+    tab = np.zeros((V + 1, V + 1)) if alpha == 0.0 else -np.round(3.0 * rs.random_sample((V + 1, V + 1)), 0)   # (integer LM scores: ties survive them)
+    want, wscore, wst = beam_ref.decode_ids(probs.transpose(1, 0, 2), lens, tab, alpha, W)
+    for fast in (1, 0):
+        ops.set_option("beam_fast", fast)
+        try:
+            got, score, st = ops.beam_decode(torch.from_numpy(probs).to(dev), lens, tab, alpha, W, 0, input_is_prob=True)
+        finally:
+            ops.set_option("beam_fast", 1)
+        assert list(st) == list(wst), fast
+        assert got == [list(map(int, s_)) for s_ in want], fast
+        score, wscore = np.asarray(score), np.asarray(wscore)
+        assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore))), fast
+
+
 @pytest.mark.parametrize("fast", [1, 0])
 def test_beam_nbest_golden_and_oracle(dev, fast):
     """ctcn_beam_decode_nbest (the optional n-best output): the labellings equal the reference's whole final `last.sort()`
