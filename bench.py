@@ -493,10 +493,11 @@ def decode_leg(dev, steps=5):
         del warm
         torch.cuda.synchronize()
         # (the id -> phone-string assembly BeamDecoder.decode performs on the host is part of a decoded batch: inside the timed loop)
-        # (a byte-table gather per batch instead of str.join per utterance was tried: numpy's mask / compress passes cost as much, 2.0 ms per flat
-        # batch of 52 k tokens against 1.9 ms -- the flat regime's 560-token labellings make its loop host-bound at ~90 k utt/s either way)
+        # (as BeamDecoder.decode_async does it: one pass of native host code over the pinned result buffer -- ctcn_join_tokens -- instead of
+        # str.join per utterance, which made the flat regime's loop host-bound: 72 k tokens per batch, 2.3 ms of interpreter against 0.8 ms of
+        # device time per batch with three searches in flight)
         phones = [i2c[i] for i in range(V)]
-        finish = lambda h: [" ".join(map(phones.__getitem__, seq)) for seq in h.result()[0]]
+        finish = lambda h: h.strings(phones, " ")[0]
         t0 = time.perf_counter()
         pend = []
         for k in range(nfl):

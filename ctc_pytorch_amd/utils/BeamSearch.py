@@ -46,6 +46,12 @@ class ctcBeamSearch(object):
         h = ops.beam_decode_async(x_tbv, lens, self._lm_table_on(x_tbv.device), self.lm_alpha, self.beamWidth, self.blank_index, input_is_prob)
         return lambda: self._checked(*h.result())
 
+    def decode_strings_async(self, x_tbv, lens, input_is_prob=False):
+        """decode() enqueued on the current stream; returns a callable that waits for this search alone and returns the reference's strings
+        (' '.join of the classes, BeamSearch.py:152-153), assembled in native host code from the pinned result buffer."""
+        h = ops.beam_decode_async(x_tbv, lens, self._lm_table_on(x_tbv.device), self.lm_alpha, self.beamWidth, self.blank_index, input_is_prob)
+        return lambda: self._checked(*h.strings(self.classes, " "))[0]
+
     def decode_ids(self, x_tbv, lens, input_is_prob=False):
         """x (T,B,V) device tensor -> (list of id lists, float64 scores).  Raises what the reference raises:
         IndexError when an empty labelling reaches the final LM step (BeamSearch.py:135), ValueError on log(0)."""
@@ -64,8 +70,7 @@ class ctcBeamSearch(object):
         x = inputs.transpose(0, 1)
         if not x.is_cuda:
             x = x.to("cuda")
-        ids, _ = self.decode_ids(x, inputs_list, input_is_prob=True)
-        return [" ".join(self.classes[k] for k in seq) for seq in ids]
+        return self.decode_strings_async(x, inputs_list, input_is_prob=True)()
 
     def decode_nbest(self, inputs, inputs_list, nbest):
         """The `nbest` best labellings per utterance, best first, as strings -- `last.sort()[0:nbest]` where the reference's decode keeps

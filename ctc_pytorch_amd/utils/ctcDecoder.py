@@ -133,8 +133,7 @@ class BeamDecoder(Decoder):
         lp = _to_device(prob_tensor)
         if frame_seq_len is None:
             frame_seq_len = [lp.shape[0]] * lp.shape[1]
-        ids, _ = self._decoder.decode_ids(lp, frame_seq_len, input_is_prob=False)
-        return [" ".join(self.int_to_char[k] for k in seq) for seq in ids]
+        return self._decoder.decode_strings_async(lp, frame_seq_len, input_is_prob=False)()
 
     def decode_async(self, prob_tensor, frame_seq_len=None):
         """decode() enqueued on the current stream: returns a callable that waits for this batch alone and returns its strings
@@ -144,5 +143,4 @@ class BeamDecoder(Decoder):
         lp = _to_device(prob_tensor)
         if frame_seq_len is None:
             frame_seq_len = [lp.shape[0]] * lp.shape[1]
-        wait = self._decoder.decode_ids_async(lp, frame_seq_len, input_is_prob=False)
-        return lambda: [" ".join(self.int_to_char[k] for k in seq) for seq in wait()[0]]
+        return self._decoder.decode_strings_async(lp, frame_seq_len, input_is_prob=False)      # (strings assembled in native host code)

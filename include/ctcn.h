@@ -363,6 +363,16 @@ int ctcn_diag_squat(int wgs_per_xcd, int threads, int lds_bytes, unsigned usec, 
 int ctcn_diag_pipeline_chunks(int cell, int T, int B, int I, int H, int dirs, int xcds, int cus, unsigned xcd_allow);
 const char *ctcn_rnn_last_kernel(int which);
 
+/* ---- host end of the decoders (hostjoin.hip; no kernel, no HIP call: works without a GPU) -------------------------------------------------
+ * replaces: `' '.join(self.classes[k] for k in labelling)` (BeamSearch.py:152-153; ctcDecoder.py:60-118 for the greedy decoder), once per
+ * utterance of a decoded batch.  ids: B rows of `row_stride` int32 label ids (the pinned copy of ctcn_beam_decode's out_ids), lens[b] valid
+ * per row; words / word_off[V + 1]: the vocabulary's UTF-8 bytes back to back, followed by 16 readable bytes, and their offsets
+ * (word_off[k] > word_off[k + 1]: id k has no word); sep: the byte between two words (0: none).  Writes row b's string to
+ * out[out_off[b] .. out_off[b + 1]) and returns out_off[B]; CTCN_EINVAL on bad arguments, CTCN_EWORKSPACE when out_cap is too small (result + 17 bytes), -(16 + k) for an id k outside the vocabulary (the KeyError /
+ * IndexError of the Python expression). */
+long long ctcn_join_tokens(const int32_t *ids, long long row_stride, const int32_t *lens, int B, const char *words, const int32_t *word_off,
+                           int V, int sep, char *out, long long out_cap, long long *out_off);
+
 #ifdef __cplusplus
 }
 #endif

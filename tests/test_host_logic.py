@@ -552,3 +552,41 @@ def test_persistent_batch_limit_matches_the_documented_limits():
     assert [lim(H, 2) for H in (128, 256, 320, 384, 512)] == [256, 128, 64, 64, 64]
     assert lim(320, 1) == 128 and lim(128, 1) == 512
     assert lim(640, 2) == 0 and ops.persistent_batch_limit(320, 2, 1, 256) == 0
+
+
+def test_join_tokens_equals_the_python_join():
+    """ops.join_tokens / ctcn_join_tokens (hostjoin.hip, host code only): the decoders' `' '.join(self.classes[k] for k in labelling)`
+    (BeamSearch.py:152-153) for a whole decoded batch in one native pass -- equal to the Python expression on ragged rows (empty, one token,
+    full width), list and {id: word} vocabularies, '' and ' ' separators, non-ASCII and > 16-byte words; ids outside the vocabulary raise what
+    the expression raises."""
+    from ctc_pytorch_amd import ops
+    from oracle import synth
+    rs = np.random.RandomState(3)
+    V, B, T = 62, 37, 90
+    phones = [synth.int2char(V)[i] for i in range(V)]
+    ids = rs.randint(0, V, size=(B, T)).astype(np.int32)
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32)
+    lens[0], lens[1], lens[2] = 0, 1, T
+    for words in (phones, {i: w for i, w in enumerate(phones)}, ["\u00e9", "\u00df", "\u6c34", "a-word-of-more-than-sixteen-bytes"] + phones[4:]):
+        for sep in (" ", ""):
+            assert ops.join_tokens(ids, lens, words, sep) == [sep.join(words[int(k)] for k in ids[b, : lens[b]]) for b in range(B)]
+    assert ops.join_tokens(ids[:, ::2], lens // 2, phones) == [" ".join(phones[int(k)] for k in ids[b, ::2][: lens[b] // 2]) for b in range(B)]   # strided view
+    assert ops.join_tokens(np.zeros((0, 5), np.int32), np.zeros(0, np.int32), phones) == []
+    holes = {i: w for i, w in enumerate(phones) if i != 7}
+    with pytest.raises(KeyError):
+        ops.join_tokens(np.full((1, 3), 7, np.int32), np.array([3], np.int32), holes)
+    assert ops.join_tokens(np.full((1, 3), 8, np.int32), np.array([3], np.int32), holes) == [" ".join([phones[8]] * 3)]
+    with pytest.raises(IndexError):
+        ops.join_tokens(np.full((1, 3), V, np.int32), np.array([2], np.int32), phones)
+    with pytest.raises(IndexError):
+        ops.join_tokens(np.full((1, 3), -1, np.int32), np.array([2], np.int32), phones)
+    with pytest.raises(ValueError):
+        ops.join_tokens(ids, lens[:-1], phones)
+    with pytest.raises(ValueError):
+        ops.join_tokens(ids, lens, phones, sep=", ")
+    # the raw entry point: a capacity that is too small is reported, not overrun
+    from ctc_pytorch_amd import _lib
+    blob, off, longest, Vv = ops._vocabulary(phones)
+    out, oo = np.zeros(8, np.uint8), np.zeros(B + 1, np.int64)
+    assert _lib.lib().ctcn_join_tokens(ids.ctypes.data, T, lens.ctypes.data, B, blob, off.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -4
+    assert _lib.lib().ctcn_join_tokens(None, T, lens.ctypes.data, B, blob, off.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -1
