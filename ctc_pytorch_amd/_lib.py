@@ -81,6 +81,7 @@ _SIGS = {
     "ctcn_diag_squat": (I, [I, I, I, ctypes.c_uint, P]),
     "ctcn_diag_pipeline_chunks": (I, [I, I, I, I, I, I, I, I, ctypes.c_uint]),
     "ctcn_rnn_last_kernel": (ctypes.c_char_p, [I]),
+    "ctcn_levenshtein": (ctypes.c_longlong, [P, ctypes.c_longlong, P, ctypes.c_longlong]),
     "ctcn_join_tokens": (ctypes.c_longlong, [P, ctypes.c_longlong, P, I, P, P, I, I, P, ctypes.c_longlong, P]),
     "ctcn_beam_ws_bytes": (Z, [I, I, I, I]),
     "ctcn_beam_decode": (I, [P, I, P, P, D, I, I, P, P, P, P, I, I, I, P, Z, P]),

@@ -6,6 +6,7 @@
 // the flat regime's decode loop was host-bound.  One pass in C over the pinned result buffer: ~0.1 ms.  Host code only (no kernel, no HIP
 // call): usable without a GPU, and tested there.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -38,4 +39,34 @@ extern "C" long long ctcn_join_tokens(const int32_t *ids, long long row_stride, 
   }
   out_off[B] = pos;
   return pos;
+}
+
+// ctcn_levenshtein: unit-cost edit distance of two int32 sequences (code points of two strings for the character error count, word ids for
+// the word error count).  replaces: Decoder._edit_distance (ctcDecoder.py:131-150, an (L1 + 1) x (L2 + 1) list-of-lists in the interpreter,
+// called twice per decoded utterance by test_ctc.py:88-95).  Two rolling rows; -1 on bad arguments.
+extern "C" long long ctcn_levenshtein(const int32_t *a, long long na, const int32_t *b, long long nb) {
+  if (na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return CTCN_EINVAL;
+  if (na == 0) return nb;
+  if (nb == 0) return na;
+  if (nb > na) { const int32_t *t = a; a = b; b = t; const long long n = na; na = nb; nb = n; }     // (symmetric: the shorter one along the row)
+  int32_t *row = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)(nb + 1)));
+  if (!row) return CTCN_EINVAL;
+  for (long long j = 0; j <= nb; ++j) row[j] = (int32_t)j;
+  for (long long i = 1; i <= na; ++i) {
+    const int32_t ai = a[i - 1];
+    int32_t diag = row[0];                                  // dist[i-1][j-1]
+    row[0] = (int32_t)i;
+    int32_t left = row[0];                                  // dist[i][j-1]
+    for (long long j = 1; j <= nb; ++j) {
+      const int32_t up = row[j];                            // dist[i-1][j]
+      int32_t best = diag + (ai != b[j - 1] ? 1 : 0);
+      best = up + 1 < best ? up + 1 : best;
+      best = left + 1 < best ? left + 1 : best;
+      diag = up;
+      row[j] = left = best;
+    }
+  }
+  const long long d = row[nb];
+  free(row);
+  return d;
 }

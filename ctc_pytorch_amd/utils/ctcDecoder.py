@@ -29,23 +29,23 @@ class Decoder(object):
     # ---- scoring ---------------------------------------------------------------------------------------
     @staticmethod
     def _edit_distance(src_seq, tgt_seq):
-        """Levenshtein distance (unit costs) with a rolling numpy row; works on strings and id lists alike."""
+        """Levenshtein distance (unit costs) of two strings or two lists of hashables (ctcDecoder.py:131-150), in the library's host code
+        (ctcn_levenshtein): the reference's interpreter loop over an (L1 + 1) x (L2 + 1) table is seconds per long utterance."""
         n_src, n_tgt = len(src_seq), len(tgt_seq)
         if 0 in (n_src, n_tgt):
             return n_src + n_tgt
-        tgt = np.asarray([hash(t) for t in tgt_seq] if not isinstance(tgt_seq, str) else [ord(c) for c in tgt_seq])
-        row = np.arange(n_tgt + 1)
-        for i, a in enumerate(src_seq, start=1):
-            key = hash(a) if not isinstance(src_seq, str) else ord(a)
-            diag = row[:-1] + (tgt != key)                       # substitute / match
-            up = row[1:] + 1                                     # delete from src
-            best = np.minimum(diag, up)
-            new = np.empty_like(row)
-            new[0] = i
-            for j in range(n_tgt):                               # insert: running minimum along the row
-                new[j + 1] = best[j] if best[j] < new[j] + 1 else new[j] + 1
-            row = new
-        return int(row[-1])
+        if isinstance(src_seq, str) and isinstance(tgt_seq, str):
+            a = np.frombuffer(src_seq.encode("utf-32-le", "surrogatepass"), dtype=np.int32)
+            b = np.frombuffer(tgt_seq.encode("utf-32-le", "surrogatepass"), dtype=np.int32)
+        else:
+            ids = {}
+            a = np.asarray([ids.setdefault(t, len(ids)) for t in src_seq], dtype=np.int32)
+            b = np.asarray([ids.setdefault(t, len(ids)) for t in tgt_seq], dtype=np.int32)
+        from ctc_pytorch_amd import _lib
+        d = _lib.lib().ctcn_levenshtein(a.ctypes.data, len(a), b.ctypes.data, len(b))
+        if d < 0:
+            raise RuntimeError("ctcn_levenshtein failed")
+        return int(d)
 
     def cer(self, s1, s2):
         return self._edit_distance(s1, s2)
@@ -106,17 +106,26 @@ class GreedyDecoder(Decoder):
         ids_c, len_c = ids.cpu().numpy(), out_len.cpu().numpy()
         return [list(map(int, ids_c[b, : len_c[b]])) for b in range(ids_c.shape[0])]
 
-    def decode(self, prob_tensor, frame_seq_len):
-        """Same strings as the reference: each kept frame contributes ' '+phone when space_idx == -1."""
-        res = []
-        for seq in self.decode_ids(prob_tensor, frame_seq_len):
-            chars = [self.int_to_char[k] for k in seq]
+    def _strings(self, ids_c, len_c):
+        """Collapsed ids (B, T) + lengths -> the reference's strings: each kept frame contributes ' ' + phone when space_idx == -1, else the
+        space symbol becomes ' ' (ctcDecoder.py:80-92) -- one native pass (ops.join_tokens) over a vocabulary with that already applied."""
+        voc = getattr(self, "_voc", None)
+        if voc is None or voc[0] is not self.int_to_char or voc[1] != self.space_idx:
+            items = self.int_to_char.items() if isinstance(self.int_to_char, dict) else enumerate(self.int_to_char)
             if self.space_idx == -1:
-                res.append("".join(" " + c for c in chars))
+                words = {k: " " + w for k, w in items}
             else:
                 sp = self.int_to_char[self.space_idx]
-                res.append("".join(" " if c == sp else c for c in chars))
-        return res
+                words = {k: (" " if w == sp else w) for k, w in items}
+            voc = self._voc = (self.int_to_char, self.space_idx, words)
+        return ops.join_tokens(ids_c, len_c, voc[2], "")
+
+    def decode(self, prob_tensor, frame_seq_len):
+        """Same strings as the reference: each kept frame contributes ' '+phone when space_idx == -1."""
+        lp = _to_device(prob_tensor)
+        idx = ops.argmax_last(lp)
+        ids, out_len = ops.greedy_collapse(idx, frame_seq_len, blank=self.blank_index)
+        return self._strings(ids.cpu().numpy(), out_len.cpu().numpy())
 
 
 class BeamDecoder(Decoder):

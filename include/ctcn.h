@@ -372,6 +372,10 @@ const char *ctcn_rnn_last_kernel(int which);
  * IndexError of the Python expression). */
 long long ctcn_join_tokens(const int32_t *ids, long long row_stride, const int32_t *lens, int B, const char *words, const int32_t *word_off,
                            int V, int sep, char *out, long long out_cap, long long *out_off);
+/* ctcn_levenshtein: unit-cost edit distance of two int32 sequences (the code points of two strings, or word ids), host code.
+ * replaces: Decoder._edit_distance (ctcDecoder.py:131-150; cer :127-129 and wer :118-125 call it once per decoded utterance).  -1 on bad
+ * arguments. */
+long long ctcn_levenshtein(const int32_t *a, long long na, const int32_t *b, long long nb);
 
 #ifdef __cplusplus
 }

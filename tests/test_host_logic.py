@@ -590,3 +590,50 @@ def test_join_tokens_equals_the_python_join():
     out, oo = np.zeros(8, np.uint8), np.zeros(B + 1, np.int64)
     assert _lib.lib().ctcn_join_tokens(ids.ctypes.data, T, lens.ctypes.data, B, blob, off.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -4
     assert _lib.lib().ctcn_join_tokens(None, T, lens.ctypes.data, B, blob, off.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -1
+
+
+def test_greedy_decoder_strings_equal_the_reference_expression():
+    """GreedyDecoder._strings (the host end of GreedyDecoder.decode): ' ' + phone per kept frame when the vocabulary has no space symbol, the
+    space symbol as ' ' otherwise (ctcDecoder.py:80-92,152-166), list and dict vocabularies."""
+    from ctc_pytorch_amd.utils.ctcDecoder import GreedyDecoder
+    from oracle import synth
+    rs = np.random.RandomState(5)
+    V, B, T = 62, 9, 40
+    i2c = synth.int2char(V)
+    ids = rs.randint(1, V, size=(B, T)).astype(np.int32)
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32)
+    lens[0] = 0
+    for voc in (i2c, [i2c[i] for i in range(V)]):
+        g = GreedyDecoder(voc, space_idx=-1, blank_index=0)
+        assert g._strings(ids, lens) == ["".join(" " + voc[int(k)] for k in ids[b, : lens[b]]) for b in range(B)]
+        g = GreedyDecoder(voc, space_idx=5, blank_index=0)
+        sp = voc[5]
+        assert g._strings(ids, lens) == ["".join(" " if voc[int(k)] == sp else voc[int(k)] for k in ids[b, : lens[b]]) for b in range(B)]
+
+
+def test_decoder_edit_distance_equals_the_reference_table():
+    """Decoder.cer / wer / _edit_distance (ctcn_levenshtein, host code) against the oracle's restatement of ctcDecoder.py:131-150: strings
+    (non-ASCII included), word lists, lists of arbitrary hashables, empty sides, and the symmetric / long cases the rolling row must get right."""
+    import random
+    from ctc_pytorch_amd import _lib
+    from ctc_pytorch_amd.utils.ctcDecoder import Decoder
+    random.seed(4)
+    dec = Decoder({0: "_", 1: "a"}, space_idx=-1)
+    alphabet = "abc \u00e9\u6c34"
+    for trial in range(200):
+        n, m = random.randint(0, 30), random.randint(0, 30)
+        s = "".join(random.choice(alphabet) for _ in range(n))
+        t = "".join(random.choice(alphabet) for _ in range(m))
+        want = int(R.edit_distance([ord(c) for c in s], [ord(c) for c in t]))
+        assert dec.cer(s, t) == want and dec.cer(t, s) == want
+        assert dec.wer(s, t) == int(R.edit_distance(_word_ids(s, t)[0], _word_ids(s, t)[1]))
+        assert Decoder._edit_distance(list(s), tuple(t)) == want
+    assert dec.cer("", "abc") == 3 and dec.cer("abc", "") == 3 and dec.cer("", "") == 0 and dec.wer("a b", "") == 2
+    long_a, long_b = "ab" * 700, "ba" * 650 + "c"
+    assert dec.cer(long_a, long_b) == int(R.edit_distance([ord(c) for c in long_a], [ord(c) for c in long_b]))
+    assert _lib.lib().ctcn_levenshtein(None, 3, None, 0) == -1
+
+
+def _word_ids(s, t):
+    ids = {}
+    return [ids.setdefault(w, len(ids)) for w in s.split()], [ids.setdefault(w, len(ids)) for w in t.split()]
