@@ -15,15 +15,6 @@ from torch.utils.data import DataLoader, Dataset
 
 
 # ---- Kaldi binary matrix I/O -----------------------------------------------------------------------------
-def _read_token(f):
-    tok = b""
-    while True:
-        c = f.read(1)
-        if c in (b" ", b""):
-            return tok.decode()
-        tok += c
-
-
 def read_kaldi_matrix(path_with_offset):
     """'file.ark:12345' -> float32 ndarray (rows, cols).  Supports binary 'FM ' and 'DM ' matrices."""
     if ":" in path_with_offset and not path_with_offset.rsplit(":", 1)[1].strip() == "":
@@ -33,18 +24,20 @@ def read_kaldi_matrix(path_with_offset):
         path, off = path_with_offset, 0
     with open(path, "rb") as f:
         f.seek(off)
-        if f.read(2) != b"\0B":
+        head = f.read(15)                                 # "\0B" + "FM " + "\4" rows(4) + "\4" cols(4): one read instead of nine
+        if head[:2] != b"\0B":
             raise ValueError("%s: not a binary Kaldi object at offset %d" % (path, off))
-        tok = _read_token(f)
-        if tok not in ("FM", "DM"):
-            raise NotImplementedError("Kaldi matrix type %r (compressed matrices are not supported)" % tok)
-        assert f.read(1) == b"\4"
-        rows = struct.unpack("<i", f.read(4))[0]
-        assert f.read(1) == b"\4"
-        cols = struct.unpack("<i", f.read(4))[0]
-        dt = np.dtype("<f4") if tok == "FM" else np.dtype("<f8")
-        data = np.frombuffer(f.read(rows * cols * dt.itemsize), dtype=dt).reshape(rows, cols)
-    return np.ascontiguousarray(data, dtype=np.float32)
+        tok = head[2:5]
+        if tok not in (b"FM ", b"DM "):
+            raise NotImplementedError("Kaldi matrix type %r (compressed matrices are not supported)" % head[2:5].split(b" ")[0].decode("latin-1"))
+        if head[5:6] != b"\4" or head[10:11] != b"\4":
+            raise ValueError("%s: malformed matrix header at offset %d" % (path, off))
+        rows, cols = struct.unpack("<i", head[6:10])[0], struct.unpack("<i", head[11:15])[0]
+        dt = np.dtype("<f4") if tok == b"FM " else np.dtype("<f8")
+        data = np.empty((rows, cols), dtype=dt)
+        if f.readinto(data) != data.nbytes:               # straight into the array that is returned (no bytes object, no second copy)
+            raise ValueError("%s: truncated matrix at offset %d" % (path, off))
+    return data if dt == np.dtype("<f4") else data.astype(np.float32)
 
 
 def write_kaldi_ark(ark_path, scp_path, mats):
@@ -59,14 +52,22 @@ def write_kaldi_ark(ark_path, scp_path, mats):
 
 
 # ---- feature helpers -------------------------------------------------------------------------------------
-def make_context(feature, left, right):
-    """Splice `left` past and `right` future frames (edge frames repeated) -> (T, (left+1+right)*F)."""
+def make_context(feature, left, right, as_view=False):
+    """Splice `left` past and `right` future frames (edge frames repeated) -> (T, (left+1+right)*F).  as_view: return the overlapping
+    window view itself (read-only use: the dataset hands it to the collate function, whose copy into the batch is then the only one)."""
     if left == 0 and right == 0:
         return feature
-    T = feature.shape[0]
-    idx = np.arange(T)
-    cols = [feature[np.clip(idx + d, 0, T - 1)] for d in range(-left, right + 1)]
-    return np.hstack(cols)
+    # row t of the result = rows t - left .. t + right of the edge-padded matrix back to back, i.e. ONE contiguous run of (left + 1 + right) * F
+    # floats of it: a strided window view, materialised by a single row-wise copy (the stack of 9 gathered copies this replaces ran at
+    # 0.7 M frames/s for the shipped 243-d configuration, below what the GPU trains at)
+    feature = np.ascontiguousarray(feature)
+    T, F = feature.shape
+    if T == 0:
+        return np.zeros((0, (left + 1 + right) * F), dtype=feature.dtype)
+    padded = np.concatenate([np.repeat(feature[:1], left, axis=0), feature, np.repeat(feature[-1:], right, axis=0)])
+    item = padded.itemsize
+    view = np.lib.stride_tricks.as_strided(padded, shape=(T, (left + 1 + right) * F), strides=(F * item, item))
+    return view if as_view else np.ascontiguousarray(view)
 
 
 def skip_feat(feature, skip):
@@ -129,12 +130,14 @@ class SpeechDataset(Dataset):
 
     def __getitem__(self, idx):
         path, label, utt = self.item[idx]
-        feat = skip_feat(make_context(read_kaldi_matrix(path), self.left_ctx, self.right_ctx), self.n_skip_frame)
+        # (the spliced / frame-skipped matrix stays a strided view of the matrix just read -- an array of its own -- until create_input copies
+        # it into the batch: one pass over the 9x larger spliced data instead of three)
+        feat = skip_feat(make_context(read_kaldi_matrix(path), self.left_ctx, self.right_ctx, as_view=True), self.n_skip_frame)
         seq_len, dim = feat.shape
         if seq_len % self.n_downsample != 0:
             pad_len = self.n_downsample - seq_len % self.n_downsample
             feat = np.vstack([feat, np.zeros((pad_len, dim), dtype=feat.dtype)])
-        return torch.from_numpy(np.array(feat, dtype=np.float32, order="C")), torch.LongTensor(label), utt   # own, writable copy
+        return torch.from_numpy(feat), torch.LongTensor(label), utt
 
     def __len__(self):
         return len(self.item)
@@ -145,18 +148,23 @@ def create_input(batch):
     feat_size = batch[0][0].size(1)
     lmax = max(x[1].size(0) for x in batch)
     n = len(batch)
-    data = torch.zeros(n, tmax, feat_size)
-    label = torch.zeros(n, lmax)
-    input_sizes = torch.zeros(n)
-    target_sizes = torch.zeros(n)
+    # (every element is written exactly once -- the utterance's frames, then zeros behind them -- instead of zero-filling the whole padded
+    # batch first: the batch is 3-25 MB and this runs on the thread that also enqueues the training step)
+    data = torch.empty(n, tmax, feat_size)
+    label = torch.zeros(n, lmax, dtype=torch.long)
+    input_sizes = torch.empty(n)
+    target_sizes = torch.empty(n, dtype=torch.long)
     utt_list = []
     for i, (feature, lab, utt) in enumerate(batch):
-        data[i, : feature.size(0)] = feature
+        t = feature.size(0)
+        data[i, :t] = feature
+        if t < tmax:
+            data[i, t:].zero_()
         label[i, : lab.size(0)] = lab
-        input_sizes[i] = feature.size(0) / tmax          # python float -> float32 element: the fraction the path consumes
+        input_sizes[i] = t / tmax                        # python float -> float32 element: the fraction the path consumes
         target_sizes[i] = lab.size(0)
         utt_list.append(utt)
-    return data.float(), input_sizes.float(), label.long(), target_sizes.long(), utt_list
+    return data, input_sizes, label, target_sizes, utt_list
 
 
 class SpeechDataLoader(DataLoader):

@@ -259,6 +259,34 @@ def test_input_pipeline_contract(tmp_path):
     assert x.shape == (3, 50, 120) and x.dtype == torch.float32 and frac.dtype == torch.float32 and tg.dtype == torch.int64
     assert frac.tolist() == [np.float32(28 / 50), 1.0, np.float32(40 / 50)] and tl.tolist() == [3, 2, 4]
     assert float(x[0, 28:].abs().sum()) == 0 and tg[1, 2:].tolist() == [0, 0]
+    # the padded batch is written element by element (no zero-fill first): dirty the allocator's free blocks and look at every padding frame
+    for _ in range(3):
+        junk = torch.full((3, 50, 120), float("nan"))
+        del junk
+        x2 = dl.create_input([ds[i] for i in range(3)])[0]
+        assert torch.equal(x2, x) and not torch.isnan(x2).any()
+    # left context + both edges against the gather form, as a window view and as a copy; double-precision matrices; broken headers
+    m5 = mats["utt2"][:5]
+    idx = np.arange(5)
+    want = np.hstack([m5[np.clip(idx + d, 0, 4)] for d in range(-3, 2)])
+    assert np.array_equal(dl.make_context(m5, 3, 1), want) and np.array_equal(dl.make_context(m5, 3, 1, as_view=True), want)
+    assert dl.make_context(m5[:0], 3, 1).shape == (0, 200)
+    dpath = str(tmp_path / "d.ark")
+    with open(dpath, "wb") as f:
+        f.write(b"u \0BDM \4" + np.int32(2).tobytes() + b"\4" + np.int32(3).tobytes() + np.arange(6, dtype="<f8").tobytes())
+    got = dl.read_kaldi_matrix(dpath + ":2")
+    assert got.dtype == np.float32 and np.array_equal(got, np.arange(6, dtype=np.float32).reshape(2, 3))
+    with open(dpath, "r+b") as f:
+        f.truncate(30)
+    with pytest.raises(ValueError):
+        dl.read_kaldi_matrix(dpath + ":2")
+    with pytest.raises(ValueError):
+        dl.read_kaldi_matrix(dpath + ":3")
+    cpath = str(tmp_path / "c.ark")
+    with open(cpath, "wb") as f:
+        f.write(b"\0BCM " + b"\0" * 32)
+    with pytest.raises(NotImplementedError):
+        dl.read_kaldi_matrix(cpath)
 
 
 def test_lr_controller_schedule():
