@@ -8,6 +8,10 @@
 // (ctcn_comm_init .. ctcn_comm_destroy); everything else follows the conventions of include/ctcn.h.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -32,6 +36,23 @@ struct Rccl {
 };
 
 Rccl &rccl_state() { static Rccl r; return r; }
+
+// the communicators ctcn_comm_init handed out and ctcn_comm_destroy has not taken back: a handle is RCCL's own pointer, and RCCL dereferences
+// whatever it is given -- a stale or foreign handle is answered with CTCN_EINVAL here instead of a crash there
+struct LiveComms {
+  std::mutex mu;
+  std::vector<void *> live;
+  bool has(void *c) { std::lock_guard<std::mutex> g(mu); return std::find(live.begin(), live.end(), c) != live.end(); }
+  void add(void *c) { std::lock_guard<std::mutex> g(mu); live.push_back(c); }
+  bool drop(void *c) {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = std::find(live.begin(), live.end(), c);
+    if (it == live.end()) return false;
+    live.erase(it);
+    return true;
+  }
+};
+LiveComms &live_comms() { static LiveComms l; return l; }
 Rccl *rccl() {
   Rccl &r = rccl_state();
   static bool tried = false;
@@ -85,12 +106,14 @@ extern "C" int ctcn_comm_init(const void *id128, int rank, int world, void **com
   void *c = nullptr;
   const int rc = r->comm_init_rank(&c, world, id, rank);
   if (rc) return fail("ctcn_comm_init", rc);
+  live_comms().add(c);
   *comm = c;
   return CTCN_OK;
 }
 
 extern "C" int ctcn_comm_allreduce_sum_f32(void *comm, float *buf, size_t n, void *stream) {
   CTCN_REQUIRE(comm && (buf || n == 0), "ctcn_comm_allreduce_sum_f32: null pointer");
+  CTCN_REQUIRE(live_comms().has(comm), "ctcn_comm_allreduce_sum_f32: not a communicator of ctcn_comm_init (or already destroyed)");
   if (n == 0) return CTCN_OK;
   Rccl *r = rccl();
   if (!r) { ctcn_set_error("ctcn_comm_allreduce_sum_f32: librccl.so is not loaded"); return CTCN_EUNSUPPORTED; }
@@ -101,6 +124,7 @@ extern "C" int ctcn_comm_allreduce_sum_f32(void *comm, float *buf, size_t n, voi
 
 extern "C" int ctcn_comm_destroy(void *comm) {
   if (!comm) return CTCN_OK;
+  CTCN_REQUIRE(live_comms().drop(comm), "ctcn_comm_destroy: not a communicator of ctcn_comm_init (or already destroyed)");
   Rccl *r = rccl();
   if (!r) { ctcn_set_error("ctcn_comm_destroy: librccl.so is not loaded"); return CTCN_EUNSUPPORTED; }
   const int rc = r->comm_destroy(comm);

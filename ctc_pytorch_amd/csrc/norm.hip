@@ -340,6 +340,7 @@ int launch_reduce(F f, int outer, int C, int inner, double *part, int *nchunks_o
 }  // namespace
 
 extern "C" size_t ctcn_bn_ws_bytes(int outer, int C, int inner) {
+  if (outer <= 0 || C <= 0 || inner <= 0) return 0;                  // (as the other *_ws_bytes queries answer bad dims; the chunk planners divide by them)
   const int n = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C, inner).n;
   return align_up((size_t)(n + 1) * C * 2 * sizeof(double), 256) + (size_t)2 * C * sizeof(float);
 }

@@ -207,7 +207,7 @@ int ctcn_rnn_bwd_weights(int cell, int T, int B, int I, int H, int dirs, const f
  * train fwd: y = gamma*(x-mean)*rstd+beta; saves mean,rstd (C each); updates running stats in place
  * (momentum 0.1 semantics: rm = (1-mom)*rm + mom*mean; rv uses the unbiased variance).
  * relu!=0 fuses nn.ReLU (model_ctc.py:64) into the apply pass and its mask into the backward pass.
- * ws: >= ctcn_bn_ws_bytes(outer, C, inner). */
+ * ws: >= ctcn_bn_ws_bytes(outer, C, inner) (0 for dims that are not positive). */
 size_t ctcn_bn_ws_bytes(int outer, int C, int inner);
 int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                       float *running_var, float *save_mean, float *save_rstd, int outer, int C, int inner,

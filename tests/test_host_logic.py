@@ -665,3 +665,38 @@ def test_decoder_edit_distance_equals_the_reference_table():
 def _word_ids(s, t):
     ids = {}
     return [ids.setdefault(w, len(ids)) for w in s.split()], [ids.setdefault(w, len(ids)) for w in t.split()]
+
+
+def test_every_entry_point_rejects_null_and_zero_arguments_without_a_gpu():
+    """The C ABI's error behaviour on the host side: every entry point of include/ctcn.h called with null pointers and zero sizes answers with
+    an error code (or 0 bytes for the size queries) BEFORE it touches the device -- no crash, no HIP call -- each in a process of its own (a
+    division by a zero dimension in a workspace query was found this way)."""
+    code = r"""
+import ctypes, sys
+from ctc_pytorch_amd import _lib
+L = _lib.lib()
+bad = []
+for name, (res, args) in _lib._SIGS.items():
+    vals = []
+    for a in args:
+        if a in (ctypes.c_double, ctypes.c_float):
+            vals.append(0.0)
+        elif a in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(a, "contents"):
+            vals.append(None)
+        else:
+            vals.append(0)
+    sys.stdout.write(name + "\n"); sys.stdout.flush()
+    r = getattr(L, name)(*vals)
+    if name in ("ctcn_version", "ctcn_last_error", "ctcn_rnn_last_kernel", "ctcn_device_cus", "ctcn_device_xcds", "ctcn_set_status_buffer", "ctcn_comm_destroy",
+                "ctcn_levenshtein"):
+        continue                                  # (queries and no-ops that have no failing form with these arguments)
+    if name.endswith("_bytes"):
+        if r != 0: bad.append((name, r))
+    elif not (isinstance(r, int) and r < 0):
+        bad.append((name, r))
+print("BAD", bad)
+"""
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
+    assert p.returncode == 0, "crashed in %s: %s" % ((p.stdout.strip().splitlines() or ["?"])[-1], p.stderr[-400:])
+    assert p.stdout.strip().splitlines()[-1] == "BAD []", p.stdout[-600:]
