@@ -299,7 +299,9 @@ int ctcn_adam_step(float *p, const float *g, float *m, float *v, size_t n, float
  * sharded data parallelism inserts this one collective between the two calls.  librccl.so is opened at run time.
  *   rank 0 calls ctcn_comm_unique_id (128 bytes) and hands the blob to the other ranks by any host channel; every rank then
  *   calls ctcn_comm_init (collective: blocks until all `world` ranks arrived).  The communicator is the only object the library
- *   owns; ctcn_comm_allreduce_sum_f32 is enqueued on `stream` (in place) and returns without synchronising. */
+ *   owns; ctcn_comm_allreduce_sum_f32 is enqueued on `stream` (in place) and returns without synchronising.  A handle that ctcn_comm_init
+ *   did not hand out, or that ctcn_comm_destroy has taken back, is answered with CTCN_EINVAL (the library keeps the list of live handles)
+ *   instead of reaching RCCL, which would dereference it. */
 int ctcn_comm_unique_id(void *id128);
 int ctcn_comm_init(const void *id128, int rank, int world, void **comm);
 int ctcn_comm_allreduce_sum_f32(void *comm, float *buf, size_t n, void *stream);

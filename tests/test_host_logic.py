@@ -700,3 +700,11 @@ print("BAD", bad)
                        env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")))
     assert p.returncode == 0, "crashed in %s: %s" % ((p.stdout.strip().splitlines() or ["?"])[-1], p.stderr[-400:])
     assert p.stdout.strip().splitlines()[-1] == "BAD []", p.stdout[-600:]
+    # a communicator handle the library did not hand out never reaches RCCL (which would dereference it)
+    import ctypes
+    from ctc_pytorch_amd import _lib
+    L = _lib.lib()
+    fake = ctypes.create_string_buffer(4096)
+    assert L.ctcn_comm_allreduce_sum_f32(ctypes.cast(fake, ctypes.c_void_p), ctypes.cast(fake, ctypes.c_void_p), 4, None) == -1
+    assert b"not a communicator" in L.ctcn_last_error()
+    assert L.ctcn_comm_destroy(ctypes.cast(fake, ctypes.c_void_p)) == -1 and L.ctcn_comm_destroy(None) == 0
