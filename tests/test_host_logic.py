@@ -402,6 +402,39 @@ assert torch.equal(bn[0].running_mean, torch.full((3,), 1.5)) and torch.equal(bn
 parallel.enable_sync_bn(True)
 assert parallel.sync_bn_buffers(bn) == 0              # global statistics already: nothing to do
 parallel.enable_sync_bn(False)
+# replicas-only decode (SURVEY 8e "Decode", steps/test_ctc.decode_and_score_sharded): rank r scores minibatches r, r + world, ...; the four
+# totals are summed over the ranks -- same CER / WER and counts as one process over all minibatches (a host-side stand-in for the model and
+# the decoder: the class logic, the scoring and the reduction are what is under test here)
+from ctc_pytorch_amd.steps.test_ctc import decode_and_score, decode_and_score_sharded
+from ctc_pytorch_amd.utils.ctcDecoder import Decoder
+class _Model(torch.nn.Module):
+    def forward(self, x):
+        return x.transpose(0, 1).contiguous()                      # (B, T, V) -> (T, B, V) "log-probs"
+class _Dec(Decoder):
+    def decode(self, probs, lens):
+        out = []
+        for b in range(probs.shape[1]):
+            path = probs[: int(lens[b]), b].argmax(-1).tolist()
+            keep = [k for i, k in enumerate(path) if k != 0 and (i == 0 or k != path[i - 1])]
+            out.append(" ".join(self.int_to_char[k] for k in keep))
+        return out
+i2w = {k: "w%%d" %% k for k in range(12)}
+rs = np.random.RandomState(9)
+loader = []
+for nb in (3, 4, 2, 5, 1):
+    T = int(rs.randint(8, 15))
+    x = torch.from_numpy(rs.standard_normal((nb, T, 12)).astype(np.float32))
+    frac = torch.from_numpy(rs.randint(T // 2, T + 1, size=nb).astype(np.float32) / T)
+    tl = torch.from_numpy(rs.randint(1, 6, size=nb).astype(np.int64))
+    tg = torch.from_numpy(rs.randint(1, 12, size=(nb, 5)).astype(np.int64))
+    loader.append((x, frac, tg, tl, ["u"] * nb))
+one = _Dec(i2w, space_idx=-1, blank_index=0)
+cer1, wer1 = decode_and_score(_Model(), loader, one, i2w, "cpu", log=lambda *_: None)
+two = _Dec(i2w, space_idx=-1, blank_index=0)
+logged = []
+cer2, wer2 = decode_and_score_sharded(_Model(), loader, two, i2w, "cpu", rank=rank, world=world, log=logged.append)
+assert abs(cer1 - cer2) < 1e-9 and abs(wer1 - wer2) < 1e-9 and (two.num_char, two.num_word) == (one.num_char, one.num_word), (cer1, cer2, wer1, wer2)
+assert (len(logged) == 2) == (rank == 0)
 dist.barrier()
 print("rank", rank, "ok")
 """
