@@ -21,13 +21,23 @@ def tm(f, n):
     return (time.perf_counter() - t) / n * 1e3
 
 
+def _rows(a, b):
+    """the interpreter form of the edit distance (two rolling rows)"""
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
 def main():
     from ctc_pytorch_amd import ops
     from ctc_pytorch_amd.utils import data_loader as dl
     from ctc_pytorch_amd.utils.ctcDecoder import Decoder
-    from oracle import np_ref, synth
     V = 62
-    phones = [synth.int2char(V)[i] for i in range(V)]
+    phones = ["blank", "UNK"] + ["p%d" % i for i in range(V - 2)]          # (2-5 byte words, like the 60 TIMIT phones)
     rs = np.random.RandomState(0)
     print("host threads: 1; python %s; numpy %s" % (sys.version.split()[0], np.__version__))
     for name, lo, hi in (("peaky-like (60-120 tokens per utterance)", 60, 121), ("flat-like (400-720 tokens per utterance)", 400, 721)):
@@ -43,7 +53,7 @@ def main():
         a = "".join(rs.choice(list("abcdefgh ")) for _ in range(n))
         b = "".join(rs.choice(list("abcdefgh ")) for _ in range(n - n // 20))
         t0 = time.perf_counter()
-        want = np_ref.edit_distance(a, b)
+        want = _rows(a, b)
         t_py = (time.perf_counter() - t0) * 1e3
         assert dec.cer(a, b) == want
         print("edit distance of two %d-character strings: interpreter rows %.1f ms, ctcn_levenshtein %.3f ms" % (n, t_py, tm(lambda: dec.cer(a, b), 20)))
@@ -52,10 +62,10 @@ def main():
         mats = {"utt%04d" % i: rs.standard_normal((rs.randint(400, 801), 40)).astype(np.float32) for i in range(N)}
         dl.write_kaldi_ark(os.path.join(d, "f.ark"), os.path.join(d, "f.scp"), mats)
         with open(os.path.join(d, "units"), "w") as f:
-            f.write("\n".join(synth.TIMIT_60) + "\n")
+            f.write("\n".join(phones[2:]) + "\n")
         with open(os.path.join(d, "lab"), "w") as f:
             for u in mats:
-                f.write(u + " " + " ".join(synth.TIMIT_60[rs.randint(60)] for _ in range(rs.randint(30, 60))) + "\n")
+                f.write(u + " " + " ".join(phones[2 + rs.randint(60)] for _ in range(rs.randint(30, 60))) + "\n")
         vocab = dl.Vocab(os.path.join(d, "units"))
         for ctx, what in ((0, "40-d features"), (4, "9-frame splice, 360-d")):
             opts = types.SimpleNamespace(left_ctx=ctx, right_ctx=ctx, n_skip_frame=1, n_downsample=1)
