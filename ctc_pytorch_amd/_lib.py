@@ -82,7 +82,7 @@ _SIGS = {
     "ctcn_diag_pipeline_chunks": (I, [I, I, I, I, I, I, I, I, ctypes.c_uint]),
     "ctcn_rnn_last_kernel": (ctypes.c_char_p, [I]),
     "ctcn_levenshtein": (ctypes.c_longlong, [P, ctypes.c_longlong, P, ctypes.c_longlong]),
-    "ctcn_join_tokens": (ctypes.c_longlong, [P, ctypes.c_longlong, P, I, P, P, I, I, P, ctypes.c_longlong, P]),
+    "ctcn_join_tokens": (ctypes.c_longlong, [P, ctypes.c_longlong, P, I, P, P, P, I, I, P, ctypes.c_longlong, P]),
     "ctcn_beam_ws_bytes": (Z, [I, I, I, I]),
     "ctcn_beam_decode": (I, [P, I, P, P, D, I, I, P, P, P, P, I, I, I, P, Z, P]),
     "ctcn_beam_decode_nbest": (I, [P, I, P, P, D, I, I, I, P, P, P, P, P, I, I, I, P, Z, P]),
@@ -93,7 +93,8 @@ class RnnCall(ctypes.Structure):
     """ctcn_rnn_call of include/ctcn.h: the per-call extras of ctcn_rnn_fwd_ex / ctcn_rnn_bwd_ex (the library keeps no state between calls)."""
     _fields_ = [("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint64), ("drop_offset", ctypes.c_uint64), ("y_drop", ctypes.c_void_p),
                 ("dy_tmp", ctypes.c_void_p), ("side_stream", ctypes.c_void_p), ("side_event", ctypes.c_void_p), ("side_ws", ctypes.c_void_p),
-                ("side_ws_bytes", ctypes.c_size_t), ("xcd_allow", ctypes.c_uint), ("prelaunch_event", ctypes.c_void_p), ("status", ctypes.c_void_p)]
+                ("side_ws_bytes", ctypes.c_size_t), ("xcd_allow", ctypes.c_uint), ("prelaunch_event", ctypes.c_void_p), ("status", ctypes.c_void_p),
+                ("launched", ctypes.POINTER(ctypes.c_char_p))]
 
 
 def sources():

@@ -12,13 +12,16 @@
 #include "common.h"
 
 // ctcn_join_tokens: for every row b < B the words of ids[b * row_stride + t], t < lens[b], joined by `sep` (one byte; 0: nothing between
-// them) into out[out_off[b] .. out_off[b + 1]); words = the vocabulary's UTF-8 bytes back to back FOLLOWED BY 16 readable bytes, word_off[V + 1] their offsets (a word
-// with word_off[k] > word_off[k + 1] marks an id the vocabulary does not have).  Returns the bytes written (out_off[B]), CTCN_EINVAL on bad
+// them) into out[out_off[b] .. out_off[b + 1]); words = the vocabulary's UTF-8 bytes back to back FOLLOWED BY 16 readable bytes, word_off[V] the
+// byte offset of every word and word_len[V] its length in bytes (word_len[k] < 0: the vocabulary has no id k -- a separate array, so that a
+// hole changes nothing about its neighbours; round 4 marked holes by perturbing shared offsets, which lengthened the word in front of a hole
+// and made two adjacent holes cancel).  Returns the bytes written (out_off[B]), CTCN_EINVAL on bad
 // arguments, CTCN_EWORKSPACE when out_cap is too small (it must hold the result + 17 bytes: nothing usable written), or -(16 + k) for an id k outside the vocabulary (the
 // KeyError / IndexError of the Python expression).
 extern "C" long long ctcn_join_tokens(const int32_t *ids, long long row_stride, const int32_t *lens, int B, const char *words,
-                                      const int32_t *word_off, int V, int sep, char *out, long long out_cap, long long *out_off) {
-  if (!ids || !lens || !words || !word_off || !out || !out_off || B < 0 || V <= 0 || row_stride < 0 || out_cap < 0 || sep < 0 || sep > 255)
+                                      const int32_t *word_off, const int32_t *word_len, int V, int sep, char *out, long long out_cap,
+                                      long long *out_off) {
+  if (!ids || !lens || !words || !word_off || !word_len || !out || !out_off || B < 0 || V <= 0 || row_stride < 0 || out_cap < 0 || sep < 0 || sep > 255)
     return CTCN_EINVAL;
   long long pos = 0;
   for (int b = 0; b < B; ++b) {
@@ -28,8 +31,8 @@ extern "C" long long ctcn_join_tokens(const int32_t *ids, long long row_stride, 
     const int32_t *row = ids + (long long)b * row_stride;
     for (int t = 0; t < n; ++t) {
       const int k = row[t];
-      if (k < 0 || k >= V || word_off[k] > word_off[k + 1]) return -(16LL + (k < 0 ? 0x7fffffffLL : (long long)k));
-      const int w0 = word_off[k], wl = word_off[k + 1] - w0;
+      if (k < 0 || k >= V || word_len[k] < 0) return -(16LL + (k < 0 ? 0x7fffffffLL : (long long)k));
+      const int w0 = word_off[k], wl = word_len[k];
       if (pos + (wl > 16 ? wl : 16) + 1 > out_cap) return CTCN_EWORKSPACE;
       if (t > 0 && sep) out[pos++] = (char)sep;
       if (wl <= 16) std::memcpy(out + pos, words + w0, 16);          // (phones are a few bytes: one fixed 16-byte move -- the caller pads `words`

@@ -2662,7 +2662,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();
-          g_last_kernel[0] = "rnn_fwd_tagged";
+          { g_last_kernel[0] = "rnn_fwd_tagged"; if (call.launched) *call.launched = "rnn_fwd_tagged"; }
           if (fuse_drop) drop_pending = false;
           if (piped) {          // the remaining chunk pairs, next to the recurrence on the XCDs it does not use
             hipStream_t sd = (hipStream_t)ov.stream;
@@ -2718,7 +2718,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
       else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
       if (launch_fwd_persist(prec, NT, kq, pgrid, lds, st, pa, wpx)) {
         CTCN_LAUNCH_CHECK();
-        g_last_kernel[0] = "rnn_fwd_persist";
+        { g_last_kernel[0] = "rnn_fwd_persist"; if (call.launched) *call.launched = "rnn_fwd_persist"; }
         return CTCN_OK;
       }
     }
@@ -2728,6 +2728,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
   }
   const int kq4 = pick_kq4(H, 4, MT, 20);
   g_last_kernel[0] = "rnn_fwd_step";
+  if (call.launched) *call.launched = "rnn_fwd_step";
   for (int s = 0; s < T; ++s) {
     a.step = s;
     if (MT == 1) launch_fwd<1>(kq4, grid, st, a);
@@ -2947,10 +2948,10 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
           pa.poll_delay = ctcn_get_option("bwd_poll_delay");
           if (pa.poll_delay < 0) pa.poll_delay = nsl <= 24 ? 16 : 24;        // auto: the exchange phase grows with the tiles per wave (cfg4: 2.69 -> 2.55 us per step)
           done = launch_bwd_scatter2(nsl, pgrid, st, pa, wpx);
-          if (done) g_last_kernel[1] = "rnn_bwd_scatter2";
+          if (done) { g_last_kernel[1] = "rnn_bwd_scatter2"; if (call.launched) *call.launched = "rnn_bwd_scatter2"; }
         } else {
           done = launch_bwd_scatter(prec, ntw, pgrid, st, pa, wpx);
-          if (done) g_last_kernel[1] = "rnn_bwd_scatter";
+          if (done) { g_last_kernel[1] = "rnn_bwd_scatter"; if (call.launched) *call.launched = "rnn_bwd_scatter"; }
         }
       } else {
         if (!dy_dropped) {
@@ -2961,7 +2962,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
         else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         record_prelaunch(st);
         done = launch_bwd_persist(prec, kq, pgrid, lds, st, pa, wpx);
-        if (done) g_last_kernel[1] = "rnn_bwd_persist";
+        if (done) { g_last_kernel[1] = "rnn_bwd_persist"; if (call.launched) *call.launched = "rnn_bwd_persist"; }
       }
     }
   }
@@ -2978,6 +2979,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
     CTCN_HIP(hipMemsetAsync(state, 0, (size_t)B * dirs * H * sizeof(float), st));
     const int kq4 = pick_kq4(GH, 16, 1, 5);
     g_last_kernel[1] = "rnn_bwd_step";
+    if (call.launched) *call.launched = "rnn_bwd_step";
     for (int s = 0; s < T; ++s) {
       a.step = s;
       launch_bwd(kq4, grid, st, a);

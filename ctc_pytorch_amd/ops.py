@@ -391,9 +391,11 @@ class _RNNLayer(torch.autograd.Function):
             seed, off = _next_dropout_stream(y.numel())
             ctx.drop = (float(drop_p), seed, off)
             call.y_drop, call.drop_p, call.drop_seed, call.drop_offset = y_drop.data_ptr(), float(drop_p), seed, off
+        launched = ctypes.c_char_p(None)            # the kernel THIS call launched (per call: the process-wide ctcn_rnn_last_kernel is last-writer-wins across threads)
+        call.launched = ctypes.pointer(launched)
         _lib.check(L.ctcn_rnn_fwd_ex(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
                                      _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr(), ctypes.byref(call)), "rnn_fwd_ex")
-        if T > 1 and B > 16 and (L.ctcn_rnn_last_kernel(0) or b"") == b"rnn_fwd_step" and get_option("rnn_persistent"):
+        if T > 1 and B > 16 and (launched.value or b"") == b"rnn_fwd_step" and get_option("rnn_persistent"):
             _fallback_shapes.add((cell, H, dirs, B))       # (rnn_layer chunks this shape's batch from the next call on)
         if piped:
             # by the time the recurrence ends the side stream's GEMMs have long finished (the kernel waited for their counter); the join
@@ -454,6 +456,12 @@ class _RNNLayer(torch.autograd.Function):
         # with the side stream (2.27 ms inline, 2.8-4.5 with it) and set the threshold at 2^21; with the queue-form GEMMs and the deferred issue
         # of rounds 2-3 the picture is the opposite (round 4: cfg1 2.02 -> 1.95 ms, the shipped-YAML shape 4.69 -> 4.36): set_side_stream
         side = into_flat and _side["enabled"] and nx > 1 and T > 1 and T * B * H >= _side["min_items_bwd"]
+        # one of several batch chunks of a layer (rnn_layer): every chunk accumulates (beta = 1, read-modify-write) into the SAME gradient
+        # views, so all of them write on the main stream, in order -- a chunk whose weight GEMMs were deferred to the side stream would race
+        # with a sibling chunk's inline GEMMs on the same buffers (test_rnn_batch_chunks_into_flat_gradients)
+        chunk = not ctx.early_ok
+        if chunk:
+            side = False
         if side:                    # where the weight GEMMs can run next to the recurrence of the layer below: idle XCDs, or free CUs on every XCD
             allow = side_stream_plan(cell, T, B, I, H, dirs, nx, L.ctcn_device_cus(), _side["capacity_slack"])
             side = allow != 0
@@ -465,13 +473,13 @@ class _RNNLayer(torch.autograd.Function):
         if dx is None or _side["live"].get(key, 0) == 0:
             # bottom recurrent layer: no recurrence follows, so its weight GEMMs get the whole device -- one direction per stream
             # (eight small dependent launches per direction that do not fill 256 CUs one at a time: 440 -> ~250 us at cfg2)
-            split_dirs = side and dirs == 2
+            split_dirs = side and dirs == 2 and not chunk
             side = False
         # small layers (below min_items: weight GEMMs inline): the two directions' weight gradients are independent chains of small launches
         # that do not fill the device one at a time -- one direction per stream, joined at once (nothing runs next to a recurrence)
         # (not when the layer ABOVE has parked side work: the join below waits for the whole side stream, which would then hold that layer's
         # deferred weight GEMMs -- and its early all-reduce -- in front of the main stream; a mixed large / small stack keeps this layer inline)
-        small_split = (not side and not split_dirs and into_flat and _side["enabled"] and _side["small_split"] and dirs == 2 and T > 1
+        small_split = (not side and not split_dirs and not chunk and into_flat and _side["enabled"] and _side["small_split"] and dirs == 2 and T > 1
                        and key not in _side["deferred"])
         if small_split:
             split_dirs = True
@@ -488,6 +496,8 @@ class _RNNLayer(torch.autograd.Function):
             p_, seed_, off_ = ctx.drop                      # a dropout pass into gd where that kernel does not apply)
             gd = torch.empty_like(gy)
             call.dy_tmp, call.drop_p, call.drop_seed, call.drop_offset = gd.data_ptr(), p_, seed_, off_
+        launched = ctypes.c_char_p(None)
+        call.launched = ctypes.pointer(launched)
         try:
             _lib.check(L.ctcn_rnn_bwd_ex(cell, T, B, I, H, dirs, _ptr(x), _ptr(w_ih0), _ptr(w_hh0), _ptr(w_ih1), _ptr(w_hh1),
                                          _ptr(y), _ptr(gates), _ptr(aux), _ptr(gy), _ptr(dx),
@@ -498,7 +508,7 @@ class _RNNLayer(torch.autograd.Function):
             if above is not None:                       # keep the parked work for the join
                 _side["deferred"][key] = above
             raise
-        if T > 1 and B > 16 and (L.ctcn_rnn_last_kernel(1) or b"") == b"rnn_bwd_step" and get_option("rnn_persistent"):
+        if T > 1 and B > 16 and (launched.value or b"") == b"rnn_bwd_step" and get_option("rnn_persistent"):
             _fallback_shapes.add((cell, H, dirs, B))           # (rnn_layer chunks this shape's batch from the next call on)
         if above is not None:
             above(ev)
@@ -1037,37 +1047,36 @@ _vocab_cache = {}
 
 
 def _vocabulary(words):
-    """(UTF-8 bytes of words[0], words[1], ... back to back, int32 offsets (V + 1), longest word in bytes) for a list or an {id: word}
-    mapping; ids without a word get a descending offset pair (ctcn_join_tokens reports them as the KeyError they are in Python)."""
+    """(UTF-8 bytes of the words back to back + 17 pad bytes, int32 byte offsets (V), int32 byte lengths (V; -1 = the vocabulary has no such
+    id: ctcn_join_tokens reports it as the KeyError it is in Python), longest word in bytes, V) for a list or an {id: word} mapping.
+    Cached per object; a hit is confirmed by CONTENT (a list or dict edited in place -- a replaced phone symbol, a remapped space index --
+    must not return the stale blob), which costs one tuple comparison per decoded batch."""
     key = id(words)
+    snap = tuple(words.items()) if isinstance(words, dict) else tuple(words)
     hit = _vocab_cache.get(key)
-    n = len(words)
-    if hit is not None and hit[0] is words and hit[1] == n:
+    if hit is not None and hit[0] is words and hit[1] == snap:
         return hit[2]
     if isinstance(words, dict):
         V = (max(words) + 1) if words else 1
         get = words.get
     else:
+        n = len(words)
         V = max(n, 1)
         get = lambda k: words[k] if k < n else None
-    blob, off, longest = bytearray(), np.zeros(V + 1, dtype=np.int32), 0
-    missing = []
+    blob, off, ln, longest = bytearray(), np.zeros(V, dtype=np.int32), np.full(V, -1, dtype=np.int32), 0
     for k in range(V):
         w = get(k)
         off[k] = len(blob)
         if w is None:
-            missing.append(k)
             continue
         b = str(w).encode("utf-8")
         blob += b
+        ln[k] = len(b)
         longest = max(longest, len(b))
-    off[V] = len(blob)
-    for k in missing:                       # a descending pair marks "no such word" (the blob gets one pad byte so offsets stay in range)
-        off[k] = off[k + 1] + 1
-    voc = (bytes(blob) + b"\0" * 17, off, longest, V)       # (ctcn_join_tokens moves 16 bytes per short word)
+    voc = (bytes(blob) + b"\0" * 17, off, ln, longest, V)       # (ctcn_join_tokens moves 16 bytes per short word)
     if len(_vocab_cache) > 16:
         _vocab_cache.clear()
-    _vocab_cache[key] = (words, n, voc)
+    _vocab_cache[key] = (words, snap, voc)
     return voc
 
 
@@ -1082,12 +1091,12 @@ def join_tokens(ids, lens, words, sep=" "):
     if len(sep) > 1 or (sep and ord(sep) > 127):
         raise ValueError("join_tokens: sep must be '' or one ASCII character")
     B, T = ids.shape
-    blob, off, longest, V = _vocabulary(words)
+    blob, off, ln, longest, V = _vocabulary(words)
     total = int(np.minimum(lens, T).clip(min=0).sum())
     cap = total * (longest + 1) + 32
     out = np.empty(cap, dtype=np.uint8)
     out_off = np.empty(B + 1, dtype=np.int64)
-    n = _lib.lib().ctcn_join_tokens(ids.ctypes.data, T, lens.ctypes.data, B, blob, off.ctypes.data, V, ord(sep) if sep else 0,
+    n = _lib.lib().ctcn_join_tokens(ids.ctypes.data, T, lens.ctypes.data, B, blob, off.ctypes.data, ln.ctypes.data, V, ord(sep) if sep else 0,
                                     out.ctypes.data, cap, out_off.ctypes.data)
     if n <= -16:
         k = -(n + 16)
@@ -1143,6 +1152,8 @@ class BeamResult(object):
         ids_c = h[8 * B: 8 * B + 4 * B * T].view(np.int32).reshape(B, T)
         len_c = h[8 * B + 4 * B * T: 8 * B + 4 * B * T + 4 * B].view(np.int32)
         status = h[8 * B + 4 * B * T + 4 * B:].view(np.int32)
+        if status.any():            # a search that reported an error owes no consistent labelling: its rows join as '' and the caller raises from `status`
+            len_c = np.where(status != 0, 0, len_c).astype(np.int32)
         return join_tokens(ids_c, len_c, words, sep), score.copy(), status.copy()
 
 

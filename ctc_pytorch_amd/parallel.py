@@ -172,12 +172,15 @@ def allreduce_grads(flat_grad):
 # Utterances of the current minibatch: (global, in this rank's shard).  Every shard is padded to the GLOBAL T_max, so a
 # BatchNorm layer's global element count is local_count * B_global / B_local -- known on the host without a collective
 # (and without a device sync), also when the shards are uneven.  None: equal shards (count = local_count * world).
-_batch = {"global": None, "local": None}
+_batch = {"global": None, "local": None, "seen": 0}
 
 
 def set_batch_split(global_b=None, local_b=None):
-    """Tell the synchronised BatchNorm how the current minibatch is split (run_epoch calls it per step)."""
+    """Tell the synchronised BatchNorm how the current minibatch is split (run_epoch calls it per step); the utterances this rank has seen
+    since the last sync_bn_buffers are counted on the way (its pooling weights)."""
     _batch["global"], _batch["local"] = global_b, local_b
+    if local_b:
+        _batch["seen"] = _batch.get("seen", 0) + int(local_b)
 
 
 def _sync_bn_reduce(sums, local_count):
@@ -236,36 +239,52 @@ def enable_sync_bn(flag=True):
     ops.set_sync_bn(_sync_bn_reduce if flag else None)
 
 
-def sync_bn_buffers(model):
+def sync_bn_buffers(model, weight=None):
     """Per-shard BatchNorm (the default, sync_bn off) leaves every rank with running_mean / running_var of its OWN shards; evaluation and
-    the checkpoint (written by rank 0) would then depend on the rank.  Called at the end of a training epoch: the floating-point buffers
-    are averaged over the ranks (num_batches_tracked is identical everywhere).  A no-op without collectives or with sync_bn on (the
-    statistics are already global there, averaging identical values changes nothing but rounding -- skipped).
+    the checkpoint (written by rank 0) would then depend on the rank.  Called at the end of a training epoch: the buffers of all ranks are
+    merged the way two populations are pooled (law of total variance), weighted by the utterances every rank has seen since the last
+    merge (`weight`; default: the count set_batch_split accumulated, 1 if none -- equal shards):
 
-    An APPROXIMATION of the single-process buffers, by construction of per-shard statistics: running_mean is exact for equal shards (the
-    moving average is linear in the per-step means); running_var becomes the rank average of the per-shard variances, i.e. the global
-    batch variance MINUS the between-shard variance of the means, E_k[Var_r(mu_{r,k})] -- about 1 / (rows per shard) of the variance for
-    i.i.d. shards (1 / 25 600 at cfg2), and not recoverable from the averaged buffers: the moving average of a variance of means is not
-    the variance of the moving averages.  Uneven shards (the last batch of an epoch) are weighted equally.  `enable_sync_bn()` is the
-    exact mode."""
+        running_mean = sum_r p_r rm_r                     running_var = sum_r p_r rv_r + sum_r p_r (rm_r - running_mean)^2
+
+    (round 4 averaged the variances and dropped the second term).  What this recovers and what it cannot: with per-shard statistics the
+    single-process running_var is the moving average of [E_r var_{r,k} + Var_r mu_{r,k}] over the steps k; the buffers hold the moving
+    averages of var_{r,k} and of mu_{r,k} SEPARATELY, so the between-shard term is available only as the variance of the AVERAGED means:
+    exact for differences between the shards that persist over the steps, while step-to-step sampling noise of the shard means is
+    averaged away before it can be squared (the cross-rank product mu_{r,k} mu_{s,k} of one step is not in any rank's buffer).  The
+    remainder is of the order of var / (independent frames per shard) and goes to zero as the shards grow; `enable_sync_bn()` is the exact
+    mode.  num_batches_tracked is identical everywhere.  A no-op without collectives or with sync_bn on.  Returns the
+    number of buffers merged."""
     if not _collectives_on() or world_size() == 1:
         return 0
     from . import ops
     if ops._sync_bn["reduce"] is not None:
         return 0
-    bufs = [b for _, b in model.named_buffers() if b.is_floating_point()]
-    if not bufs:
+    mods = [m for m in model.modules() if getattr(m, "running_mean", None) is not None and getattr(m, "running_var", None) is not None]
+    if not mods:
         return 0
-    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= world_size()
+    w = float(_batch["seen"] if weight is None and _batch.get("seen") else (1.0 if weight is None else weight))
+    _batch["seen"] = 0
+    means = torch.cat([m.running_mean.detach().reshape(-1).double() for m in mods])
+    vars_ = torch.cat([m.running_var.detach().reshape(-1).double() for m in mods])
+    n = means.numel()
+    # one collective: [w, w * mean, w * (var + mean^2)] -- the pooled second moment minus the pooled mean squared is the formula above
+    pack = torch.cat([torch.full((1,), w, dtype=torch.float64, device=means.device), w * means, w * (vars_ + means * means)])
+    if dist.get_backend() == "nccl" and not pack.is_cuda:
+        pack = pack.cuda()
+    dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    pack = pack.to(means.device)
+    tot = pack[0]
+    mean = pack[1:1 + n] / tot
+    var = (pack[1 + n:] / tot - mean * mean).clamp_(min=0.0)
     off = 0
     with torch.no_grad():
-        for b in bufs:
-            n = b.numel()
-            b.copy_(flat[off:off + n].view_as(b))
-            off += n
-    return len(bufs)
+        for m in mods:
+            c = m.running_mean.numel()
+            m.running_mean.copy_(mean[off:off + c].view_as(m.running_mean))
+            m.running_var.copy_(var[off:off + c].view_as(m.running_var))
+            off += c
+    return 2 * len(mods)
 
 
 def broadcast_params(flat_params, src=0):

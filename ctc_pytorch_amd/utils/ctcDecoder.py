@@ -110,14 +110,15 @@ class GreedyDecoder(Decoder):
         """Collapsed ids (B, T) + lengths -> the reference's strings: each kept frame contributes ' ' + phone when space_idx == -1, else the
         space symbol becomes ' ' (ctcDecoder.py:80-92) -- one native pass (ops.join_tokens) over a vocabulary with that already applied."""
         voc = getattr(self, "_voc", None)
-        if voc is None or voc[0] is not self.int_to_char or voc[1] != self.space_idx:
+        snap = tuple(self.int_to_char.items()) if isinstance(self.int_to_char, dict) else tuple(self.int_to_char)     # (content, not identity: an edited vocabulary must not decode through the old one)
+        if voc is None or voc[0] != snap or voc[1] != self.space_idx:
             items = self.int_to_char.items() if isinstance(self.int_to_char, dict) else enumerate(self.int_to_char)
             if self.space_idx == -1:
                 words = {k: " " + w for k, w in items}
             else:
                 sp = self.int_to_char[self.space_idx]
                 words = {k: (" " if w == sp else w) for k, w in items}
-            voc = self._voc = (self.int_to_char, self.space_idx, words)
+            voc = self._voc = (snap, self.space_idx, words)
         return ops.join_tokens(ids_c, len_c, voc[2], "")
 
     def decode(self, prob_tensor, frame_seq_len):

@@ -79,32 +79,48 @@ def skip_feat(feature, skip):
 
 # ---- vocabulary / dataset / collate -----------------------------------------------------------------------
 class Vocab(object):
+    """Phone / character inventory of a `units` file (timit/utils/data_loader.py:12-48): ids 0 and 1 are the CTC blank and UNK, every other
+    symbol gets the next free id in order of first appearance; a line is either `symbol` or `key symbol symbol ...` (the key is dropped).
+    Public surface the drivers and checkpoints read: word2index, index2word, word2count, n_words (+ add_word / add_sentence for callers that
+    extend an inventory).  Built in one pass: the file's symbols are counted, then numbered from the counter's insertion order."""
+
+    RESERVED = ("blank", "UNK")
+
     def __init__(self, vocab_file):
         self.vocab_file = vocab_file
-        self.word2index = {"blank": 0, "UNK": 1}
-        self.index2word = {0: "blank", 1: "UNK"}
+        self.word2index = {w: i for i, w in enumerate(self.RESERVED)}
+        self.index2word = dict(enumerate(self.RESERVED))
         self.word2count = {}
-        self.n_words = 2
         self.read_lang()
 
-    def add_sentence(self, sentence):
-        for word in sentence.split(" "):
-            self.add_word(word)
+    @property
+    def n_words(self):
+        return len(self.word2index)
+
+    def _absorb(self, symbols):
+        """Count `symbols` (an iterable) and number the unseen ones behind the current inventory."""
+        from collections import Counter
+        seen = Counter(symbols)                    # insertion-ordered: first appearance decides the id
+        for w, c in seen.items():
+            if w in self.word2index:               # (a reserved name inside the file raises KeyError in the reference's counter too)
+                self.word2count[w] += c
+                continue
+            k = len(self.word2index)
+            self.word2index[w], self.index2word[k], self.word2count[w] = k, w, c
 
     def add_word(self, word):
-        if word not in self.word2index:
-            self.word2index[word] = self.n_words
-            self.word2count[word] = 1
-            self.index2word[self.n_words] = word
-            self.n_words += 1
-        else:
-            self.word2count[word] += 1
+        self._absorb((word,))
+
+    def add_sentence(self, sentence):
+        self._absorb(sentence.split(" "))
 
     def read_lang(self):
-        with open(self.vocab_file, "r") as rf:
-            for raw in rf:
-                parts = raw.strip().split(" ")
-                self.add_sentence(" ".join(parts[1:]) if len(parts) > 1 else parts[0])
+        def symbols(fh):
+            for raw in fh:
+                fields = raw.strip().split(" ")
+                yield from (fields[1:] if len(fields) > 1 else fields)
+        with open(self.vocab_file, "r") as fh:
+            self._absorb(symbols(fh))
 
 
 class SpeechDataset(Dataset):

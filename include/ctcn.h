@@ -182,6 +182,11 @@ typedef struct ctcn_rnn_call {
   /* device int32 the persistent kernels of THIS call set on a hand-off timeout (sticky); NULL: the process default of
    * ctcn_set_status_buffer (which may be NULL too: timeouts then only poison the output). */
   int *status;
+  /* out (the one field the library writes): where the name of the recurrent kernel THIS call launched is stored (a string literal:
+   * "rnn_fwd_tagged", "rnn_fwd_persist", "rnn_fwd_step", "rnn_bwd_scatter2", "rnn_bwd_scatter", "rnn_bwd_persist", "rnn_bwd_step"); NULL: not
+   * wanted.  Per call, unlike the process-wide ctcn_rnn_last_kernel (last writer of any thread wins): what the host's batch-chunk decision
+   * reads. */
+  const char **launched;
 } ctcn_rnn_call;
 int ctcn_rnn_fwd_ex(int cell, int T, int B, int I, int H, int dirs, const float *x, const float *w_ih0, const float *w_hh0,
                     const float *w_ih1, const float *w_hh1, float *y, float *gates, float *aux, int precision, void *ws, size_t ws_bytes,
@@ -368,12 +373,12 @@ const char *ctcn_rnn_last_kernel(int which);
 /* ---- host end of the decoders (hostjoin.hip; no kernel, no HIP call: works without a GPU) -------------------------------------------------
  * replaces: `' '.join(self.classes[k] for k in labelling)` (BeamSearch.py:152-153; ctcDecoder.py:60-118 for the greedy decoder), once per
  * utterance of a decoded batch.  ids: B rows of `row_stride` int32 label ids (the pinned copy of ctcn_beam_decode's out_ids), lens[b] valid
- * per row; words / word_off[V + 1]: the vocabulary's UTF-8 bytes back to back, followed by 16 readable bytes, and their offsets
- * (word_off[k] > word_off[k + 1]: id k has no word); sep: the byte between two words (0: none).  Writes row b's string to
+ * per row; words / word_off[V] / word_len[V]: the vocabulary's UTF-8 bytes back to back, followed by 16 readable bytes, the byte offset and
+ * the byte length of every word (word_len[k] < 0: id k has no word); sep: the byte between two words (0: none).  Writes row b's string to
  * out[out_off[b] .. out_off[b + 1]) and returns out_off[B]; CTCN_EINVAL on bad arguments, CTCN_EWORKSPACE when out_cap is too small (result + 17 bytes), -(16 + k) for an id k outside the vocabulary (the KeyError /
  * IndexError of the Python expression). */
 long long ctcn_join_tokens(const int32_t *ids, long long row_stride, const int32_t *lens, int B, const char *words, const int32_t *word_off,
-                           int V, int sep, char *out, long long out_cap, long long *out_off);
+                           const int32_t *word_len, int V, int sep, char *out, long long out_cap, long long *out_off);
 /* ctcn_levenshtein: unit-cost edit distance of two int32 sequences (the code points of two strings, or word ids), host code.
  * replaces: Decoder._edit_distance (ctcDecoder.py:131-150; cer :127-129 and wer :118-125 call it once per decoded utterance).  -1 on bad
  * arguments. */

@@ -309,7 +309,7 @@ def test_rnn_persistent_equals_per_step_launches(dev, kind, T, B, I, H, bi):
         assert rel_l2(g1, g0) < 2e-6
 
 
-@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 40, 144, 48, 320, True), ("gru", 33, 300, 24, 256, True), ("lstm", 25, 600, 16, 64, False), ("lstm", 30, 140, 40, 512, True)])
+@pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 40, 144, 48, 320, True), ("gru", 33, 300, 24, 256, True), ("lstm", 25, 288, 16, 320, False), ("lstm", 30, 140, 40, 512, True)])
 def test_rnn_batch_chunks_equal_one_launch_per_timestep(dev, kind, T, B, I, H, bi):
     """A batch that no persistent launch holds runs as batch chunks of ops.persistent_batch_limit rows, one persistent launch each (round 4),
     from the shape's second call on -- the first call is seen to fall back to the per-timestep kernels and marks the shape.  Output, input
@@ -349,6 +349,60 @@ def test_rnn_batch_chunks_equal_one_launch_per_timestep(dev, kind, T, B, I, H, b
         assert torch.isfinite(g1).all() and rel_l2(g1, g0) < 5e-5
     ops._drop_counter[0] = 77
     assert torch.equal(runs["chunks_drop"][0], ops.dropout(runs["chunks"][0], 0.3, True))
+
+
+@pytest.mark.parametrize("B,H", [(160, 320), (144, 512)])
+def test_rnn_batch_chunks_into_flat_gradients(dev, B, H):
+    """ Batch chunks whose weight gradients ACCUMULATE into shared flat-gradient views (the FlatAdam arrangement, `_ctcn_grad`)
+    with the side stream forced on for every size: all chunks of a layer must write those views on the main stream, in order (a 32-row
+    chunk at H = 320 has idle XCDs and would otherwise defer its GEMMs to the side stream, next to a sibling chunk's inline
+    read-modify-write of the same buffers).  Two stacked layers, so that a recurrence follows and the deferral path is live; three
+    repetitions must give bit-identical gradients, and they must agree with the unchunked per-timestep kernels."""
+    from ctc_pytorch_amd import ops
+    ops.set_precision(1)
+    T, I = 30, 48
+    torch.manual_seed(5)
+    x = torch.randn(T, B, I, device=dev)
+    mk = lambda i: [torch.randn(4 * H, i, device=dev) * 0.1, torch.randn(4 * H, H, device=dev) * (1.0 / H ** 0.5),
+                    torch.randn(4 * H, i, device=dev) * 0.1, torch.randn(4 * H, H, device=dev) * (1.0 / H ** 0.5)]
+    w0, w1 = mk(I), mk(2 * H)
+    dy = torch.randn(T, B, 2 * H, device=dev)
+    key = (0, H, 2, B)
+
+    def run(chunks, flat):
+        ops.set_batch_chunks(chunks)
+        ws = [t.clone().requires_grad_(True) for t in w0 + w1]
+        views = None
+        if flat:
+            views = [torch.zeros_like(t) for t in ws]
+            for t, g in zip(ws, views):
+                t._ctcn_grad = g
+        xs = x.clone().requires_grad_(True)
+        h = ops.rnn_layer(xs, ws[0], ws[1], ws[2], ws[3], "lstm", True, 0.0)
+        y = ops.rnn_layer(h, ws[4], ws[5], ws[6], ws[7], "lstm", True, 0.0)
+        y.backward(dy)
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        ops.check_health(dev)
+        return [xs.grad.clone()] + ([g.clone() for g in views] if flat else [t.grad.clone() for t in ws]), ops.rnn_last_kernels()
+
+    ops._fallback_shapes.discard(key)
+    try:
+        ops.set_side_stream(True, 0)
+        ref, names_ref = run(False, False)                 # unchunked: the per-timestep kernels
+        assert "step" in names_ref[0] + names_ref[1], names_ref
+        ops.mark_batch_chunks("lstm", H, 2, B)
+        got = [run(True, True) for _ in range(3)]
+    finally:
+        ops.set_side_stream(True, ops.SIDE_MIN_ITEMS_FWD, ops.SIDE_MIN_ITEMS_BWD)
+        ops.set_batch_chunks(True)
+        ops._fallback_shapes.discard(key)
+    assert "step" not in got[0][1][0] + got[0][1][1], got[0][1]
+    for rep in got[1:]:
+        for a, b in zip(got[0][0], rep[0]):
+            assert torch.equal(a, b), "chunked weight gradients differ between repetitions (a race on the shared views)"
+    for g1, g0 in zip(got[0][0], ref):
+        assert torch.isfinite(g1).all() and rel_l2(g1, g0) < 5e-5
 
 
 @pytest.mark.parametrize("kind,T,B,I,H,bi,drop", [("lstm", 50, 32, 40, 320, True, 0.0), ("lstm", 40, 8, 64, 384, True, 0.2), ("gru", 30, 64, 24, 512, True, 0.0),

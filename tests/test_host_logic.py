@@ -397,8 +397,26 @@ import torch.nn as tnn
 bn = tnn.Sequential(tnn.BatchNorm1d(3), tnn.Linear(3, 2))
 with torch.no_grad():
     bn[0].running_mean.fill_(1.0 + rank); bn[0].running_var.fill_(2.0 + 2 * rank); bn[0].num_batches_tracked.fill_(5)
+parallel._batch["seen"] = 0                            # (the splits set above counted utterances: equal weights for this one)
 assert parallel.sync_bn_buffers(bn) == 2
-assert torch.equal(bn[0].running_mean, torch.full((3,), 1.5)) and torch.equal(bn[0].running_var, torch.full((3,), 3.0)) and int(bn[0].num_batches_tracked) == 5
+# pooled like two populations: mean 1.5, variance = E[var] + Var[mean] = 3 + 0.25 (round 4 dropped the second term)
+assert torch.equal(bn[0].running_mean, torch.full((3,), 1.5)) and torch.equal(bn[0].running_var, torch.full((3,), 3.25)) and int(bn[0].num_batches_tracked) == 5
+# uneven shards: weighted by the utterances each rank saw since the last merge (set_batch_split counts them)
+with torch.no_grad():
+    bn[0].running_mean.fill_(1.0 + rank); bn[0].running_var.fill_(2.0 + 2 * rank)
+parallel.set_batch_split(4, 3 if rank == 0 else 1)
+parallel.set_batch_split(None, None)
+assert parallel.sync_bn_buffers(bn) == 2
+assert torch.allclose(bn[0].running_mean, torch.full((3,), 1.25)) and torch.allclose(bn[0].running_var, torch.full((3,), 2.5 + 0.1875))
+# against the single-process buffers: shards that differ systematically (momentum 1: the buffers are the last batch's statistics)
+gen = torch.Generator().manual_seed(11)
+data = torch.randn(2, 4000, 3, generator=gen) * torch.tensor([1.0, 2.0, 0.5]) + torch.tensor([[[0.0, 1.0, -2.0]], [[3.0, 1.5, -2.5]]])
+one = tnn.BatchNorm1d(3, momentum=1.0).train(); one(data.reshape(-1, 3))
+mine = tnn.BatchNorm1d(3, momentum=1.0).train(); mine(data[rank])
+assert parallel.sync_bn_buffers(mine) == 2
+assert torch.allclose(mine.running_mean, one.running_mean, atol=1e-5) and torch.allclose(mine.running_var, one.running_var, rtol=1e-3)
+avg_only = 0.5 * (data[0].var(0) + data[1].var(0))
+assert (one.running_var - avg_only).abs().max() > 0.05          # (what the rank average of the variances alone misses here)
 parallel.enable_sync_bn(True)
 assert parallel.sync_bn_buffers(bn) == 0              # global statistics already: nothing to do
 parallel.enable_sync_bn(False)
@@ -637,6 +655,19 @@ def test_join_tokens_equals_the_python_join():
     with pytest.raises(KeyError):
         ops.join_tokens(np.full((1, 3), 7, np.int32), np.array([3], np.int32), holes)
     assert ops.join_tokens(np.full((1, 3), 8, np.int32), np.array([3], np.int32), holes) == [" ".join([phones[8]] * 3)]
+    #  a hole must not touch its neighbours: the id in front of it, the id behind it, two holes in a row, a hole at the end
+    assert ops.join_tokens(np.array([[0, 1, 3]], np.int32), np.array([3], np.int32), {0: "ab", 1: "cd", 3: "ef"}) == ["ab cd ef"]
+    two = {0: "ab", 1: "cd", 4: "gh"}
+    assert ops.join_tokens(np.array([[1, 4, 0]], np.int32), np.array([3], np.int32), two) == ["cd gh ab"]
+    for k in (2, 3):
+        with pytest.raises(KeyError):
+            ops.join_tokens(np.array([[0, k]], np.int32), np.array([2], np.int32), two)
+    assert ops.join_tokens(np.array([[6, 5, 6]], np.int32), np.array([3], np.int32), holes) == [" ".join([phones[6], phones[5], phones[6]])]
+    # a vocabulary edited in place is seen (the cache is confirmed by content)
+    edit = list(phones)
+    assert ops.join_tokens(np.array([[2, 3]], np.int32), np.array([2], np.int32), edit) == [phones[2] + " " + phones[3]]
+    edit[3] = "zz"
+    assert ops.join_tokens(np.array([[2, 3]], np.int32), np.array([2], np.int32), edit) == [phones[2] + " zz"]
     with pytest.raises(IndexError):
         ops.join_tokens(np.full((1, 3), V, np.int32), np.array([2], np.int32), phones)
     with pytest.raises(IndexError):
@@ -647,10 +678,10 @@ def test_join_tokens_equals_the_python_join():
         ops.join_tokens(ids, lens, phones, sep=", ")
     # the raw entry point: a capacity that is too small is reported, not overrun
     from ctc_pytorch_amd import _lib
-    blob, off, longest, Vv = ops._vocabulary(phones)
+    blob, off, ln, longest, Vv = ops._vocabulary(phones)
     out, oo = np.zeros(8, np.uint8), np.zeros(B + 1, np.int64)
-    assert _lib.lib().ctcn_join_tokens(ids.ctypes.data, T, lens.ctypes.data, B, blob, off.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -4
-    assert _lib.lib().ctcn_join_tokens(None, T, lens.ctypes.data, B, blob, off.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -1
+    assert _lib.lib().ctcn_join_tokens(ids.ctypes.data, T, lens.ctypes.data, B, blob, off.ctypes.data, ln.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -4
+    assert _lib.lib().ctcn_join_tokens(None, T, lens.ctypes.data, B, blob, off.ctypes.data, ln.ctypes.data, Vv, 32, out.ctypes.data, 8, oo.ctypes.data) == -1
 
 
 def test_greedy_decoder_strings_equal_the_reference_expression():
