@@ -216,26 +216,12 @@ def recurrence_probe(dev, c):
                      "W_hh transposes); layer_*: with the input-projection (fwd) / deferred gradient (bwd) GEMMs")
 
 
-def run_train(args):
-    from ctc_pytorch_amd import nn, parallel
+def make_training_step(c, dev, rank, world):
+    """Model, optimiser, resident synthetic batch and the step closure of one workload: forward -> CTC (sum) / B_global -> backward ->
+    gradient all-reduce -> fused Adam.  The SAME closure is what the headline number and the `other_workloads` entries time."""
+    from ctc_pytorch_amd import nn, parallel, ops as _ops
     from ctc_pytorch_amd.optim import FlatAdam
     from oracle import synth                      # synthetic inputs only (no arithmetic)
-    rank, world, local = parallel.init_from_env()
-    parallel.enable_sync_bn(bool(getattr(args, "sync_bn", False)))
-    parallel.enable_overlap(True)       # per-layer gradient slices are all-reduced behind their weight GEMMs (no-op without collectives)
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    c = dict(WORKLOADS[args.workload])
-    for key in ("T", "B", "H", "L"):                                           # experiment aid (tools/ab_env.sh): the named workload at another T / B / H / L --
-        if os.environ.get("CTCN_BENCH_" + key):                                # the config string of the line reports them; never a headline number
-            c[key] = int(os.environ["CTCN_BENCH_" + key])
-    if os.environ.get("CTCN_BENCH_RNN"):
-        c["rnn"] = os.environ["CTCN_BENCH_RNN"]
-    from ctc_pytorch_amd import ops as _ops
-    _ops.set_precision(args.precision)
     torch.manual_seed(1)
     model = build(c, dev, drop_out=c.get("drop", 0.1)).train()
     opt = FlatAdam(model, lr=1e-3, weight_decay=5e-4)
@@ -247,18 +233,14 @@ def run_train(args):
     tl = torch.from_numpy(batch["tgt_len"]).to(dev)
     loss_fn = nn.CTCLoss(reduction="sum")
     global_b = c["B"] * world
-    in_len = None
-    losses = []
-    overlapped = [0]
-
-    early_bytes = [0]
+    state = {"in_len": None}
+    overlapped, early_bytes = [0], [0]
 
     def step(mark=None):
-        nonlocal in_len
         out = model(x)
-        if in_len is None:
-            in_len = torch.full((c["B"],), out.size(0), dtype=torch.int64, device=dev)
-        loss = loss_fn(out, tg, in_len, tl) / global_b
+        if state["in_len"] is None:
+            state["in_len"] = torch.full((c["B"],), out.size(0), dtype=torch.int64, device=dev)
+        loss = loss_fn(out, tg, state["in_len"], tl) / global_b
         opt.zero_grad()
         loss.backward()
         _ops.join_side_stream()
@@ -282,6 +264,77 @@ def run_train(args):
         if i >= 2:
             ring[(i - 2) % 3].synchronize()
         return out
+
+    return dict(step=step, paced=paced, model=model, opt=opt, batch=batch, loss_fn=loss_fn, global_b=global_b, overlapped=overlapped,
+                early_bytes=early_bytes)
+
+
+def other_workloads(dev, precision, names=("cfg1", "cfg3", "cfg4", "ref_yaml"), steps=10, warmup=2, prewarm=12):
+    """The other single-GPU BASELINE workloads (and the reference's shipped YAML shape) through the SAME step closure as the headline,
+    in the same process, so that a driver-run line carries them (VERDICT r4 #1 iv): ms per step (barrier-free single rank: wall clock over
+    `steps` steps between two synchronisations, after `prewarm` + `warmup` untimed ones), frames/s, and the per-timestep time of both
+    persistent recurrences of one layer.  No CPU leg, no decode leg; a few seconds per workload."""
+    from ctc_pytorch_amd import ops as _ops
+    out = {}
+    for name in names:
+        c = dict(WORKLOADS[name])
+        try:
+            ts = make_training_step(c, dev, 0, 1)
+            for i in range(prewarm + warmup):
+                ts["paced"](i)
+            torch.cuda.synchronize()
+            gc_was = gc.isenabled()
+            gc.collect()
+            gc.disable()
+            try:
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    loss = ts["paced"](i)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+            finally:
+                if gc_was:
+                    gc.enable()
+            _ops.check_health()
+            rec = recurrence_probe(dev, c)
+            out[name] = dict(ms_per_step=dt * 1e3, value=c["B"] * c["T"] / dt, unit="frames/s", steps=steps, warmup=warmup, prewarm_steps=prewarm,
+                             final_loss=float(loss.detach()),
+                             fwd_us_per_timestep=rec["fwd_us_per_timestep"], bwd_us_per_timestep=rec["bwd_us_per_timestep"],
+                             fwd_kernel=rec["fwd_kernel"], bwd_kernel=rec["bwd_kernel"], recurrent_steps_per_layer=rec["T"],
+                             workload="%s: %dx%d Bi%s, B=%d, T=%d, F=%d, V=%d%s, dropout %.1f" % (name, c["L"], c["H"], c["rnn"], c["B"], c["T"], c.get("F", 40),
+                                                                                              c["V"], ", 2-layer CNN front-end" if c["cnn"] else "", c.get("drop", 0.1)))
+            del ts
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def run_train(args):
+    from ctc_pytorch_amd import nn, parallel
+    from ctc_pytorch_amd.optim import FlatAdam
+    from oracle import synth                      # synthetic inputs only (no arithmetic)
+    rank, world, local = parallel.init_from_env()
+    parallel.enable_sync_bn(bool(getattr(args, "sync_bn", False)))
+    parallel.enable_overlap(True)       # per-layer gradient slices are all-reduced behind their weight GEMMs (no-op without collectives)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    c = dict(WORKLOADS[args.workload])
+    for key in ("T", "B", "H", "L"):                                           # experiment aid (tools/ab_env.sh): the named workload at another T / B / H / L --
+        if os.environ.get("CTCN_BENCH_" + key):                                # the config string of the line reports them; never a headline number
+            c[key] = int(os.environ["CTCN_BENCH_" + key])
+    if os.environ.get("CTCN_BENCH_RNN"):
+        c["rnn"] = os.environ["CTCN_BENCH_RNN"]
+    from ctc_pytorch_amd import ops as _ops
+    _ops.set_precision(args.precision)
+    ts = make_training_step(c, dev, rank, world)
+    step, paced, model, opt, batch, loss_fn, global_b = ts["step"], ts["paced"], ts["model"], ts["opt"], ts["batch"], ts["loss_fn"], ts["global_b"]
+    overlapped, early_bytes = ts["overlapped"], ts["early_bytes"]
+    losses = []
 
     # start-up transient: the first tens of steps of a fresh process carry allocator growth and the interpreter's first cyclic-GC passes
     # (five runs with 5 warm-up steps: 13.7-14.9 ms, with 40: 13.75-13.77), so PREWARM untimed steps run before the W warm-up steps the
@@ -442,6 +495,8 @@ def run_train(args):
             res["decode"] = decode_leg(dev)
         except Exception as e:
             res["decode"] = {"error": repr(e)}
+    if world == 1 and args.workload == "cfg2" and not args.no_others:
+        res["other_workloads"] = other_workloads(dev, args.precision)
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_train(c, batch, steps=args.cpu_steps)
     print(json.dumps(res))
@@ -567,6 +622,7 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="train", choices=["train", "decode"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the cfg5 beam-decode leg of the default (N=1, train) run")
+    ap.add_argument("--no-others", action="store_true", help="skip the `other_workloads` object (cfg1 / cfg3 / cfg4 / ref_yaml) of the default cfg2 run")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed CPU train steps per thread setting of the sweep")
     ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "1")), choices=[0, 1],
                     help="0: exact f32 MFMA GEMMs; 1: bf16x3 split-operand MFMA GEMMs (f32-class accuracy)")

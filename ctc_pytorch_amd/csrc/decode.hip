@@ -383,7 +383,7 @@ constexpr int FAST_NCT = 1024 - 192;                           // candidate thre
 constexpr int FAST_NTH = 1024, FAST_NWV = FAST_NTH / 64;      // 16 waves: the parallel phases are instruction-issue bound (~10 cycles per
                                                                // dependent instruction and wave), so more waves per SIMD is what shortens them
 template <int NPT, bool LM_LDS>
-__global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
+__device__ __forceinline__ void beam_fast_body(FastArgs a) {
   constexpr int NTH = FAST_NTH, NWV = FAST_NWV;
   // dynamic LDS: [alpha*LM (V+1)^2 doubles] | cand[W*V] doubles | lg[2][V] doubles (by frame parity) | mslot[W*V] ints | flist[T] ints | trie[slots] uints
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
@@ -1097,6 +1097,16 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) {
   }
 }
 
+// the two launch forms of the fast search.  beam_fast_kernel: one workgroup per CU (120 VGPRs, up to 144 KB of dynamic LDS: the 16 K-slot
+// trie).  beam_fast_kernel_occ2 (round 5, option "beam_occ2"): the same body compiled for eight waves per SIMD (<= 64 VGPRs) and launched
+// with <= 68 KB of dynamic LDS, so that TWO utterances share a CU and each one's serial chain runs in the other's shadow -- the body is
+// latency-bound (wave 0's ~2 k-cycle chain per frame), so the second workgroup costs the first little as long as more than one workgroup per
+// CU is in flight (three 128-utterance batches on three streams: 384 workgroups on 256 CUs).
+template <int NPT, bool LM_LDS>
+__global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) { beam_fast_body<NPT, LM_LDS>(a); }
+template <int NPT, bool LM_LDS>
+__global__ __launch_bounds__(FAST_NTH) __attribute__((amdgpu_waves_per_eu(8, 8))) void beam_fast_kernel_occ2(FastArgs a) { beam_fast_body<NPT, LM_LDS>(a); }
+
 struct BeamLayout { size_t keys, ids, npar, nsym, cand, total; int ht_size, max_nodes; };
 BeamLayout beam_layout(int T, int B, int V, int W) {
   BeamLayout l;
@@ -1116,7 +1126,7 @@ BeamLayout beam_layout(int T, int B, int V, int W) {
 
 // fast path: [hash table | node parents | node symbols | ln p (T,B,V) double | p_blank (T,B) | log(0) flags (T,B)]
 struct FastLayout { size_t ht, npar, nsym, lgd, pb, zf, total; int ht_size, max_nodes, npt, trie_slots; bool ok, lm_lds; size_t lds; };
-FastLayout fast_layout(int T, int B, int V, int W) {
+FastLayout fast_layout(int T, int B, int V, int W, int occ2 = 0) {
   FastLayout l = {};
   l.max_nodes = W * T + 2;
   int ht = 1024;
@@ -1134,11 +1144,14 @@ FastLayout fast_layout(int T, int B, int V, int W) {
   if (l.npt > 4) l.npt = 0;
   const size_t core = ((size_t)W * V + 2 * V) * sizeof(double) + ((size_t)W * V + T) * sizeof(int);   // cand, lg[2] | mslot, flist
   const size_t lm = (size_t)(V + 1) * (V + 1) * sizeof(double);
-  const size_t budget = 144 * 1024;                     // of the CU's 160 KB (the kernel also has ~8 KB of static LDS)
+  // of the CU's 160 KB (the kernel also has ~12 KB of static LDS); occ2: two workgroups per CU, 80 KB each
+  const size_t budget = occ2 ? 68 * 1024 : 144 * 1024;
   // LDS trie: as many slots as fit, at most 16 K (node ids of the LDS table must fit 14 bits); then the LM if it still fits
+  // (occ2 == 2: the LM stays in global memory -- L1 / L2 gathers in the parallel scoring phase -- and the trie gets its share)
+  const bool want_lm = lm <= 40 * 1024 && occ2 != 2;
   l.trie_slots = 16384;
-  while (l.trie_slots > 1024 && core + (size_t)l.trie_slots * 4 + (lm <= 40 * 1024 ? lm : 0) > budget) l.trie_slots >>= 1;
-  l.lm_lds = core + (size_t)l.trie_slots * 4 + lm <= budget;
+  while (l.trie_slots > 1024 && core + (size_t)l.trie_slots * 4 + (want_lm ? lm : 0) > budget) l.trie_slots >>= 1;
+  l.lm_lds = occ2 != 2 && core + (size_t)l.trie_slots * 4 + lm <= budget;
   l.lds = core + (size_t)l.trie_slots * 4 + (l.lm_lds ? lm : 0);
   l.ok = W <= 60 && l.npt > 0 && V <= 256 && l.max_nodes < (1 << 24) && T < (1 << 22) && l.lds <= budget;
   return l;
@@ -1148,7 +1161,19 @@ FastLayout fast_layout(int T, int B, int V, int W) {
 long long *g_beam_stats_dev = nullptr;
 #endif
 template <int NPT>
-int launch_fast(const FastLayout &l, const FastArgs &a, hipStream_t st) {
+int launch_fast(const FastLayout &l, const FastArgs &a, hipStream_t st, int occ2) {
+  if (occ2) {
+    if (l.lm_lds) {
+      auto kern = beam_fast_kernel_occ2<NPT, true>;
+      CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+      hipLaunchKernelGGL(kern, dim3(a.B), dim3(FAST_NTH), l.lds, st, a);
+    } else {
+      auto kern = beam_fast_kernel_occ2<NPT, false>;
+      CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+      hipLaunchKernelGGL(kern, dim3(a.B), dim3(FAST_NTH), l.lds, st, a);
+    }
+    return CTCN_OK;
+  }
   if (l.lm_lds) {
     auto kern = beam_fast_kernel<NPT, true>;
     CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
@@ -1177,7 +1202,8 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   CTCN_REQUIRE(nbest >= 1 && nbest <= W, "ctcn_beam_decode_nbest: nbest %d outside [1, beam width %d]", nbest, W);
   hipStream_t st = (hipStream_t)stream;
   char *base = (char *)ws;
-  const FastLayout fl = fast_layout(T, B, V, W);
+  const int occ2 = ctcn_get_option("beam_occ2");
+  const FastLayout fl = fast_layout(T, B, V, W, occ2);
   if (fl.ok && ctcn_get_option("beam_fast") != 0) {
     if (ws_bytes < fl.total) { ctcn_set_error("ctcn_beam_decode: workspace too small (%zu < %zu)", ws_bytes, fl.total); return CTCN_EWORKSPACE; }
     CTCN_HIP(hipMemsetAsync(base + fl.ht, 0xFF, (size_t)B * fl.ht_size * sizeof(unsigned long long), st));
@@ -1201,10 +1227,10 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
     CTCN_LAUNCH_CHECK();
     int rc;
     switch (fl.npt) {
-      case 1: rc = launch_fast<1>(fl, a, st); break;
-      case 2: rc = launch_fast<2>(fl, a, st); break;
-      case 3: rc = launch_fast<3>(fl, a, st); break;
-      default: rc = launch_fast<4>(fl, a, st); break;
+      case 1: rc = launch_fast<1>(fl, a, st, occ2); break;
+      case 2: rc = launch_fast<2>(fl, a, st, occ2); break;
+      case 3: rc = launch_fast<3>(fl, a, st, occ2); break;
+      default: rc = launch_fast<4>(fl, a, st, occ2); break;
     }
     if (rc) return rc;
     CTCN_LAUNCH_CHECK();

@@ -1749,8 +1749,31 @@ static int launch_planes(bool queued, int nt, int psplits, hipStream_t st, int M
 __global__ void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int M, int N, int ldc,
                                      int splits, float beta) {
   const size_t total = (size_t)M * N;
+  // the partials are summed in split order (the result does not depend on the launch), eight loads in flight at a time.
+  // Round 5: 16-B loads / stores and a 32-bit division per FOUR outputs where the shape allows (every product of the training step:
+  // N, ldc multiples of 4, 16-B aligned C and partials) -- the same additions in the same order, bit-identical to the scalar form below.
+  if ((N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)C | (uintptr_t)ws) & 15) == 0 && total < ((size_t)1 << 33)) {
+    const unsigned n4 = (unsigned)(N >> 2), total4 = (unsigned)(total >> 2);
+    const float4 *w4 = reinterpret_cast<const float4 *>(ws);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+      float4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+      int z = 0;
+      for (; z + 8 <= splits; z += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w4[(size_t)(z + u) * total4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; z < splits; ++z) { const float4 v = w4[(size_t)z * total4 + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      const unsigned m = i / n4, n = (i - m * n4) << 2;
+      float4 *p = reinterpret_cast<float4 *>(C + (size_t)m * ldc + n);
+      if (beta != 0.0f) { const float4 o = *p; s.x += beta * o.x; s.y += beta * o.y; s.z += beta * o.z; s.w += beta * o.w; }
+      *p = s;
+    }
+    return;
+  }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    // the partials are summed in split order (the result does not depend on the launch), eight loads in flight at a time
     float s = 0.0f;
     int z = 0;
     for (; z + 8 <= splits; z += 8) {

@@ -483,15 +483,21 @@ def gen_lm():
 # ---------------------------------------------------------------------------------------------
 # (6) large-shape checksums (BASELINE cfg2/cfg3/cfg4): loss + per-parameter grad norms
 # ---------------------------------------------------------------------------------------------
-def gen_large():
-    res = {}
+def gen_large(only=""):
+    path = os.path.join(GOLD, "large_checksums.json")
+    res = json.load(open(path)) if (only and os.path.exists(path)) else {}
     cfgs = {
         "cfg2": dict(B=32, T=800, V=62, H=320, L=4, rnn=nn.LSTM, cnn=False),
         "cfg3": dict(B=32, T=800, V=62, H=320, L=4, rnn=nn.LSTM, cnn=True),
         "cfg4": dict(B=8, T=1200, V=200, H=512, L=5, rnn=nn.GRU, cnn=False),
+        # BASELINE config 4 at the FULL per-GPU batch bench.py times (round 5): B = 64 is the launch geometry with 8
+        # groups on every XCD (rnn_bwd_scatter2<8,4,1>), which the B = 8 shard above never reaches
+        "cfg4_b64": dict(B=64, T=1200, V=200, H=512, L=5, rnn=nn.GRU, cnn=False),
     }
     for name, c in cfgs.items():
-        lab = (60, 100) if name == "cfg4" else (30, 60)
+        if only and name not in only.split(","):
+            continue
+        lab = (60, 100) if name.startswith("cfg4") else (30, 60)
         b = synth.make_batch(seed=1, B=c["B"], T=c["T"], F=40, V=c["V"], lab_lo=lab[0], lab_hi=lab[1])
         rp = {"rnn_input_size": 40, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": c["rnn"],
               "bidirectional": True, "batch_norm": True}
@@ -514,8 +520,37 @@ def gen_large():
                  argmax_sum=int(torch.max(lp, dim=-1)[1].sum().item()), shape=dict((k, (v if not isinstance(v, type) else v.__name__)) for k, v in c.items()))
         res[name] = r
         print(name, "loss", r["loss"], "params", r["n_params"])
-        with open(os.path.join(GOLD, "large_checksums.json"), "w") as f:
+        with open(path, "w") as f:
             json.dump(res, f, indent=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# (6b) the reference's BeamDecoder with its DEFAULT arguments (ctcDecoder.py:170: beam_width = 200, lm_alpha = 0.01) and the widths around
+#      the fast / generic kernel seam of csrc/decode.hip (60 | 61), on the log-probs of decoders.npz: the strings of the reference's own
+#      interpreter loop (round 5; VERDICT r4 weak 1a -- no test ran a beam wider than 57)
+# ---------------------------------------------------------------------------------------------
+def gen_wide_beam():
+    V = 62
+    i2c = synth.int2char(V)
+    arpa = os.path.join(GOLD, "lm_phone_bg.arpa")
+    T, B = 120, 6
+    lens = [120, 97, 64, 110, 33, 81]
+    meta = {"lens": lens}
+    for regime in ("peaky", "flat"):
+        lp = synth.make_logprobs(seed=81 if regime == "peaky" else 82, T=T, B=B, V=V, regime=regime)
+        lpt = torch.from_numpy(lp)
+        bd = BeamDecoder(i2c, lm_path=arpa)                     # every other argument at its default
+        assert bd.beam_width == 200
+        meta["beam_%s_default" % regime] = bd.decode(lpt, lens)
+        print("beam", regime, "defaults done")
+        for W in (60, 61, 128):
+            if regime == "flat" and W == 128:
+                continue
+            bd = BeamDecoder(i2c, beam_width=W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.1)
+            meta["beam_%s_W%d_a0.1" % (regime, W)] = bd.decode(lpt, lens)
+            print("beam", regime, W, "done")
+        with open(os.path.join(GOLD, "decoders_wide.json"), "w") as f:
+            json.dump(meta, f, indent=1)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -605,9 +640,10 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
-                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml, nbest=gen_nbest)
+                 run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml, nbest=gen_nbest,
+                 wide_beam=gen_wide_beam)
     if a.large:
-        gen_large()
+        gen_large(a.only)
     else:
         for k, fn in steps.items():
             if a.only and k not in a.only.split(","):

@@ -1420,7 +1420,7 @@ def _full_size_model(name, dev):
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
     shapes = json.load(open(os.path.join(G, "large_checksums.json")))
     c = dict(B=8, T=300, V=62, H=128, L=2, rnn="LSTM", cnn=False) if name == "cfg1" else shapes[name]["shape"]
-    lab = c.get("lab") or ((60, 100) if name == "cfg4" else ((10, 35) if name == "cfg1" else (30, 60)))
+    lab = c.get("lab") or ((60, 100) if name.startswith("cfg4") else ((10, 35) if name == "cfg1" else (30, 60)))
     Fd = c.get("F", 40)                      # ref_yaml: the shipped timit/conf/ctc_config.yaml shape (243-d spliced input)
     b = synth.make_batch(seed=1, B=c["B"], T=c["T"], F=Fd, V=c["V"], lab_lo=lab[0], lab_hi=lab[1])
     rp = {"rnn_input_size": Fd, "rnn_hidden_size": c["H"], "rnn_layers": c["L"], "rnn_type": getattr(nn, c["rnn"]),
@@ -1624,10 +1624,12 @@ def test_full_size_elementwise_vs_torch_cpu_oracle(dev, name, prec):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "ref_yaml"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "ref_yaml", "cfg4_b64"])
 def test_large_shape_checksums(dev, name, prec):
     """BASELINE.json full-size configs at both matmul precisions: loss / log-prob checksums / per-parameter gradient norms
-    captured from the reference (cfg4 at B=8 per rank, as one DP shard); gradient norms within 1e-3."""
+    captured from the reference (cfg4 at B=8 per rank, as one DP shard, and -- round 5 -- cfg4_b64: the full per-GPU batch of 64 that
+    bench.py times, whose launch geometry (8 groups on every XCD, rnn_bwd_scatter2<8,4,1>) the B = 8 shard never reaches); gradient
+    norms within 1e-3."""
     from ctc_pytorch_amd import nn, ops
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
     ops.set_precision(prec)
@@ -1646,6 +1648,10 @@ def test_large_shape_checksums(dev, name, prec):
             assert gn < 0.05
             continue
         assert abs(gn - want["grad_norm"][k]) <= 1e-3 * want["grad_norm"][k] + 1e-6, (k, gn, want["grad_norm"][k])
+    names = ops.rnn_last_kernels()
+    assert "step" not in names[0] + names[1], names          # the persistent recurrences, not one launch per timestep
+    if name == "cfg4_b64" and prec == 1:
+        assert names == ("rnn_fwd_tagged", "rnn_bwd_scatter2"), names      # the kernels bench.py --workload cfg4 times
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -1871,6 +1877,69 @@ def test_beam_cfg5_full_batch_vs_c_oracle(dev, regime):
     assert got == [list(map(int, s_)) for s_ in want]
     score, wscore = np.asarray(score), np.asarray(wscore)
     assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
+
+
+@pytest.mark.parametrize("regime", ["peaky", "flat"])
+@pytest.mark.parametrize("W", [60, 61, 64, 65, 128, 200, 256])
+def test_beam_wide_vs_c_oracle(dev, regime, W):
+    """ Beams wider than any earlier test ran: the last width of beam_fast_kernel (60), the first of the generic
+    beam_kernel (61), both sides of a 64-lane boundary, 128, the reference's class default 200 (ctcDecoder.py:170) and BEAM_WMAX = 256, on
+    the golden batch shape (T = 120, B = 6, ragged lengths) against the C restatement of BeamSearch.py: labellings and status equal,
+    float64 scores to the last places."""
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    V, T, B = 62, 120, 6
+    i2c = synth.int2char(V)
+    tab = LanguageModel(os.path.join(G, "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    lp = synth.make_logprobs(seed=81 if regime == "peaky" else 82, T=T, B=B, V=V, regime=regime)
+    lens = [120, 97, 64, 110, 33, 81]
+    probs = torch.exp(torch.from_numpy(lp))
+    want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, 0.1, W)
+    got, score, st = ops.beam_decode(probs.to(dev), lens, tab, 0.1, W, 0, input_is_prob=True)
+    assert list(st) == list(wst) and not any(st)
+    assert got == [list(map(int, s_)) for s_ in want]
+    score, wscore = np.asarray(score), np.asarray(wscore)
+    assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
+
+
+def test_beam_width_above_the_maximum_is_refused(dev):
+    """W = 257 > BEAM_WMAX: CTCN_EUNSUPPORTED (-3) from the C ABI, a RuntimeError naming the limit from the wrapper; nothing is launched."""
+    from ctc_pytorch_amd import _lib, ops
+    V, T, B = 62, 20, 2
+    lp = torch.from_numpy(synth.make_logprobs(seed=5, T=T, B=B, V=V, regime="peaky")).to(dev)
+    tab = np.zeros((V + 1, V + 1))
+    with pytest.raises(RuntimeError, match="beam width 257"):
+        ops.beam_decode(lp, [T, T], tab, 0.1, 257)
+    L = _lib.lib()
+    lens = torch.tensor([T, T], dtype=torch.int32, device=dev)
+    lm = torch.zeros((V + 1) * (V + 1), dtype=torch.float64, device=dev)
+    ws = torch.empty(max(L.ctcn_beam_ws_bytes(T, B, V, 256), 1), dtype=torch.uint8, device=dev)
+    oi, ol = torch.zeros((B, T), dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    sc, stt = torch.zeros(B, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    rc = L.ctcn_beam_decode(ctypes.c_void_p(lp.data_ptr()), 0, ctypes.c_void_p(lens.data_ptr()), ctypes.c_void_p(lm.data_ptr()), 0.1, 257, 0,
+                            ctypes.c_void_p(oi.data_ptr()), ctypes.c_void_p(ol.data_ptr()), ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(stt.data_ptr()),
+                            T, B, V, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
+    assert rc == -3
+
+
+def test_beam_decoder_reference_defaults_golden(dev):
+    """BeamDecoder(int2char, lm_path=...) with every other argument at the reference's default (ctcDecoder.py:170: beam_width = 200,
+    lm_alpha = 0.01, blank 0, no space symbol) on the golden log-probs: the strings the reference's interpreter loop returned
+    (oracle/gen_golden.py gen_wide_beam -> tests/golden/decoders_wide.json), plus W = 60 / 61 / 128 at alpha 0.1."""
+    from ctc_pytorch_amd.utils.ctcDecoder import BeamDecoder
+    meta = json.load(open(os.path.join(G, "decoders_wide.json")))
+    z = load("decoders")
+    i2c = synth.int2char(62)
+    arpa = os.path.join(G, "lm_phone_bg.arpa")
+    for regime in ("peaky", "flat"):
+        lp = torch.from_numpy(z["lp_" + regime])
+        bd = BeamDecoder(i2c, lm_path=arpa)
+        assert bd.beam_width == 200 and bd._decoder.lm_alpha == 0.01
+        assert bd.decode(lp, meta["lens"]) == meta["beam_%s_default" % regime], regime
+        for key in sorted(k for k in meta if k.startswith("beam_%s_W" % regime)):
+            W = int(key.split("_W")[1].split("_")[0])
+            bd = BeamDecoder(i2c, beam_width=W, blank_index=0, space_idx=-1, lm_path=arpa, lm_alpha=0.1)
+            assert bd.decode(lp, meta["lens"]) == meta[key], key
 
 
 @pytest.mark.parametrize("V,W,regime,alpha", [(3, 2, "flat", 0.0), (4, 5, "flat", 0.5), (4, 20, "flat", 0.1), (8, 33, "flat", 0.3), (8, 52, "peaky", 0.1),

@@ -1,24 +1,43 @@
 #!/bin/bash
-# One GPU-box session: smoke -> parity tests -> short bench -> rocprofv3 kernel stats.  Logs under gpurun_out/.
-# usage: tools/gpu_session.sh [tests|bench|prof|all] (default all)
+# The command list of ONE GPU-box session (overwritten per session; outputs under gpurun_out/s<N>/, which is scratch -- what is kept is
+# copied to profiles/ by hand).  usage: tools/gpu_session.sh <N>
 set -u
-cd "$(dirname "$0")/.."
-mkdir -p gpurun_out
-what="${1:-all}"
-export PYTHONDONTWRITEBYTECODE=1
-if [[ "$what" == "all" || "$what" == "tests" ]]; then
-  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/summary.log
-  timeout 1500 python -m pytest tests -m gpu -q -n 1 --timeout 300 -p no:cacheprovider ${PYTEST_K:+-k "$PYTEST_K"} > gpurun_out/pytest_gpu.log 2>&1
-  echo "pytest rc=$?" | tee -a gpurun_out/summary.log
-  tail -n 60 gpurun_out/pytest_gpu.log
-fi
-if [[ "$what" == "all" || "$what" == "bench" ]]; then
-  timeout 600 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" | tee -a gpurun_out/summary.log
-  tail -n 3 gpurun_out/bench.log; tail -n 5 gpurun_out/bench.err
-fi
-if [[ "$what" == "all" || "$what" == "prof" ]]; then
-  export TMPDIR=/tmp
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o cfg2 -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1 ); echo "prof rc=$?" | tee -a gpurun_out/summary.log
-  find gpurun_out/prof -name "*kernel_stats*" | head -3
-  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 25 "$f"
-fi
+cd "$(dirname "$0")/.."; R=$PWD; S=${1:-1}; O=$R/gpurun_out/s$S; rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+case $S in
+1)
+  # full parity suite at HEAD (new: wide beams, reference-default BeamDecoder, cfg4 at B = 64, chunks into flat gradients)
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/summary.log
+  tail -n 15 $O/pytest_gpu.log
+  # fresh cycle accounts of the shipped recurrences
+  ( timeout 200 ./tools/mb_step.bin > $O/mb_step.txt 2>&1 ); ( timeout 200 ./tools/mb_bwd2.bin 320 32 800 > $O/mb_bwd2_cfg2.txt 2>&1 ); ( timeout 100 ./tools/mb_bwd2.bin 512 64 1200 > $O/mb_bwd2_h512.txt 2>&1 )
+  # cfg4: step timeline with the side stream listed, and the A/B of the direction split
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/cfg4prof -o cfg4 -- python $R/bench.py --workload cfg4 --steps 6 --warmup 2 --no-decode --no-cpu-baseline --no-others > $O/cfg4_under_rocprof.json 2> $O/cfg4prof.log )
+  db=$(find $O/cfg4prof -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/prof_timeline.py $db -1 all > $O/cfg4_step_timeline_all.txt 2>&1 && python tools/prof_stats.py $db > $O/cfg4_kernel_stats.txt 2>&1
+  rm -rf $O/cfg4prof
+  for v in 1 0; do CTCN_SMALL_SPLIT=$v timeout 300 python bench.py --workload cfg4 --steps 15 --warmup 3 --no-decode --no-cpu-baseline --no-others > $O/cfg4_smallsplit$v.json 2> $O/cfg4_smallsplit$v.err; done
+  # beam search: two workgroups per CU (option beam_occ2: 64-VGPR build, <= 80 KB LDS; 2 = LM in global memory, larger trie) x searches in flight
+  for occ in 0 1 2; do for ns in 3 4; do
+    CTCN_OPT_BEAM_OCC2=$occ CTCN_DECODE_STREAMS=$ns timeout 200 python bench.py --mode decode --steps 5 > $O/decode_occ${occ}_ns$ns.json 2> $O/decode_occ${occ}_ns$ns.err
+  done; done
+  { for r in peaky flat; do timeout 120 python tools/mb_beam.py run $r 2>&1 | grep -v amdgpu.ids; done; } > $O/mb_beam.txt 2>&1
+  # the default driver command with the new other_workloads object
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  ;;
+esac
+ls -la $O; cat $O/summary.log
+python - "$O" <<'PY'
+import json, sys, glob, os
+for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        if "regimes" in d:
+            print(os.path.basename(f), {k: (round(v["value"]), round(v["kernel_us_per_batch"]), v["strings_match_oracle"]) for k, v in d["regimes"].items()})
+            continue
+        print(os.path.basename(f), "ms/step %.3f" % d["ms_per_step"], "fwd %.3f bwd %.3f" % (d["recurrence"]["fwd_us_per_timestep"], d["recurrence"]["bwd_us_per_timestep"]),
+              "decode", (d.get("decode") or {}).get("value"), (d.get("decode") or {}).get("value_flat"),
+              {k: (round(v.get("ms_per_step", -1), 3) if isinstance(v, dict) else v) for k, v in (d.get("other_workloads") or {}).items()})
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
