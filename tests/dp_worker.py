@@ -21,8 +21,8 @@ from ctc_pytorch_amd.optim import FlatAdam  # noqa: E402
 from oracle import synth  # noqa: E402  (synthetic inputs only)
 
 
-def build(dev, cnn):
-    rp = {"rnn_input_size": 40, "rnn_hidden_size": 32, "rnn_layers": 2, "rnn_type": nn.LSTM, "bidirectional": True, "batch_norm": True}
+def build(dev, cnn, H=32):
+    rp = {"rnn_input_size": 40, "rnn_hidden_size": H, "rnn_layers": 2, "rnn_type": nn.LSTM, "bidirectional": True, "batch_norm": True}
     if cnn:
         cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}
         m = CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=30, drop_out=0.0)
@@ -51,7 +51,11 @@ def one_step(model, opt, batch, lo, hi, global_b, dev):
 def equiv(out_path):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    ops.set_precision(0)
+    # CTCN_TEST_H / CTCN_TEST_PRECISION (round 5): the same comparison on the BENCHMARKED kernels -- persistent recurrences (the caller leaves
+    # CTCN_RNN_PERSISTENT at 1) and bf16x3 GEMMs -- at a hidden size whose grids (dirs x 1 batch tile x H / 16 workgroups per rank) fit
+    # the chip twice, so that the two ranks' launches can be co-resident
+    H = int(os.environ.get("CTCN_TEST_H", "32"))
+    ops.set_precision(int(os.environ.get("CTCN_TEST_PRECISION", "0")))
     world = int(os.environ["WORLD_SIZE"])
     rank = int(os.environ["RANK"])
     results = {}
@@ -60,7 +64,7 @@ def equiv(out_path):
         batch = synth.make_batch(seed=5, B=B, T=48, F=40, V=30, lab_lo=3, lab_hi=6)
         ref = None
         if rank == 0:                                   # single process, whole batch, plain BatchNorm, no collective
-            m = build(dev, cnn)
+            m = build(dev, cnn, H)
             opt = FlatAdam(m, lr=1e-3)
             loss, lp = one_step(m, opt, batch, 0, B, B, dev)
             ref = (float(loss), opt.grad.clone(), lp.clone(),
@@ -69,11 +73,12 @@ def equiv(out_path):
             parallel.init_from_env(backend="gloo")
         torch.distributed.barrier()
         parallel.enable_sync_bn(True)
-        m = build(dev, cnn)
+        m = build(dev, cnn, H)
         opt = FlatAdam(m, lr=1e-3)
         parallel.broadcast_params(opt.flat)
         lo, hi = parallel.shard_range(B, rank, world)
         loss, lp = one_step(m, opt, batch, lo, hi, B, dev)
+        kernels = ops.rnn_last_kernels()
         parallel.allreduce_grads(opt.grad)
         tot = parallel.allreduce_stats(loss.reshape(1).clone())
         torch.cuda.synchronize()
@@ -86,7 +91,8 @@ def equiv(out_path):
             results["cnn" if cnn else "rnn"] = dict(
                 loss_ref=ref[0], loss_dp=float(tot[0]), loss_rel=abs(float(tot[0]) - ref[0]) / abs(ref[0]),
                 grad_rel_l2=float((g - g_ref).norm() / g_ref.norm()), grad_norm=float(g_ref.norm()),
-                lp_shard_maxabs=float((lp - ref[2][:, lo:hi]).abs().max()), running_stats_maxabs=max(stats.values()))
+                lp_shard_maxabs=float((lp - ref[2][:, lo:hi]).abs().max()), running_stats_maxabs=max(stats.values()),
+                kernels=list(kernels), precision=ops.get_precision(), H=H)
         torch.distributed.barrier()
     if rank == 0:
         json.dump(results, open(out_path, "w"))

@@ -2135,6 +2135,24 @@ def test_data_parallel_two_ranks_equal_single_process(dev, tmp_path):
         assert r["lp_shard_maxabs"] < 2e-5 and r["running_stats_maxabs"] < 1e-6, r
 
 
+def test_data_parallel_two_ranks_on_the_benchmarked_kernels(dev, tmp_path):
+    """ The same equivalence on the kernels bench.py times: PERSISTENT recurrences (rnn_fwd_tagged / rnn_bwd_scatter)
+    and bf16x3 GEMMs (precision 1), two ranks on the one GPU at H = 128, where both ranks' grids (2 directions x 1 batch tile x 8 slices
+    = 16 workgroups each) are co-resident.  The reference is the single process at the same precision, so the gates are those of the f32
+    run: the shards change the batch-tile composition and the order of the BatchNorm / gradient sums, not the per-row arithmetic."""
+    out = str(tmp_path / "equiv_p.json")
+    _spawn_ranks(["equiv", out], 2, 29639, extra_env={"CTCN_RNN_PERSISTENT": "1", "CTCN_PRECISION": "1", "CTCN_TEST_H": "128", "CTCN_TEST_PRECISION": "1"},
+                 timeout=300)
+    res = json.load(open(out))
+    for kind in ("rnn", "cnn"):
+        r = res[kind]
+        assert r["precision"] == 1 and r["H"] == 128
+        assert r["kernels"][0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and r["kernels"][1] in ("rnn_bwd_scatter", "rnn_bwd_scatter2", "rnn_bwd_persist"), r
+        assert r["loss_rel"] < 1e-5, r
+        assert r["grad_rel_l2"] < 2e-5 and r["grad_norm"] > 0, r
+        assert r["lp_shard_maxabs"] < 5e-5 and r["running_stats_maxabs"] < 1e-5, r
+
+
 def test_data_parallel_overlap_is_rank_invariant(dev, tmp_path):
     """the early all-reduce of a recurrent layer's gradient slice is a collective, so every rank must decide alike.
     even = 16 + 16 utterances: both ranks reduce the top layer's slice early; uneven = 17 + 16 with the side-stream threshold between the

@@ -25,6 +25,17 @@ case $S in
   # the default driver command with the new other_workloads object
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
   ;;
+2)
+  # the new two-rank test on the benchmarked kernels, alone (two processes share the GPU: bounded by its own timeout)
+  timeout 400 python -m pytest tests -m gpu -q --timeout 350 -p no:cacheprovider -k "two_ranks_on_the_benchmarked" > $O/pytest_dp.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 5 $O/pytest_dp.log
+  # step timelines of every workload at HEAD (main stream + side stream)
+  for wl in cfg3 ref_yaml cfg1 cfg2; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$wl -o p -- python $R/bench.py --workload $wl --steps 6 --warmup 2 --no-decode --no-cpu-baseline --no-others > $O/${wl}_under_rocprof.json 2> $O/prof_$wl.log )
+    db=$(find $O/prof_$wl -name "*.db" | head -1)
+    [ -n "$db" ] && python tools/prof_timeline.py $db -1 all > $O/${wl}_step_timeline_all.txt 2>&1 && python tools/prof_stats.py $db > $O/${wl}_kernel_stats.txt 2>&1
+    rm -rf $O/prof_$wl
+  done
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
