@@ -154,6 +154,46 @@ def pmc_traffic(kernel):
     return None
 
 
+def measure_recurrence_traffic(c, kernel, precision, timeout=150):
+    """HBM bytes per launch of the dominant recurrence MEASURED IN THIS RUN: two child processes -- rocprofv3
+    --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE, separate passes as /opt/skills/guides/MI355X_MICROARCH.md prescribes (nothing but
+    the kernel trace next to the counters) -- over tools/pmc_probe.py's single-layer set at this workload's shape; FETCH_SIZE doubled (the
+    guide's gfx950 correction: 128-B requests of wide reads are tallied as 64 B), both counters in KiB.  Returns (bytes, note) or (None, why)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("CTCN_BENCH_PMC", "1") == "0":
+        return None, "rocprofv3 not on PATH" if exe is None else "CTCN_BENCH_PMC=0"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):            # this process is itself being profiled: no profiler inside a profiler
+        return None, "bench.py is running under a profiler"
+    T = c["T"] // 2 if c["cnn"] else c["T"]
+    env = dict(os.environ, PMC_PROBE_SET="recurrence", PMC_T=str(T), PMC_B=str(c["B"]), PMC_H=str(c["H"]), PMC_CELL={"LSTM": "lstm", "GRU": "gru"}[c["rnn"]],
+               CTCN_PRECISION=str(precision), PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp")
+    vals = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+                dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+                if r.returncode != 0 or not dbs:
+                    return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+                cur = sqlite3.connect(dbs[0]).cursor()
+                rows = list(cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)))
+                hit = [(n, a) for name, n, a in rows if (kernel + "<") in name or (kernel + "(") in name]
+                if not hit:
+                    return None, "kernel %s not in the %s pass" % (kernel, counter)
+                vals[counter] = hit[0]
+    except Exception as e:      # noqa: BLE001
+        return None, repr(e)
+    nbytes = int(2 * vals["FETCH_SIZE"][1] * 1024 + vals["WRITE_SIZE"][1] * 1024)
+    return nbytes, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two separate child passes over tools/pmc_probe.py, one layer of this "
+                    "workload, %d launches averaged); FETCH_SIZE x 2 (gfx950 correction of MI355X_MICROARCH.md), KiB units" % vals["FETCH_SIZE"][0])
+
+
 def recurrence_traffic(workload, kernel="rnn_bwd_scatter"):
     """HBM bytes per launch of the dominant recurrence from the committed PMC passes, for the two shapes tools/pmc_probe.py runs (a cfg2
     layer; a ref_yaml layer for rnn_bwd_scatter2)."""
@@ -208,10 +248,14 @@ def recurrence_probe(dev, c):
         ops.set_option("rnn_recurrence_only", 0)
     ops.check_health()
     flops = 2.0 * T * 2 * B * (G * H) * H              # recurrent matmul of one launch (both directions)
+    # HBM bytes a recurrent launch must move (both directions): forward = pre-activations in + saved gates out (2 x G*H) + c / n
+    # out (LSTM / GRU: H) + y out (H); backward = saved gates in (G*H) + c in (H) + dy in (H) + d(pre-act) out (G*H) -- both (2G + 2) * H floats
+    # per (frame, row, direction)
+    abytes = T * B * 2 * (2 * G + 2) * H * 4
     names = ops.rnn_last_kernels()                     # what the library really launched for this shape (not what the host expects)
     return dict(layer_fwd_us=lf, layer_bwd_us=lb, kernel_fwd_us=kf, kernel_bwd_us=kb, fwd_us_per_timestep=kf / T, bwd_us_per_timestep=kb / T,
                 fwd_kernel=names[0], bwd_kernel=names[1], T=T,
-                algorithmic_flops_per_launch=flops,
+                algorithmic_flops_per_launch=flops, algorithmic_bytes_per_launch=abytes,
                 note="kernel_*: persistent recurrent launch alone (T dependent timesteps, both directions; includes its <10 us of memsets / "
                      "W_hh transposes); layer_*: with the input-projection (fwd) / deferred gradient (bwd) GEMMs")
 
@@ -313,8 +357,12 @@ def other_workloads(dev, precision, names=("cfg1", "cfg3", "cfg4", "ref_yaml"), 
 
 def run_train(args):
     from ctc_pytorch_amd import nn, parallel
-    from ctc_pytorch_amd.optim import FlatAdam
-    from oracle import synth                      # synthetic inputs only (no arithmetic)
+    # N > 1: have RCCL say what it built (rings / trees, channels, protocol) into a per-rank file, so that the first real SCALE record can be
+    # interpreted -- must be in the environment before the communicator exists; the summary goes into the line's `comm` object
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "NCCL_DEBUG" not in os.environ:
+        rccl_log = "/tmp/ctcn_rccl_%d_rank%s.log" % (os.getppid(), os.environ.get("RANK", "0"))
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV", NCCL_DEBUG_FILE=rccl_log)
     rank, world, local = parallel.init_from_env()
     parallel.enable_sync_bn(bool(getattr(args, "sync_bn", False)))
     parallel.enable_overlap(True)       # per-layer gradient slices are all-reduced behind their weight GEMMs (no-op without collectives)
@@ -366,6 +414,7 @@ def run_train(args):
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     _ops.check_health()                # a hand-off timeout in a persistent kernel poisons the step: never report such a run
+    per_rank_s = parallel.gather_over_ranks(dt, dev)     # every rank's own wall clock over the K steps (the headline uses the MAX)
     dt = parallel.max_over_ranks(dt, dev)
     last_loss = float(losses[-1].detach()) * world if losses else float("nan")
     # Everything below that issues a collective must run on EVERY rank (the other ranks are gone after the return): the exchange-step
@@ -410,7 +459,13 @@ def run_train(args):
             raise RuntimeError(comm_err)
         exposed = sorted(a.elapsed_time(b) * 1e3 for a, b in comm_marks)
         on = parallel._collectives_on()
-        res["comm"] = dict(ranks=world, collectives_issued=bool(on),
+        rccl_lines = None
+        if rccl_log and os.path.exists(rccl_log):           # rank 0's view of the communicator: topology, channels, algorithm / protocol tuning
+            keep = ("Channel", "Ring", "Tree", "nChannels", "Connected all", "Algo", "algo", "proto", "NET/", "P2P", "xgmi", "XGMI", "comm 0x", "NCCL_")
+            with open(rccl_log, errors="replace") as fh:
+                rccl_lines = [ln.strip()[-220:] for ln in fh if any(k in ln for k in keep)][:48]
+        res["per_rank_ms_per_step"] = [t / args.steps * 1e3 for t in per_rank_s]
+        res["comm"] = dict(ranks=world, collectives_issued=bool(on), rccl_info=rccl_lines,
                            backend=("none (single rank: allreduce_grads returns at once)" if not on else
                                     ("ctcn_comm_* (RCCL behind the C ABI)" if os.environ.get("CTCN_COMM", "0") == "1" else "torch.distributed/" + tdist.get_backend() + " (= RCCL on ROCm)")),
                            allreduce_bytes_per_step=int(opt.grad.numel() * 4), early_slices=overlapped[0], early_slice_bytes=int(early_bytes[0]),
@@ -433,12 +488,16 @@ def run_train(args):
         kname, kus, kstep = ((rec["fwd_kernel"], rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
                              (rec["bwd_kernel"], rec["kernel_bwd_us"], rec["bwd_us_per_timestep"]))
         tf = rec["algorithmic_flops_per_launch"] / (kus * 1e-6) / 1e12
-        traffic = recurrence_traffic(args.workload, kname)
+        traffic, traffic_note = (None, "--no-pmc") if args.no_pmc else measure_recurrence_traffic(c, kname, args.precision)
+        if traffic is None:             # fall back to the committed passes (same kernel instantiation, same shape), and say so
+            traffic = recurrence_traffic(args.workload, kname)
+            traffic_note = None if traffic is None else ("HBM bytes per launch of this kernel instantiation from the committed rocprofv3 PMC passes (profiles/%s), not a "
+                                                         "counter read of this run (%s)" % (PMC_FILE, traffic_note))
         res["roofline"] = dict(kernel="%s (%s recurrence of one Bi%s layer, T=%d dependent steps, both directions)" % (
                                    kname, "forward" if fwd_dom else "backward", c["rnn"], rec["T"]),
                                bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=traffic,
-                               traffic_source=None if traffic is None else "HBM bytes per launch of this kernel instantiation from the committed rocprofv3 PMC "
-                               "passes (profiles/%s), not a counter read of this run" % PMC_FILE,
+                               traffic_source=traffic_note,
+                               algorithmic_bytes_per_launch=rec["algorithmic_bytes_per_launch"],
                                frac_of_bf16x3_ceiling=None if args.precision == 0 else tf / (peak / 3.0),
                                us_per_launch=kus, us_per_dependent_step=kstep, dependent_steps_per_launch=rec["T"],
                                algorithmic_flops_per_launch=rec["algorithmic_flops_per_launch"],
@@ -622,6 +681,7 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="train", choices=["train", "decode"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the cfg5 beam-decode leg of the default (N=1, train) run")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (the committed profile is quoted instead)")
     ap.add_argument("--no-others", action="store_true", help="skip the `other_workloads` object (cfg1 / cfg3 / cfg4 / ref_yaml) of the default cfg2 run")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed CPU train steps per thread setting of the sweep")
     ap.add_argument("--precision", type=int, default=int(os.environ.get("CTCN_PRECISION", "1")), choices=[0, 1],

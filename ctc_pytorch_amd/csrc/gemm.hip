@@ -1662,9 +1662,11 @@ __global__ __launch_bounds__(512) void gemm_tn_f32_pp_kernel(int M, int N, int K
 }
 
 // split count and launch of the TN tile; `part` must hold splits * M * N floats when splits > 1
-static int tn_splits(int M, int N, int K, int wnt, size_t part_bytes) {
+static int tn_splits(int M, int N, int K, int wnt, size_t part_bytes, int cus) {
   const int tiles = ceil_div(M, 256) * ceil_div(N, 128 * wnt);
-  int s = std::min(std::max(256 / tiles, 1), std::max(K / 512, 1));      // <= 256 items: one round on a whole device, two on half of it
+  // `cus`: the CUs the launch may run on -- 256, or (round 5, option "tn_splits_xcd") the CUs of the XCDs of xcd_allow: one round of items there
+  // instead of two rounds of half-length items (each item pays a prologue, a 128-KB partial store and its share of the reduce pass)
+  int s = std::min(std::max(cus / tiles, 1), std::max(K / 512, 1));      // <= 256 items: one round on a whole device
   s = std::min(s, 32);                                                    // (a handful of tiles: the reduce pass over the partials would take over)
   s = std::min(s, (int)(part_bytes / ((size_t)M * N * sizeof(float))));
   return s < 2 ? 1 : s;
@@ -1845,7 +1847,12 @@ static int gemm_core(int transA, int transB, int M, int N, int K, const float *A
     pl.a_valid = false; pl.b_valid = false;
     const int wnt = ceil_div(N, 256) * 256 == ceil_div(N, 128) * 128 ? 2 : 1;     // (N = 640 as 3 x 256 or 5 x 128: the same time)
     unsigned *queue = (unsigned *)((char *)ws + ((ws_bytes - 256) & ~(size_t)255));
-    const int tsplits = tn_splits(M, N, K, wnt, ws_bytes - 512);
+    int tn_cus = 256;
+    if (xcd_allow && ctcn_get_option("tn_splits_xcd") != 0) {
+      const int nx = std::max(1, std::min(ctcn_device_xcds(), 16));
+      tn_cus = std::max(ctcn_device_cus() / nx * __builtin_popcount(xcd_allow & ((1u << nx) - 1u)), 32);
+    }
+    const int tsplits = tn_splits(M, N, K, wnt, ws_bytes - 512, tn_cus);
     return wnt == 2 ? launch_tn<2>(st, M, N, K, A, lda, B, ldb, C, ldc, beta, tsplits, (float *)ws, xcd_allow, queue)
                     : launch_tn<1>(st, M, N, K, A, lda, B, ldb, C, ldc, beta, tsplits, (float *)ws, xcd_allow, queue);
   }

@@ -129,6 +129,7 @@ _side = {"fwd_overlap": os.environ.get("CTCN_FWD_OVERLAP", "1") != "0", "enabled
 
 
 SIDE_MIN_ITEMS_FWD, SIDE_MIN_ITEMS_BWD = 1 << 21, 1 << 18
+SMALL_SPLIT_MAX_ITEMS = 1 << 23       # T*B*H above which an inline layer's two directions stay on one stream (their GEMMs fill the device one at a time)
 
 
 def set_side_stream(flag, min_items=None, min_items_bwd=None):
@@ -479,8 +480,12 @@ class _RNNLayer(torch.autograd.Function):
         # that do not fill the device one at a time -- one direction per stream, joined at once (nothing runs next to a recurrence)
         # (not when the layer ABOVE has parked side work: the join below waits for the whole side stream, which would then hold that layer's
         # deferred weight GEMMs -- and its early all-reduce -- in front of the main stream; a mixed large / small stack keeps this layer inline)
+        # (and not for LARGE layers that stay inline because the capacity rule says the side stream cannot keep up -- cfg4: B = 64, H = 512 --:
+        # their weight GEMMs are full-device queue kernels of 131 KB LDS per workgroup, two of which never share a CU, so the two streams ran
+        # them one after the other anyway; round 5: 52.10 | 51.95 ms per cfg4 step with | without the split, and rocprofv3 charged the wait for
+        # the other stream's GEMM to whatever small kernel came next on this one -- the "650-us split-K reduce" of profiles/r03_cfg4_*)
         small_split = (not side and not split_dirs and not chunk and into_flat and _side["enabled"] and _side["small_split"] and dirs == 2 and T > 1
-                       and key not in _side["deferred"])
+                       and key not in _side["deferred"] and T * B * H < SMALL_SPLIT_MAX_ITEMS)
         if small_split:
             split_dirs = True
         # the layer above: its weight GEMMs start together with this layer's recurrence -- the library records `ev` right
@@ -515,6 +520,8 @@ class _RNNLayer(torch.autograd.Function):
         if split_dirs:
             st = _side_stream(dev)
             prec = get_precision()
+            # (round 5, measured and not kept: each direction's GEMMs restricted to one half of the XCDs, so that the two streams' full-device
+            # queue kernels run side by side instead of one after the other -- cfg2 13.221 | 13.220 ms, cfg3 7.898 | 7.935: the same work either way)
             st.wait_stream(torch.cuda.current_stream(dev))          # (behind the layer above's weight GEMMs already queued there)
             with torch.cuda.stream(st):
                 w2, wp2, wn2 = _ws(x, tag="side")

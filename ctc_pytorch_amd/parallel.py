@@ -298,3 +298,13 @@ def max_over_ranks(value, device):
     if _collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value, device):
+    """[value of rank 0, value of rank 1, ...] on every rank (one small all-gather); [value] without collectives."""
+    if not _collectives_on():
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]

@@ -2075,7 +2075,7 @@ def test_bench_under_torchrun_with_rccl_collectives(dev, workload, comm):
     env = dict(os.environ, CTCN_FORCE_COLLECTIVES="1", CTCN_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", workload,
-           "--sync-bn", "--no-cpu-baseline", "--no-decode"]
+           "--sync-bn", "--no-cpu-baseline", "--no-decode", "--no-others", "--no-pmc"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -2084,6 +2084,30 @@ def test_bench_under_torchrun_with_rccl_collectives(dev, workload, comm):
     assert res["value"] > 0 and np.isfinite(res["final_loss"])
     if workload == "cfg2":
         assert res["overlapped_allreduce_slices_last_step"] >= 2, res.get("overlapped_allreduce_slices_last_step")
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo(dev):
+    """The N > 1 code path of bench.py end to end with two REAL ranks (the driver's launch form needs two GPUs; here both ranks share the one
+    GPU and gloo carries the collectives, RCCL refusing two ranks per device): parameter broadcast, sharded seeds, the step-end all-reduce
+    behind the side stream, barriers, max-over-ranks and the per-rank clocks of the line (round 5).  cfg1: both ranks' persistent grids
+    (16 workgroups each) are co-resident."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", LOCAL_RANK="0", CTCN_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1", CTCN_QUIET="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg1", "--no-cpu-baseline",
+           "--no-decode", "--no-others", "--no-pmc"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=280) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # rank 0 alone prints the line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["scaling"] == "weak"
+    assert len(res["per_rank_ms_per_step"]) == 2 and max(res["per_rank_ms_per_step"]) <= res["ms_per_step"] * 1.0001
+    assert res["value"] > 0 and np.isfinite(res["final_loss"]) and res["comm"]["collectives_issued"] and res["comm"]["ranks"] == 2
+    assert abs(res["value"] - 2 * 8 * 300 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]      # whole-job frames / max-over-ranks time
 
 
 @pytest.mark.parametrize("workload,steps", [("cfg2", 60), ("cfg4", 12)])

@@ -333,6 +333,7 @@ p = torch.arange(5.0) * (rank + 1)
 parallel.broadcast_params(p)
 assert torch.equal(p, torch.arange(5.0))
 assert parallel.max_over_ranks(1.5 + rank, torch.device("cpu")) == 2.5
+assert parallel.gather_over_ranks(1.5 + rank, torch.device("cpu")) == [1.5, 2.5]
 # synchronised BatchNorm: the per-channel fp64 sums of the two shards are added, the count doubles
 sums = torch.full((6, 2), float(rank + 1), dtype=torch.float64)
 assert parallel._sync_bn_reduce(sums, 100) == 200.0 and torch.equal(sums, torch.full((6, 2), 3.0, dtype=torch.float64))

@@ -36,6 +36,23 @@ case $S in
     rm -rf $O/prof_$wl
   done
   ;;
+3)
+  # bottom-layer weight GEMMs on XCD halves (CTCN_SPLIT_HALVES) x TN split count sized for the allowed XCDs (tn_splits_xcd)
+  for wl in cfg2 cfg3; do for h in 0 1; do for x in 0 1; do
+    CTCN_SPLIT_HALVES=$h CTCN_OPT_TN_SPLITS_XCD=$x timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others > $O/${wl}_halves${h}_xcd$x.json 2> $O/${wl}_halves${h}_xcd$x.err
+  done; done; done
+  timeout 300 python bench.py --workload cfg4 --steps 15 --warmup 3 --no-decode --no-cpu-baseline --no-others > $O/cfg4.json 2> $O/cfg4.err
+  timeout 600 python -m pytest tests -m gpu -q --maxfail=5 --timeout 600 -p no:cacheprovider -k "full_size or large_shape or model_ or batch_chunks or soak or persistent" > $O/pytest_sub.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 4 $O/pytest_sub.log
+  ;;
+4)
+  timeout 600 python -m pytest tests -m gpu -q --maxfail=5 --timeout 600 -p no:cacheprovider -k "bench_two_ranks or bench_under_torchrun or two_ranks" > $O/pytest_sub.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 6 $O/pytest_sub.log
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  python - $O/bench_default.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(json.dumps(d["roofline"], indent=1))
+PY
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'

@@ -16,6 +16,20 @@ if os.environ.get("PMC_PROBE_SET") == "scatter2":
     torch.cuda.synchronize()
     print(ops.rnn_last_kernels())
     sys.exit(0)
+if os.environ.get("PMC_PROBE_SET") == "recurrence":
+    # bench.py's in-run traffic measurement: ONE layer of the benchmarked workload, forward + backward (the persistent recurrences), nothing else
+    T, B, H = int(os.environ.get("PMC_T", "800")), int(os.environ.get("PMC_B", "32")), int(os.environ.get("PMC_H", "320"))
+    cell = os.environ.get("PMC_CELL", "lstm")
+    G = 4 if cell == "lstm" else 3
+    xr = torch.randn(T, B, 2 * H, device=dev, requires_grad=True)
+    wr = [(torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True),
+          (torch.randn(G * H, 2 * H, device=dev) * 0.05).requires_grad_(True), (torch.randn(G * H, H, device=dev) * 0.05).requires_grad_(True)]
+    for _ in range(3):
+        yr = ops.rnn_layer(xr, wr[0], wr[1], wr[2], wr[3], cell)
+        yr.backward(torch.ones_like(yr))
+    torch.cuda.synchronize()
+    print(ops.rnn_last_kernels())
+    sys.exit(0)
 M, K, N = 25600, 640, 1280
 A, W, C = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev)
 for _ in range(4):
