@@ -623,12 +623,26 @@ def decode_leg(dev, steps=5):
             strings = finish(h)
         dt = (time.perf_counter() - t0) / nfl
         assert strings == [" ".join(map(phones.__getitem__, seq)) for seq in ids] and len(strings) == B
+        # host side of one batch, apart: the time to ENQUEUE a search (workspace, launches, pinned copy, event) with the queue kept short, and
+        # to FINISH one whose results are already on the host (string assembly) -- what the loop above needs per batch next to the device
+        torch.cuda.synchronize()
+        te, tf = [], []
+        for k in range(12):
+            t1 = time.perf_counter()
+            with torch.cuda.stream(streams[k % NS]):
+                hh = ops.beam_decode_async(x, lens_dev, tab_dev, 0.1, W)
+            te.append(time.perf_counter() - t1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            finish(hh)
+            tf.append(time.perf_counter() - t1)
+        te.sort(); tf.sort()
         # frames the search really processes: the reference skips a frame when 1 - p(blank) < 0.1 (BeamSearch.py:93-94)
         pb = np.exp(lp[:, :, 0])
         processed = int(sum(int(((1.0 - pb[:lens[b], b]) >= 0.1).sum()) for b in range(B)))
         longest = max(int(((1.0 - pb[:lens[b], b]) >= 0.1).sum()) for b in range(B))
         r = {"value": B / dt, "ms_per_batch": dt * 1e3, "batches_in_flight": "%d on %d streams + %d queued behind them" % (NS, NS, NS), "value_one_batch_at_a_time": B / dt1, "kernel_us_per_batch": kernel_us,
-             "processed_frames": processed,
+             "processed_frames": processed, "host_us_per_batch": {"enqueue": te[len(te) // 2] * 1e6, "finish": tf[len(tf) // 2] * 1e6},
              "us_per_processed_frame_on_the_longest_utterance": kernel_us / max(longest, 1)}
         nref = 4 if regime == "flat" else 16
         probs = np.exp(lp[:, :nref, :]).transpose(1, 0, 2)

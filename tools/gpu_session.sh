@@ -53,6 +53,26 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(json.dumps(d["roofline"], indent=1))
 PY
   ;;
+5)
+  for i in 1 2 3; do timeout 200 python bench.py --mode decode --steps 5 > $O/decode_$i.json 2> $O/decode_$i.err; done
+  python - $O <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/decode_*.json")):
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f.split("/")[-1], {k: (round(v["value"]), round(v["ms_per_batch"], 3), round(v["kernel_us_per_batch"]), {a: round(b) for a, b in v["host_us_per_batch"].items()}) for k, v in d["regimes"].items()})
+PY
+  ;;
+6)
+  for i in 1 2; do for q in 4 8; do
+    GPU_MAX_HW_QUEUES=$q timeout 300 python bench.py --no-cpu-baseline --no-others --no-pmc > $O/bench_q${q}_$i.json 2> $O/bench_q${q}_$i.err
+  done; done
+  ;;
+7)
+  for i in 1 2; do
+    timeout 300 python bench.py --no-cpu-baseline > $O/bench_pmc_$i.json 2> $O/bench_pmc_$i.err
+    timeout 300 python bench.py --no-cpu-baseline --no-pmc > $O/bench_nopmc_$i.json 2> $O/bench_nopmc_$i.err
+  done
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
