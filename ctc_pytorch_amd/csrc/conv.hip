@@ -216,10 +216,13 @@ __device__ __forceinline__ void conv_fill_koff(int *koff, const ConvTile &m) {
   }
 }
 
+#ifndef CONV_LOAD_DEPTH
+#define CONV_LOAD_DEPTH 8
+#endif
 // raw[c][rh][rw] = src[b, c, h0 + rh, w0 + rw] (0 outside the tensor); a group of RWP lanes walks one row.  Loads are issued
 // eight rows at a time from clamped (always valid) addresses and masked afterwards, so that eight HBM/L2 latencies overlap.
 __device__ __forceinline__ void conv_load_raw(float *raw, const float *__restrict__ src, const ConvTile &m, int b, int h0, int w0, int rwp_log) {
-  constexpr int U = 8;
+  constexpr int U = CONV_LOAD_DEPTH;
   const int tid = threadIdx.x, rw = tid & ((1 << rwp_log) - 1), grp = tid >> rwp_log, ngrp = CONV_THREADS >> rwp_log;
   if (rw >= m.RW) return;
   const int rows = m.Cs * m.RH, ws = w0 + rw;
@@ -255,7 +258,8 @@ __device__ __forceinline__ void conv_tile_origin(const ConvTile &m, int tile, in
 
 template <int NT>
 __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(const float *__restrict__ src, const float *__restrict__ w, const float *__restrict__ bias,
-                                                                 float *__restrict__ out, ConvTile m, int rwp_log, int region_floats) {
+                                                                 float *__restrict__ out, ConvTile m, int rwp_log, int region_floats, int dbg) {
+  // dbg (option "conv_dbg", development: tools/conv_phase_probe.py): 1 = no window load, 2 = no MFMA loop, 4 = no output phase (results invalid)
   extern __shared__ __attribute__((aligned(16))) float csm[];   // region[max(raw, transpose)] | wmat[K4][WS] | koff[K4]
   constexpr int N16 = 16 * NT, OS = TP + 1;
   const int WS = conv_ws_stride(NT);
@@ -273,16 +277,52 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(const float *__
   const int p = wave * 16 + r, ptr_ = p / m.C, ptc = p - ptr_ * m.C;
   const int posoff = ptr_ < m.R ? ptr_ * m.ssh * m.RW + ptc * m.ssw : 0;
   const int RC = m.R * m.C;
+  // output phase (round 5): wave v stores channels v, v + 8, ...; a lane owns positions pp = lane, lane + 64 of EVERY tile, so their
+  // (row, column) inside the tile and their offset inside a destination plane are computed once per launch -- the phase used to divide
+  // twice per stored element (i -> (n, pp) -> (tr, tc)) and was 38 of the 62 us of cfg3's first layer (tools/conv_phase_probe.py)
+  int otr[2], otc[2], odo[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int pp = lane + 64 * jj;
+    otr[jj] = pp / m.C; otc[jj] = pp - otr[jj] * m.C;
+    odo[jj] = (m.a + otr[jj] * m.osh) * m.Wd + m.b + otc[jj] * m.osw;
+    if (pp >= RC) otr[jj] = 1 << 20;                                   // never inside the image
+  }
   __syncthreads();
   for (int tile = blockIdx.x; tile < m.ntiles; tile += gridDim.x) {
     int b, hc0, wc0;
     conv_tile_origin(m, tile, b, hc0, wc0);
-    if (m.K > 0) conv_load_raw(raw, src, m, b, hc0 * m.ssh + m.dh0, wc0 * m.ssw + m.dw0, rwp_log);
+    // (eight row loads in flight per thread; 16 / 32 measured 98 / 97 us against 101 at cfg3's second layer -- and three instantiations of the
+    // loader in one kernel cost the first layer its occupancy: 39 -> 61 us)
+    if (m.K > 0 && !(dbg & 1)) conv_load_raw(raw, src, m, b, hc0 * m.ssh + m.dh0, wc0 * m.ssw + m.dw0, rwp_log);
     __syncthreads();
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < m.K4; k0 += 4) {
+    // four k-steps per trip: the four table reads, then the four window reads, then the filter reads are independent of each other, so their
+    // LDS latencies overlap (one step at a time the chain koff -> raw -> MFMA was ~150 cycles per step with two waves per SIMD to hide it:
+    // 45 of the 123 us of cfg3's second layer).  K4 is a multiple of 4; the tail runs step by step.  Same products in the same order.
+    const int kend = (dbg & 2) ? 4 : m.K4;
+    int k0 = 0;
+    for (; k0 + 16 <= kend; k0 += 16) {
+      int ko[4];
+      float av[4], bv[4][NT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ko[u] = koff[k0 + 4 * u + q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = raw[ko[u] + posoff];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[u][nt] = wmat[(k0 + 4 * u + q) * WS + nt * 16 + r];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = (k0 + 4 * u + q) < m.K ? av[u] : 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[u][nt], acc[nt], 0, 0, 0);
+      }
+    }
+    for (; k0 < kend; k0 += 4) {
       const int kk = k0 + q;
       float av = raw[koff[kk] + posoff];
       av = kk < m.K ? av : 0.0f;
@@ -290,17 +330,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(const float *__
       for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wmat[kk * WS + nt * 16 + r], acc[nt], 0, 0, 0);
     }
     __syncthreads();
+    if (dbg & 4) { if (acc[0][0] == 12345.678f) out[0] = 1.0f; continue; }
     // C layout: column r (= channel within the 16-tile), rows 4q .. 4q+3 (= positions of this wave's 16) -> ot[n][p]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) raw[(nt * 16 + r) * OS + wave * 16 + 4 * q + e] = acc[nt][e];
     __syncthreads();
-    for (int i = tid; i < m.N * RC; i += CONV_THREADS) {
-      const int n = i / RC, pp = i - n * RC, tr = pp / m.C, tc = pp - tr * m.C;
-      const int hc = hc0 + tr, wc = wc0 + tc;
-      if (hc < m.Hc && wc < m.Wc)
-        out[(((size_t)b * m.N + n) * m.Hd + m.a + hc * m.osh) * m.Wd + m.b + wc * m.osw] = raw[n * OS + pp] + (bias ? bias[n] : 0.0f);
+    {
+      const size_t plane = (size_t)m.Hd * m.Wd;
+      float *ob = out + (size_t)b * m.N * plane + (size_t)hc0 * m.osh * m.Wd + (size_t)wc0 * m.osw;
+      bool ov[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) ov[jj] = hc0 + otr[jj] < m.Hc && wc0 + otc[jj] < m.Wc;
+      for (int n = wave; n < m.N; n += CONV_THREADS / 64) {
+        const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          if (ov[jj]) ob[(size_t)n * plane + odo[jj]] = raw[n * OS + lane + 64 * jj] + bn;
+      }
     }
     __syncthreads();
   }
@@ -357,20 +405,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_wgrad_mfma_kernel(const flo
     }
     __syncthreads();
     if (wave < nkt) {
-      for (int s = 0; s < TP; s += 4) {
-        const int po = posoff[s + q];
-        float av[NTC];
+      // two position steps per trip (round 5): the table reads, then the dy and window reads of both steps are independent of each other, so
+      // their LDS latencies overlap (the chain posoff -> raw -> MFMA one step at a time, as in conv_mfma_kernel).  TP is a multiple of 8; the
+      // products enter every accumulator in the same ascending position order as before.
+      for (int s = 0; s < TP; s += 8) {
+        int po[2];
+        float av[2][NTC], bv[2][JR];
 #pragma unroll
-        for (int ct = 0; ct < NTC; ++ct) av[ct] = dyT[(s + q) * DS + ct * 16 + r];
+        for (int u = 0; u < 2; ++u) po[u] = posoff[s + 4 * u + q];
 #pragma unroll
-        for (int j = 0; j < JR; ++j) {
-          if (wave + 8 * j < nkt) {
-            float bv = raw[kbase[j] + po];
-            bv = kone[j] ? 1.0f : bv;
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int ct = 0; ct < NTC; ++ct) acc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct], bv, acc[j][ct], 0, 0, 0);
-          }
+          for (int ct = 0; ct < NTC; ++ct) av[u][ct] = dyT[(s + 4 * u + q) * DS + ct * 16 + r];
+#pragma unroll
+          for (int j = 0; j < JR; ++j) bv[u][j] = raw[kbase[j] + po[u]];
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < JR; ++j) {
+            if (wave + 8 * j < nkt) {
+              const float b1 = kone[j] ? 1.0f : bv[u][j];
+#pragma unroll
+              for (int ct = 0; ct < NTC; ++ct) acc[j][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][ct], b1, acc[j][ct], 0, 0, 0);
+            }
+          }
       }
     }
     __syncthreads();
@@ -514,7 +573,7 @@ int launch_gemm_nt(const float *src, const float *w, const float *bias, float *o
   auto kern = conv_mfma_kernel<NT>;
   CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds));
   const int blocks = std::min(P.m.ntiles, 2 * std::max(ctcn_device_cus(), 64));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(CONV_THREADS), P.lds, st, src, w, bias, out, P.m, P.rwp_log, P.region_floats);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(CONV_THREADS), P.lds, st, src, w, bias, out, P.m, P.rwp_log, P.region_floats, ctcn_get_option("conv_dbg"));
   return CTCN_OK;
 }
 int launch_gemm(const float *src, const float *w, const float *bias, float *out, const ConvPlan &P, hipStream_t st) {

@@ -73,6 +73,23 @@ PY
     timeout 300 python bench.py --no-cpu-baseline --no-pmc > $O/bench_nopmc_$i.json 2> $O/bench_nopmc_$i.err
   done
   ;;
+8)
+  timeout 300 python -m pytest tests -m gpu -q --maxfail=5 --timeout 300 -p no:cacheprovider -k "conv or cnn or pool" > $O/pytest_conv.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 4 $O/pytest_conv.log
+  for pf in 0 1; do CTCN_OPT_CONV_PREFETCH=$pf timeout 200 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids | grep '"mfma": 1' | sed "s/^/prefetch=$pf /"; done | tee $O/conv_bench.txt
+  for pf in 0 1; do for wl in cfg3 ref_yaml; do
+    CTCN_OPT_CONV_PREFETCH=$pf timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/${wl}_prefetch$pf.json 2> $O/${wl}_prefetch$pf.err
+  done; done
+  ;;
+9)
+  timeout 300 python -m pytest tests -m gpu -q --maxfail=5 --timeout 300 -p no:cacheprovider -k "conv or cnn or pool" > $O/pytest_conv.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 3 $O/pytest_conv.log
+  timeout 200 python tools/conv_phase_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/conv_phase_probe.txt
+  for wl in cfg3 ref_yaml; do timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/${wl}.json 2> $O/${wl}.err; done
+  ;;
+10)
+  timeout 300 python -m pytest tests -m gpu -q --maxfail=5 --timeout 300 -p no:cacheprovider -k "conv or cnn or pool" > $O/pytest_conv.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 3 $O/pytest_conv.log
+  timeout 200 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids | grep '"mfma": 1' | tee $O/conv_bench.txt
+  for wl in cfg3 ref_yaml; do timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/${wl}.json 2> $O/${wl}.err; done
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
