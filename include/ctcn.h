@@ -73,6 +73,16 @@ int ctcn_device_xcds(void);
  * "edit_wave" = 1 (default): ctcn_edit_distance runs one wavefront per utterance along anti-diagonals (labels up to 512 symbols);
  * 0: one lane per utterance with its DP row in LDS (also the path for longer labels).
  * "gemm_big_tiles" = 0 (default): 1 lets the bf16x3 GEMM use 256x128 / 128x256 workgroup tiles (same results, measured slower).
+ * "tn_splits_xcd" = 1 (default, round 5): the TN tile sizes its split-K count for the CUs of the XCDs it may run on (xcd_allow of
+ * ctcn_rnn_bwd_weights: one round of items on the idle XCDs next to a recurrence) instead of for the whole device (two rounds of items half
+ * as long, each paying a prologue, a 128-KB partial store and its share of the reduce pass): cfg2 13.22 -> 13.15 ms per step; 0: as before.
+ * The k-sums are grouped differently (float32 rounding of the sums), deterministically either way.
+ * "beam_occ2" = 0 (default, round 5): 1 / 2 launch the fast beam search compiled for eight waves per SIMD (<= 64 VGPRs, 43 spilled dwords)
+ * with <= 68 KB of dynamic LDS (4 096-slot trie; 2: LM in global memory, 8 192 slots) so that two utterances share a CU.  Same results;
+ * measured SLOWER (cfg5, three searches in flight: 279 k -> 248 k utt/s peaky, 128 k -> 97 k flat; profiles/r05_beam_occ2_ab.txt) and kept
+ * as an experiment switch.
+ * "conv_dbg" = 0 (default): development only (tools/conv_phase_probe.py) -- conv_mfma_kernel skips its window load (1), MFMA loop (2) and /
+ * or output phase (4); results are invalid.
  * "fwd_pipe_any_chunking" = 0 (default): the input projection is pipelined with the forward recurrence (ctcn_rnn_call.side_stream) only
  * when a time-chunk count exists whose chunk pair the side stream digests in one round of 256-row tiles on the idle XCDs (cfg2: 10 chunks
  * of 2 560 rows), with at least 72 steps per chunk, at a flop rate the idle XCDs sustain within the recurrence's time for the chunk, and with
