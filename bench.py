@@ -138,7 +138,7 @@ def gemm_roofline(dev, c):
                 peak_note="f32 MFMA 157.3 TFLOP/s (dense)" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s; 3 bf16 MFMAs per algorithmic product (bf16x3)")
 
 
-PMC_FILE = next((f for f in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_hbm_traffic.json")
+PMC_FILE = next((f for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(kernel):
@@ -313,7 +313,7 @@ def make_training_step(c, dev, rank, world):
                 early_bytes=early_bytes)
 
 
-def other_workloads(dev, precision, names=("cfg1", "cfg3", "cfg4", "ref_yaml"), steps=10, warmup=2, prewarm=12):
+def other_workloads(dev, precision, names=("cfg1", "cfg3", "cfg4", "ref_yaml"), steps=12, warmup=2, prewarm=25):
     """The other single-GPU BASELINE workloads (and the reference's shipped YAML shape) through the SAME step closure as the headline,
     in the same process, so that a driver-run line carries them (VERDICT r4 #1 iv): ms per step (barrier-free single rank: wall clock over
     `steps` steps between two synchronisations, after `prewarm` + `warmup` untimed ones), frames/s, and the per-timestep time of both

@@ -48,6 +48,7 @@ static int g_opt_fwd_rsv_lds = 2;       // rnn_fwd_tagged: reserve traffic throu
 static int g_opt_fwd_pipe_any_chunking = 0;  // 1: pipeline the input projection with the forward recurrence even when no chunk count fits the side stream's one-round criterion (tests)
 static int g_opt_fwd_pipe_min_input = 0;       // smallest layer input width whose projection is pipelined with the forward recurrence
 static int g_opt_conv_dbg = 0;          // development: conv_mfma_kernel skips phases (1 window load, 2 MFMA loop, 4 output phase); results invalid
+static int g_opt_rnn_rsv_nt = 0;        // rnn_bwd_scatter2: non-temporal hint on the reserve traffic (experiment: keep the exchange tiles in L2 at H = 512)
 static int g_opt_tn_splits_xcd = 1;     // TN weight-gradient tile: split count sized for the CUs of xcd_allow (one round of items there), not for the whole device
 static int g_opt_beam_occ2 = 0;         // fast beam search compiled / launched for TWO workgroups per CU (<= 64 VGPRs, <= 80 KB LDS): 0 off, 1 on, 2 on with the LM in global memory
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
@@ -64,6 +65,7 @@ extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "gemm_big_tiles")) { g_opt_gemm_big_tiles = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "beam_fast")) { g_opt_beam_fast = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "conv_dbg")) { g_opt_conv_dbg = value & 7; return CTCN_OK; }
+  if (name && !strcmp(name, "rnn_rsv_nt")) { g_opt_rnn_rsv_nt = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "tn_splits_xcd")) { g_opt_tn_splits_xcd = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "beam_occ2")) { g_opt_beam_occ2 = value < 0 ? 0 : (value > 2 ? 2 : value); return CTCN_OK; }
   if (name && !strcmp(name, "fwd_pipe_min_input")) { g_opt_fwd_pipe_min_input = value < 0 ? 0 : value; return CTCN_OK; }
@@ -97,6 +99,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "beam_fast")) return g_opt_beam_fast;
   if (name && !strcmp(name, "beam_occ2")) return g_opt_beam_occ2;
   if (name && !strcmp(name, "tn_splits_xcd")) return g_opt_tn_splits_xcd;
+  if (name && !strcmp(name, "rnn_rsv_nt")) return g_opt_rnn_rsv_nt;
   if (name && !strcmp(name, "conv_dbg")) return g_opt_conv_dbg;
   if (name && !strcmp(name, "fwd_pipe_min_input")) return g_opt_fwd_pipe_min_input;
   if (name && !strcmp(name, "fwd_pipe_any_chunking")) return g_opt_fwd_pipe_any_chunking;

@@ -399,6 +399,7 @@ struct PersistArgs {
   unsigned *chunk_ready; //   ... and the counter the side stream raises after each chunk PAIR (p covers chunks p and nchunk-1-p)
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
+  int rsv_nt;           // rnn_bwd_scatter2: reserve loads / stores carry the non-temporal hint (streaming data must not evict the exchange tiles from L2)
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
                         // gathering wave polls the block itself; 0 = stores drained, then a flag per block
   float *ydrop;         // rnn_fwd_tagged: when set, the inverted dropout of y (Philox4x32-10, the dropout kernel's counters) is stored here as well
@@ -2069,7 +2070,8 @@ __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs p
     else if (a == 4) src = p.dy + (size_t)tx * slab_h + xh;
     else if (a == 5) src = (is_tanh ? p.y : p.aux) + (size_t)tx * slab_h + xh;
     else src = (is_lstm ? p.aux : p.y) + (size_t)tx1 * slab_h + xh;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&resv[set][a][0], 16, 0, 0);
+    if (pa.rsv_nt) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&resv[set][a][0], 16, 0, 2);      // aux 2 = nt
+    else __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&resv[set][a][0], 16, 0, 0);
   };
   auto dma = [&](int x, int set) {
     if (needed(ew)) dma1(ew, x, set);
@@ -2272,7 +2274,10 @@ __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs p
       if (ew < (is_tanh ? 1 : 4)) {
         const f32x4 vst = *reinterpret_cast<const f32x4 *>(&outf[sb][ew][lane * 4]);
         float *dst = (is_gru && ew == 3) ? p.aux + (size_t)t * slab_h + xh : p.gates + (size_t)t * slab_g + xg + (size_t)ew * H;
-        if (xvalid) *reinterpret_cast<f32x4 *>(dst) = vst;
+        if (xvalid) {
+          if (pa.rsv_nt) __builtin_nontemporal_store(vst, reinterpret_cast<f32x4 *>(dst));
+          else *reinterpret_cast<f32x4 *>(dst) = vst;
+        }
       }
       // LAST in program order: the vmcnt(ndma) wait before the next barrier then lets exactly these loads stay in flight, whatever the
       // order in which the counter retires loads against stores
@@ -2945,6 +2950,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
         }
         record_prelaunch(st);
         if (gather2) {
+          pa.rsv_nt = ctcn_get_option("rnn_rsv_nt");
           pa.poll_delay = ctcn_get_option("bwd_poll_delay");
           if (pa.poll_delay < 0) pa.poll_delay = nsl <= 24 ? 16 : 24;        // auto: the exchange phase grows with the tiles per wave (cfg4: 2.69 -> 2.55 us per step)
           done = launch_bwd_scatter2(nsl, pgrid, st, pa, wpx);

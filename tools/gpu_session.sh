@@ -90,6 +90,23 @@ PY
   timeout 200 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids | grep '"mfma": 1' | tee $O/conv_bench.txt
   for wl in cfg3 ref_yaml; do timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/${wl}.json 2> $O/${wl}.err; done
   ;;
+11)
+  for shape in "1200 64 512 gru" "800 32 320 lstm" "1200 32 512 gru" "1200 64 384 gru"; do set -- $shape
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && PMC_PROBE_SET=recurrence PMC_T=$1 PMC_B=$2 PMC_H=$3 PMC_CELL=$4 timeout 200 rocprofv3 --kernel-trace --pmc $c -d $O/p_$c -o p -- python $R/tools/pmc_probe.py > $O/p.log 2>&1 )
+      echo "== T=$1 B=$2 H=$3 $4 $c"; python tools/pmc_dump.py $(find $O/p_$c -name "*.db" | head -1) rnn_; rm -rf $O/p_$c
+    done
+  done | tee $O/rnn_traffic.txt
+  ;;
+12)
+  for nt in 0 1; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && CTCN_OPT_RNN_RSV_NT=$nt PMC_PROBE_SET=recurrence PMC_T=1200 PMC_B=64 PMC_H=512 PMC_CELL=gru timeout 200 rocprofv3 --kernel-trace --pmc $c -d $O/p_$c -o p -- python $R/tools/pmc_probe.py > $O/p.log 2>&1 )
+      echo "== rsv_nt=$nt $c"; python tools/pmc_dump.py $(find $O/p_$c -name "*.db" | head -1) rnn_bwd; rm -rf $O/p_$c
+    done
+    CTCN_OPT_RNN_RSV_NT=$nt timeout 300 python bench.py --workload cfg4 --steps 15 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/cfg4_nt$nt.json 2> $O/cfg4_nt$nt.err
+  done | tee $O/rsv_nt.txt
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
