@@ -24,6 +24,7 @@
 namespace {
 
 constexpr int BEAM_WMAX = 256;
+constexpr int SEL_SMAX = 1024;          // beam_kernel: survivors of the selection's pruning step held in LDS (more: the arg-max rounds)
 constexpr double LOG_ZERO = -99999999.0;
 constexpr unsigned long long HT_EMPTY = ~0ull;
 
@@ -62,19 +63,40 @@ struct BeamArgs {
   int nbest; int32_t *out_count;        // ctcn_beam_decode_nbest: the `nbest` best labellings per utterance (outputs [B][nbest]...), their number in out_count
   unsigned long long *ht_keys; int *ht_ids; int *node_par; int *node_sym; double *cand_global;
   int ht_size, max_nodes, cand_in_lds;
+#ifdef CTCN_BEAM_STATS
+  long long *stats;     // development instrumentation (tools/mb_beam.py generic): cycles per phase of workgroup 0, thread 0
+#endif
 };
+#ifdef CTCN_BEAM_STATS
+#define GSTAMP(i) do { if (b == 0 && tid == 0) { const long long now_ = clock64(); gst[i] += now_ - glast; glast = now_; } } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool cand_better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }
+// order-preserving map double -> uint64 for the selection's bound (v > w <=> dkey(v) > dkey(w); -0.0 folded onto +0.0, which compare equal; no NaN
+// among the scores); never 0 for a finite value
+__device__ __forceinline__ unsigned long long dkey(double v) {
+  const unsigned long long bts = (unsigned long long)__double_as_longlong(v == 0.0 ? 0.0 : v);
+  return (bts >> 63) ? ~bts : (bts | 0x8000000000000000ull);
+}
 
-__global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
+// NT threads per utterance: 256 up to W = 64, 1 024 beyond (round 5: every phase of a frame is a loop over nb * V candidates or over the beam, and the
+// kernel ran one wave per SIMD -- nothing hid an LDS or L2 latency)
+template <int NT>
+__global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
+  constexpr int NWV = NT / 64;
   extern __shared__ __attribute__((aligned(16))) double dsm[];   // lg[V] | cand[W*V] (if it fits)
   __shared__ BeamState S[2];
   __shared__ double sNB[BEAM_WMAX], sB[BEAM_WMAX], sT[BEAM_WMAX];
   __shared__ int mfrom[BEAM_WMAX], sel[BEAM_WMAX];
   __shared__ double selv[BEAM_WMAX];
-  __shared__ double red_v[4];
-  __shared__ int red_i[4];
+  __shared__ double red_v[NWV];
+  __shared__ int red_i[NWV];
+  __shared__ unsigned long long wthr[NWV];                     // selection: every wave's bound
   __shared__ int s_flag, s_nodes, s_best;
+  __shared__ double sv_v[SEL_SMAX];                            // selection: survivors of the pruning bound (value | candidate index)
+  __shared__ int sv_i[SEL_SMAX], s_scnt, s_ovf;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, V = a.V, W = a.W, B = a.B, T = a.T, blank = a.blank;
@@ -87,6 +109,9 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
   const int htmask = a.ht_size - 1;
 
   int cur = 0, nb = 1, status = 0;
+#ifdef CTCN_BEAM_STATS
+  long long gst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, glast = clock64(), gframes = 0;
+#endif
   if (tid == 0) {
     S[0].node[0] = 0; S[0].len[0] = 0; S[0].last[0] = -1; S[0].par[0] = -1;
     S[0].pB[0] = 0.0; S[0].pNB[0] = LOG_ZERO; S[0].pT[0] = 0.0;   // BeamSearch.py:83-87
@@ -101,8 +126,12 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
     if ((1.0f - pblank) < 0.1f) continue;                         // BeamSearch.py:93-94 (float32 compare)
     BeamState &L = S[cur];
     BeamState &N = S[cur ^ 1];
+    GSTAMP(0);
+#ifdef CTCN_BEAM_STATS
+    ++gframes;
+#endif
     // 1. ln of the frame's probabilities (math.log of the float32 value widened to double)
-    for (int k = tid; k < V; k += 256) {
+    for (int k = tid; k < V; k += NT) {
       const float p = a.input_is_prob ? row[k] : expf(row[k]);
       if (!(p > 0.0f)) s_flag = 2;
       lg[k] = log((double)p);
@@ -118,15 +147,24 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       int m = -1;
       if (L.len[tid] > 0) {
         const int pnode = L.par[tid];
-        for (int i2 = 0; i2 < nb; ++i2) if (L.node[i2] == pnode) m = i2;
+        int i2 = 0;
+        for (; i2 + 8 <= nb; i2 += 8) {
+          int nd[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) nd[u] = L.node[i2 + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (nd[u] == pnode) m = i2 + u;
+        }
+        for (; i2 < nb; ++i2) if (L.node[i2] == pnode) m = i2;
       }
       mfrom[tid] = m;
     }
     __syncthreads();
     if (s_flag == 2) { status = 2; break; }
+    GSTAMP(1);
     // 3a. extension scores (calcExtPr), candidate slot c = i*V + 1 + kk  (kk enumerates k != blank in order)
     const int ncand = nb * V;
-    for (int c = tid; c < ncand; c += 256) {
+    for (int c = tid; c < ncand; c += NT) {
       const int i = c / V, kk = c - i * V;
       if (kk == 0) continue;
       const int k = (kk - 1 < blank) ? kk - 1 : kk;
@@ -136,6 +174,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       cand[c] = lg[k] + bigram + base;
     }
     __syncthreads();
+    GSTAMP(2);
     // 3b. stay entries, merged with the matching extension in the reference's visiting order
     if (tid < nb) {
       const int ip = tid;
@@ -158,11 +197,115 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       sNB[ip] = e.nb; sB[ip] = e.b; sT[ip] = e.t;
     }
     __syncthreads();
-    // 4. BHat = top-W by (prTotal desc, insertion index asc)
+    GSTAMP(3);
+    // 4. BHat = top-W by (prTotal desc, insertion index asc).
+    // Round 5 (wide beams: the reference's class default is W = 200, ctcDecoder.py:170): NOT W block-wide arg-max rounds any more -- each a scan
+    // of all nb * V candidates (99 KB of global memory at W = 200, V = 62), a shuffle tree and two barriers -- but the selection scheme of the
+    // fast kernel in its plainest form:
+    //  (a) a lower bound of the W-th best candidate: every thread keeps the best of its candidates (two, of disjoint halves of its share, with
+    //      256 threads), every WAVE finds the k-th largest of its maxima, k = ceil(W / waves), by a bitwise binary search on the order-preserving
+    //      64-bit keys (ballot + popcount: no LDS, no barrier), and the bound is the smallest of the waves' values -- at least waves * k >= W
+    //      distinct candidates reach it, so the true top W all do (exact pruning; a tighter bound only means fewer survivors);
+    //  (b) the survivors (about W, more when values tie at the bound) are compacted into LDS;
+    //  (c) each is ranked by counting the survivors that beat it under the same explicit order cand_better() the rounds used.
+    // Same set, same order.  The rounds remain as the fallback (a wave with fewer than k candidates, or more than SEL_SMAX survivors: exact ties
+    // by the hundred).
     int m = 0;
-    for (int r = 0; r < W; ++r) {
+    bool ranked = false;
+    {
+      // (the candidate table is in global memory from W * V > 4 096 on: eight loads in flight per thread, or every scan is a chain of L2 round trips)
+      auto scan = [&](auto &&visit) {
+        int c = tid;
+        for (; c + 7 * NT < ncand; c += 8 * NT) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = cand[c + NT * u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) visit(v[u], c + NT * u);
+        }
+        for (; c < ncand; c += NT) visit(cand[c], c);
+      };
+      constexpr int NH = NT >= 1024 ? 1 : 2;                   // maxima per thread
+      unsigned long long tk[NH];
+      int nval = 0;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) tk[h] = 0ull;               // (no candidate: below every key of a finite value)
+      scan([&](double v, int c) {
+        if (v != -INFINITY) {
+          ++nval;
+          const unsigned long long key = dkey(v);
+          const int h = NH == 2 ? (c / NT) & 1 : 0;
+          if (NH == 2 && h) tk[NH - 1] = key > tk[NH - 1] ? key : tk[NH - 1];
+          else tk[0] = key > tk[0] ? key : tk[0];
+        }
+      });
+      GSTAMP(8);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) nval += __shfl_xor(nval, o, 64);
+      if (lane == 0) red_i[wave] = nval;
+      {
+        const int kth = (W + NWV - 1) / NWV;
+        unsigned long long p = 0ull;
+        for (int bit = 63; bit >= 0; --bit) {
+          const unsigned long long t = p | (1ull << bit);
+          int cnt = __popcll(__ballot(tk[0] >= t));
+          if (NH == 2) cnt += __popcll(__ballot(tk[NH - 1] >= t));
+          if (cnt >= kth) p = t;
+        }
+        if (lane == 0) wthr[wave] = p;
+      }
+      if (tid == 0) { s_scnt = 0; s_ovf = 0; }
+      __syncthreads();
+      int total = 0;
+      unsigned long long theta = ~0ull;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) { total += red_i[w]; theta = wthr[w] < theta ? wthr[w] : theta; }
+      GSTAMP(9);
+      // (a wave without k candidates -- the first frames, when the beam is still narrow -- gives no bound: then everything valid is ranked, if it fits)
+      const bool prune = total > W && theta != 0ull;
+      if (prune || total <= SEL_SMAX) {
+        int cnt = 0;
+        scan([&](double v, int c) { if (v != -INFINITY && (!prune || dkey(v) >= theta)) ++cnt; });
+        int pos = cnt ? atomicAdd(&s_scnt, cnt) : 0;
+        if (pos + cnt > SEL_SMAX) s_ovf = 1;
+        else scan([&](double v, int c) { if (v != -INFINITY && (!prune || dkey(v) >= theta)) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
+        __syncthreads();
+        GSTAMP(10);
+#ifdef CTCN_BEAM_STATS
+        if (b == 0 && tid == 0) { gst[6] += s_scnt; gst[7] += s_ovf ? 1 : 0; }
+#endif
+        if (!s_ovf) {
+          // P threads per survivor (a power of two, neighbouring lanes), thread part p counts among the survivors p, p + P, ...; eight entries
+          // are read before they are compared (a loop of dependent LDS reads costs a full LDS latency per entry); butterfly sum over the P lanes
+          const int S = s_scnt;
+          int P = 1;
+          while (2 * P * S <= NT && P < 16) P *= 2;
+          for (int e0 = 0; e0 < S; e0 += NT / P) {
+            const int e = e0 + tid / P, part = tid & (P - 1);
+            const bool have = e < S;
+            const double mv = sv_v[have ? e : 0]; const int mi = sv_i[have ? e : 0];
+            int rank = 0, q = part;
+            for (; q + 7 * P < S; q += 8 * P) {
+              double qv[8]; int qi[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) { qv[u] = sv_v[q + u * P]; qi[u] = sv_i[q + u * P]; }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) rank += cand_better(qv[u], qi[u], mv, mi) ? 1 : 0;
+            }
+            for (; q < S; q += P) rank += cand_better(sv_v[q], sv_i[q], mv, mi) ? 1 : 0;
+            for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (have && part == 0 && rank < W) { sel[rank] = mi; selv[rank] = mv; }
+          }
+          m = min(W, total);
+          ranked = true;
+        }
+        __syncthreads();
+        GSTAMP(11);
+      }
+    }
+    for (int r = 0; r < W && !ranked; ++r) {
       double bv = -INFINITY; int bi = 0x7fffffff;
-      for (int c = tid; c < ncand; c += 256) {
+      for (int c = tid; c < ncand; c += NT) {
         const double v = cand[c];
         if (v != -INFINITY && cand_better(v, c, bv, bi)) { bv = v; bi = c; }
       }
@@ -176,7 +319,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       __syncthreads();
       if (tid == 0) {
         double v = red_v[0]; int ix = red_i[0];
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NWV; ++w)
           if (red_i[w] != 0x7fffffff && (ix == 0x7fffffff || cand_better(red_v[w], red_i[w], v, ix))) { v = red_v[w]; ix = red_i[w]; }
         s_best = ix;
         if (ix != 0x7fffffff) { sel[r] = ix; selv[r] = v; cand[ix] = -INFINITY; }
@@ -185,6 +328,7 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       if (s_best == 0x7fffffff) break;
       ++m;
     }
+    GSTAMP(4);
     // 5. materialise the new beam
     if (tid < m) {
       const int c = sel[tid];
@@ -195,7 +339,17 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       } else {
         const int k = (kk - 1 < blank) ? kk - 1 : kk;
         int ip = -1;
-        for (int j = 0; j < nb; ++j) if (mfrom[j] == i && L.last[j] == k) ip = j;
+        {                                                            // (eight slots read before they are tested: independent LDS reads)
+          int j = 0;
+          for (; j + 8 <= nb; j += 8) {
+            int mf[8], ls[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { mf[u] = mfrom[j + u]; ls[u] = L.last[j + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (mf[u] == i && ls[u] == k) ip = j + u;
+          }
+          for (; j < nb; ++j) if (mfrom[j] == i && L.last[j] == k) ip = j;
+        }
         if (ip >= 0) {   // this slot holds the merged entry of existing labelling ip (first touched as an extension)
           N.node[tid] = L.node[ip]; N.len[tid] = L.len[ip]; N.last[tid] = L.last[ip]; N.par[tid] = L.par[ip];
           N.pNB[tid] = sNB[ip]; N.pB[tid] = sB[ip]; N.pT[tid] = sT[ip];
@@ -223,10 +377,14 @@ __global__ __launch_bounds__(256) void beam_kernel(BeamArgs a) {
       }
     }
     __syncthreads();
+    GSTAMP(5);
     nb = m;
     cur ^= 1;
   }
   __syncthreads();
+#ifdef CTCN_BEAM_STATS
+  if (a.stats && b == 0 && tid == 0) { for (int i = 0; i < 16; ++i) a.stats[32 + i] = gst[i]; a.stats[48] = gframes; }
+#endif
   // final LM step, length normalisation and best labelling (BeamSearch.py:130-151)
   BeamState &L = S[cur];
   if (status == 0 && tid == 0) {
@@ -1215,11 +1373,9 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
     a.ht = (unsigned long long *)(base + fl.ht); a.node_par = (int *)(base + fl.npar); a.node_sym = (int *)(base + fl.nsym);
     a.ht_size = fl.ht_size; a.max_nodes = fl.max_nodes; a.trie_slots = fl.trie_slots;
 #ifdef CTCN_BEAM_STATS
-    static long long *g_stats = nullptr;
-    if (!g_stats) { CTCN_HIP(hipMalloc(&g_stats, 64 * sizeof(long long))); }
-    CTCN_HIP(hipMemsetAsync(g_stats, 0, 64 * sizeof(long long), st));
-    a.stats = g_stats;
-    g_beam_stats_dev = g_stats;
+    if (!g_beam_stats_dev) { CTCN_HIP(hipMalloc(&g_beam_stats_dev, 64 * sizeof(long long))); }
+    CTCN_HIP(hipMemsetAsync(g_beam_stats_dev, 0, 64 * sizeof(long long), st));
+    a.stats = g_beam_stats_dev;
 #endif
     const size_t rows = (size_t)T * B;
     hipLaunchKernelGGL(beam_prep_kernel, dim3((unsigned)ceil_div_z(rows, 4)), dim3(256), 0, st, x, input_is_prob, (double *)(base + fl.lgd),
@@ -1246,10 +1402,23 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   a.ht_keys = (unsigned long long *)(base + l.keys); a.ht_ids = (int *)(base + l.ids);
   a.node_par = (int *)(base + l.npar); a.node_sym = (int *)(base + l.nsym); a.cand_global = (double *)(base + l.cand);
   a.ht_size = l.ht_size; a.max_nodes = l.max_nodes;
+#ifdef CTCN_BEAM_STATS
+  if (!g_beam_stats_dev) { CTCN_HIP(hipMalloc(&g_beam_stats_dev, 64 * sizeof(long long))); }
+  CTCN_HIP(hipMemsetAsync(g_beam_stats_dev, 0, 64 * sizeof(long long), st));
+  a.stats = g_beam_stats_dev;
+#endif
   const size_t cand_bytes = (size_t)W * V * sizeof(double);
   a.cand_in_lds = cand_bytes <= 32 * 1024 ? 1 : 0;
   const size_t sm = (size_t)V * sizeof(double) + (a.cand_in_lds ? cand_bytes : 0);
-  hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(256), sm, st, a);
+  // (static LDS of the kernel is ~46 KB since the selection holds its survivors there: together with the candidate table the block can pass
+  // the 64 KB a launch gets without asking)
+  if (W > 64) {
+    CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(beam_kernel<1024>, dim3(B), dim3(1024), sm, st, a);
+  } else {
+    CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(beam_kernel<256>, dim3(B), dim3(256), sm, st, a);
+  }
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }

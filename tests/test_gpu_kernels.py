@@ -1959,17 +1959,22 @@ def test_beam_fuzz_small_alphabets_vs_c_oracle(dev, V, W, regime, alpha):
     tab = -3.0 * rs.random_sample((V + 1, V + 1))
     probs = torch.exp(torch.from_numpy(lp))
     want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, alpha, W)
-    got, score, st = ops.beam_decode(probs.to(dev), lens, tab, alpha, W, 0, input_is_prob=True)
-    assert list(st) == list(wst)
-    assert got == [list(map(int, s_)) for s_ in want]
-    # float64 scores: the device's exp / log (ocml) and glibc's differ in the last place on some arguments -- 0-2 ulp of the final score on
-    # these batches, the same with the round-3 kernel (tools/beam_fuzz_ab.py runs both: bit-equal to each other); the golden sets are bit-equal
-    score, wscore = np.asarray(score), np.asarray(wscore)
-    assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
+    for fast in (1, 0):                  # (0: the generic kernel, whose selection -- pruning bound + rank count since round 5 -- these batches stress as well)
+        ops.set_option("beam_fast", fast)
+        try:
+            got, score, st = ops.beam_decode(probs.to(dev), lens, tab, alpha, W, 0, input_is_prob=True)
+        finally:
+            ops.set_option("beam_fast", 1)
+        assert list(st) == list(wst), fast
+        assert got == [list(map(int, s_)) for s_ in want], fast
+        # float64 scores: the device's exp / log (ocml) and glibc's differ in the last place on some arguments -- 0-2 ulp of the final score on
+        # these batches, the same with the round-3 kernel (tools/beam_fuzz_ab.py runs both: bit-equal to each other); the golden sets are bit-equal
+        score, wscore = np.asarray(score), np.asarray(wscore)
+        assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore))), fast
 
 
 @pytest.mark.parametrize("kind,V,W,alpha", [("uniform", 62, 20, 0.0), ("uniform", 62, 20, 0.1), ("uniform", 16, 52, 0.0), ("quantised", 62, 20, 0.0),
-                                             ("quantised", 30, 40, 0.3)])
+                                             ("quantised", 30, 40, 0.3), ("uniform", 62, 200, 0.0), ("quantised", 40, 100, 0.3), ("uniform", 8, 256, 0.1)])
 def test_beam_exact_ties_vs_c_oracle(dev, kind, V, W, alpha):
     """Collisions, as this domain has them: EXACT ties of prTotal.  Uniform posteriors (every class 1 / V) make all extensions of a slot --
     and, from the second frame on, of all slots -- tie to the last bit; posteriors quantised to powers of two make most of them tie.  The

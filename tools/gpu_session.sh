@@ -107,6 +107,41 @@ PY
     CTCN_OPT_RNN_RSV_NT=$nt timeout 300 python bench.py --workload cfg4 --steps 15 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/cfg4_nt$nt.json 2> $O/cfg4_nt$nt.err
   done | tee $O/rsv_nt.txt
   ;;
+13)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" > $O/summary.log; tail -n 2 $O/smoke.log
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/summary.log; tail -n 6 $O/pytest_gpu.log
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  ;;
+14)
+  timeout 900 python -m pytest tests -m gpu -q --maxfail=10 --timeout 600 -p no:cacheprovider -k "beam or decoder or decode" > $O/pytest_beam.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 12 $O/pytest_beam.log
+  cat > /tmp/wide_time.py <<'PY'
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from ctc_pytorch_amd import ops
+from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+from oracle import synth
+dev = torch.device("cuda", 0)
+V, T, B = 62, 800, 128
+i2c = synth.int2char(V)
+tab = torch.as_tensor(LanguageModel("tests/golden/lm_phone_bg.arpa").table([i2c[i] for i in range(V)]), dtype=torch.float64).to(dev)
+for regime in ("peaky", "flat"):
+    x = torch.from_numpy(synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)).to(dev)
+    lens = torch.as_tensor(np.random.RandomState(2).randint(400, 801, size=B), dtype=torch.int32).to(dev)
+    for W in (20, 60, 61, 128, 200, 256):
+        for fast in ((1, 0) if W <= 60 else (1,)):
+            ops.set_option("beam_fast", fast)
+            ops.beam_decode_device(x, lens, tab, 0.01, W); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = ops.beam_decode_device(x, lens, tab, 0.01, W); e1.record(); torch.cuda.synchronize()
+            print("cfg5 batch (128 x 800 x 62) %-5s W=%3d %s kernel: %9.2f ms  status ok %s" % (regime, W, "fast   " if (fast and W <= 60) else "generic", e0.elapsed_time(e1), bool((out[3] == 0).all())), flush=True)
+ops.set_option("beam_fast", 1)
+PY
+  { echo "## this build"; python /tmp/wide_time.py 2>&1 | grep -v amdgpu.ids
+    if [ -f tools/libctcn_r5base.so ]; then cp ctc_pytorch_amd/libctcn.so /tmp/libctcn_new.so; cp tools/libctcn_r5base.so ctc_pytorch_amd/libctcn.so
+      echo "## the build before round 5's generic kernel (W block-wide arg-max rounds per frame, 256 threads)"; timeout 600 python /tmp/wide_time.py 2>&1 | grep -v amdgpu.ids; cp /tmp/libctcn_new.so ctc_pytorch_amd/libctcn.so; fi
+    echo "## cycles per phase and frame of the generic kernel (tools/mb_beam.py generic <regime> <W>)"
+    for r in peaky flat; do for W in 128 200 256; do timeout 200 python tools/mb_beam.py generic $r $W 2>&1 | grep -v amdgpu.ids; done; done; } | tee $O/wide_beam_time.txt
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'

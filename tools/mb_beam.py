@@ -60,6 +60,48 @@ def run(regime):
             print("    %-36s %8.0f cycles/frame" % (n, st[base + i] / nfl))
 
 
+def run_generic(regime, W):
+    """cycles per phase and frame of the GENERIC beam_kernel (workgroup 0, thread 0) on the cfg5 batch at beam width W (> 60: the generic kernel)"""
+    import numpy as np
+    import torch
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    from oracle import synth
+    L = ctypes.CDLL(SO)
+    V, T, B = 62, 800, 128
+    i2c = synth.int2char(V)
+    tab = LanguageModel(os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)).to(dev)
+    lens_t = torch.from_numpy(np.random.RandomState(2).randint(400, 801, size=B).astype(np.int32)).to(dev)
+    lm = torch.from_numpy(np.asarray(tab, dtype=np.float64)).to(dev)
+    L.ctcn_beam_ws_bytes.restype = ctypes.c_size_t
+    nb = L.ctcn_beam_ws_bytes(T, B, V, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out_ids = torch.zeros((B, T), dtype=torch.int32, device=dev)
+    out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    score = torch.zeros(B, dtype=torch.float64, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.ctcn_beam_decode.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    for _ in range(2):
+        assert L.ctcn_beam_decode(P(x), 0, P(lens_t), P(lm), 0.1, W, 0, P(out_ids), P(out_len), P(score), P(status), T, B, V, P(ws), nb, None) == 0
+        torch.cuda.synchronize()
+    st = (ctypes.c_longlong * 64)()
+    assert L.ctcn_beam_stats(st) == 0
+    nfl = max(st[48], 1)
+    names = ["loop top (skip test, pointers)", "ln p of the frame + parent slots (mfrom) + barrier", "extension scores + barrier", "stay entries / merges + barrier",
+             "selection (maxima, bound, compaction, rank count | arg-max rounds)", "new beam (trie lookups / inserts) + barrier"]
+    print("%s W=%d generic kernel, workgroup 0: %d processed frames, %.0f cycles per frame" % (regime, W, nfl, (sum(st[32 + i] for i in range(6)) + sum(st[40 + i] for i in range(4))) / nfl))
+    for i, n in enumerate(names):
+        print("    %-70s %9.0f cycles/frame" % (n, st[32 + i] / nfl))
+    for i, n in enumerate(["selection: scan for the maxima per thread", "selection: wave-local k-th largest (64-step ballot search) -> bound (+ barrier)", "selection: count + compact the survivors (two scans, + barrier)",
+                           "selection: rank count of the survivors (+ barrier)"]):
+        print("    %-70s %9.0f cycles/frame" % (n, st[40 + i] / nfl))
+    print("    survivors of the pruning bound per frame %.0f; frames whose survivors overflowed into the arg-max rounds %d" % (st[38] / nfl, st[39]))
+
+
 def build_plain(src, out):
     """decode.hip `src` (e.g. an older revision written to a temporary file) -> un-instrumented library `out`, for A/B timing on one box"""
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CS, "-o", out, src,
@@ -113,6 +155,8 @@ def time_lib(so, iters=20):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "generic":
+        run_generic(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "build_plain":
         build_plain(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "time":
