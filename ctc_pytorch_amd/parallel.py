@@ -263,8 +263,14 @@ def sync_bn_buffers(model, weight=None):
     mods = [m for m in model.modules() if getattr(m, "running_mean", None) is not None and getattr(m, "running_var", None) is not None]
     if not mods:
         return 0
-    w = float(_batch["seen"] if weight is None and _batch.get("seen") else (1.0 if weight is None else weight))
+    # the weights must mean the same thing on every rank: utterance counts where EVERY rank has one (or was given one), else equal weights
+    mine = float(weight) if weight is not None else float(_batch.get("seen") or 0)
     _batch["seen"] = 0
+    have = torch.tensor([1.0 if mine > 0 else 0.0], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        have = have.cuda()
+    dist.all_reduce(have, op=dist.ReduceOp.SUM)
+    w = mine if int(have.item()) == world_size() else 1.0
     means = torch.cat([m.running_mean.detach().reshape(-1).double() for m in mods])
     vars_ = torch.cat([m.running_var.detach().reshape(-1).double() for m in mods])
     n = means.numel()
