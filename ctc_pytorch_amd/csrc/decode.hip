@@ -81,7 +81,7 @@ __device__ __forceinline__ unsigned long long dkey(double v) {
   return (bts >> 63) ? ~bts : (bts | 0x8000000000000000ull);
 }
 
-// NT threads per utterance: 256 up to W = 64, 1 024 beyond (round 5: every phase of a frame is a loop over nb * V candidates or over the beam, and the
+// NT threads per utterance: 256 for small tables, 1 024 beyond W = 64 or 3 500 candidates per frame (round 5: every phase of a frame is a loop over nb * V candidates or over the beam, and the
 // kernel ran one wave per SIMD -- nothing hid an LDS or L2 latency)
 template <int NT>
 __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
@@ -1412,7 +1412,9 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   const size_t sm = (size_t)V * sizeof(double) + (a.cand_in_lds ? cand_bytes : 0);
   // (static LDS of the kernel is ~46 KB since the selection holds its survivors there: together with the candidate table the block can pass
   // the 64 KB a launch gets without asking)
-  if (W > 64) {
+  const int gthreads = ctcn_get_option("beam_generic_threads");          // 0 (default): by beam width; 256 / 1024: forced (measurements)
+  // (measured, tools/beam_generic_probe.py, 128 x 800 batches: 3 720 candidates per frame 7.9 -> 6.3 ms with 1 024 threads, 12 000: 21 -> 16 ms; 1 240: 4.7 -> 4.9)
+  if (gthreads == 1024 || (gthreads != 256 && (W > 64 || (long)W * V > 3500))) {
     CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipLaunchKernelGGL(beam_kernel<1024>, dim3(B), dim3(1024), sm, st, a);
   } else {

@@ -85,6 +85,10 @@ int ctcn_device_xcds(void);
  * with <= 68 KB of dynamic LDS (4 096-slot trie; 2: LM in global memory, 8 192 slots) so that two utterances share a CU.  Same results;
  * measured SLOWER (cfg5, three searches in flight: 279 k -> 248 k utt/s peaky, 128 k -> 97 k flat; profiles/r05_beam_occ2_ab.txt) and kept
  * as an experiment switch.
+ * "beam_generic_threads" = 0 (default): the generic beam kernel runs 256 threads per utterance, 1 024 beyond W = 64 or 3 500 candidates per frame;
+ * 256 / 1024 force one (measurements).
+ * "rnn_rsv_nt" = 0 (default): 1 puts the non-temporal hint on rnn_bwd_scatter2's reserve loads / stores (experiment: -15 % L2 write-backs at H = 512, no
+ * change of the step).
  * "conv_dbg" = 0 (default): development only (tools/conv_phase_probe.py) -- conv_mfma_kernel skips its window load (1), MFMA loop (2) and /
  * or output phase (4); results are invalid.
  * "fwd_pipe_any_chunking" = 0 (default): the input projection is pipelined with the forward recurrence (ctcn_rnn_call.side_stream) only
