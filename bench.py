@@ -488,7 +488,8 @@ def run_train(args):
         kname, kus, kstep = ((rec["fwd_kernel"], rec["kernel_fwd_us"], rec["fwd_us_per_timestep"]) if fwd_dom else
                              (rec["bwd_kernel"], rec["kernel_bwd_us"], rec["bwd_us_per_timestep"]))
         tf = rec["algorithmic_flops_per_launch"] / (kus * 1e-6) / 1e12
-        traffic, traffic_note = (None, "--no-pmc") if args.no_pmc else measure_recurrence_traffic(c, kname, args.precision)
+        traffic, traffic_note = ((None, "--no-pmc" if args.no_pmc else "N > 1: single-rank measurement") if (args.no_pmc or world > 1)
+                                 else measure_recurrence_traffic(c, kname, args.precision))
         if traffic is None:             # fall back to the committed passes (same kernel instantiation, same shape), and say so
             traffic = recurrence_traffic(args.workload, kname)
             traffic_note = None if traffic is None else ("HBM bytes per launch of this kernel instantiation from the committed rocprofv3 PMC passes (profiles/%s), not a "
