@@ -1943,7 +1943,8 @@ def test_beam_decoder_reference_defaults_golden(dev):
 
 
 @pytest.mark.parametrize("V,W,regime,alpha", [(3, 2, "flat", 0.0), (4, 5, "flat", 0.5), (4, 20, "flat", 0.1), (8, 33, "flat", 0.3), (8, 52, "peaky", 0.1),
-                                                 (5, 52, "flat", 1.0), (30, 10, "flat", 0.1), (200, 10, "peaky", 0.1), (200, 16, "flat", 0.2), (62, 1, "flat", 0.1)])
+                                                 (5, 52, "flat", 1.0), (30, 10, "flat", 0.1), (200, 10, "peaky", 0.1), (200, 16, "flat", 0.2), (62, 1, "flat", 0.1),
+                                                 (200, 20, "peaky", 0.1), (200, 40, "flat", 0.2)])     # (4 000 / 8 000 candidates per frame: the generic kernel with 1 024 threads)
 def test_beam_fuzz_small_alphabets_vs_c_oracle(dev, V, W, regime, alpha):
     """Round 4 moved the prefix trie to a wave of its own: wave 0 recognises "this labelling's parent was created in this very frame" from
     (grandparent id, parent's last class) keys instead of node ids.  Small alphabets are what stresses that logic -- labellings leave the beam
