@@ -54,6 +54,8 @@ _SIGS = {
     "ctcn_bn_bwd_sums": (I, [P, P, P, P, P, P, I, I, I, I, P, Z, P]),
     "ctcn_bn_bwd_finish": (I, [P, P, P, P, P, P, P, P, P, P, P, D, I, I, I, I, F, P, Z, P]),
     "ctcn_bn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P, Z, P]),
+    "ctcn_bn_fwd_train_dropout": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, Z, P, P, F, U, U]),
+    "ctcn_bn_bwd_dropout": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, F, P, Z, P, F, U, U]),
     "ctcn_dropout": (I, [P, P, Z, F, U, U, P]),
     "ctcn_conv2d_ws_bytes": (Z, [I] * 11),
     "ctcn_conv2d_fwd": (I, [P, P, P, P] + [I] * 11 + [P]),

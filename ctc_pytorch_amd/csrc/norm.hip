@@ -36,12 +36,29 @@ struct StatVal {   // (x, x*x)
   }
   __host__ __device__ __forceinline__ bool aligned16() const { return ((uintptr_t)x & 15) == 0; }
 };
-struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu
+// Fused dropout behind BatchNorm (+ ReLU) (round 5: LayerCNN's Conv2d -> BatchNorm2d -> ReLU -> Dropout, model_ctc.py:61-67): `dy` is the
+// gradient of the DROPPED output; the keep mask is regenerated from the Philox counters of the forward pass (ctcn_dropout's: word i & 3 of
+// group offset + (i >> 2)), and the ReLU mask is recomputed from x -- the forward pass stored nothing but the dropped tensor.
+struct DropSpec { float p, scale; uint64_t seed, offset; const float *gamma, *beta; };     // p == 0: plain BatchNorm backward (relu mask from y)
+__device__ __forceinline__ float bn_value(float x, float m, float rs, float g, float b) { return fmaf((x - m) * rs, g, b); }   // ONE rounding sequence: forward and recomputation
+__device__ __forceinline__ bool drop_keep(uint32_t word, float p) { return (word >> 8) * (1.0f / 16777216.0f) >= p; }
+// dx = gamma * rstd * (dy' - sum(dy') / N - xhat * sum(dy' xhat) / N), ONE rounding sequence for every dx kernel (the fused and the plain ones agree bit for bit)
+__device__ __forceinline__ float bn_dx_value(float g, float xh, float ga, float rs, float s0, float s1, float inv_n) {
+  return ga * rs * fmaf(-xh, s1 * inv_n, fmaf(-s0, inv_n, g));
+}
+
+struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu (and, with a DropSpec, first by the dropout's keep mask, scaled)
   const float *x, *y, *dy, *mean, *rstd;
   int relu;
+  DropSpec d;
   __device__ __forceinline__ Pair operator()(size_t idx, int c) const {
     float g = dy[idx];
-    if (relu && !(y[idx] > 0.0f)) g = 0.0f;
+    if (d.p > 0.0f) {
+      uint32_t r[4];
+      philox4(d.seed, d.offset + (idx >> 2), r);
+      g = drop_keep(r[idx & 3], d.p) ? g * d.scale : 0.0f;
+      if (relu && !(bn_value(x[idx], mean[c], rstd[c], d.gamma[c], d.beta[c]) > 0.0f)) g = 0.0f;
+    } else if (relu && !(y[idx] > 0.0f)) g = 0.0f;
     const float xh = (x[idx] - mean[c]) * rstd[c];
     return {(double)g, (double)g * (double)xh};
   }
@@ -50,21 +67,33 @@ struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu
     Quad q;
     q.x = *reinterpret_cast<const f32x4 *>(x + idx);
     q.dy = *reinterpret_cast<const f32x4 *>(dy + idx);
-    q.y = relu ? *reinterpret_cast<const f32x4 *>(y + idx) : q.x;
+    if (d.p > 0.0f) {                   // dy' of the four elements; the relu test is recomputed per channel in add4
+      uint32_t r[4];
+      philox4(d.seed, d.offset + (idx >> 2), r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q.dy[e] = drop_keep(r[e], d.p) ? q.dy[e] * d.scale : 0.0f;
+      q.y = q.x;
+    } else q.y = relu ? *reinterpret_cast<const f32x4 *>(y + idx) : q.x;
     return q;
   }
   __device__ __forceinline__ void add4(const Quad &q, int c, double &a, double &b) const {
     const float m = mean[c], rs = rstd[c];
+    const bool rec = d.p > 0.0f;
+    const float ga = rec ? d.gamma[c] : 0.0f, be = rec ? d.beta[c] : 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float g = q.dy[e];
-      if (relu && !(q.y[e] > 0.0f)) g = 0.0f;
+      const float yv = rec ? bn_value(q.x[e], m, rs, ga, be) : q.y[e];
+      if (relu && !(yv > 0.0f)) g = 0.0f;
       const float xh = (q.x[e] - m) * rs;
       a += (double)g; b += (double)g * (double)xh;
     }
   }
-  __host__ __device__ __forceinline__ bool aligned16() const { return (((uintptr_t)x | (uintptr_t)dy | (relu ? (uintptr_t)y : 0)) & 15) == 0; }
+  __host__ __device__ __forceinline__ bool aligned16() const {
+    return (((uintptr_t)x | (uintptr_t)dy | ((relu && !(d.p > 0.0f)) ? (uintptr_t)y : 0)) & 15) == 0;
+  }
 };
+static const DropSpec k_no_drop = {0.0f, 1.0f, 0, 0, nullptr, nullptr};
 
 template <class F>
 __global__ __launch_bounds__(256) void colreduce_rows_kernel(F f, int rows, int C, int rows_per_chunk, double *__restrict__ part) {
@@ -196,7 +225,7 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, float *__restrict__
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)((i / inner) % C);
     const float rs = var_is_variance ? 1.0f / sqrtf(rstd_or_var[c] + eps) : rstd_or_var[c];
-    float v = (x[i] - mean[c]) * rs * gamma[c] + beta[c];
+    float v = bn_value(x[i], mean[c], rs, gamma[c], beta[c]);
     if (relu) v = fmaxf(v, 0.0f);
     y[i] = v;
   }
@@ -219,13 +248,69 @@ __global__ void bn_apply_rows4_kernel(const float *__restrict__ x, float *__rest
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float rs = var_is_variance ? 1.0f / sqrtf(rv[k] + eps) : rv[k];
-      float v = (xs[k] - ms[k]) * rs * gv[k] + bv[k];
+      float v = bn_value(xs[k], ms[k], rs, gv[k], bv[k]);
       if (relu) v = fmaxf(v, 0.0f);
       o[k] = v;
     }
     reinterpret_cast<float4 *>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
+// BatchNorm (+ ReLU) + inverted dropout in one pass: y = keep ? relu(bn(x)) * scale : 0 -- the values BatchNorm -> ctcn_dropout produce, bit for
+// bit (same expression, same Philox words).  Four consecutive elements per thread (one Philox group); the channel per element (inner % 4 may be
+// anything).
+__global__ void bn_apply_drop_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                     const float *__restrict__ mean, const float *__restrict__ rstd, size_t total, int C, int inner, int relu, DropSpec d) {
+  const size_t ngroups = (total + 3) / 4;
+  const bool vec = ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+  for (size_t gi = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (size_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(d.seed, d.offset + gi, r);
+    const size_t i0 = gi * 4;
+    float xv[4], o[4];
+    const bool full = i0 + 3 < total && vec;
+    if (full) { const float4 v = *reinterpret_cast<const float4 *>(x + i0); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+    else for (int e = 0; e < 4; ++e) xv[e] = i0 + e < total ? x[i0 + e] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = (int)(((i0 + e) / inner) % C);
+      float v = bn_value(xv[e], mean[c], rstd[c], gamma[c], beta[c]);
+      if (relu) v = fmaxf(v, 0.0f);
+      o[e] = drop_keep(r[e], d.p) ? v * d.scale : 0.0f;
+    }
+    if (full) *reinterpret_cast<float4 *>(y + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    else for (int e = 0; e < 4 && i0 + e < total; ++e) y[i0 + e] = o[e];
+  }
+}
+// dx of the same fused block: dy is the gradient of the dropped output
+__global__ void bn_dx_drop_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                  const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ sums, float *__restrict__ dx,
+                                  size_t total, int C, int inner, float inv_n, int relu, DropSpec d) {
+  const size_t ngroups = (total + 3) / 4;
+  const bool vec = ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
+  for (size_t gi = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gi < ngroups; gi += (size_t)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4(d.seed, d.offset + gi, r);
+    const size_t i0 = gi * 4;
+    float xv[4], gv[4], o[4];
+    const bool full = i0 + 3 < total && vec;
+    if (full) {
+      const float4 v = *reinterpret_cast<const float4 *>(x + i0), g4 = *reinterpret_cast<const float4 *>(dy + i0);
+      xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+    } else for (int e = 0; e < 4; ++e) { xv[e] = i0 + e < total ? x[i0 + e] : 0.0f; gv[e] = i0 + e < total ? dy[i0 + e] : 0.0f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = (int)(((i0 + e) / inner) % C);
+      const float m = mean[c], rs = rstd[c], ga = gamma[c];
+      float g = drop_keep(r[e], d.p) ? gv[e] * d.scale : 0.0f;
+      if (relu && !(bn_value(xv[e], m, rs, ga, beta[c]) > 0.0f)) g = 0.0f;
+      const float xh = (xv[e] - m) * rs;
+      o[e] = bn_dx_value(g, xh, ga, rs, sums[c], sums[C + c], inv_n);
+    }
+    if (full) *reinterpret_cast<float4 *>(dx + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    else for (int e = 0; e < 4 && i0 + e < total; ++e) dx[i0 + e] = o[e];
+  }
+}
+
 static void launch_bn_apply(hipStream_t st, const float *x, float *y, const float *gamma, const float *beta, const float *mean, const float *rstd_or_var,
                             float eps, int var_is_variance, size_t total, int C, int inner, int relu) {
   const bool al = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd_or_var) & 15) == 0);
@@ -249,7 +334,7 @@ __global__ void bn_dx_kernel(const float *__restrict__ x, const float *__restric
     float g = dy[i];
     if (relu && !(y[i] > 0.0f)) g = 0.0f;
     const float xh = (x[i] - mean[c]) * rstd[c];
-    dx[i] = gamma[c] * rstd[c] * (g - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+    dx[i] = bn_dx_value(g, xh, gamma[c], rstd[c], sums[c], sums[C + c], inv_n);
   }
 }
 
@@ -275,7 +360,7 @@ __global__ void bn_dx_rows4_kernel(const float *__restrict__ x, const float *__r
       float g = gs[k];
       if (relu && !(ys[k] > 0.0f)) g = 0.0f;
       const float xh = (xs[k] - ms[k]) * rs[k];
-      o[k] = gm[k] * rs[k] * (g - a0[k] * inv_n - xh * a1[k] * inv_n);
+      o[k] = bn_dx_value(g, xh, gm[k], rs[k], a0[k], a1[k], inv_n);
     }
     reinterpret_cast<float4 *>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -366,6 +451,55 @@ extern "C" int ctcn_bn_fwd_train(const float *x, float *y, const float *gamma, c
   return CTCN_OK;
 }
 
+// BatchNorm (training statistics) + ReLU + dropout in one apply pass (LayerCNN: conv -> BN -> ReLU -> Dropout).  y_drop receives
+// ctcn_dropout(relu(bn(x)), p, seed, offset) bit for bit; the un-dropped activation is not stored (ctcn_bn_bwd_dropout recomputes what it needs).
+extern "C" int ctcn_bn_fwd_train_dropout(const float *x, float *y_drop, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                         float *save_mean, float *save_rstd, int outer, int C, int inner, float eps, float momentum, int relu, void *ws,
+                                         size_t ws_bytes, void *stream, long long *num_batches_tracked, float p, uint64_t seed, uint64_t offset) {
+  CTCN_REQUIRE(x && y_drop && gamma && beta && save_mean && save_rstd && ws, "ctcn_bn_fwd_train_dropout: null pointer");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_fwd_train_dropout: bad dims");
+  CTCN_REQUIRE(p > 0.0f && p < 1.0f, "ctcn_bn_fwd_train_dropout: p=%f outside (0,1)", (double)p);
+  if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_fwd_train_dropout: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double *part = (double *)ws;
+  int nchunks = 0;
+  launch_reduce(StatVal{x}, outer, C, inner, part, &nchunks, st);
+  CTCN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, (double)outer * inner, eps, momentum,
+                     save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
+  CTCN_LAUNCH_CHECK();
+  const size_t total = (size_t)outer * C * inner;
+  const DropSpec d = {p, 1.0f / (1.0f - p), seed, offset, gamma, beta};
+  hipLaunchKernelGGL(bn_apply_drop_kernel, dim3((int)std::min((size_t)4096, ceil_div_z((total + 3) / 4, 256))), dim3(256), 0, st, x, y_drop, gamma, beta,
+                     save_mean, save_rstd, total, C, inner, relu, d);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
+extern "C" int ctcn_bn_bwd_dropout(const float *x, const float *dy_drop, const float *gamma, const float *beta, const float *save_mean,
+                                   const float *save_rstd, float *dx, float *dgamma, float *dbeta, int outer, int C, int inner, int relu, float beta_acc,
+                                   void *ws, size_t ws_bytes, void *stream, float p, uint64_t seed, uint64_t offset) {
+  CTCN_REQUIRE(x && dy_drop && gamma && beta && save_mean && save_rstd && dx && ws, "ctcn_bn_bwd_dropout: null pointer");
+  CTCN_REQUIRE(outer > 0 && C > 0 && inner > 0, "ctcn_bn_bwd_dropout: bad dims");
+  CTCN_REQUIRE(p > 0.0f && p < 1.0f, "ctcn_bn_bwd_dropout: p=%f outside (0,1)", (double)p);
+  if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_bwd_dropout: workspace too small"); return CTCN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  double *part = (double *)ws;
+  const int nmax = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C, inner).n;
+  float *sums = (float *)((char *)ws + align_up((size_t)(nmax + 1) * C * 2 * sizeof(double), 256));
+  const DropSpec d = {p, 1.0f / (1.0f - p), seed, offset, gamma, beta};
+  int nchunks = 0;
+  launch_reduce(BwdVal{x, nullptr, dy_drop, save_mean, save_rstd, relu, d}, outer, C, inner, part, &nchunks, st);
+  CTCN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, dgamma, dbeta, sums, beta_acc);
+  CTCN_LAUNCH_CHECK();
+  const size_t total = (size_t)outer * C * inner;
+  hipLaunchKernelGGL(bn_dx_drop_kernel, dim3((int)std::min((size_t)4096, ceil_div_z((total + 3) / 4, 256))), dim3(256), 0, st, x, dy_drop, gamma, beta,
+                     save_mean, save_rstd, sums, dx, total, C, inner, (float)(1.0 / ((double)outer * inner)), relu, d);
+  CTCN_LAUNCH_CHECK();
+  return CTCN_OK;
+}
+
 // ---- synchronised BatchNorm (data parallel): statistics over the GLOBAL batch --------------------------------------
 // Each rank computes its per-channel sums (fp64, [C][2]), the host all-reduces them (2*C doubles), and the finish call
 // normalises with the global count.  With one rank the result equals ctcn_bn_fwd_train / ctcn_bn_bwd exactly.
@@ -405,7 +539,7 @@ extern "C" int ctcn_bn_bwd_sums(const float *x, const float *y, const float *dy,
   if (ws_bytes < ctcn_bn_ws_bytes(outer, C, inner)) { ctcn_set_error("ctcn_bn_bwd_sums: workspace too small"); return CTCN_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   int nchunks = 0;
-  launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu}, outer, C, inner, (double *)ws, &nchunks, st);
+  launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu, k_no_drop}, outer, C, inner, (double *)ws, &nchunks, st);
   CTCN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_sum_chunks_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double *)ws, nchunks, C, sums);
   CTCN_LAUNCH_CHECK();
@@ -454,7 +588,7 @@ extern "C" int ctcn_bn_bwd(const float *x, const float *y, const float *dy, cons
   const int nmax = inner == 1 ? chunks_rows(outer, C) : chunks_nchw(outer, C, inner).n;
   float *sums = (float *)((char *)ws + align_up((size_t)(nmax + 1) * C * 2 * sizeof(double), 256));
   int nchunks = 0;
-  launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu}, outer, C, inner, part, &nchunks, st);
+  launch_reduce(BwdVal{x, y, dy, save_mean, save_rstd, relu, k_no_drop}, outer, C, inner, part, &nchunks, st);
   CTCN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nchunks, C, dgamma, dbeta, sums, beta_acc);
   CTCN_LAUNCH_CHECK();

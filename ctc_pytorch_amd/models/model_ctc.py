@@ -84,6 +84,8 @@ class LayerCNN(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
+        if self._fused and self.pooling is None and self.dropout.training and self.dropout.p > 0.0:
+            return self.batch_norm(x, drop_p=float(self.dropout.p))     # BN + ReLU + dropout in one pass (round 5): same values, same random stream
         if self._fused:
             x = self.batch_norm(x)              # BN + ReLU in one pass
         else:

@@ -120,7 +120,8 @@ class BatchNorm2d(_tnn.BatchNorm2d):
 
     fuse_relu = False
 
-    def forward(self, x):
+    def forward(self, x, drop_p=0.0):
+        """drop_p > 0 (LayerCNN, training): the layer's dropout rides along with the apply pass (ops.batch_norm)."""
         if not (self.affine and self.track_running_stats):
             raise NotImplementedError("affine=True, track_running_stats=True only")
         if x.dim() != 4 or x.shape[1] != self.num_features:
@@ -128,7 +129,8 @@ class BatchNorm2d(_tnn.BatchNorm2d):
         mom = 0.1 if self.momentum is None else self.momentum
         x = ops.contiguous(x)
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, x.shape[0], x.shape[1],
-                              x.shape[2] * x.shape[3], self.training, mom, self.eps, self.fuse_relu, self.num_batches_tracked)
+                              x.shape[2] * x.shape[3], self.training, mom, self.eps, self.fuse_relu, self.num_batches_tracked,
+                              drop_p=float(drop_p) if self.training else 0.0)
 
 
 class Linear(_tnn.Linear):

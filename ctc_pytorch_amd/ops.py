@@ -635,7 +635,7 @@ def set_sync_bn(reducer):
 
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, outer, C, inner, training, momentum, eps, relu, nbt=None):
+    def forward(ctx, x, gamma, beta, rm, rv, outer, C, inner, training, momentum, eps, relu, nbt=None, drop_p=0.0):
         _need_gpu(x, gamma, beta)
         ctx.gviews = (_gview(gamma), _gview(beta))
         x = _f32c(x)
@@ -643,6 +643,22 @@ class _BatchNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         L = _lib.lib()
         ctx.sync = None
+        ctx.drop = None
+        if training and drop_p > 0.0:
+            # BatchNorm (+ ReLU) + the dropout behind it in one apply pass (LayerCNN, model_ctc.py:62-67); the Philox counters are drawn exactly
+            # where the separate dropout would draw them (batch_norm() only fuses when nothing random sits between the two)
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            rstd = torch.empty(C, dtype=torch.float32, device=dev)
+            seed, off = _next_dropout_stream(x.numel())
+            w, wp, wn = _ws(x)
+            _lib.check(L.ctcn_bn_fwd_train_dropout(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(mean), _ptr(rstd),
+                                                   outer, C, inner, float(eps), float(momentum), int(relu), wp, wn, _lib.stream_ptr(), _ptr(nbt),
+                                                   float(drop_p), seed, off), "bn_fwd_train_dropout")
+            ctx.save_for_backward(x, None, gamma, mean, rstd, beta)
+            ctx.train_mode = True
+            ctx.drop = (float(drop_p), seed, off)
+            ctx.geom = (outer, C, inner, relu, eps)
+            return y
         if training and _sync_bn["reduce"] is not None:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             rstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -676,6 +692,20 @@ class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         outer, C, inner, relu, eps = ctx.geom
+        if ctx.drop is not None:
+            x, _, gamma, a, b, beta = ctx.saved_tensors
+            gy = _f32c(gy)
+            dx = torch.empty_like(x)
+            into_flat = ctx.gviews[0] is not None and ctx.gviews[1] is not None
+            dgamma, dbeta = ctx.gviews if into_flat else (torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device))
+            w, wp, wn = _ws(x)
+            p_, seed_, off_ = ctx.drop
+            _lib.check(_lib.lib().ctcn_bn_bwd_dropout(_ptr(x), _ptr(gy), _ptr(gamma), _ptr(beta), _ptr(a), _ptr(b), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                                      outer, C, inner, int(relu), 1.0 if into_flat else 0.0, wp, wn, _lib.stream_ptr(), p_, seed_, off_),
+                       "bn_bwd_dropout")
+            if into_flat:
+                dgamma = dbeta = None
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         x, y, gamma, a, b = ctx.saved_tensors
         gy = _f32c(gy)
         dev = x.device
@@ -707,17 +737,32 @@ class _BatchNorm(torch.autograd.Function):
                                               _lib.stream_ptr()), "bn_bwd")
         if into_flat:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum=0.1, eps=1e-5, relu=False, num_batches_tracked=None):
+def batch_norm(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum=0.1, eps=1e-5, relu=False, num_batches_tracked=None,
+               drop_p=0.0):
     """num_batches_tracked: nn.BatchNorm's int64 counter (device tensor) or None -- in training the statistics kernel adds 1 to it (no launch
-    of its own)."""
+    of its own).  drop_p > 0 (training only): returns dropout(batch_norm(x), drop_p) from ONE apply pass -- the same values, the same Philox
+    counters as a separate ops.dropout behind it (round 5; per-shard statistics only: with synchronised BatchNorm the two stay separate)."""
+    if training and drop_p > 0.0 and (_sync_bn["reduce"] is not None or not _fuse_bn_dropout[0]):
+        y = batch_norm(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum, eps, relu, num_batches_tracked)
+        return dropout(y, drop_p, training)
+    if not training:
+        drop_p = 0.0
     if num_batches_tracked is not None and (not training or num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         if training:
             num_batches_tracked += 1
         num_batches_tracked = None
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum, eps, relu, num_batches_tracked)
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, outer, C, inner, training, momentum, eps, relu, num_batches_tracked, float(drop_p))
+
+
+_fuse_bn_dropout = [os.environ.get("CTCN_FUSE_BN_DROPOUT", "1") != "0"]
+
+
+def set_fuse_bn_dropout(flag):
+    """BatchNorm (+ ReLU) and the dropout behind it in one pass (default on; CTCN_FUSE_BN_DROPOUT=0: two passes, the same values)."""
+    _fuse_bn_dropout[0] = bool(flag)
 
 
 class _ReLU(torch.autograd.Function):

@@ -257,6 +257,18 @@ int ctcn_bn_fwd_eval(const float *x, float *y, const float *gamma, const float *
 int ctcn_bn_bwd(const float *x, const float *y, const float *dy, const float *gamma, const float *save_mean,
                 const float *save_rstd, float *dx, float *dgamma, float *dbeta, int outer, int C, int inner,
                 int relu, float beta_acc, void *ws, size_t ws_bytes, void *stream);
+/* BatchNorm (training statistics) + ReLU + inverted dropout in ONE apply pass, and its backward (round 5).
+ * replaces: LayerCNN.forward's `x = self.batch_norm(x); x = self.activation(x); ...; x = self.dropout(x)` (model_ctc.py:62-67, no pooling between
+ * them) and its autograd.  y_drop = ctcn_dropout(relu(bn(x)), p, seed, offset) bit for bit (same expression per element, same Philox words: word
+ * i & 3 of group offset + (i >> 2)); the un-dropped activation is not stored.  ctcn_bn_bwd_dropout takes dy_drop = the gradient of the DROPPED
+ * output, regenerates the keep mask from the counters and recomputes the ReLU mask from x (it needs beta for that): dx, dgamma, dbeta as
+ * ctcn_dropout backward followed by ctcn_bn_bwd would give them, without the two passes over the dropped / un-dropped tensors.  0 < p < 1. */
+int ctcn_bn_fwd_train_dropout(const float *x, float *y_drop, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                              float *save_mean, float *save_rstd, int outer, int C, int inner, float eps, float momentum, int relu, void *ws,
+                              size_t ws_bytes, void *stream, long long *num_batches_tracked, float p, uint64_t seed, uint64_t offset);
+int ctcn_bn_bwd_dropout(const float *x, const float *dy_drop, const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
+                        float *dx, float *dgamma, float *dbeta, int outer, int C, int inner, int relu, float beta_acc, void *ws, size_t ws_bytes,
+                        void *stream, float p, uint64_t seed, uint64_t offset);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dropout (inverted, Philox4x32-10 counter RNG keyed by (seed, offset + element index)).

@@ -1879,6 +1879,45 @@ def test_beam_cfg5_full_batch_vs_c_oracle(dev, regime):
     assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
 
 
+@pytest.mark.parametrize("p", [0.1, 0.5])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("shape", [(4, 32, 50 * 20), (3, 8, 37 * 7), (5, 6, 3), (257, 64, 1), (2, 3, 5)])
+def test_bn_relu_dropout_fused_equals_two_passes(dev, shape, relu, p):
+    """Round 5: BatchNorm (+ ReLU) with the dropout behind it in ONE apply pass (ctcn_bn_fwd_train_dropout / ctcn_bn_bwd_dropout: LayerCNN's
+    conv -> BN -> ReLU -> Dropout, model_ctc.py:62-67) against the two passes it replaces -- ops.batch_norm then ops.dropout from the same Philox
+    counters: the dropped output, dx, dgamma, dbeta and the running statistics are equal BIT FOR BIT (the keep mask is regenerated from the
+    counters, the ReLU mask recomputed from x by the forward's own rounding sequence).  NCHW shapes incl. an inner size that is no multiple of
+    four (a Philox group then spans two channels), rows of channels, a tensor whose size is no multiple of four."""
+    from ctc_pytorch_amd import ops
+    outer, C, inner = shape
+    torch.manual_seed(7)
+    x0 = torch.randn(outer, C, inner, device=dev) * 1.5 + 0.3
+    g0, b0 = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.2
+    dy = torch.randn(outer, C, inner, device=dev)
+    runs = {}
+    for fused in (True, False):
+        ops.set_fuse_bn_dropout(fused)
+        try:
+            ops._drop_counter[0] = 1234
+            x = x0.clone().requires_grad_(True)
+            g, b = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            y = ops.batch_norm(x, g, b, rm, rv, outer, C, inner, True, 0.1, 1e-5, relu, None, drop_p=p)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            runs[fused] = [t.detach().clone() for t in (y, x.grad, g.grad, b.grad, rm, rv)] + [ops._drop_counter[0]]
+        finally:
+            ops.set_fuse_bn_dropout(True)
+    for a, c, name in zip(runs[True], runs[False], ("y", "dx", "dgamma", "dbeta", "running_mean", "running_var", "counter")):
+        if name == "counter":
+            assert a == c
+        else:
+            assert torch.equal(a, c), (name, float((a - c).abs().max()))
+    if x0.numel() > 5000:
+        kept = float((runs[True][0] != 0).float().mean())
+        assert abs(kept - (1.0 - p) * (0.5 if relu else 1.0)) < 0.08, kept      # (about half of the activations pass the ReLU)
+
+
 @pytest.mark.parametrize("regime", ["peaky", "flat"])
 @pytest.mark.parametrize("W", [60, 61, 64, 65, 128, 200, 256])
 def test_beam_wide_vs_c_oracle(dev, regime, W):

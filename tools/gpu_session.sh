@@ -142,6 +142,12 @@ PY
     echo "## cycles per phase and frame of the generic kernel (tools/mb_beam.py generic <regime> <W>)"
     for r in peaky flat; do for W in 128 200 256; do timeout 200 python tools/mb_beam.py generic $r $W 2>&1 | grep -v amdgpu.ids; done; done; } | tee $O/wide_beam_time.txt
   ;;
+15)
+  timeout 600 python -m pytest tests -m gpu -q --maxfail=10 --timeout 600 -p no:cacheprovider -k "bn_relu_dropout or batchnorm or conv or cnn or model_ or dropout or shipped or end_to_end" > $O/pytest_sub.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 6 $O/pytest_sub.log
+  for f in 0 1; do for wl in cfg3 ref_yaml; do
+    CTCN_FUSE_BN_DROPOUT=$f timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/${wl}_fuse$f.json 2> $O/${wl}_fuse$f.err
+  done; done
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
