@@ -660,6 +660,33 @@ def decode_leg(dev, steps=5):
                              traffic=(pmc_traffic("beam_fast_kernel") or 0) + (pmc_traffic("beam_prep_kernel") or 0) or None if regime == "peaky" else None,
                              algorithmic_bytes_per_launch=int(lp.nbytes), us_per_launch=kernel_us)
         out["regimes"][regime] = r
+    # the reference's class-default beam (ctcDecoder.py:170: beam_width = 200, lm_alpha = 0.01) on the same batches: the generic kernel (round 5:
+    # pruning bound + rank count instead of W arg-max rounds per frame); one batch at a time, HIP events; one utterance per regime checked
+    # against the C oracle (bounded: the oracle needs seconds per utterance at this width)
+    try:
+        wide = {"beam_width": 200, "lm_alpha": 0.01, "kernel": "beam_kernel<1024> (generic)"}
+        for regime in ("peaky", "flat"):
+            lp = synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)
+            lens = list(np.random.RandomState(2).randint(400, 801, size=B))
+            x = torch.from_numpy(lp).to(dev)
+            lens_dev = torch.as_tensor(lens, dtype=torch.int32).to(dev)
+            ops.beam_decode_device(x, lens_dev, tab_dev, 0.01, 200)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dev_out = ops.beam_decode_device(x, lens_dev, tab_dev, 0.01, 200)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            t0 = time.time()
+            want, _, _ = beam_ref.decode_ids(np.exp(lp[:, :1, :]).transpose(1, 0, 2), lens[:1], tab, 0.01, 200)
+            cdt = time.time() - t0
+            got = dev_out[0][0, : int(dev_out[1][0])].cpu().tolist()
+            wide[regime] = {"ms_per_batch": ms, "utt_per_s_one_batch_at_a_time": B / (ms * 1e-3), "first_utterance_matches_oracle": bool(list(map(int, want[0])) == got) and bool((dev_out[3] == 0).all()),
+                            "cpu_oracle_utt_per_s": 1.0 / cdt}
+        out["wide_beam"] = wide
+    except Exception as e:      # noqa: BLE001
+        out["wide_beam"] = {"error": repr(e)}
     out["value"] = out["regimes"]["peaky"]["value"]
     out["value_flat"] = out["regimes"]["flat"]["value"]
     out["strings_match_oracle"] = all(r["strings_match_oracle"] for r in out["regimes"].values())
