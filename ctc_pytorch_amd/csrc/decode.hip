@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   __shared__ double red_v[NWV];
   __shared__ int red_i[NWV];
   __shared__ unsigned long long wthr[NWV];                     // selection: every wave's bound
+  __shared__ int wcnt[NWV][NWV];                               //            ... and how many of wave w's maxima reach wave j's
   __shared__ int s_flag, s_nodes, s_best;
   __shared__ double sv_v[SEL_SMAX];                            // selection: survivors of the pruning bound (value | candidate index)
   __shared__ int sv_i[SEL_SMAX], s_scnt, s_ovf;
@@ -164,14 +165,35 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
     GSTAMP(1);
     // 3a. extension scores (calcExtPr), candidate slot c = i*V + 1 + kk  (kk enumerates k != blank in order)
     const int ncand = nb * V;
-    for (int c = tid; c < ncand; c += NT) {
-      const int i = c / V, kk = c - i * V;
-      if (kk == 0) continue;
-      const int k = (kk - 1 < blank) ? kk - 1 : kk;
-      const int c1 = L.len[i] > 0 ? L.last[i] : V;
-      const double bigram = a.lm[(size_t)c1 * (V + 1) + k] * a.alpha;
-      const double base = (L.len[i] > 0 && L.last[i] == k && rep_ok) ? L.pB[i] : L.pT[i];
-      cand[c] = lg[k] + bigram + base;
+    // (four candidates per trip with 256 threads -- two with 1 024 --: the slot reads, then the LM gathers -- global memory -- of all four are issued before the first is used; the same
+    // expression per candidate)
+    constexpr int EU = NT >= 1024 ? 2 : 4;
+    for (int c0 = tid; c0 < ncand; c0 += EU * NT) {
+      int ci[EU], ck[EU], cl[EU], cln[EU];
+      double lmv[EU];
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = min(c0 + u * NT, ncand - 1);
+        ci[u] = c / V;
+        const int kk = c - ci[u] * V;
+        ck[u] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
+        cln[u] = L.len[ci[u]]; cl[u] = L.last[ci[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c1 = cln[u] > 0 ? cl[u] : V;
+        lmv[u] = a.lm[(size_t)c1 * (V + 1) + max(ck[u], 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < EU; ++u) {
+        const int c = c0 + u * NT;
+        if (c < ncand && ck[u] >= 0) {
+          const int i = ci[u], k = ck[u];
+          const double bigram = lmv[u] * a.alpha;
+          const double base = (cln[u] > 0 && cl[u] == k && rep_ok) ? L.pB[i] : L.pT[i];
+          cand[c] = lg[k] + bigram + base;
+        }
+      }
     }
     __syncthreads();
     GSTAMP(2);
@@ -215,13 +237,14 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
     {
       // (the candidate table is in global memory from W * V > 4 096 on: eight loads in flight per thread, or every scan is a chain of L2 round trips)
       auto scan = [&](auto &&visit) {
+        constexpr int SU = NT >= 1024 ? 4 : 8;          // (1 024 threads: 128 registers each, and a fourth of the candidates per thread)
         int c = tid;
-        for (; c + 7 * NT < ncand; c += 8 * NT) {
-          double v[8];
+        for (; c + (SU - 1) * NT < ncand; c += SU * NT) {
+          double v[SU];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = cand[c + NT * u];
+          for (int u = 0; u < SU; ++u) v[u] = cand[c + NT * u];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) visit(v[u], c + NT * u);
+          for (int u = 0; u < SU; ++u) visit(v[u], c + NT * u);
         }
         for (; c < ncand; c += NT) visit(cand[c], c);
       };
@@ -234,9 +257,10 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         if (v != -INFINITY) {
           ++nval;
           const unsigned long long key = dkey(v);
-          const int h = NH == 2 ? (c / NT) & 1 : 0;
-          if (NH == 2 && h) tk[NH - 1] = key > tk[NH - 1] ? key : tk[NH - 1];
-          else tk[0] = key > tk[0] ? key : tk[0];
+          const bool hi = NH == 2 && ((c / NT) & 1);
+          const unsigned long long cur = hi ? tk[NH - 1] : tk[0], nk = key > cur ? key : cur;
+          tk[0] = hi ? tk[0] : nk;
+          if (NH == 2) tk[NH - 1] = hi ? nk : tk[NH - 1];
         }
       });
       GSTAMP(8);
@@ -256,19 +280,52 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       }
       if (tid == 0) { s_scnt = 0; s_ovf = 0; }
       __syncthreads();
+      // the waves' values are NWV candidate bounds; the smallest is always valid, a larger one is valid whenever W of ALL the maxima still reach
+      // it: every wave counts its own maxima against every candidate (NWV ballots), the largest candidate with a block-wide count >= W wins --
+      // the survivors drop from ~1.9 W to ~1.2 W at W = 200, and a wave that has no k candidates (narrow beam) no longer voids the bound
+#pragma nounroll
+      for (int j = 0; j < NWV; ++j) {
+        const unsigned long long t = wthr[j];
+        int cnt = __popcll(__ballot(tk[0] >= t));
+        if (NH == 2) cnt += __popcll(__ballot(tk[NH - 1] >= t));
+        if (lane == 0) wcnt[wave][j] = t != 0ull ? cnt : 0;
+      }
+      __syncthreads();
+      if (tid < NWV) {                                   // thread j: how many of ALL the maxima reach candidate j
+        int reach = 0;
+#pragma nounroll
+        for (int w = 0; w < NWV; ++w) reach += wcnt[w][tid];
+        wcnt[0][tid] = reach;                            // (row 0 is read by its own column's thread only)
+      }
+      __syncthreads();
       int total = 0;
-      unsigned long long theta = ~0ull;
-#pragma unroll
-      for (int w = 0; w < NWV; ++w) { total += red_i[w]; theta = wthr[w] < theta ? wthr[w] : theta; }
+      unsigned long long theta = 0ull;
+#pragma nounroll
+      for (int j = 0; j < NWV; ++j) {
+        total += red_i[j];
+        const unsigned long long t = wthr[j];
+        if (wcnt[0][j] >= W && t > theta) theta = t;
+      }
       GSTAMP(9);
-      // (a wave without k candidates -- the first frames, when the beam is still narrow -- gives no bound: then everything valid is ranked, if it fits)
+      // (no candidate bound that W maxima reach -- the first frames, when the beam is still narrow --: then everything valid is ranked, if it fits)
       const bool prune = total > W && theta != 0ull;
       if (prune || total <= SEL_SMAX) {
+        // one scan: a thread's first two survivors wait in registers (it rarely has more than one), a second scan only for a thread with more
         int cnt = 0;
-        scan([&](double v, int c) { if (v != -INFINITY && (!prune || dkey(v) >= theta)) ++cnt; });
+        double kv0 = 0.0, kv1 = 0.0; int kc0 = 0, kc1 = 0;
+        scan([&](double v, int c) {
+          if (v != -INFINITY && (!prune || dkey(v) >= theta)) {
+            kv0 = cnt == 0 ? v : kv0; kc0 = cnt == 0 ? c : kc0;          // (selects: an if-chain becomes an indexed store into a stack array)
+            kv1 = cnt == 1 ? v : kv1; kc1 = cnt == 1 ? c : kc1;
+            ++cnt;
+          }
+        });
         int pos = cnt ? atomicAdd(&s_scnt, cnt) : 0;
         if (pos + cnt > SEL_SMAX) s_ovf = 1;
-        else scan([&](double v, int c) { if (v != -INFINITY && (!prune || dkey(v) >= theta)) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
+        else if (cnt <= 2) {
+          if (cnt > 0) { sv_v[pos] = kv0; sv_i[pos] = kc0; }
+          if (cnt > 1) { sv_v[pos + 1] = kv1; sv_i[pos + 1] = kc1; }
+        } else scan([&](double v, int c) { if (v != -INFINITY && (!prune || dkey(v) >= theta)) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
         __syncthreads();
         GSTAMP(10);
 #ifdef CTCN_BEAM_STATS
@@ -284,13 +341,14 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
             const int e = e0 + tid / P, part = tid & (P - 1);
             const bool have = e < S;
             const double mv = sv_v[have ? e : 0]; const int mi = sv_i[have ? e : 0];
+            constexpr int RU = NT >= 1024 ? 4 : 8;
             int rank = 0, q = part;
-            for (; q + 7 * P < S; q += 8 * P) {
-              double qv[8]; int qi[8];
+            for (; q + (RU - 1) * P < S; q += RU * P) {
+              double qv[RU]; int qi[RU];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) { qv[u] = sv_v[q + u * P]; qi[u] = sv_i[q + u * P]; }
+              for (int u = 0; u < RU; ++u) { qv[u] = sv_v[q + u * P]; qi[u] = sv_i[q + u * P]; }
 #pragma unroll
-              for (int u = 0; u < 8; ++u) rank += cand_better(qv[u], qi[u], mv, mi) ? 1 : 0;
+              for (int u = 0; u < RU; ++u) rank += cand_better(qv[u], qi[u], mv, mi) ? 1 : 0;
             }
             for (; q < S; q += P) rank += cand_better(sv_v[q], sv_i[q], mv, mi) ? 1 : 0;
             for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o, 64);

@@ -54,7 +54,7 @@ int ctcn_device_xcds(void);
  * Wider beams -- the reference's class default is beam_width = 200 (ctcDecoder.py:170) -- always run the generic kernel beam_kernel<NT>, 1 024 threads per
  * utterance beyond W = 64.  Round 5: its selection is a pruning bound (every wave's k-th largest thread maximum by a ballot search on order-preserving
  * keys) + a rank count of the ~W survivors instead of W block-wide arg-max rounds per frame: the cfg5 batch (128 x 800 x 62) at W = 200 takes
- * 13.0 ms (peaky) / 28.9 ms (flat) instead of 657 / 1 556 ms, W = 256 15.4 / 36.7 instead of 1 066 / 2 514 (profiles/r05_wide_beam.txt).
+ * 11.8 ms (peaky) / 28.1 ms (flat) instead of 657 / 1 556 ms, W = 256 14.2 / 34.8 instead of 1 066 / 2 514 (profiles/r05_wide_beam.txt).
  * "gemm_tile256" = 1 (default): the bf16x3 GEMM multiplies activation-sized products (M >= 1024 rows, enough tiles to fill the
  * device) with 256 x 256 / 256 x 128 workgroup tiles staged by global_load_lds; 0: always the 128 x 128 tile (same results).
  * "gemm_a_inline" = 1 (default): those tiles take a row-major float32 A operand as it is and split it into bf16 planes while staging
