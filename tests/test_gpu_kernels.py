@@ -1939,6 +1939,10 @@ def test_beam_wide_vs_c_oracle(dev, regime, W):
     assert got == [list(map(int, s_)) for s_ in want]
     score, wscore = np.asarray(score), np.asarray(wscore)
     assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))
+    # the selection compacts its survivors through an atomic counter and the trie hands out node ids the same way: neither order may show in
+    # the results -- a second run returns the same labellings and the same scores bit for bit
+    got2, score2, st2 = ops.beam_decode(probs.to(dev), lens, tab, 0.1, W, 0, input_is_prob=True)
+    assert got2 == got and np.array_equal(np.asarray(score2), score) and list(st2) == list(st)
 
 
 def test_beam_width_above_the_maximum_is_refused(dev):
