@@ -360,7 +360,9 @@ def run_train(args):
     # N > 1: have RCCL say what it built (rings / trees, channels, protocol) into a per-rank file, so that the first real SCALE record can be
     # interpreted -- must be in the environment before the communicator exists; the summary goes into the line's `comm` object
     rccl_log = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "NCCL_DEBUG" not in os.environ:
+    # (the GPU image exports NCCL_DEBUG=VERSION; only a caller who asked for INFO / TRACE or named a file of their own is left alone)
+    theirs = os.environ.get("NCCL_DEBUG", "").upper() in ("INFO", "TRACE") or "NCCL_DEBUG_FILE" in os.environ
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("CTCN_FORCE_COLLECTIVES", "0") == "1") and not theirs:
         rccl_log = "/tmp/ctcn_rccl_%d_rank%s.log" % (os.getppid(), os.environ.get("RANK", "0"))
         os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV", NCCL_DEBUG_FILE=rccl_log)
     rank, world, local = parallel.init_from_env()
@@ -462,8 +464,20 @@ def run_train(args):
         rccl_lines = None
         if rccl_log and os.path.exists(rccl_log):           # rank 0's view of the communicator: topology, channels, algorithm / protocol tuning
             keep = ("Channel", "Ring", "Tree", "nChannels", "Connected all", "Algo", "algo", "proto", "NET/", "P2P", "xgmi", "XGMI", "comm 0x", "NCCL_")
+            import re
+            per_channel, rccl_lines = {}, []
             with open(rccl_log, errors="replace") as fh:
-                rccl_lines = [ln.strip()[-220:] for ln in fh if any(k in ln for k in keep)][:48]
+                for ln in fh:
+                    if not any(k in ln for k in keep):
+                        continue
+                    m = re.search(r"NCCL INFO (Tree|Ring|Channel) \d+", ln)    # one line per channel (64 of them): first two of a kind + the count
+                    if m:
+                        per_channel[m.group(1)] = per_channel.get(m.group(1), 0) + 1
+                        if per_channel[m.group(1)] > 2:
+                            continue
+                    if len(rccl_lines) < 48:
+                        rccl_lines.append(ln.strip()[-220:])
+            rccl_lines += ["(%d '%s N' lines in all)" % (n, k) for k, n in sorted(per_channel.items())]
         res["per_rank_ms_per_step"] = [t / args.steps * 1e3 for t in per_rank_s]
         res["comm"] = dict(ranks=world, collectives_issued=bool(on), rccl_info=rccl_lines,
                            backend=("none (single rank: allreduce_grads returns at once)" if not on else

@@ -2133,6 +2133,9 @@ def test_bench_under_torchrun_with_rccl_collectives(dev, workload, comm):
     assert res["value"] > 0 and np.isfinite(res["final_loss"])
     if workload == "cfg2":
         assert res["overlapped_allreduce_slices_last_step"] >= 2, res.get("overlapped_allreduce_slices_last_step")
+    # RCCL's own account of the communicator (NCCL_DEBUG=INFO into a per-rank file, round 5) made it into the line
+    assert res["comm"]["collectives_issued"] and len(res["per_rank_ms_per_step"]) == 1
+    assert isinstance(res["comm"]["rccl_info"], list) and len(res["comm"]["rccl_info"]) > 0, res["comm"]
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo(dev):
