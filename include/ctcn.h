@@ -81,6 +81,14 @@ int ctcn_device_xcds(void);
  * ctcn_rnn_bwd_weights: one round of items on the idle XCDs next to a recurrence) instead of for the whole device (two rounds of items half
  * as long, each paying a prologue, a 128-KB partial store and its share of the reduce pass): cfg2 13.22 -> 13.15 ms per step; 0: as before.
  * The k-sums are grouped differently (float32 rounding of the sums), deterministically either way.
+ * "gemm_bf16_single" = 0 (default): 1 = the opt-in bf16 mode (round 5).  With precision 1 the 256-row GEMM tiles -- every product over the T*B
+ * rows of a layer: input projections, dx, weight gradients (plane, float32-A and TN tile) -- multiply the bf16 ROUNDINGS of their operands once
+ * (ah*bh, f32 accumulate) instead of the three bf16x3 products (al*bh + ah*bl + ah*bh); the recurrent matmul and the small tiles keep bf16x3.
+ * Result = the product of the rounded operands to f32 summation order (tools/gemm_single_probe.py: 2-5e-6 of mean |C|); against the exact product
+ * an element moves by up to 1.5e-2 of mean |C|.  BASELINE.json's north_star tolerance ("loss and activations within 1e-3 bf16 tolerance"):
+ * full-size cfg2 / cfg3 / cfg4 loss within 1e-5 .. 3e-5 of the REFERENCE's, gradient norms within 6e-4 .. 4e-3, log-probs 2-3e-3 mean (1.8e-2 max)
+ * next to the default mode's (test_bf16_single_mode_against_reference_checksums).  Tile time 1.27-1.84x shorter; cfg2 13.21 -> 12.69 ms per
+ * step, cfg3 7.71 -> 7.42, cfg4 52.6 -> 45.5.  The default (0) keeps every parity statement of this header (1e-5 against the reference).
  * "beam_occ2" = 0 (default, round 5): 1 / 2 launch the fast beam search compiled for eight waves per SIMD (<= 64 VGPRs, 43 spilled dwords)
  * with <= 68 KB of dynamic LDS (4 096-slot trie; 2: LM in global memory, 8 192 slots) so that two utterances share a CU.  Same results;
  * measured SLOWER (cfg5, three searches in flight: 279 k -> 248 k utt/s peaky, 128 k -> 97 k flat; profiles/r05_beam_occ2_ab.txt) and kept

@@ -203,6 +203,44 @@ def test_gemm_bf16x3_tile256_equals_tile128(dev, M, N, K, ta, tb, beta):
     assert float((outs[1][rows].double() - ref).abs().max()) < 2e-4 * (K ** 0.5)
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K,beta", [(0, 1, 8192, 1536, 136, 0.0), (0, 1, 25600, 2560, 640, 1.0),          # plane tile 256 x 256
+                                                  (0, 1, 16390, 1664, 200, 1.0),                                        # plane tile 256 x 128, ragged
+                                                  (0, 0, 25600, 640, 2560, 0.0), (0, 0, 25001, 512, 204, 1.0),          # float32-A tile, K tail, ragged M
+                                                  (0, 1, 16390, 384, 1300, 1.0),                                        # float32-A tile 256 x 128
+                                                  (1, 0, 1280, 640, 25600, 0.0), (1, 0, 1280, 320, 25568, 1.0),         # TN tile, split-K
+                                                  (1, 0, 644, 132, 5000, 1.0), (1, 0, 4096, 4100, 1056, 1.0)])          # TN tile ragged / without split-K
+def test_gemm_bf16_single_is_the_product_of_the_rounded_operands(dev, ta, tb, M, N, K, beta):
+    """Option "gemm_bf16_single" on the three 256-row tiles: C = bf16(A) bf16(B) with f32 accumulation -- against the float64 product of the
+    bf16-rounded operands (only the f32 summation differs: 2e-5 of the result's scale), which is NOT the bf16x3 result of the default mode (the
+    mode did switch tiles); beta = 1 and the columns outside the ldc window as in the other tile tests; a second run is bit-identical."""
+    from ctc_pytorch_amd import ops
+    rs = np.random.RandomState(M % 1000 + K + N)
+    A = torch.from_numpy(rs.standard_normal((K, M) if ta else (M, K)).astype(np.float32)).to(dev)
+    B = torch.from_numpy(rs.standard_normal((N, K) if tb else (K, N)).astype(np.float32)).to(dev)
+    C0 = torch.from_numpy(rs.standard_normal((M, N + 4)).astype(np.float32)).to(dev)
+    outs = []
+    ops.set_precision(1)
+    try:
+        for single in (0, 1, 1):
+            ops.set_option("gemm_bf16_single", single)
+            C = C0.clone()
+            ops.gemm(ta, tb, M, N, K, A, A.shape[1], B, B.shape[1], C, N + 4, beta=beta)
+            outs.append(C)
+    finally:
+        ops.set_option("gemm_bf16_single", 0)
+        ops.set_precision(0)
+    rows = torch.arange(0, M, max(1, M // 96), device=dev)
+    Ar, Br = (A.t() if ta else A)[rows], (B.t() if tb else B)
+    exact = Ar.double() @ Br.double() + beta * C0[rows, :N].double()
+    rounded = Ar.bfloat16().double() @ Br.bfloat16().double() + beta * C0[rows, :N].double()
+    scale = K ** 0.5
+    assert torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[1][:, N:], C0[:, N:]), "wrote outside the ldc window"
+    assert float((outs[1][rows, :N].double() - rounded).abs().max()) < 2e-5 * scale
+    assert float((outs[0][rows, :N].double() - exact).abs().max()) < 2e-4 * scale
+    assert float((outs[1][rows, :N].double() - exact).abs().max()) > 1e-3 * scale          # bf16 operands: the third digit moves
+
+
 @pytest.mark.parametrize("kind", ["lstm", "gru", "rnn"])
 def test_rnn_layer_golden(dev, kind):
     from ctc_pytorch_amd import ops
@@ -1652,6 +1690,43 @@ def test_large_shape_checksums(dev, name, prec):
     assert "step" not in names[0] + names[1], names          # the persistent recurrences, not one launch per timestep
     if name == "cfg4_b64" and prec == 1:
         assert names == ("rnn_fwd_tagged", "rnn_bwd_scatter2"), names      # the kernels bench.py --workload cfg4 times
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4_b64"])
+def test_bf16_single_mode_against_reference_checksums(dev, name):
+    """Option "gemm_bf16_single" (the 256-row GEMM tiles multiply the bf16 roundings of their operands once instead of the three bf16x3
+    products): the tolerance BASELINE.json's north_star states -- "CTC loss and LSTM activations within 1e-3 bf16 tolerance" -- on the
+    full-size configs against the REFERENCE's checksums: loss and mean |log-prob| within 1e-3 relative (measured: 1e-5 .. 3e-5), every
+    parameter's gradient norm within 1 % (measured: 6e-4 .. 4e-3), and the log-probs (magnitude ~4) next to the default mode's on the same
+    weights: mean |difference| below 5e-3, none above 5e-2 (measured: 2e-3 .. 3e-3 / 1.8e-2 -- plain bf16 operands carry 8 significant
+    bits, so single elements do move in the third digit; the 1e-3 is met by the loss and the averages, not by every element).
+    Not the default, not the headline."""
+    from ctc_pytorch_amd import nn, ops
+    want = json.load(open(os.path.join(G, "large_checksums.json")))[name]
+    ops.set_precision(1)
+    got = {}
+    try:
+        for mode in (0, 1):
+            ops.set_option("gemm_bf16_single", mode)
+            m, b, c = _full_size_model(name, dev)
+            lp = m(gpu(b["x"], dev))
+            in_len = torch.from_numpy(R.frames_from_fraction(b["frac"], lp.size(0))).to(dev)
+            loss = nn.CTCLoss(reduction="sum")(lp, gpu(b["targets"], dev), in_len, gpu(b["tgt_len"], dev)) / c["B"]
+            loss.backward()
+            got[mode] = (float(loss.detach()), lp.detach().double(), {k: float(p.grad.double().norm()) for k, p in m.named_parameters()})
+    finally:
+        ops.set_option("gemm_bf16_single", 0)
+    loss1, lp1, gn1 = got[1]
+    dlp = (lp1 - got[0][1]).abs()
+    worst = max(abs(gn1[k] - want["grad_norm"][k]) / want["grad_norm"][k] for k in gn1 if not k.endswith("conv.bias"))
+    print("%s: loss %.6f (reference %.6f, rel %.1e)  mean|lp| rel %.1e  |lp - default lp| mean %.1e max %.1e  worst gradient-norm rel %.1e"
+          % (name, loss1, want["loss"], abs(loss1 - want["loss"]) / want["loss"],
+             abs(float(lp1.abs().mean()) - want["lp_abs_mean"]) / want["lp_abs_mean"], float(dlp.mean()), float(dlp.max()), worst))
+    assert abs(loss1 - want["loss"]) / want["loss"] < 1e-3
+    assert abs(float(lp1.abs().mean()) - want["lp_abs_mean"]) / want["lp_abs_mean"] < 1e-3
+    assert float(dlp.mean()) < 5e-3 and float(dlp.max()) < 5e-2
+    assert worst < 1e-2
+    assert got[0][0] != loss1                    # (the mode did switch tiles)
 
 
 # ---------------------------------------------------------------------------------------------------------
