@@ -1712,6 +1712,7 @@ static int tn_splits(int M, int N, int K, int wnt, size_t part_bytes, int cus) {
   // instead of two rounds of half-length items (each item pays a prologue, a 128-KB partial store and its share of the reduce pass)
   int s = std::min(std::max(cus / tiles, 1), std::max(K / 512, 1));      // <= 256 items: one round on a whole device
   s = std::min(s, 32);                                                    // (a handful of tiles: the reduce pass over the partials would take over)
+  if (const int f = ctcn_get_option("tn_splits_force")) s = std::min(f, std::max(K / 64, 1));       // (development)
   s = std::min(s, (int)(part_bytes / ((size_t)M * N * sizeof(float))));
   return s < 2 ? 1 : s;
 }
