@@ -148,6 +148,36 @@ PY
     CTCN_FUSE_BN_DROPOUT=$f timeout 300 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/${wl}_fuse$f.json 2> $O/${wl}_fuse$f.err
   done; done
   ;;
+17)
+  # the round's last evidence session: full parity suite + smoke at HEAD, the driver's command (new: bf16_gemm_mode, comm.rccl_info under forced
+  # collectives), the bf16 mode's tile probe, kernel stats / all-stream timeline of cfg4 in the bf16 mode
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/summary.log
+  tail -n 6 $O/pytest_gpu.log
+  timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+  timeout 900 python bench.py --steps 20 --warmup 3 > $O/r05_bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  { echo "# tools/gemm_single_probe.py: option gemm_bf16_single on the three 256-row GEMM tiles (us per product incl. its split passes; errors in units of mean |C|)"
+    timeout 300 python tools/gemm_single_probe.py 2>&1 | grep -v amdgpu.ids; } > $O/r05_gemm_single_probe.txt
+  for wl in cfg2 cfg3 cfg4 ref_yaml; do
+    CTCN_OPT_GEMM_BF16_SINGLE=1 timeout 400 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/r05_bench_${wl}_bf16_single.json 2> $O/bench_${wl}_bf16.err
+  done
+  ( cd /tmp && CTCN_OPT_GEMM_BF16_SINGLE=1 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_cfg4 -o p -- python $R/bench.py --workload cfg4 --steps 8 --warmup 2 --no-decode --no-cpu-baseline --no-others --no-pmc > $O/cfg4_bf16_under_rocprof.json 2> $O/prof_cfg4.log )
+  db=$(find $O/prof_cfg4 -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/prof_timeline.py $db -1 all > $O/r05_cfg4_bf16_single_step_timeline.txt 2>&1 && python tools/prof_stats.py $db > $O/r05_cfg4_bf16_single_kernel_stats.txt 2>&1
+  rm -rf $O/prof_cfg4
+  cat $O/summary.log
+  python - $O <<'PY'
+import json, sys, os
+O = sys.argv[1]
+d = json.loads(open(os.path.join(O, "r05_bench_default.json")).read().strip().splitlines()[-1])
+print("default: %.3f ms/step  decode %s  others %s  bf16 mode %s  traffic %s" % (
+    d["ms_per_step"], {k: round(v["value"]) for k, v in d["decode"]["regimes"].items()},
+    {k: round(v.get("ms_per_step", -1), 2) for k, v in d["other_workloads"].items()},
+    {k: round(v.get("ms_per_step", -1), 2) for k, v in d["bf16_gemm_mode"].items() if isinstance(v, dict)}, d["roofline"].get("traffic")))
+for wl in ("cfg2", "cfg3", "cfg4", "ref_yaml"):
+    e = json.loads(open(os.path.join(O, "r05_bench_%s_bf16_single.json" % wl)).read().strip().splitlines()[-1])
+    print(wl, "bf16 single: %.3f ms/step" % e["ms_per_step"])
+PY
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
