@@ -35,6 +35,14 @@ struct StatVal {   // (x, x*x)
     for (int e = 0; e < 4; ++e) { const double v = q.x[e]; a += v; b += v * v; }
   }
   __host__ __device__ __forceinline__ bool aligned16() const { return ((uintptr_t)x & 15) == 0; }
+  // (colreduce_rows4_kernel) the four elements are four neighbouring COLUMNS of one row: an accumulator pair each
+  struct ColK {};
+  static constexpr int ROWS_IN_FLIGHT = 8;
+  __device__ __forceinline__ ColK colk(int) const { return {}; }
+  __device__ __forceinline__ void cols4(const Quad &q, const ColK &, double (&a)[4], double (&b)[4]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const double v = q.x[e]; a[e] += v; b[e] += v * v; }
+  }
 };
 // Fused dropout behind BatchNorm (+ ReLU) (round 5: LayerCNN's Conv2d -> BatchNorm2d -> ReLU -> Dropout, model_ctc.py:61-67): `dy` is the
 // gradient of the DROPPED output; the keep mask is regenerated from the Philox counters of the forward pass (ctcn_dropout's: word i & 3 of
@@ -92,6 +100,28 @@ struct BwdVal {    // (dy', dy' * xhat), dy' = dy masked by relu (and, with a Dr
   __host__ __device__ __forceinline__ bool aligned16() const {
     return (((uintptr_t)x | (uintptr_t)dy | ((relu && !(d.p > 0.0f)) ? (uintptr_t)y : 0)) & 15) == 0;
   }
+  // (colreduce_rows4_kernel) four neighbouring columns of one row: their per-column constants are loaded once per thread; the value of
+  // every element is formed by the expressions of operator() / add4 above
+  struct ColK { float m[4], rs[4], ga[4], be[4]; };
+  static constexpr int ROWS_IN_FLIGHT = 4;
+  __device__ __forceinline__ ColK colk(int c0) const {
+    ColK k;
+    const bool rec = d.p > 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { k.m[e] = mean[c0 + e]; k.rs[e] = rstd[c0 + e]; k.ga[e] = rec ? d.gamma[c0 + e] : 0.0f; k.be[e] = rec ? d.beta[c0 + e] : 0.0f; }
+    return k;
+  }
+  __device__ __forceinline__ void cols4(const Quad &q, const ColK &k, double (&a)[4], double (&b)[4]) const {
+    const bool rec = d.p > 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = q.dy[e];
+      const float yv = rec ? bn_value(q.x[e], k.m[e], k.rs[e], k.ga[e], k.be[e]) : q.y[e];
+      if (relu && !(yv > 0.0f)) g = 0.0f;
+      const float xh = (q.x[e] - k.m[e]) * k.rs[e];
+      a[e] += (double)g; b[e] += (double)g * (double)xh;
+    }
+  }
 };
 static const DropSpec k_no_drop = {0.0f, 1.0f, 0, 0, nullptr, nullptr};
 
@@ -125,6 +155,45 @@ __global__ __launch_bounds__(256) void colreduce_rows_kernel(F f, int rows, int 
     b = sb[0][cx] + sb[1][cx] + sb[2][cx] + sb[3][cx];
     part[((size_t)blockIdx.y * C + c) * 2 + 0] = a;
     part[((size_t)blockIdx.y * C + c) * 2 + 1] = b;
+  }
+}
+
+// The same sums with 16-B loads (round 5; C % 4 == 0, 16-B aligned operands): a lane takes four neighbouring columns of a row, sixteen lanes a
+// 256-B run of it, the workgroup's sixteen row phases x ROWS_IN_FLIGHT rows are requested before the first is added -- 8-32 KB in flight per
+// wave instead of 2.  tools/bn_rows_probe.py (whole BatchNorm calls): backward 412 -> 338 us at cfg4's 76 800 x 1 024, 136 -> 111 at cfg2's
+// 25 600 x 640; forward 73 -> 63 at cfg2, unchanged at cfg4 (315 MB in 90 us: the rate a pure read reduction gets from this chip either way).
+// Steps: cfg2 13.33 -> 13.25 ms, cfg4 53.2 -> 52.8 (A/B in one session, option "bn_rows4"), losses bit-identical.
+// Same chunks (grid, rows_per_chunk) and the same per-element values as colreduce_rows_kernel; a column's rows are grouped into sixteen
+// phases instead of four before the (fixed-order) float64 sums, so the two kernels agree to float64 rounding, not bit for bit.
+template <class F>
+__global__ __launch_bounds__(256) void colreduce_rows4_kernel(F f, int rows, int C, int rows_per_chunk, double *__restrict__ part) {
+  __shared__ double sa[16][65], sb[16][65];
+  const int l16 = threadIdx.x & 15, rp = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + 4 * l16;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c0 < C && r0 < r1) {                         // (C % 4 == 0: a quad is inside or outside as a whole)
+    const typename F::ColK k = f.colk(c0);
+    constexpr int U = F::ROWS_IN_FLIGHT;
+    for (int r = r0 + rp; r < r1; r += 16 * U) {
+      typename F::Quad q[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) q[u] = f.load4((size_t)min(r + 16 * u, r1 - 1) * C + c0);     // (clamped address; the row test is on the addition)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (r + 16 * u < r1) f.cols4(q[u], k, a, b);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sa[rp][4 * l16 + e] = a[e]; sb[rp][4 * l16 + e] = b[e]; }
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && c < C) {
+    double ta = sa[0][threadIdx.x], tb = sb[0][threadIdx.x];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) { ta += sa[p][threadIdx.x]; tb += sb[p][threadIdx.x]; }
+    part[((size_t)blockIdx.y * C + c) * 2 + 0] = ta;
+    part[((size_t)blockIdx.y * C + c) * 2 + 1] = tb;
   }
 }
 
@@ -410,7 +479,10 @@ int launch_reduce(F f, int outer, int C, int inner, double *part, int *nchunks_o
     const int n = chunks_rows(outer, C);
     const int rpc = ceil_div(outer, n);
     const int nn = ceil_div(outer, rpc);
-    hipLaunchKernelGGL((colreduce_rows_kernel<F>), dim3(ceil_div(C, 64), nn), dim3(256), 0, st, f, outer, C, rpc, part);
+    if (C % 4 == 0 && f.aligned16() && ctcn_get_option("bn_rows4") != 0)
+      hipLaunchKernelGGL((colreduce_rows4_kernel<F>), dim3(ceil_div(C, 64), nn), dim3(256), 0, st, f, outer, C, rpc, part);
+    else
+      hipLaunchKernelGGL((colreduce_rows_kernel<F>), dim3(ceil_div(C, 64), nn), dim3(256), 0, st, f, outer, C, rpc, part);
     *nchunks_out = nn;
   } else {
     const NchwChunks k = chunks_nchw(outer, C, inner);

@@ -81,6 +81,9 @@ int ctcn_device_xcds(void);
  * ctcn_rnn_bwd_weights: one round of items on the idle XCDs next to a recurrence) instead of for the whole device (two rounds of items half
  * as long, each paying a prologue, a 128-KB partial store and its share of the reduce pass): cfg2 13.22 -> 13.15 ms per step; 0: as before.
  * The k-sums are grouped differently (float32 rounding of the sums), deterministically either way.
+ * "bn_rows4" = 1 (default, round 5): BatchNorm over (rows, C) with C % 4 == 0 forms its column sums with 16-B loads, sixteen row phases per
+ * workgroup (colreduce_rows4_kernel); 0: the dword kernel.  Same chunks, same element values, float64 partials grouped differently: the float32
+ * results agreed bit for bit wherever compared (tools/bn_rows_probe.py).  cfg2 13.33 -> 13.25 ms per step, cfg4 53.2 -> 52.8.
  * "tn_splits_force" = 0 (default; development): n > 0 forces the split-K count of the TN tile (tools/gemm_tn_splits_probe.py: the rule's own
  * choice -- one round of (tile, split) items on the CUs the launch may use -- is where the time is shortest on the cfg2 / cfg4 products).
  * "gemm_bf16_single" = 0 (default): 1 = the opt-in bf16 mode (round 5).  With precision 1 the 256-row GEMM tiles -- every product over the T*B
