@@ -520,6 +520,9 @@ class _RNNLayer(torch.autograd.Function):
         if split_dirs:
             st = _side_stream(dev)
             prec = get_precision()
+            # (round 5, measured and not kept: the four products dealt by MATRIX instead of by direction -- the main stream the heavier pair, both
+            # dW_hh, so that the side stream is done first and the optimiser's wait for it falls through instead of costing the ~55 us of wake-up
+            # the step timeline shows in front of adam_kernel: cfg2 13.08 | 13.10 ms, cfg1 1.96 | 1.95, cfg3 7.68 | 7.69, shipped YAML 4.23 | 4.23)
             # (round 5, measured and not kept: each direction's GEMMs restricted to one half of the XCDs, so that the two streams' full-device
             # queue kernels run side by side instead of one after the other -- cfg2 13.221 | 13.220 ms, cfg3 7.898 | 7.935: the same work either way)
             st.wait_stream(torch.cuda.current_stream(dev))          # (behind the layer above's weight GEMMs already queued there)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Timeline of the last training step in a rocprofv3 rocpd database: per stream, every kernel with its start offset,
 duration and the idle gap before it; plus per-stream busy / gap totals.  usage: prof_timeline.py results.db [min_gap_us] [all]
-(`all`: list the side streams' kernels as well, offsets from the same origin)"""
+(`all`: list the side streams' kernels as well, offsets from the same origin; environment PROF_STEP=<n>: the step that ends with the n-th
+optimiser launch of the run instead of the last one -- e.g. a step of bench.py's timed loop rather than of its epoch loop)"""
+import os
 import sqlite3
 import sys
 
@@ -12,15 +14,18 @@ cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, stream_id, start, end from kernels order by start"))
 adam = [i for i, r in enumerate(rows) if r[0].startswith("adam_kernel") or "adam_kernel" in r[0]]
 assert len(adam) >= 2, "need two optimiser steps to delimit one training step"
-lo, hi = adam[-2] + 1, adam[-1] + 1
+sel = int(os.environ.get("PROF_STEP", "-1"))
+assert sel == -1 or 1 <= sel < len(adam), "PROF_STEP outside the run's %d optimiser launches" % len(adam)
+a0, a1 = adam[sel - 1], adam[sel]
+lo, hi = a0 + 1, a1 + 1
 step = rows[lo:hi]
-t0, t1 = rows[adam[-2]][3], rows[adam[-1]][3]
-print("# step between the last two adam_kernel ends: %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))
+t0, t1 = rows[a0][3], rows[a1][3]
+print("# step between %s adam_kernel ends: %.3f ms, %d kernels" % ("the last two" if sel == -1 else "the %d. and %d." % (sel, sel + 1), (t1 - t0) / 1e6, len(step)))
 streams = {}
 for r in step:
     streams.setdefault(r[1], []).append(r)
 # the main stream is the one that carries the optimiser step (the side stream can hold more launches: chunked GEMMs, split passes)
-main = rows[adam[-1]][1]
+main = rows[a1][1]
 for sid, ks in sorted(streams.items(), key=lambda kv: -len(kv[1])):
     busy = sum(k[3] - k[2] for k in ks) / 1e3
     print("## stream %s%s: %d kernels, busy %.1f us" % (sid, " (main)" if sid == main else "", len(ks), busy))
