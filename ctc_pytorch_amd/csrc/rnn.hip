@@ -2569,6 +2569,12 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
                              wsp, wsb, strm, allow, &pl);
   };
   if (getenv("CTCN_LOG_PIPE")) fprintf(stderr, "libctcn: rnn_fwd T=%d B=%d I=%d H=%d: projection pipeline %s (chunks %d x %d steps, fits=%d)\n", T, B, I, H, piped ? "ON" : "off", NCHUNK, chunk_T, (int)chunking_fits);
+  // (Round 5, tools/fwd_interference_probe.sh: layers 1-3 of cfg2 -- pipelined -- run 1 310 us against the 1 190 of layer 0, which has no pipeline.
+  // That is not the recurrence waiting for a chunk: with TWO pairs projected here instead of one -- 119 us more head start, the last side pair
+  // then ready before it is needed by the model 155 us per side pair / 119 us per pair consumed -- the step is 0.16 ms SLOWER (13.20 -> 13.36,
+  // three pairs: 13.78): the extra pair costs its 75 us here and takes only ~25 off the recurrence.  The slowdown goes with the TIME the bf16x3
+  // chunk GEMMs run next to the recurrence, ~30 us per pair, and is gone with the single-product tiles of option "gemm_bf16_single" (1 186-
+  // 1 190 us for all four layers) although they still run there for 70 % of the time: the matrix pipes' power, not the counter.)
   if (piped) {
     int rc = project_chunk(0, ws, ws_bytes, stream, 0, pl_main);
     pl_main.same_b = true;                                // W_ih: split into planes once per stream (reused when the chunk has the same size)
