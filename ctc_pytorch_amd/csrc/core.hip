@@ -50,6 +50,7 @@ static int g_opt_fwd_pipe_min_input = 0;       // smallest layer input width who
 static int g_opt_conv_dbg = 0;          // development: conv_mfma_kernel skips phases (1 window load, 2 MFMA loop, 4 output phase); results invalid
 static int g_opt_rnn_rsv_nt = 0;        // rnn_bwd_scatter2: non-temporal hint on the reserve traffic (experiment: keep the exchange tiles in L2 at H = 512)
 static int g_opt_gemm_bf16_single = 0;  // 256-row GEMM tiles: one bf16 product (ah*bh) instead of the three bf16x3 products (north_star's bf16 tolerance; gemm.hip)
+static int g_opt_xcd_interleave = 0;    // which physical XCD hosts group g of a persistent recurrence (eight XCDs; 0 (default): XCD g, 1: the even XCDs first, 2-5: other orders; the host's xcd_allow masks follow: ops._idle_xcd_mask)
 static int g_opt_bn_rows4 = 1;          // BatchNorm over (T*B, C) rows: column sums with 16-B loads (colreduce_rows4_kernel); 0: the dword kernel
 static int g_opt_tn_splits_force = 0;   // development (tools/gemm_tn_bench.py): split-K count of the TN tile, 0 = the rule of gemm.hip:tn_splits
 static int g_opt_tn_splits_xcd = 1;     // TN weight-gradient tile: split count sized for the CUs of xcd_allow (one round of items there), not for the whole device
@@ -71,6 +72,7 @@ extern "C" int ctcn_set_option(const char *name, int value) {
   if (name && !strcmp(name, "conv_dbg")) { g_opt_conv_dbg = value & 7; return CTCN_OK; }
   if (name && !strcmp(name, "rnn_rsv_nt")) { g_opt_rnn_rsv_nt = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "tn_splits_xcd")) { g_opt_tn_splits_xcd = value ? 1 : 0; return CTCN_OK; }
+  if (name && !strcmp(name, "xcd_interleave")) { g_opt_xcd_interleave = value < 0 ? 0 : (value > 5 ? 5 : value); return CTCN_OK; }
   if (name && !strcmp(name, "bn_rows4")) { g_opt_bn_rows4 = value ? 1 : 0; return CTCN_OK; }
   if (name && !strcmp(name, "tn_splits_force")) { g_opt_tn_splits_force = value < 0 ? 0 : value; return CTCN_OK; }
   if (name && !strcmp(name, "gemm_bf16_single")) { g_opt_gemm_bf16_single = value ? 1 : 0; return CTCN_OK; }
@@ -108,6 +110,7 @@ extern "C" int ctcn_get_option(const char *name) {
   if (name && !strcmp(name, "beam_occ2")) return g_opt_beam_occ2;
   if (name && !strcmp(name, "beam_generic_threads")) return g_opt_beam_generic_threads;
   if (name && !strcmp(name, "tn_splits_xcd")) return g_opt_tn_splits_xcd;
+  if (name && !strcmp(name, "xcd_interleave")) return g_opt_xcd_interleave;
   if (name && !strcmp(name, "bn_rows4")) return g_opt_bn_rows4;
   if (name && !strcmp(name, "tn_splits_force")) return g_opt_tn_splits_force;
   if (name && !strcmp(name, "gemm_bf16_single")) return g_opt_gemm_bf16_single;

@@ -397,6 +397,7 @@ struct PersistArgs {
   int poll_delay;       // rnn_fwd_tagged: 64-cycle sleeps between the barrier and an exchange wave's first poll of a step
   int chunk_T, nchunk;  // rnn_fwd_tagged, pipelined input projection: frames per time chunk (0 = all pre-activations are there at launch)
   unsigned *chunk_ready; //   ... and the counter the side stream raises after each chunk PAIR (p covers chunks p and nchunk-1-p)
+  int xperm;             // option "xcd_interleave" (eight XCDs): which physical XCD is logical XCD g, i.e. hosts group g (persist_role)
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
   int rsv_nt;           // rnn_bwd_scatter2: reserve loads / stores carry the non-temporal hint (streaming data must not evict the exchange tiles from L2)
@@ -536,7 +537,11 @@ __device__ __forceinline__ PersistRole persist_role(const PersistArgs &pa, int D
   if (threadIdx.x == 0) *s_ticket = xcd < pa.nx ? (int)atomicAdd(pa.tickets + xcd, 1u) : 0x7fffffff;
   __syncthreads();
   const int idx = __builtin_amdgcn_readfirstlane(*s_ticket);   // uniform by construction: keep the role (and every address derived from it) in SGPRs
-  const int lg = idx / pa.nsl, group = lg * pa.nx + xcd;
+  // logical XCD of the physical one, 4 bits each (option "xcd_interleave" = 1 .. 5, eight XCDs): the inverse of the orders {0 2 4 6 1 3 5 7},
+  // {0 1 4 5 2 3 6 7}, {0 3 4 7 1 2 5 6}, {0 2 5 7 1 3 4 6}, {0 4 1 5 2 6 3 7} (ops._XCD_ORDERS)
+  constexpr unsigned k_logical[6] = {0x76543210u, 0x73625140u, 0x76325410u, 0x37621540u, 0x37265140u, 0x75316420u};
+  const int lxcd = pa.xperm ? (int)((k_logical[pa.xperm] >> (4 * xcd)) & 15u) : xcd;
+  const int lg = idx / pa.nsl, group = lg * pa.nx + lxcd;
   r.slice = idx - lg * pa.nsl;
   r.active = idx < pa.wpx && group < D * pa.nbt;
   r.d = group % D; r.bt = group / D;
@@ -2652,7 +2657,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
         pa.flags = (unsigned *)(tail + hx_bytes);
         pa.status = status_word;
         pa.spin_limit = SPIN_LIMIT;
-        pa.local = 1; pa.nx = nxd; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
+        pa.local = 1; pa.nx = nxd; pa.xperm = nxd == 8 ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
         // "fwd_rsv_lds": 0 off, 1 on, 2 (default) where it measured faster: more than 24 slices (cfg4, H = 512: 2.30 -> 2.24 us per step, 53.9 -> 53.2 ms
         // per step; cfg2 1.60 -> 1.70, ref_yaml 1.51 -> 1.59: there the waterfall-paced dword traffic of the item waves is the better neighbour of
         // the polls)
@@ -2719,7 +2724,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = status_word;
       pa.spin_limit = SPIN_LIMIT;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
+      pa.local = mode; pa.nx = nx; pa.xperm = (mode && nx == 8) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.nbig = nbig; pa.hsu_small = hsu_small;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
@@ -2937,7 +2942,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = status_word;
       pa.spin_limit = SPIN_LIMIT;
-      pa.local = mode; pa.nx = nx; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
+      pa.local = mode; pa.nx = nx; pa.xperm = (mode && nx == 8) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;

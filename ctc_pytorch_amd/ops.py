@@ -119,6 +119,18 @@ def _ws(t, tag="main"):
 _grad_ready = {"hook": None}
 
 
+_XCD_ORDERS = ((0, 1, 2, 3, 4, 5, 6, 7), (0, 2, 4, 6, 1, 3, 5, 7), (0, 1, 4, 5, 2, 3, 6, 7), (0, 3, 4, 7, 1, 2, 5, 6), (0, 2, 5, 7, 1, 3, 4, 6), (0, 4, 1, 5, 2, 6, 3, 7))
+
+
+def _idle_xcd_mask(nx, groups):
+    """Physical XCDs a persistent recurrence of `groups` (direction, batch tile) groups leaves idle: group g runs on logical XCD g, which is
+    physical XCD _XCD_ORDERS[option "xcd_interleave"][g] on a device of eight (rnn.hip: persist_role)."""
+    if nx == 8:
+        order = _XCD_ORDERS[min(max(get_option("xcd_interleave"), 0), 5)]
+        return sum(1 << order[g] for g in range(min(groups, nx), nx))
+    return ((1 << nx) - 1) & ~((1 << groups) - 1)
+
+
 def set_grad_ready_hook(fn):
     _grad_ready["hook"] = fn
 
@@ -177,7 +189,7 @@ def side_stream_plan(cell, T, B, I, H, dirs, nx, cus, slack=1.0):
     if groups < nx:
         if used + 2 > per:
             return 0
-        share, allow = (nx - groups) / float(nx), ((1 << nx) - 1) & ~((1 << groups) - 1)
+        share, allow = (nx - groups) / float(nx), _idle_xcd_mask(nx, groups)
     else:
         if per - used < 8:
             return 0
@@ -374,7 +386,7 @@ class _RNNLayer(torch.autograd.Function):
         # pipelined input projection: only the first pair of time chunks is projected before the recurrence starts, the rest on the
         # side stream, on the XCDs the persistent kernel leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
         nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
-        allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
+        allow = _idle_xcd_mask(nx, groups) if nx > 1 else 0
         piped = _side["enabled"] and _side["fwd_overlap"] and allow != 0 and dirs == 2 and T * B * H >= _side["min_items"]
         call = _lib.RnnCall()                      # everything the call needs beyond its tensors (the library keeps no state between calls)
         call.status = _lib.status_word(dev).data_ptr()
@@ -452,7 +464,7 @@ class _RNNLayer(torch.autograd.Function):
         L = _lib.lib()
         # XCDs a persistent recurrence of this shape leaves idle (group g = (direction, 16-row batch tile) runs on XCD g)
         nx, groups = L.ctcn_device_xcds(), dirs * ((B + 15) // 16)
-        allow = ((1 << nx) - 1) & ~((1 << groups) - 1) if nx > 1 else 0
+        allow = _idle_xcd_mask(nx, groups) if nx > 1 else 0
         # very small layers stay inline (below min_items_bwd = 2^18 (frame, row, unit) items: the test fixtures).  Round 1 measured cfg1 slower
         # with the side stream (2.27 ms inline, 2.8-4.5 with it) and set the threshold at 2^21; with the queue-form GEMMs and the deferred issue
         # of rounds 2-3 the picture is the opposite (round 4: cfg1 2.02 -> 1.95 ms, the shipped-YAML shape 4.69 -> 4.36): set_side_stream

@@ -2249,9 +2249,14 @@ def test_persistent_recurrences_survive_foreign_resident_kernels(dev, workload, 
     import squat_stress
     base = squat_stress.run(workload, steps, squat=False, dev=dev)
     hit = squat_stress.run(workload, steps, squat=True, seed=3, dev=dev)
+    print("undisturbed losses of %s: %r" % (workload, base["losses"][:7]))
     assert hit["squats"] >= steps // 2
     assert np.isfinite(hit["losses"]).all()
-    assert hit["losses"] == base["losses"], [(i, a, b) for i, (a, b) in enumerate(zip(hit["losses"], base["losses"])) if a != b][:5]
+    if hit["losses"] != base["losses"]:          # say whether the undisturbed run itself repeats (then it is the squatters) or not (then it is not)
+        again = squat_stress.run(workload, steps, squat=False, dev=dev)
+        where = [(i, a, b) for i, (a, b) in enumerate(zip(hit["losses"], base["losses"])) if a != b][:5]
+        assert False, ("disturbed != undisturbed at (step, disturbed, undisturbed) %r; a second undisturbed run is %s the first"
+                       % (where, "EQUAL to" if again["losses"] == base["losses"] else "DIFFERENT from"))
     assert hit["kernels"][0] in ("rnn_fwd_tagged", "rnn_fwd_persist") and hit["kernels"][1] in ("rnn_bwd_scatter2", "rnn_bwd_scatter", "rnn_bwd_persist"), hit["kernels"]
 
 

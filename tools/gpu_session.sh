@@ -178,6 +178,15 @@ for wl in ("cfg2", "cfg3", "cfg4", "ref_yaml"):
     print(wl, "bf16 single: %.3f ms/step" % e["ms_per_step"])
 PY
   ;;
+19)
+  # after the XCD placement change (option xcd_interleave = 1 by default): full parity suite, smoke, soak, the driver's command
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/summary.log
+  tail -n 4 $O/pytest_gpu.log
+  timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+  timeout 900 python tools/soak.py --cfg2 1500 --cfg4 300 --ref-yaml 1500 --cfg1 1500 --cfg3 1000 --decode 300 --out $O/r05_soak.json > $O/soak.out 2> $O/soak.err; echo "soak rc=$?" >> $O/summary.log
+  timeout 900 python bench.py --steps 20 --warmup 3 > $O/r05_bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  cat $O/summary.log; tail -n 3 $O/soak.out
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
