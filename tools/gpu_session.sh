@@ -187,6 +187,12 @@ PY
   timeout 900 python bench.py --steps 20 --warmup 3 > $O/r05_bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
   cat $O/summary.log; tail -n 3 $O/soak.out
   ;;
+20)
+  # the round's closing evidence at HEAD (bn_rows4 in, xcd_interleave at its default 0): the driver's command and the soak
+  timeout 900 python bench.py --steps 20 --warmup 3 > $O/r05_bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" > $O/summary.log
+  timeout 900 python tools/soak.py --cfg2 1500 --cfg4 300 --ref-yaml 1500 --cfg1 1500 --cfg3 1000 --decode 300 --out $O/r05_soak.json > $O/soak.out 2> $O/soak.err; echo "soak rc=$?" >> $O/summary.log
+  cat $O/summary.log
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
