@@ -355,6 +355,26 @@ def other_workloads(dev, precision, names=("cfg1", "cfg3", "cfg4", "ref_yaml"), 
     return out
 
 
+def summarize_rccl_log(path, limit=48):
+    """Rank 0's view of the communicator out of an NCCL_DEBUG=INFO file: topology, channels, algorithm / protocol tuning.  RCCL prints one
+    'Tree N' / 'Ring N' / 'Channel N' line per channel (64-128 of them): the first two of a kind are kept and the count is appended."""
+    import re
+    keep = ("Channel", "Ring", "Tree", "nChannels", "Connected all", "Algo", "algo", "proto", "NET/", "P2P", "xgmi", "XGMI", "comm 0x", "NCCL_")
+    per_channel, lines = {}, []
+    with open(path, errors="replace") as fh:
+        for ln in fh:
+            if not any(k in ln for k in keep):
+                continue
+            m = re.search(r"NCCL INFO (Tree|Ring|Channel) \d+", ln)
+            if m:
+                per_channel[m.group(1)] = per_channel.get(m.group(1), 0) + 1
+                if per_channel[m.group(1)] > 2:
+                    continue
+            if len(lines) < limit:
+                lines.append(ln.strip()[-220:])
+    return lines + ["(%d '%s N' lines in all)" % (n, k) for k, n in sorted(per_channel.items())]
+
+
 def run_train(args):
     from ctc_pytorch_amd import nn, parallel
     # N > 1: have RCCL say what it built (rings / trees, channels, protocol) into a per-rank file, so that the first real SCALE record can be
@@ -461,23 +481,7 @@ def run_train(args):
             raise RuntimeError(comm_err)
         exposed = sorted(a.elapsed_time(b) * 1e3 for a, b in comm_marks)
         on = parallel._collectives_on()
-        rccl_lines = None
-        if rccl_log and os.path.exists(rccl_log):           # rank 0's view of the communicator: topology, channels, algorithm / protocol tuning
-            keep = ("Channel", "Ring", "Tree", "nChannels", "Connected all", "Algo", "algo", "proto", "NET/", "P2P", "xgmi", "XGMI", "comm 0x", "NCCL_")
-            import re
-            per_channel, rccl_lines = {}, []
-            with open(rccl_log, errors="replace") as fh:
-                for ln in fh:
-                    if not any(k in ln for k in keep):
-                        continue
-                    m = re.search(r"NCCL INFO (Tree|Ring|Channel) \d+", ln)    # one line per channel (64 of them): first two of a kind + the count
-                    if m:
-                        per_channel[m.group(1)] = per_channel.get(m.group(1), 0) + 1
-                        if per_channel[m.group(1)] > 2:
-                            continue
-                    if len(rccl_lines) < 48:
-                        rccl_lines.append(ln.strip()[-220:])
-            rccl_lines += ["(%d '%s N' lines in all)" % (n, k) for k, n in sorted(per_channel.items())]
+        rccl_lines = summarize_rccl_log(rccl_log) if rccl_log and os.path.exists(rccl_log) else None
         res["per_rank_ms_per_step"] = [t / args.steps * 1e3 for t in per_rank_s]
         res["comm"] = dict(ranks=world, collectives_issued=bool(on), rccl_info=rccl_lines,
                            backend=("none (single rank: allreduce_grads returns at once)" if not on else

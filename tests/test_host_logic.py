@@ -781,3 +781,26 @@ print("BAD", bad)
     assert L.ctcn_comm_allreduce_sum_f32(ctypes.cast(fake, ctypes.c_void_p), ctypes.cast(fake, ctypes.c_void_p), 4, None) == -1
     assert b"not a communicator" in L.ctcn_last_error()
     assert L.ctcn_comm_destroy(ctypes.cast(fake, ctypes.c_void_p)) == -1 and L.ctcn_comm_destroy(None) == 0
+
+
+def test_bench_rccl_log_summary_keeps_two_lines_of_a_kind_and_counts_the_rest(tmp_path):
+    """bench.summarize_rccl_log (the `comm.rccl_info` of a multi-rank line): topology / tuning lines of an NCCL_DEBUG=INFO file, the per-channel
+    'Tree N' / 'Ring N' / 'Channel N' lines folded to the first two of a kind plus a count, everything else dropped, at most `limit` lines."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    log = ["h:1:1 [0] NCCL INFO Dmabuf feature disabled without NCCL_DMABUF_ENABLE=1",
+           "h:1:2 [0] NCCL INFO cudaDriverVersion 0",
+           "h:1:2 [0] NCCL INFO NET/Socket : Using [0]eth0:10.0.0.1<0>",
+           "h:1:2 [0] NCCL INFO comm 0x55 rank 0 nRanks 8 nNodes 1 localRanks 8 localRank 0 MNNVL 0"]
+    log += ["h:1:2 [0] NCCL INFO Tree %d : -1 -> 0 -> 1/-1/-1" % i for i in range(64)]
+    log += ["h:1:2 [0] NCCL INFO Channel %02d/128 : 0 1 2 3 4 5 6 7" % i for i in range(128)]
+    log += ["h:1:2 [0] NCCL INFO Ring %d : 7 -> 0 -> 1 comm 0x55 nRanks 08 busId 8b000" % i for i in range(128)]
+    log += ["h:1:2 [0] NCCL INFO Connected all rings", "h:1:2 [0] NCCL INFO something unrelated", "h:1:2 [0] NCCL INFO P2P Chunksize set to 524288"]
+    p = tmp_path / "rccl.log"
+    p.write_text("\n".join(log) + "\n")
+    out = bench.summarize_rccl_log(str(p))
+    assert sum("NCCL INFO Tree " in l for l in out) == 2 and sum("NCCL INFO Ring " in l for l in out) == 2 and sum("NCCL INFO Channel " in l for l in out) == 2
+    assert out[-3:] == ["(128 'Channel N' lines in all)", "(128 'Ring N' lines in all)", "(64 'Tree N' lines in all)"]
+    assert any("NET/Socket" in l for l in out) and any("nRanks 8" in l for l in out) and any("Connected all rings" in l for l in out) and any("P2P Chunksize" in l for l in out)
+    assert not any("cudaDriverVersion" in l or "unrelated" in l for l in out)
+    assert len(bench.summarize_rccl_log(str(p), limit=5)) == 5 + 3
