@@ -50,7 +50,7 @@ static int g_opt_fwd_pipe_min_input = 0;       // smallest layer input width who
 static int g_opt_conv_dbg = 0;          // development: conv_mfma_kernel skips phases (1 window load, 2 MFMA loop, 4 output phase); results invalid
 static int g_opt_rnn_rsv_nt = 0;        // rnn_bwd_scatter2: non-temporal hint on the reserve traffic (experiment: keep the exchange tiles in L2 at H = 512)
 static int g_opt_gemm_bf16_single = 0;  // 256-row GEMM tiles: one bf16 product (ah*bh) instead of the three bf16x3 products (north_star's bf16 tolerance; gemm.hip)
-static int g_opt_xcd_interleave = 0;    // which physical XCD hosts group g of a persistent recurrence (eight XCDs; 0 (default): XCD g, 1: the even XCDs first, 2-5: other orders; the host's xcd_allow masks follow: ops._idle_xcd_mask)
+static int g_opt_xcd_interleave = 1;    // which physical XCD hosts group g of a persistent recurrence that leaves XCDs idle (eight XCDs; 0: XCD g, 1 (default): the even XCDs first, 2-5: other orders; the host's xcd_allow masks follow: ops._idle_xcd_mask)
 static int g_opt_bn_rows4 = 1;          // BatchNorm over (T*B, C) rows: column sums with 16-B loads (colreduce_rows4_kernel); 0: the dword kernel
 static int g_opt_tn_splits_force = 0;   // development (tools/gemm_tn_bench.py): split-K count of the TN tile, 0 = the rule of gemm.hip:tn_splits
 static int g_opt_tn_splits_xcd = 1;     // TN weight-gradient tile: split count sized for the CUs of xcd_allow (one round of items there), not for the whole device

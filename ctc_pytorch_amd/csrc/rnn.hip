@@ -2498,6 +2498,13 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
 //  * eight CUs of every recurrence XCD stay free, counting the launch's spare workgroups: the side GEMMs' workgroups dealt to a recurrence XCD
 //    must start there to leave -- H = 384 (24 + 3 workgroups per XCD) with only its bottom layer's tiny projection pipelined: 16.4 | 15.7.
 // (Measured and not a rule: chunks that fill less than 3/4 of the side CUs but hold >= 72 steps -- B = 16 gains 1.6 %, B = 20 at T = 650 loses 1.7 %.)
+// Which physical XCD hosts group g of an XCD-local persistent recurrence (option "xcd_interleave", include/ctcn.h).  An order other than 0 is
+// applied only where the recurrence leaves XCDs idle (groups < XCDs) -- where it decides which XCDs the side-stream GEMMs get; a recurrence that
+// takes every XCD (cfg4) keeps group g on XCD g.  The host derives its xcd_allow masks from the same rule (ops._idle_xcd_mask: no idle XCD, no mask).
+static int xcd_order_for(int nx, int groups) {
+  return (nx == 8 && groups < nx) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0;
+}
+
 static int plan_projection_pipeline(int T, int B, int I, int H, int dirs, int G, int nxd, int cus, unsigned xcd_allow, int min_input) {
   if (nxd <= 1 || !xcd_allow || dirs != 2 || I < min_input) return 0;
   const int GH = G * H, N2 = 2 * GH, nidle = __builtin_popcount(xcd_allow), cus_side = cus / nxd * nidle;
@@ -2657,7 +2664,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
         pa.flags = (unsigned *)(tail + hx_bytes);
         pa.status = status_word;
         pa.spin_limit = SPIN_LIMIT;
-        pa.local = 1; pa.nx = nxd; pa.xperm = nxd == 8 ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
+        pa.local = 1; pa.nx = nxd; pa.xperm = xcd_order_for(nxd, groups); pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx;
         // "fwd_rsv_lds": 0 off, 1 on, 2 (default) where it measured faster: more than 24 slices (cfg4, H = 512: 2.30 -> 2.24 us per step, 53.9 -> 53.2 ms
         // per step; cfg2 1.60 -> 1.70, ref_yaml 1.51 -> 1.59: there the waterfall-paced dword traffic of the item waves is the better neighbour of
         // the polls)
@@ -2724,7 +2731,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = status_word;
       pa.spin_limit = SPIN_LIMIT;
-      pa.local = mode; pa.nx = nx; pa.xperm = (mode && nx == 8) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
+      pa.local = mode; pa.nx = nx; pa.xperm = mode ? xcd_order_for(nx, groups) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = HSU; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.nbig = nbig; pa.hsu_small = hsu_small;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
@@ -2942,7 +2949,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
       pa.flags = (unsigned *)(tail + hx_bytes);
       pa.status = status_word;
       pa.spin_limit = SPIN_LIMIT;
-      pa.local = mode; pa.nx = nx; pa.xperm = (mode && nx == 8) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
+      pa.local = mode; pa.nx = nx; pa.xperm = mode ? xcd_order_for(nx, groups) : 0; pa.nsl = nsl; pa.nbt = nbt; pa.hsu = 16; pa.nbig = 0; pa.hsu_small = 0; pa.wpx = wpx; pa.poll_depth = ctcn_opt_poll_depth(); pa.tagmode = 0;
       pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
       pa.stats = nullptr;

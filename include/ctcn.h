@@ -81,15 +81,15 @@ int ctcn_device_xcds(void);
  * ctcn_rnn_bwd_weights: one round of items on the idle XCDs next to a recurrence) instead of for the whole device (two rounds of items half
  * as long, each paying a prologue, a 128-KB partial store and its share of the reduce pass): cfg2 13.22 -> 13.15 ms per step; 0: as before.
  * The k-sums are grouped differently (float32 rounding of the sums), deterministically either way.
- * "xcd_interleave" = 0 (default; round 5): which physical XCD hosts group g -- (direction, 16-row batch tile) -- of a persistent recurrence on a
- * device of eight XCDs, and therefore which XCDs its side-stream GEMMs (pipelined projection chunks, weight gradients) get: 0: XCD g; 1: the
- * even XCDs first {0 2 4 6 | 1 3 5 7}; 2: {0 1 4 5 | ..}; 3: {0 3 4 7 | ..}; 4: {0 2 5 7 | ..}; 5: {0 4 1 5 | ..}.  The host must derive its
- * xcd_allow masks from the same order (ops._idle_xcd_mask).  Same results whatever the order.  Measured at cfg2 (two runs each): order 0
- * 13.19 / 13.20 ms per step; orders 1, 3, 4 -- ONE recurrence XCD and one GEMM XCD in every pair (2k, 2k + 1) -- 13.04-13.08; orders 2, 5 --
- * both XCDs of a pair on the same side -- 13.26-13.31; cfg1 / cfg3 / cfg4 / shipped YAML unchanged (no pipelined projection there).  Left at 0:
- * the one full parity run made with order 1 as the default ended with a cfg4 loss trajectory that differed from step 4 on, in the undisturbed
- * AND the disturbed run of the squatter test alike; 80 stand-alone repetitions and three runs of the suite's tail did not reproduce it with
- * either order, and nothing in the mapping explains it -- not enough to change the placement every launch depends on for 1 %.
+ * "xcd_interleave" = 1 (default; round 5): which physical XCD hosts group g -- (direction, 16-row batch tile) -- of a persistent recurrence that
+ * leaves XCDs idle on a device of eight, and therefore which XCDs its side-stream GEMMs (pipelined projection chunks, weight gradients) get:
+ * 0: XCD g; 1: the even XCDs first {0 2 4 6 | 1 3 5 7}; 2: {0 1 4 5 | ..}; 3: {0 3 4 7 | ..}; 4: {0 2 5 7 | ..}; 5: {0 4 1 5 | ..}.  The host
+ * derives its xcd_allow masks from the same order (ops._idle_xcd_mask).  Same results whatever the order.  Measured at cfg2 (two runs each):
+ * order 0 13.19 / 13.20 ms per step; orders 1, 3, 4 -- ONE recurrence XCD and one GEMM XCD in every pair (2k, 2k + 1) -- 13.04-13.08; orders 2,
+ * 5 -- both XCDs of a pair on the same side -- 13.26-13.31; cfg1 / cfg3 / shipped YAML unchanged.  A recurrence that takes EVERY XCD (cfg4:
+ * groups = XCDs) keeps group g on XCD g whatever the option says: there is nothing to place, and the one full parity run made while the order
+ * applied to it too ended with a cfg4 loss trajectory that differed from step 4 on in the undisturbed AND the disturbed run of the squatter
+ * test alike -- unreproduced since, unexplained, and therefore kept away from that launch.
  * "bn_rows4" = 1 (default, round 5): BatchNorm over (rows, C) with C % 4 == 0 forms its column sums with 16-B loads, sixteen row phases per
  * workgroup (colreduce_rows4_kernel); 0: the dword kernel.  Same chunks, same element values, float64 partials grouped differently: the float32
  * results agreed bit for bit wherever compared (tools/bn_rows_probe.py).  cfg2 13.33 -> 13.25 ms per step, cfg4 53.2 -> 52.8.

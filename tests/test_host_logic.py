@@ -589,16 +589,16 @@ def test_side_stream_capacity_rule_on_the_measured_shapes():
     assert not fits(1, 1200, 64, 1024, 512)      # cfg4
     assert not ops.side_stream_fits(0, 800, 32, 640, 320, 2, 1, 256)     # a device without XCDs to split
     plan = lambda cell, T, B, I, H: ops.side_stream_plan(cell, T, B, I, H, 2, 8, 256)
-    # the idle XCDs' mask: group g of a recurrence runs on physical XCD _XCD_ORDERS[option "xcd_interleave"][g] -- XCD g by default; order 1 (the
-    # even XCDs first: every XCD pair (2k, 2k + 1) then hosts one recurrence XCD and one XCD of side-stream GEMMs) measured 13.19 -> 13.06 ms
-    # per cfg2 step in round 5, both GEMM XCDs of a pair next to each other 13.28 (include/ctcn.h)
-    assert ops.get_option("xcd_interleave") == 0
-    assert plan(0, 800, 32, 640, 320) == 0xF0 and plan(0, 800, 16, 640, 320) == 0xFC
-    ops.set_option("xcd_interleave", 1)
+    # the idle XCDs' mask: group g of a recurrence that leaves XCDs idle runs on physical XCD _XCD_ORDERS[option "xcd_interleave"][g] -- by
+    # default (1) the even XCDs first, so that every XCD pair (2k, 2k + 1) hosts one recurrence XCD and one XCD of side-stream GEMMs (round 5:
+    # cfg2 13.19 -> 13.06 ms per step; both GEMM XCDs of a pair next to each other 13.28; include/ctcn.h)
+    assert ops.get_option("xcd_interleave") == 1
+    assert plan(0, 800, 32, 640, 320) == 0xAA and plan(0, 800, 16, 640, 320) == 0xFA
+    ops.set_option("xcd_interleave", 0)
     try:
-        assert plan(0, 800, 32, 640, 320) == 0xAA and plan(0, 800, 16, 640, 320) == 0xFA
+        assert plan(0, 800, 32, 640, 320) == 0xF0 and plan(0, 800, 16, 640, 320) == 0xFC
     finally:
-        ops.set_option("xcd_interleave", 0)
+        ops.set_option("xcd_interleave", 1)
     assert plan(0, 800, 64, 512, 256) == 0xFF                            # no idle XCD, 14 free CUs per XCD: everywhere (14.97 | 16.36)
     assert plan(0, 800, 64, 256, 128) == 0xFF                            # (11.39 | 11.92)
     assert plan(0, 800, 64, 640, 320) == 0 and plan(1, 1200, 64, 1024, 512) == 0

@@ -193,6 +193,14 @@ PY
   timeout 900 python tools/soak.py --cfg2 1500 --cfg4 300 --ref-yaml 1500 --cfg1 1500 --cfg3 1000 --decode 300 --out $O/r05_soak.json > $O/soak.out 2> $O/soak.err; echo "soak rc=$?" >> $O/summary.log
   cat $O/summary.log
   ;;
+22)
+  # XCD order 1 as the default where XCDs stay idle (cfg4's launch untouched): full parity suite, smoke, the driver's command
+  timeout 1200 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/summary.log
+  tail -n 3 $O/pytest_gpu.log
+  timeout 200 python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+  timeout 600 python bench.py --steps 20 --warmup 3 > $O/r05_bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  cat $O/summary.log
+  ;;
 esac
 ls -la $O; cat $O/summary.log
 python - "$O" <<'PY'
