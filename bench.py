@@ -265,7 +265,7 @@ def make_training_step(c, dev, rank, world):
     gradient all-reduce -> fused Adam.  The SAME closure is what the headline number and the `other_workloads` entries time."""
     from ctc_pytorch_amd import nn, parallel, ops as _ops
     from ctc_pytorch_amd.optim import FlatAdam
-    from oracle import synth                      # synthetic inputs only (no arithmetic)
+    from ctc_pytorch_amd.testing import synth                      # synthetic inputs only (no arithmetic)
     torch.manual_seed(1)
     model = build(c, dev, drop_out=c.get("drop", 0.1)).train()
     opt = FlatAdam(model, lr=1e-3, weight_decay=5e-4)
@@ -602,7 +602,8 @@ def decode_leg(dev, steps=5):
     BeamSearch.py (oracle/beam_ref.c) on a bounded sample, which is also the CPU baseline (1 host core)."""
     from ctc_pytorch_amd import ops
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
-    from oracle import synth, beam_ref
+    from oracle import beam_ref
+    from ctc_pytorch_amd.testing import synth
     V, T, B, W = 62, 800, 128, 20
     i2c = synth.int2char(V)
     arpa = os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")

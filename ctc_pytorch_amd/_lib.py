@@ -32,6 +32,7 @@ _SIGS = {
     "ctcn_device_xcds": (I, []),
     "ctcn_set_option": (I, [ctypes.c_char_p, I]),
     "ctcn_get_option": (I, [ctypes.c_char_p]),
+    "ctcn_option_name": (ctypes.c_char_p, [I]),
     "ctcn_set_status_buffer": (I, [P]),
     "ctcn_gemm": (I, [I, I, I, I, I, P, I, P, I, P, I, F, I, P, Z, P]),
     "ctcn_transpose01": (I, [P, P, I, I, I, P]),

@@ -57,83 +57,66 @@ static int g_opt_tn_splits_xcd = 1;     // TN weight-gradient tile: split count 
 static int g_opt_beam_generic_threads = 0;  // generic beam kernel: 0 = 256 threads per utterance up to W = 64 and 1 024 beyond; 256 / 1024 = forced
 static int g_opt_beam_occ2 = 0;         // fast beam search compiled / launched for TWO workgroups per CU (<= 64 VGPRs, <= 80 KB LDS): 0 off, 1 on, 2 on with the LM in global memory
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
+static int g_opt_xcd_interleave_force = 0;  // development / parity harness: apply "xcd_interleave" to a recurrence that takes EVERY XCD too (rnn.hip: xcd_order_for)
 static int *g_status_dev = nullptr;
 
+// One table for the setter, the getter and the enumerator (ctcn_option_name: what a test harness snapshots -- tests/conftest.py): an option
+// that exists is listed here once, with the normalisation its setter applies.
+struct OptionRow { const char *name; int *var; int (*norm)(int); };
+static const OptionRow k_options[] = {
+  {"rnn_persistent", &g_opt_rnn_persistent, [](int value) -> int { return value; }},
+  {"handoff", &g_opt_handoff, [](int value) -> int { return value; }},
+  {"poll_depth", &g_opt_poll_depth, [](int value) -> int { return value; }},
+  {"rnn_recurrence_only", &g_opt_recurrence_only, [](int value) -> int { return value ? 1 : 0; }},
+  {"bwd_scatter", &g_opt_bwd_scatter, [](int value) -> int { return value ? 1 : 0; }},
+  {"handoff_tags", &g_opt_handoff_tags, [](int value) -> int { return value ? 1 : 0; }},
+  {"side_split_wgs", &g_opt_side_split_wgs, [](int value) -> int { return value < 1 ? 1 : (value > 16 ? 16 : value); }},
+  {"gemm_big_tiles", &g_opt_gemm_big_tiles, [](int value) -> int { return value ? 1 : 0; }},
+  {"beam_fast", &g_opt_beam_fast, [](int value) -> int { return value ? 1 : 0; }},
+  {"conv_dbg", &g_opt_conv_dbg, [](int value) -> int { return value & 7; }},
+  {"rnn_rsv_nt", &g_opt_rnn_rsv_nt, [](int value) -> int { return value ? 1 : 0; }},
+  {"tn_splits_xcd", &g_opt_tn_splits_xcd, [](int value) -> int { return value ? 1 : 0; }},
+  {"xcd_interleave", &g_opt_xcd_interleave, [](int value) -> int { return value < 0 ? 0 : (value > 5 ? 5 : value); }},
+  {"bn_rows4", &g_opt_bn_rows4, [](int value) -> int { return value ? 1 : 0; }},
+  {"tn_splits_force", &g_opt_tn_splits_force, [](int value) -> int { return value < 0 ? 0 : value; }},
+  {"gemm_bf16_single", &g_opt_gemm_bf16_single, [](int value) -> int { return value ? 1 : 0; }},
+  {"beam_generic_threads", &g_opt_beam_generic_threads, [](int value) -> int { return (value == 256 || value == 1024) ? value : 0; }},
+  {"beam_occ2", &g_opt_beam_occ2, [](int value) -> int { return value < 0 ? 0 : (value > 2 ? 2 : value); }},
+  {"fwd_pipe_min_input", &g_opt_fwd_pipe_min_input, [](int value) -> int { return value < 0 ? 0 : value; }},
+  {"fwd_pipe_any_chunking", &g_opt_fwd_pipe_any_chunking, [](int value) -> int { return value ? 1 : 0; }},
+  {"fwd_rsv_lds", &g_opt_fwd_rsv_lds, [](int value) -> int { return value < 0 ? 0 : (value > 2 ? 2 : value); }},
+  {"bwd_item_gather", &g_opt_bwd_item_gather, [](int value) -> int { return value < 0 ? 0 : (value > 2 ? 2 : value); }},
+  {"bwd_poll_delay", &g_opt_bwd_poll_delay, [](int value) -> int { return value < 0 ? -1 : (value > 256 ? 256 : value); }},
+  {"conv_mfma", &g_opt_conv_mfma, [](int value) -> int { return value ? 1 : 0; }},
+  {"edit_wave", &g_opt_edit_wave, [](int value) -> int { return value ? 1 : 0; }},
+  {"gemm_tn", &g_opt_gemm_tn, [](int value) -> int { return value != 0; }},
+  {"rnn_fused_dropout", &g_opt_rnn_fused_dropout, [](int value) -> int { return value != 0; }},
+  {"tag_poll_delay", &g_opt_tag_poll_delay, [](int value) -> int { return value < 0 ? 0 : (value > 64 ? 64 : value); }},
+  {"rnn_fwd_tagged", &g_opt_rnn_fwd_tagged, [](int value) -> int { return value ? 1 : 0; }},
+  {"rnn_mixed_slices", &g_opt_rnn_mixed_slices, [](int value) -> int { return value ? 1 : 0; }},
+  {"gemm_pingpong", &g_opt_gemm_pingpong, [](int value) -> int { return value ? 1 : 0; }},
+  {"gemm_a_inline", &g_opt_gemm_a_inline, [](int value) -> int { return value ? 1 : 0; }},
+  {"gemm_dbg", &g_opt_gemm_dbg, [](int value) -> int { return value; }},
+  {"gemm_tile256", &g_opt_gemm_tile256, [](int value) -> int { return value ? 1 : 0; }},
+  {"xcd_interleave_force", &g_opt_xcd_interleave_force, [](int value) -> int { return value ? 1 : 0; }},
+};
+static const int k_noptions = (int)(sizeof(k_options) / sizeof(k_options[0]));
+static const OptionRow *find_option(const char *name) {
+  if (name)
+    for (int i = 0; i < k_noptions; ++i)
+      if (!strcmp(name, k_options[i].name)) return &k_options[i];
+  return nullptr;
+}
 extern "C" int ctcn_set_option(const char *name, int value) {
-  if (name && !strcmp(name, "rnn_persistent")) { g_opt_rnn_persistent = value; return CTCN_OK; }
-  if (name && !strcmp(name, "handoff")) { g_opt_handoff = value; return CTCN_OK; }
-  if (name && !strcmp(name, "poll_depth")) { g_opt_poll_depth = value; return CTCN_OK; }
-  if (name && !strcmp(name, "rnn_recurrence_only")) { g_opt_recurrence_only = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "bwd_scatter")) { g_opt_bwd_scatter = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "handoff_tags")) { g_opt_handoff_tags = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "side_split_wgs")) { g_opt_side_split_wgs = value < 1 ? 1 : (value > 16 ? 16 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_big_tiles")) { g_opt_gemm_big_tiles = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "beam_fast")) { g_opt_beam_fast = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "conv_dbg")) { g_opt_conv_dbg = value & 7; return CTCN_OK; }
-  if (name && !strcmp(name, "rnn_rsv_nt")) { g_opt_rnn_rsv_nt = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "tn_splits_xcd")) { g_opt_tn_splits_xcd = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "xcd_interleave")) { g_opt_xcd_interleave = value < 0 ? 0 : (value > 5 ? 5 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "bn_rows4")) { g_opt_bn_rows4 = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "tn_splits_force")) { g_opt_tn_splits_force = value < 0 ? 0 : value; return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_bf16_single")) { g_opt_gemm_bf16_single = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "beam_generic_threads")) { g_opt_beam_generic_threads = (value == 256 || value == 1024) ? value : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "beam_occ2")) { g_opt_beam_occ2 = value < 0 ? 0 : (value > 2 ? 2 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "fwd_pipe_min_input")) { g_opt_fwd_pipe_min_input = value < 0 ? 0 : value; return CTCN_OK; }
-  if (name && !strcmp(name, "fwd_pipe_any_chunking")) { g_opt_fwd_pipe_any_chunking = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "fwd_rsv_lds")) { g_opt_fwd_rsv_lds = value < 0 ? 0 : (value > 2 ? 2 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "bwd_item_gather")) { g_opt_bwd_item_gather = value < 0 ? 0 : (value > 2 ? 2 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "bwd_poll_delay")) { g_opt_bwd_poll_delay = value < 0 ? -1 : (value > 256 ? 256 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "conv_mfma")) { g_opt_conv_mfma = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "edit_wave")) { g_opt_edit_wave = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_tn")) { g_opt_gemm_tn = value != 0; return CTCN_OK; }
-  if (name && !strcmp(name, "rnn_fused_dropout")) { g_opt_rnn_fused_dropout = value != 0; return CTCN_OK; }
-  if (name && !strcmp(name, "tag_poll_delay")) { g_opt_tag_poll_delay = value < 0 ? 0 : (value > 64 ? 64 : value); return CTCN_OK; }
-  if (name && !strcmp(name, "rnn_fwd_tagged")) { g_opt_rnn_fwd_tagged = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "rnn_mixed_slices")) { g_opt_rnn_mixed_slices = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_pingpong")) { g_opt_gemm_pingpong = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_a_inline")) { g_opt_gemm_a_inline = value ? 1 : 0; return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_dbg")) { g_opt_gemm_dbg = value; return CTCN_OK; }
-  if (name && !strcmp(name, "gemm_tile256")) { g_opt_gemm_tile256 = value ? 1 : 0; return CTCN_OK; }
+  if (const OptionRow *o = find_option(name)) { *o->var = o->norm(value); return CTCN_OK; }
   ctcn_set_error("ctcn_set_option: unknown option %s", name ? name : "(null)");
   return CTCN_EINVAL;
 }
 extern "C" int ctcn_get_option(const char *name) {
-  if (name && !strcmp(name, "rnn_persistent")) return g_opt_rnn_persistent;
-  if (name && !strcmp(name, "handoff")) return g_opt_handoff;
-  if (name && !strcmp(name, "poll_depth")) return g_opt_poll_depth;
-  if (name && !strcmp(name, "rnn_recurrence_only")) return g_opt_recurrence_only;
-  if (name && !strcmp(name, "bwd_scatter")) return g_opt_bwd_scatter;
-  if (name && !strcmp(name, "handoff_tags")) return g_opt_handoff_tags;
-  if (name && !strcmp(name, "side_split_wgs")) return g_opt_side_split_wgs;
-  if (name && !strcmp(name, "gemm_big_tiles")) return g_opt_gemm_big_tiles;
-  if (name && !strcmp(name, "beam_fast")) return g_opt_beam_fast;
-  if (name && !strcmp(name, "beam_occ2")) return g_opt_beam_occ2;
-  if (name && !strcmp(name, "beam_generic_threads")) return g_opt_beam_generic_threads;
-  if (name && !strcmp(name, "tn_splits_xcd")) return g_opt_tn_splits_xcd;
-  if (name && !strcmp(name, "xcd_interleave")) return g_opt_xcd_interleave;
-  if (name && !strcmp(name, "bn_rows4")) return g_opt_bn_rows4;
-  if (name && !strcmp(name, "tn_splits_force")) return g_opt_tn_splits_force;
-  if (name && !strcmp(name, "gemm_bf16_single")) return g_opt_gemm_bf16_single;
-  if (name && !strcmp(name, "rnn_rsv_nt")) return g_opt_rnn_rsv_nt;
-  if (name && !strcmp(name, "conv_dbg")) return g_opt_conv_dbg;
-  if (name && !strcmp(name, "fwd_pipe_min_input")) return g_opt_fwd_pipe_min_input;
-  if (name && !strcmp(name, "fwd_pipe_any_chunking")) return g_opt_fwd_pipe_any_chunking;
-  if (name && !strcmp(name, "fwd_rsv_lds")) return g_opt_fwd_rsv_lds;
-  if (name && !strcmp(name, "bwd_item_gather")) return g_opt_bwd_item_gather;
-  if (name && !strcmp(name, "bwd_poll_delay")) return g_opt_bwd_poll_delay;
-  if (name && !strcmp(name, "conv_mfma")) return g_opt_conv_mfma;
-  if (name && !strcmp(name, "edit_wave")) return g_opt_edit_wave;
-  if (name && !strcmp(name, "gemm_tn")) return g_opt_gemm_tn;
-  if (name && !strcmp(name, "rnn_fused_dropout")) return g_opt_rnn_fused_dropout;
-  if (name && !strcmp(name, "tag_poll_delay")) return g_opt_tag_poll_delay;
-  if (name && !strcmp(name, "rnn_fwd_tagged")) return g_opt_rnn_fwd_tagged;
-  if (name && !strcmp(name, "rnn_mixed_slices")) return g_opt_rnn_mixed_slices;
-  if (name && !strcmp(name, "gemm_pingpong")) return g_opt_gemm_pingpong;
-  if (name && !strcmp(name, "gemm_a_inline")) return g_opt_gemm_a_inline;
-  if (name && !strcmp(name, "gemm_dbg")) return g_opt_gemm_dbg;
-  if (name && !strcmp(name, "gemm_tile256")) return g_opt_gemm_tile256;
-  return -1;
+  const OptionRow *o = find_option(name);
+  return o ? *o->var : -1;
 }
+extern "C" const char *ctcn_option_name(int index) { return index >= 0 && index < k_noptions ? k_options[index].name : nullptr; }
 extern "C" int ctcn_set_status_buffer(int *dev_word) { g_status_dev = dev_word; return CTCN_OK; }
 int *ctcn_status_word(void) { return g_status_dev; }
 int ctcn_opt_rnn_persistent(void) { return g_opt_rnn_persistent; }

@@ -2502,7 +2502,9 @@ extern "C" size_t ctcn_rnn_scratch_bytes(int cell, int B, int H, int dirs) {
 // applied only where the recurrence leaves XCDs idle (groups < XCDs) -- where it decides which XCDs the side-stream GEMMs get; a recurrence that
 // takes every XCD (cfg4) keeps group g on XCD g.  The host derives its xcd_allow masks from the same rule (ops._idle_xcd_mask: no idle XCD, no mask).
 static int xcd_order_for(int nx, int groups) {
-  return (nx == 8 && groups < nx) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0;
+  // ("xcd_interleave_force": the parity harness applies the order to a launch that takes every XCD as well -- a relabelling of XCDs, bit-identical
+  // results: tests/test_gpu_kernels.py:test_rnn_results_do_not_depend_on_the_xcd_order)
+  return (nx == 8 && (groups < nx || ctcn_get_option("xcd_interleave_force") != 0)) ? std::min(std::max(ctcn_get_option("xcd_interleave"), 0), 5) : 0;
 }
 
 static int plan_projection_pipeline(int T, int B, int I, int H, int dirs, int G, int nxd, int cus, unsigned xcd_allow, int min_input) {

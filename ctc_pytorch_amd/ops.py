@@ -77,6 +77,68 @@ def get_option(name):
     return int(_lib.lib().ctcn_get_option(name.encode()))
 
 
+def option_names():
+    """Every name ctcn_set_option knows (ctcn_option_name, include/ctcn.h)."""
+    L, out, i = _lib.lib(), [], 0
+    while True:
+        n = L.ctcn_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def state_snapshot():
+    """Everything process-wide that can change what a later call computes or which kernels it launches -- the library's option table and the
+    module-level state of this layer: a dict of plain values, comparable with ==.  tests/conftest.py takes one
+    before and after every GPU test, asserts that the configuration part is left as found and puts the learnt part (`fallback_shapes`,
+    `drop_counter`) back; tools/soak.py and tools/squat_stress.py print it next to a trajectory."""
+    from . import parallel
+    return {
+        "options": {n: get_option(n) for n in option_names()},
+        "precision": get_precision(),
+        "fallback_shapes": sorted(_fallback_shapes),
+        "drop_counter": _drop_counter[0],
+        "chunks_on": _chunks_on[0],
+        "fuse_bn_dropout": _fuse_bn_dropout[0],
+        "side": {k: _side[k] for k in ("fwd_overlap", "enabled", "min_items", "min_items_bwd")},
+        "small_split_max_items": SMALL_SPLIT_MAX_ITEMS,
+        "grad_ready_hook": _grad_ready["hook"] is not None,
+        "sync_bn": _sync_bn["reduce"] is not None,
+        "batch_split": (parallel._batch["global"], parallel._batch["local"]),
+        "overlap_pending": len(parallel._overlap["works"]) + len(parallel._overlap["events"]),
+    }
+
+
+LEARNT_STATE = ("fallback_shapes", "drop_counter")
+
+
+def restore_learnt_state(snap):
+    """Put back the part of `state_snapshot` a call may legitimately move (shapes learnt to need batch chunks, the dropout stream position)."""
+    _fallback_shapes.clear()
+    _fallback_shapes.update(tuple(k) for k in snap["fallback_shapes"])
+    _drop_counter[0] = snap["drop_counter"]
+
+
+def restore_state(snap):
+    """Everything `state_snapshot` lists, put back (hooks can only be cleared, not re-created: a snapshot records whether one was set)."""
+    from . import parallel
+    restore_learnt_state(snap)
+    for n, v in snap["options"].items():
+        if get_option(n) != v:
+            set_option(n, v)
+    set_precision(snap["precision"])
+    _chunks_on[0], _fuse_bn_dropout[0] = snap["chunks_on"], snap["fuse_bn_dropout"]
+    for k, v in snap["side"].items():
+        _side[k] = v
+    if not snap["grad_ready_hook"]:
+        parallel.enable_overlap(False)
+    if not snap["sync_bn"]:
+        _sync_bn["reduce"] = None
+    parallel._batch["global"], parallel._batch["local"] = snap["batch_split"]
+    parallel._overlap["works"], parallel._overlap["done"], parallel._overlap["events"] = [], [], []
+
+
 def rnn_last_kernels():
     """(forward, backward) names of the recurrent kernels the library launched last (ctcn_rnn_last_kernel)."""
     L = _lib.lib()

@@ -1,7 +1,7 @@
 """Synthetic, seed-reproducible inputs for the CTC hot path.
 
-TEST INFRASTRUCTURE ONLY (see oracle/README.md): imported by tests/, bench.py's
-input generation and oracle/gen_golden.py.  Contains no arithmetic of the path,
+Imported by tests/, tools/, bench.py's input generation and oracle/gen_golden.py -- never by
+the product modules of this package.  Contains no arithmetic of the path,
 only NumPy ``RandomState`` data generators, so that the same tensors can be
 re-created here (next to the reference) and on the GPU box (without it).
 

@@ -130,6 +130,11 @@ int ctcn_device_xcds(void);
  * and deferred gradient GEMMs so that bench.py can time the recurrent kernel alone -- outputs are not valid. */
 int ctcn_set_option(const char *name, int value);
 int ctcn_get_option(const char *name);
+/* The names ctcn_set_option knows, index 0 .. n-1; NULL past the end.  (Round 6: what a harness needs to snapshot the whole table -- the
+ * reference has no counterpart; tests/conftest.py asserts that every GPU test leaves the table as it found it.)
+ * "xcd_interleave_force" = 0 (default; development): 1 applies "xcd_interleave" to a recurrence that takes EVERY XCD too (cfg4) -- a
+ * relabelling of XCDs with bit-identical results, held to that by test_rnn_results_do_not_depend_on_the_xcd_order. */
+const char *ctcn_option_name(int index);
 /* optional device int that persistent kernels set to a non-zero code if an in-launch hand-off times out (sticky);
  * the caller zeroes it and reads it at its own synchronisation points.  PROCESS-WIDE default (one word for every call that does not
  * bring its own in ctcn_rnn_call.status): a caller with several models / devices passes per-call words instead. */

@@ -29,7 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
-from oracle import synth  # noqa: E402
+from ctc_pytorch_amd.testing import synth  # noqa: E402
 
 # ---- stubs for absent third-party modules ------------------------------
 ed = types.ModuleType("editdistance")

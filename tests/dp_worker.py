@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 from ctc_pytorch_amd import nn, ops, parallel  # noqa: E402
 from ctc_pytorch_amd.models.model_ctc import CTC_Model  # noqa: E402
 from ctc_pytorch_amd.optim import FlatAdam  # noqa: E402
-from oracle import synth  # noqa: E402  (synthetic inputs only)
+from ctc_pytorch_amd.testing import synth  # noqa: E402  (synthetic inputs only)
 
 
 def build(dev, cnn, H=32):

@@ -13,7 +13,8 @@ import torch
 import torch.nn as tnn
 
 from oracle import np_ref as R
-from oracle import synth, torch_cpu
+from oracle import torch_cpu
+from ctc_pytorch_amd.testing import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
@@ -648,7 +649,7 @@ def test_join_tokens_equals_the_python_join():
     full width), list and {id: word} vocabularies, '' and ' ' separators, non-ASCII and > 16-byte words; ids outside the vocabulary raise what
     the expression raises."""
     from ctc_pytorch_amd import ops
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     rs = np.random.RandomState(3)
     V, B, T = 62, 37, 90
     phones = [synth.int2char(V)[i] for i in range(V)]
@@ -697,7 +698,7 @@ def test_greedy_decoder_strings_equal_the_reference_expression():
     """GreedyDecoder._strings (the host end of GreedyDecoder.decode): ' ' + phone per kept frame when the vocabulary has no space symbol, the
     space symbol as ' ' otherwise (ctcDecoder.py:80-92,152-166), list and dict vocabularies."""
     from ctc_pytorch_amd.utils.ctcDecoder import GreedyDecoder
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     rs = np.random.RandomState(5)
     V, B, T = 62, 9, 40
     i2c = synth.int2char(V)
@@ -740,6 +741,34 @@ def _word_ids(s, t):
     return [ids.setdefault(w, len(ids)) for w in s.split()], [ids.setdefault(w, len(ids)) for w in t.split()]
 
 
+def test_option_table_enumerates_and_round_trips():
+    """ctcn_option_name lists every name ctcn_set_option / ctcn_get_option know (the table the GPU tests' state harness snapshots,
+    tests/conftest.py); unknown names are refused; a set value is normalised as documented and read back; ops.state_snapshot /
+    restore_state put a moved option, precision and the learnt state back."""
+    from ctc_pytorch_amd import _lib, ops
+    L = _lib.lib()
+    names = ops.option_names()
+    assert len(names) == len(set(names)) >= 35 and "xcd_interleave" in names and "xcd_interleave_force" in names and "rnn_persistent" in names
+    assert L.ctcn_option_name(len(names)) is None and L.ctcn_option_name(-1) is None
+    assert L.ctcn_set_option(b"no_such_option", 1) < 0 and L.ctcn_get_option(b"no_such_option") == -1
+    assert all(ops.get_option(n) >= -1 for n in names)
+    snap = ops.state_snapshot()
+    assert snap["options"]["xcd_interleave"] == 1 and snap["options"]["xcd_interleave_force"] == 0
+    try:
+        ops.set_option("xcd_interleave", 9)
+        assert ops.get_option("xcd_interleave") == 5                    # clamped as include/ctcn.h says
+        ops.set_option("bwd_poll_delay", -7)
+        assert ops.get_option("bwd_poll_delay") == -1
+        ops.set_precision(1 - snap["precision"])
+        ops._fallback_shapes.add((0, 320, 2, 96))
+        ops._drop_counter[0] += 5
+        moved = ops.state_snapshot()
+        assert moved != snap and moved["fallback_shapes"] == sorted(snap["fallback_shapes"] + [(0, 320, 2, 96)])
+    finally:
+        ops.restore_state(snap)
+    assert ops.state_snapshot() == snap
+
+
 def test_every_entry_point_rejects_null_and_zero_arguments_without_a_gpu():
     """The C ABI's error behaviour on the host side: every entry point of include/ctcn.h called with null pointers and zero sizes answers with
     an error code (or 0 bytes for the size queries) BEFORE it touches the device -- no crash, no HIP call -- each in a process of its own (a
@@ -761,7 +790,7 @@ for name, (res, args) in _lib._SIGS.items():
     sys.stdout.write(name + "\n"); sys.stdout.flush()
     r = getattr(L, name)(*vals)
     if name in ("ctcn_version", "ctcn_last_error", "ctcn_rnn_last_kernel", "ctcn_device_cus", "ctcn_device_xcds", "ctcn_set_status_buffer", "ctcn_comm_destroy",
-                "ctcn_levenshtein"):
+                "ctcn_levenshtein", "ctcn_option_name"):
         continue                                  # (queries and no-ops that have no failing form with these arguments)
     if name.endswith("_bytes"):
         if r != 0: bad.append((name, r))

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from oracle import np_ref as R
-from oracle import beam_ref, synth
+from oracle import beam_ref
+from ctc_pytorch_amd.testing import synth
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 

@@ -4,7 +4,8 @@ status against the C oracle, ulp distance of the float64 scores, and whether the
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
-from oracle import synth, beam_ref
+from oracle import beam_ref
+from ctc_pytorch_amd.testing import synth
 def run(so, probs_tbv, lens, tab, alpha, W):
     L = ctypes.CDLL(so)
     T, B, V = probs_tbv.shape

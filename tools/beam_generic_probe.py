@@ -2,7 +2,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ctc_pytorch_amd import ops
-from oracle import synth
+from ctc_pytorch_amd.testing import synth
 dev = torch.device("cuda", 0)
 T, B = 800, 128
 for V, W in ((62, 20), (62, 60), (200, 20), (200, 60), (200, 200), (41, 200)):

@@ -3,7 +3,8 @@ import numpy as np, torch, torch.nn as tnn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ctc_pytorch_amd import nn, ops
 from ctc_pytorch_amd.models.model_ctc import CTC_Model
-from oracle import synth, torch_cpu, np_ref as R
+from oracle import torch_cpu, np_ref as R
+from ctc_pytorch_amd.testing import synth
 dev = torch.device("cuda:0")
 z = np.load("tests/golden/model_cnn_lstm2x16.npz")
 cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]}

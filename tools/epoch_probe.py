@@ -7,7 +7,7 @@ from ctc_pytorch_amd import ops, nn, parallel, _lib
 from ctc_pytorch_amd.optim import FlatAdam
 from ctc_pytorch_amd.utils.data_loader import DevicePrefetcher
 from ctc_pytorch_amd.steps.train_ctc import run_epoch
-from oracle import synth
+from ctc_pytorch_amd.testing import synth
 
 dev = torch.device("cuda", 0)
 c = bench.WORKLOADS["cfg2"]

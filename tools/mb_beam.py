@@ -22,7 +22,7 @@ def run(regime):
     import numpy as np
     import torch
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     L = ctypes.CDLL(SO)
     V, T, B, W = 62, 800, 128, 20
     i2c = synth.int2char(V)
@@ -65,7 +65,7 @@ def run_generic(regime, W):
     import numpy as np
     import torch
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     L = ctypes.CDLL(SO)
     V, T, B = 62, 800, 128
     i2c = synth.int2char(V)
@@ -113,7 +113,7 @@ def time_lib(so, iters=20):
     import numpy as np
     import torch
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     L = ctypes.CDLL(so)
     V, T, B, W = 62, 800, 128, 20
     i2c = synth.int2char(V)

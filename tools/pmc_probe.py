@@ -61,7 +61,7 @@ torch.cuda.synchronize()
 # cfg5 beam decode (peaky regime), two launches: beam_prep_kernel + beam_fast_kernel
 import numpy as np
 from ctc_pytorch_amd.utils.NgramLM import LanguageModel
-from oracle import synth
+from ctc_pytorch_amd.testing import synth
 Vb, Tb, Bb, Wb = 62, 800, 128, 20
 i2c = synth.int2char(Vb)
 tab = LanguageModel(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lm_phone_bg.arpa")).table([i2c[i] for i in range(Vb)])

@@ -24,7 +24,7 @@ def train_run(workload, steps, dev):
     import bench
     from ctc_pytorch_amd import nn, ops, parallel
     from ctc_pytorch_amd.optim import FlatAdam
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     c = dict(bench.WORKLOADS[workload])
     for key in ("T", "B", "H", "L"):                # the same shape overrides as bench.py (CTCN_BENCH_T / B / H / L)
         if os.environ.get("CTCN_BENCH_" + key):
@@ -74,7 +74,7 @@ def train_run(workload, steps, dev):
 def decode_run(batches, dev):
     from ctc_pytorch_amd import ops
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     V, T, B, W = 62, 800, 128, 20
     i2c = synth.int2char(V)
     tab = LanguageModel(os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])

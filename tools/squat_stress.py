@@ -31,9 +31,10 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     import bench
     from ctc_pytorch_amd import nn, ops, parallel
     from ctc_pytorch_amd.optim import FlatAdam
-    from oracle import synth
+    from ctc_pytorch_amd.testing import synth
     dev = dev or torch.device("cuda", 0)
     c = bench.WORKLOADS[workload]
+    found = ops.state_snapshot()                      # (round 6) this function leaves the process-wide state as it found it, and says what it ran in
     ops.set_precision(1)
     parallel.enable_overlap(True)
     torch.manual_seed(1)
@@ -89,8 +90,15 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.check_health()
-    return dict(losses=[float(l) for l in losses], ms_per_step=dt / steps * 1e3, squats=stats["n"], squat_wg_us=stats["wg_us"],
-                kernels=ops.rnn_last_kernels())
+    res = dict(losses=[float(l) for l in losses], ms_per_step=dt / steps * 1e3, squats=stats["n"], squat_wg_us=stats["wg_us"],
+               kernels=ops.rnn_last_kernels())
+    ran_in = ops.state_snapshot()
+    ops.restore_state(dict(found, fallback_shapes=ran_in["fallback_shapes"], drop_counter=ran_in["drop_counter"]))
+    if os.environ.get("CTCN_TRAJ_LOG"):               # one line per run: the trajectory next to the state it was computed in
+        with open(os.environ["CTCN_TRAJ_LOG"], "a") as f:
+            f.write(json.dumps(dict(workload=workload, steps=steps, squat=bool(squat), seed=seed, losses=res["losses"], kernels=res["kernels"],
+                                    state_found=found, state_ran_in=ran_in)) + "\n")
+    return res
 
 
 if __name__ == "__main__":
