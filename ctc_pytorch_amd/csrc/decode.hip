@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) tk[h] = 0ull;               // (no candidate: below every key of a finite value)
       scan([&](double v, int c) {
-        if (v != -INFINITY) {
+        if (v > -INFINITY) {
           ++nval;
           const unsigned long long key = dkey(v);
           const bool hi = NH == 2 && ((c / NT) & 1);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         int cnt = 0;
         double kv0 = 0.0, kv1 = 0.0; int kc0 = 0, kc1 = 0;
         scan([&](double v, int c) {
-          if (v != -INFINITY && (!prune || dkey(v) >= theta)) {
+          if (v > -INFINITY && (!prune || dkey(v) >= theta)) {
             kv0 = cnt == 0 ? v : kv0; kc0 = cnt == 0 ? c : kc0;          // (selects: an if-chain becomes an indexed store into a stack array)
             kv1 = cnt == 1 ? v : kv1; kc1 = cnt == 1 ? c : kc1;
             ++cnt;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         else if (cnt <= 2) {
           if (cnt > 0) { sv_v[pos] = kv0; sv_i[pos] = kc0; }
           if (cnt > 1) { sv_v[pos + 1] = kv1; sv_i[pos + 1] = kc1; }
-        } else scan([&](double v, int c) { if (v != -INFINITY && (!prune || dkey(v) >= theta)) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
+        } else scan([&](double v, int c) { if (v > -INFINITY && (!prune || dkey(v) >= theta)) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
         __syncthreads();
         GSTAMP(10);
 #ifdef CTCN_BEAM_STATS
@@ -361,11 +361,14 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         GSTAMP(11);
       }
     }
+    // (the rounds reuse red_i[], which every thread has just summed into `total` -- when the ranking block was skipped no barrier
+    // separates those reads from round 0's writes; `ranked` is uniform.  A NaN score counts as "no candidate" everywhere (v > -inf).)
+    if (!ranked) __syncthreads();
     for (int r = 0; r < W && !ranked; ++r) {
       double bv = -INFINITY; int bi = 0x7fffffff;
       for (int c = tid; c < ncand; c += NT) {
         const double v = cand[c];
-        if (v != -INFINITY && cand_better(v, c, bv, bi)) { bv = v; bi = c; }
+        if (v > -INFINITY && cand_better(v, c, bv, bi)) { bv = v; bi = c; }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -1466,19 +1469,28 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   a.stats = g_beam_stats_dev;
 #endif
   const size_t cand_bytes = (size_t)W * V * sizeof(double);
-  a.cand_in_lds = cand_bytes <= 32 * 1024 ? 1 : 0;
-  const size_t sm = (size_t)V * sizeof(double) + (a.cand_in_lds ? cand_bytes : 0);
-  // (static LDS of the kernel is ~46 KB since the selection holds its survivors there: together with the candidate table the block can pass
-  // the 64 KB a launch gets without asking)
   const int gthreads = ctcn_get_option("beam_generic_threads");          // 0 (default): by beam width; 256 / 1024: forced (measurements)
   // (measured, tools/beam_generic_probe.py, 128 x 800 batches: 3 720 candidates per frame 7.9 -> 6.3 ms with 1 024 threads, 12 000: 21 -> 16 ms; 1 240: 4.7 -> 4.9)
-  if (gthreads == 1024 || (gthreads != 256 && (W > 64 || (long)W * V > 3500))) {
-    CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL(beam_kernel<1024>, dim3(B), dim3(1024), sm, st, a);
-  } else {
-    CTCN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(beam_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL(beam_kernel<256>, dim3(B), dim3(256), sm, st, a);
+  const bool wide = gthreads == 1024 || (gthreads != 256 && (W > 64 || (long)W * V > 3500));
+  const void *kern = wide ? reinterpret_cast<const void *>(beam_kernel<1024>) : reinterpret_cast<const void *>(beam_kernel<256>);
+  // The kernel's STATIC LDS is ~46 KB since the selection holds its survivors there; the candidate table joins it in LDS only if the
+  // whole block then fits what this device gives one workgroup (160 KB on gfx950; a 64-KB device falls back to the global table
+  // instead of failing the launch).
+  hipFuncAttributes fa;
+  CTCN_HIP(hipFuncGetAttributes(&fa, kern));
+  int dev_id = 0, lds_max = 64 * 1024;
+  CTCN_HIP(hipGetDevice(&dev_id));
+  if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_id) != hipSuccess) lds_max = 64 * 1024;
+  const size_t row_bytes = (size_t)V * sizeof(double);
+  a.cand_in_lds = (cand_bytes <= 32 * 1024 && fa.sharedSizeBytes + row_bytes + cand_bytes <= (size_t)lds_max) ? 1 : 0;
+  const size_t sm = row_bytes + (a.cand_in_lds ? cand_bytes : 0);
+  if (fa.sharedSizeBytes + sm > (size_t)lds_max) {
+    ctcn_set_error("ctcn_beam_decode: %zu B of LDS per workgroup needed, the device gives %d", fa.sharedSizeBytes + sm, lds_max);
+    return CTCN_EUNSUPPORTED;
   }
+  CTCN_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+  if (wide) hipLaunchKernelGGL(beam_kernel<1024>, dim3(B), dim3(1024), sm, st, a);
+  else hipLaunchKernelGGL(beam_kernel<256>, dim3(B), dim3(256), sm, st, a);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }

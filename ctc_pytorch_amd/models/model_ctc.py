@@ -84,8 +84,10 @@ class LayerCNN(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
-        if self._fused and self.pooling is None and self.dropout.training and self.dropout.p > 0.0:
-            return self.batch_norm(x, drop_p=float(self.dropout.p))     # BN + ReLU + dropout in one pass (round 5): same values, same random stream
+        # BN + ReLU + dropout in one pass (round 5): same values, same random stream.  Only when BOTH modules train and 0 < p < 1 (a
+        # frozen BatchNorm in eval mode next to a training dropout, or p = 1, take the separate modules below, as the reference's stack does)
+        if self._fused and self.pooling is None and self.dropout.training and self.batch_norm.training and 0.0 < self.dropout.p < 1.0:
+            return self.batch_norm(x, drop_p=float(self.dropout.p))
         if self._fused:
             x = self.batch_norm(x)              # BN + ReLU in one pass
         else:

@@ -139,6 +139,23 @@ def restore_state(snap):
     parallel._overlap["works"], parallel._overlap["done"], parallel._overlap["events"] = [], [], []
 
 
+_kernel_counts = {}
+
+
+def kernel_counts(reset=False):
+    """How often each recurrence kernel was launched by this process's layer calls since the last reset: {'rnn_fwd_tagged': n, 'rnn_bwd_step': m, ...}
+    (what bench.py's ragged-epoch leg reports: a shape that falls off the persistent path shows up as rnn_fwd_step / rnn_bwd_step)."""
+    out = dict(_kernel_counts)
+    if reset:
+        _kernel_counts.clear()
+    return out
+
+
+def _count_kernel(name):
+    k = (name or b"?").decode() if isinstance(name, (bytes, bytearray)) or name is None else str(name)
+    _kernel_counts[k] = _kernel_counts.get(k, 0) + 1
+
+
 def rnn_last_kernels():
     """(forward, backward) names of the recurrent kernels the library launched last (ctcn_rnn_last_kernel)."""
     L = _lib.lib()
@@ -470,6 +487,7 @@ class _RNNLayer(torch.autograd.Function):
         call.launched = ctypes.pointer(launched)
         _lib.check(L.ctcn_rnn_fwd_ex(cell, T, B, I, H, dirs, _ptr(x), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
                                      _ptr(y), _ptr(gates), _ptr(aux), get_precision(), wp, wn, _lib.stream_ptr(), ctypes.byref(call)), "rnn_fwd_ex")
+        _count_kernel(launched.value)
         if T > 1 and B > 16 and (launched.value or b"") == b"rnn_fwd_step" and get_option("rnn_persistent"):
             _fallback_shapes.add((cell, H, dirs, B))       # (rnn_layer chunks this shape's batch from the next call on)
         if piped:
@@ -587,6 +605,7 @@ class _RNNLayer(torch.autograd.Function):
             if above is not None:                       # keep the parked work for the join
                 _side["deferred"][key] = above
             raise
+        _count_kernel(launched.value)
         if T > 1 and B > 16 and (launched.value or b"") == b"rnn_bwd_step" and get_option("rnn_persistent"):
             _fallback_shapes.add((cell, H, dirs, B))           # (rnn_layer chunks this shape's batch from the next call on)
         if above is not None:
@@ -908,8 +927,10 @@ class _Dropout(torch.autograd.Function):
 def dropout(x, p, training):
     if not training or p == 0.0:
         return x
-    if p >= 1.0:
-        raise ValueError("dropout p must be < 1")
+    if p < 0.0 or p > 1.0:
+        raise ValueError("dropout probability has to be between 0 and 1, but got %r" % (p,))
+    if p == 1.0:                    # torch: everything dropped (a memset; the gradient through it is zero, i.e. nothing to propagate)
+        return torch.zeros_like(x)
     return _Dropout.apply(x, p)
 
 

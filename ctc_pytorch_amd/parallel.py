@@ -12,8 +12,18 @@ import torch
 import torch.distributed as dist
 
 
+def dp_safe():
+    """CTCN_DP_SAFE=1: the conservative data-parallel arrangement -- no early per-layer slice all-reduce, no weight-gradient side stream, no
+    pipelined input projection: every kernel of a step on ONE stream and the ONE gradient all-reduce at the step's end, when nothing of this
+    process is resident next to RCCL's kernels.  What the driver's first N > 1 run can A/B the co-residency contract of DESIGN.md section 6
+    against (the persistent recurrences next to RCCL workgroups have never met a second device)."""
+    return os.environ.get("CTCN_DP_SAFE", "0") == "1"
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  The rendezvous and every collective
+    are bounded by CTCN_DIST_TIMEOUT_S (default 120 s): a peer that never arrives ends in an exception, not in a hang."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -24,8 +34,116 @@ def init_from_env(backend=None):
             backend = os.environ.get("CTCN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("CTCN_DIST_TIMEOUT_S", "120"))))
+    if dp_safe():
+        from . import ops
+        ops.set_side_stream(False)
+        ops.set_fwd_overlap(False)
     return rank, world, local
+
+
+class RankMonitor(object):
+    """First contact with N > 1 ranks must leave evidence, not a hang.  Every rank reports through the rendezvous
+    TCPStore -- which needs no collective and lives in rank 0's process -- what phase it is in (`progress`), that it failed (`fail`) or that
+    it is done (`finish`, with its hand-off status word and the recurrence kernels it ran).  Rank 0 runs a daemon thread that watches those
+    keys: as soon as ANY rank has failed, or when `deadline_s` passes without every rank finishing, it calls `on_trouble(report)` -- bench.py
+    prints its one JSON line with `error`, the per-rank records and the RCCL summary from there -- and ends the process with `exit_code`, no
+    matter where the main thread is stuck (a collective waiting for the dead peer, a kernel spinning for a hand-off).  The other ranks wait
+    (bounded) for rank 0's `monitor/closed` key before they leave with a non-zero code, so that a launcher which tears the job down at the
+    first failed worker does not kill rank 0 before the line is out."""
+
+    def __init__(self, rank, world, store=None, deadline_s=None, poll_s=0.5, on_trouble=None, exit_code=3):
+        import threading
+        import time
+        self.rank, self.world, self.on_trouble, self.exit_code = rank, world, on_trouble, exit_code
+        self.store = store if store is not None else (dist.distributed_c10d._get_default_store() if dist.is_initialized() else None)
+        self.deadline = None if deadline_s is None else time.time() + float(deadline_s)
+        self.poll_s, self._stop, self._fired = poll_s, threading.Event(), threading.Event()
+        self._thread = None
+        if self.store is not None and rank == 0:
+            self._thread = threading.Thread(target=self._watch, name="ctcn-rank-monitor", daemon=True)
+            self._thread.start()
+
+    # -- every rank ---------------------------------------------------------------------------------------------------------------
+    def _set(self, key, obj):
+        import json
+        if self.store is not None:
+            self.store.set("monitor/%s/%d" % (key, self.rank), json.dumps(obj))
+
+    def progress(self, phase, **extra):
+        self._set("progress", dict(phase=phase, **extra))
+
+    def finish(self, **record):
+        self._set("done", record)
+
+    def fail(self, exc, wait_s=60.0, **record):
+        """Report a failure of THIS rank; on ranks other than 0, wait (bounded) until rank 0 has printed."""
+        import time
+        import traceback
+        self._set("failed", dict(error=repr(exc), where=traceback.format_exc(limit=6)[-1200:], **record))
+        if self.store is not None and self.rank != 0:
+            t_end = time.time() + wait_s
+            while time.time() < t_end:
+                try:
+                    if self.store.check(["monitor/closed"]):
+                        break
+                except Exception:       # noqa: BLE001 -- rank 0 is gone: nothing left to wait for
+                    break
+                time.sleep(0.2)
+
+    def close(self):
+        """Rank 0, after its line is out (or on the clean path): stop watching and release the waiting ranks."""
+        self._stop.set()
+        if self.store is not None and self.rank == 0:
+            try:
+                self.store.set("monitor/closed", "1")
+            except Exception:           # noqa: BLE001
+                pass
+
+    # -- rank 0 -------------------------------------------------------------------------------------------------------------------
+    def collect(self):
+        """What every rank has reported so far: {rank: {progress, failed, done}}."""
+        import json
+        out = {}
+        for r in range(self.world):
+            rec = {}
+            for key in ("progress", "failed", "done"):
+                k = "monitor/%s/%d" % (key, r)
+                try:
+                    if self.store.check([k]):
+                        rec[key] = json.loads(self.store.get(k).decode())
+                except Exception as e:  # noqa: BLE001
+                    rec[key] = {"unreadable": repr(e)}
+            out[str(r)] = rec
+        return out
+
+    def _watch(self):
+        import os as _os
+        import sys
+        import time
+        while not self._stop.wait(self.poll_s):
+            try:
+                ranks = self.collect()
+            except Exception:           # noqa: BLE001
+                continue
+            failed = [r for r, rec in ranks.items() if "failed" in rec]
+            late = self.deadline is not None and time.time() > self.deadline and any("done" not in rec for rec in ranks.values())
+            if not failed and not late:
+                continue
+            if self._stop.is_set():
+                return
+            self._fired.set()
+            why = ("rank %s failed: %s" % (failed[0], ranks[failed[0]]["failed"].get("error")) if failed else
+                   "deadline passed; unfinished ranks: %s" % [r for r, rec in ranks.items() if "done" not in rec])
+            try:
+                if self.on_trouble is not None:
+                    self.on_trouble(dict(error=why, ranks=ranks))
+            finally:
+                sys.stdout.flush()
+                self.close()
+                time.sleep(0.5)         # (the waiting ranks poll monitor/closed every 0.2 s)
+                _os._exit(self.exit_code)
 
 
 def world_size():
@@ -109,7 +227,7 @@ _overlap = {"works": [], "done": [], "events": []}
 
 def enable_overlap(flag=True):
     from . import ops
-    ops.set_grad_ready_hook(_slice_ready if flag else None)
+    ops.set_grad_ready_hook(_slice_ready if (flag and not dp_safe()) else None)      # (CTCN_DP_SAFE=1: one all-reduce at the step's end, nothing early)
     _overlap["works"], _overlap["done"], _overlap["events"] = [], [], []
 
 
@@ -175,11 +293,12 @@ def allreduce_grads(flat_grad):
 _batch = {"global": None, "local": None, "seen": 0}
 
 
-def set_batch_split(global_b=None, local_b=None):
-    """Tell the synchronised BatchNorm how the current minibatch is split (run_epoch calls it per step); the utterances this rank has seen
-    since the last sync_bn_buffers are counted on the way (its pooling weights)."""
+def set_batch_split(global_b=None, local_b=None, count=True):
+    """Tell the synchronised BatchNorm how the current minibatch is split (run_epoch calls it per step); the utterances this rank has TRAINED on
+    since the last sync_bn_buffers are counted on the way (its pooling weights).  `count=False` for a validation pass: the running statistics
+    do not move there, so its utterances must not weigh in (from epoch 2 on the weights were train + previous dev utterances)."""
     _batch["global"], _batch["local"] = global_b, local_b
-    if local_b:
+    if local_b and count:
         _batch["seen"] = _batch.get("seen", 0) + int(local_b)
 
 

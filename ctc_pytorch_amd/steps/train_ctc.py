@@ -79,7 +79,7 @@ def run_epoch(epoch_id, model, data_iter, loss_fn, device, optimizer=None, print
         # data parallel (parallel.ShardedBatches): a 6th entry carries the utterance count of the GLOBAL minibatch; the loss
         # is sum_shard nll / B_global, so that the SUM all-reduce of the gradients yields the single-process gradient
         step_global = data[5] if len(data) > 5 else global_batch
-        parallel.set_batch_split(step_global, int(inputs.shape[0]) if step_global else None)
+        parallel.set_batch_split(step_global, int(inputs.shape[0]) if step_global else None, count=is_training)
         inputs = inputs.to(device, non_blocking=True)
         targets_d = targets.to(device, non_blocking=True)
         target_sizes_d = target_sizes.to(device, non_blocking=True)

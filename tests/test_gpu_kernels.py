@@ -2257,28 +2257,60 @@ def test_bench_under_torchrun_with_rccl_collectives(dev, workload, comm):
     assert isinstance(res["comm"]["rccl_info"], list) and len(res["comm"]["rccl_info"]) > 0, res["comm"]
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo(dev):
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(dev, scaling):
     """The N > 1 code path of bench.py end to end with two REAL ranks (the driver's launch form needs two GPUs; here both ranks share the one
     GPU and gloo carries the collectives, RCCL refusing two ranks per device): parameter broadcast, sharded seeds, the step-end all-reduce
     behind the side stream, barriers, max-over-ranks and the per-rank clocks of the line (round 5).  cfg1: both ranks' persistent grids
-    (16 workgroups each) are co-resident."""
+    (16 workgroups each) are co-resident.  Round 6: `--scaling strong` (the workload's batch is the GLOBAL batch, B / N utterances
+    per rank) and the per-rank records of the RankMonitor (phase, status word, recurrence kernels) in `comm`."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", LOCAL_RANK="0", CTCN_DIST_BACKEND="gloo",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641" if scaling == "weak" else "29643", WORLD_SIZE="2", LOCAL_RANK="0", CTCN_DIST_BACKEND="gloo",
                HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1", CTCN_QUIET="1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg1", "--no-cpu-baseline",
-           "--no-decode", "--no-others", "--no-pmc"]
+           "--no-decode", "--no-others", "--no-pmc", "--scaling", scaling]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=280) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # rank 0 alone prints the line
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["scaling"] == "weak"
+    per_rank_b = 8 if scaling == "weak" else 4
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 * per_rank_b and res["scaling"] == scaling
     assert len(res["per_rank_ms_per_step"]) == 2 and max(res["per_rank_ms_per_step"]) <= res["ms_per_step"] * 1.0001
     assert res["value"] > 0 and np.isfinite(res["final_loss"]) and res["comm"]["collectives_issued"] and res["comm"]["ranks"] == 2
-    assert abs(res["value"] - 2 * 8 * 300 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]      # whole-job frames / max-over-ranks time
+    assert abs(res["value"] - 2 * per_rank_b * 300 / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]      # whole-job frames / max-over-ranks time
+    per_rank = res["comm"]["per_rank"]
+    assert sorted(per_rank) == ["0", "1"] and res["comm"]["dp_safe"] is False
+    for r in ("0", "1"):
+        assert per_rank[r]["done"]["status"] == 0 and "step" not in "".join(per_rank[r]["done"]["kernels"]), per_rank[r]
+        assert per_rank[r]["progress"]["phase"] == "timed"
+
+
+def test_bench_rank_failure_yields_a_line_with_the_diagnosis(dev):
+    """VERDICT r5 next 5, on the real bench.py: two ranks over gloo on the one GPU, rank 1 raises at step 3 of its prewarm loop
+    (CTCN_BENCH_FAIL_RANK / _STEP) while rank 0 waits in that step's all-reduce.  Rank 0's JSON line must arrive within 150 s with `error`,
+    every rank's last phase and the failing rank's message; both processes end with code 3.  CTCN_DP_SAFE=1 rides along: the line says so."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29645", WORLD_SIZE="2", LOCAL_RANK="0", CTCN_DIST_BACKEND="gloo", CTCN_DP_SAFE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1", CTCN_QUIET="1", CTCN_BENCH_FAIL_RANK="1", CTCN_BENCH_FAIL_STEP="3")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg1", "--no-cpu-baseline",
+           "--no-decode", "--no-others", "--no-pmc"]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=150) for p in procs]
+    assert time.time() - t0 < 150
+    assert [p.returncode for p in procs] == [3, 3], "\n".join(o[1][-1500:] for o in outs)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0]
+    res = json.loads(lines[0])
+    assert res["value"] is None and "rank 1 failed" in res["error"] and "injected failure" in res["error"] and res["comm"]["dp_safe"] is True
+    assert "injected failure" in res["ranks"]["1"]["failed"]["error"] and res["ranks"]["0"]["progress"]["phase"] == "prewarm"
 
 
 @pytest.mark.parametrize("workload,steps", [("cfg2", 60), ("cfg4", 12)])

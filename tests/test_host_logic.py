@@ -460,6 +460,69 @@ print("rank", rank, "ok")
 """
 
 
+_DP_FAIL_SCRIPT = r"""
+import json, os, sys, time, types, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bench
+from ctc_pytorch_amd import parallel
+mode = sys.argv[1]
+rank, world, local = parallel.init_from_env(backend="gloo")
+args = types.SimpleNamespace(gpus=world, steps=20, warmup=5, scaling="weak", workload="cfg2")
+mon = parallel.RankMonitor(rank, world, deadline_s=float(os.environ.get("CTCN_BENCH_DEADLINE_S", "900")), poll_s=0.2,
+                           on_trouble=lambda rep: print(json.dumps(bench.trouble_line(args, rep, None)), flush=True))
+mon.progress("initialised", backend=dist.get_backend())
+try:
+    g = torch.ones(1000)
+    for step in range(50):
+        mon.progress("prewarm", step=step)
+        if mode == "raise" and rank == 1 and step == 3:
+            raise RuntimeError("injected failure of rank 1 at step 3")
+        if mode == "hang" and rank == 1 and step == 3:
+            time.sleep(600)                     # a rank that neither fails nor finishes: only the deadline can end this
+        dist.all_reduce(g)                      # rank 0 blocks here from step 3 on: its peer never arrives
+    mon.finish(status=0)
+except BaseException as e:
+    mon.fail(e, kernels=["rnn_fwd_tagged", "rnn_bwd_scatter"])
+    sys.exit(3)
+mon.close()
+print("finished without trouble")
+"""
+
+
+@pytest.mark.parametrize("mode", ["raise", "hang"])
+def test_a_failing_or_hanging_rank_still_yields_the_bench_line(tmp_path, mode):
+    """the first N > 1 contact must leave evidence.  Two ranks over gloo; rank 1 raises at step 3 (or simply stops
+    answering) while rank 0 sits in the all-reduce of that step.  parallel.RankMonitor -- the net bench.py runs under for N > 1 -- must
+    get rank 0's JSON line out within 150 s (here: seconds): `error` naming the rank (or the deadline), every rank's last phase, the
+    failing rank's message and recurrence kernels; and both processes must end with a non-zero code instead of hanging."""
+    import time
+    script = tmp_path / "dp_fail.py"
+    script.write_text(_DP_FAIL_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613" if mode == "raise" else "29615", WORLD_SIZE="2", CTCN_DIST_TIMEOUT_S="120",
+               CTCN_BENCH_DEADLINE_S="900" if mode == "raise" else "8")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script), mode], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    try:
+        out0 = procs[0].communicate(timeout=150)[0].decode()
+    finally:
+        if mode == "hang":
+            procs[1].kill()                     # (the sleeping rank is the launcher's to reap once rank 0 has spoken)
+    procs[1].communicate(timeout=60)
+    assert time.time() - t0 < 150
+    line = json.loads(out0.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and line["scaling"] == "weak" and "CTCN_DP_SAFE" in line["hint"]
+    assert procs[0].returncode == 3
+    ranks = line["ranks"]
+    assert ranks["0"]["progress"]["phase"] == "prewarm" and ranks["0"]["progress"]["step"] == 3 and "done" not in ranks["0"]
+    if mode == "raise":
+        assert "rank 1 failed" in line["error"] and "injected failure" in line["error"]
+        assert "injected failure" in ranks["1"]["failed"]["error"] and ranks["1"]["failed"]["kernels"] == ["rnn_fwd_tagged", "rnn_bwd_scatter"]
+        assert procs[1].returncode == 3
+    else:
+        assert "deadline" in line["error"] and "failed" not in ranks["1"] and ranks["1"]["progress"]["step"] == 3
+
+
 def test_data_parallel_plumbing_gloo_world2(tmp_path):
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT % ROOT)

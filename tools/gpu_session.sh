@@ -16,4 +16,16 @@ case $S in
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
   cat $O/summary.log
   ;;
+2)
+  # the cfg4 nondeterminism of session 1 (three trajectories in one process): which tensor is it, and does dirtied memory move it
+  for v in "" "--poison-ws nan" "--poison-ws rand" "--poison-pool nan" "--poison-pool rand" "--squat"; do
+    n=40; [ -n "$v" ] && n=8; [ "$v" = "--squat" ] && n=30
+    echo "== nondet_probe $v" >> $O/nondet.txt
+    timeout 600 python tools/nondet_probe.py --workload cfg4 --reps $n $v 2>&1 | grep -v amdgpu.ids >> $O/nondet.txt
+  done
+  tail -n 40 $O/nondet.txt
+  timeout 900 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider -k "bench_ or xcd_order or beam or dropout or conv_front" > $O/pytest_sub.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 6 $O/pytest_sub.log
+  timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log; tail -c 600 $O/bench_default.err
+  cat $O/summary.log
+  ;;
 esac
