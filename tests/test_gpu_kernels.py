@@ -2323,13 +2323,14 @@ def test_persistent_recurrences_survive_foreign_resident_kernels(dev, workload, 
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import squat_stress
-    base = squat_stress.run(workload, steps, squat=False, dev=dev)
-    hit = squat_stress.run(workload, steps, squat=True, seed=3, dev=dev)
+    trace = bool(os.environ.get("CTCN_TRAJ_LOG"))            # (per-step device-side checksums of activations / gradients / parameters into the log)
+    base = squat_stress.run(workload, steps, squat=False, dev=dev, trace=trace)
+    hit = squat_stress.run(workload, steps, squat=True, seed=3, dev=dev, trace=trace)
     print("undisturbed losses of %s: %r" % (workload, base["losses"][:7]))
     assert hit["squats"] >= steps // 2
     assert np.isfinite(hit["losses"]).all()
     if hit["losses"] != base["losses"]:          # say whether the undisturbed run itself repeats (then it is the squatters) or not (then it is not)
-        again = squat_stress.run(workload, steps, squat=False, dev=dev)
+        again = squat_stress.run(workload, steps, squat=False, dev=dev, trace=trace)
         where = [(i, a, b) for i, (a, b) in enumerate(zip(hit["losses"], base["losses"])) if a != b][:5]
         assert False, ("disturbed != undisturbed at (step, disturbed, undisturbed) %r; a second undisturbed run is %s the first"
                        % (where, "EQUAL to" if again["losses"] == base["losses"] else "DIFFERENT from"))

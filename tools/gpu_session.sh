@@ -28,4 +28,15 @@ case $S in
   timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log; tail -c 600 $O/bench_default.err
   cat $O/summary.log
   ;;
+3)
+  # hunting the cfg4 nondeterminism: traced trajectories (device-side checksums per step) in the contexts where it showed and where it did not
+  for i in 1 2 3; do
+    CTCN_TRAJ_LOG=$O/traj_foreign_$i.jsonl timeout 400 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider -k "foreign" > $O/pytest_foreign_$i.log 2>&1; echo "foreign $i rc=$?" >> $O/summary.log
+  done
+  CTCN_TRAJ_LOG=$O/traj_full.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider > $O/pytest_full.log 2>&1; echo "full rc=$?" >> $O/summary.log
+  ( timeout 400 python tools/traj_bisect.py cfg4 12 8 2>&1 | grep -v amdgpu.ids ) > $O/bisect_fresh.txt
+  ( timeout 600 python tools/traj_bisect.py cfg4 12 8 squat cfg2 60 2>&1 | grep -v amdgpu.ids ) > $O/bisect_prelude.txt
+  python tools/traj_compare.py $O/traj_*.jsonl > $O/traj_compare.txt 2>&1
+  cat $O/summary.log $O/bisect_fresh.txt $O/bisect_prelude.txt $O/traj_compare.txt | cut -c1-300
+  ;;
 esac

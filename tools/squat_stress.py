@@ -24,7 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, squats_per_step=2.0, dev=None, log=None):
+def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, squats_per_step=2.0, dev=None, log=None, trace=False):
     """`steps` training steps of `workload` (bench.py's model, batch and step); with `squat`, squatter launches at random host-side points
     of every step (before the forward pass, between forward and backward, inside the backward pass through a gradient hook on the
     output).  Returns dict(losses, ms_per_step, squats, squat_wg_us)."""
@@ -60,6 +60,19 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
         stats["n"] += 1
         stats["wg_us"] += k * us
 
+    # trace (round 6, tools/traj_bisect.py): per step, a 64-bit sum of the bit patterns of every recurrent layer's output, of the head's
+    # output, of the flat gradient before and of the flat parameters after the optimiser step -- computed ON the device, read after the last
+    # step (no synchronisation inside the run: the launches keep the timing of the untraced loop)
+    tr_names, tr_vals = [], []
+
+    def note(name, t):
+        tr_names.append(name)
+        tr_vals.append(t.detach().reshape(-1).view(torch.int32).sum(dtype=torch.int64))
+
+    if trace:
+        for name, mod in list(model.rnns.named_children()) + [("fc", model.fc)]:
+            mod.register_forward_hook(lambda m, i, o, name=name: note("fwd %s" % name, o))
+            mod.register_full_backward_pre_hook(lambda m, g, name=name: note("grad-of-output %s" % name, g[0]))
     p = squats_per_step / 4.0
     in_len = None
     losses = []
@@ -80,7 +93,14 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
         maybe_squat(p)
         ops.join_side_stream()
         parallel.allreduce_grads(opt.grad)
+        if trace:
+            note("loss", loss)
+            note("flat-gradient", opt.grad)
         opt.step()
+        if trace:
+            note("flat-parameters", opt.flat)
+            tr_names.append("end-of-step")
+            tr_vals.append(torch.zeros((), dtype=torch.int64, device=dev))
         losses.append(loss.detach())
         ring[i % 3].record()
         if i >= 2:
@@ -92,11 +112,13 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     ops.check_health()
     res = dict(losses=[float(l) for l in losses], ms_per_step=dt / steps * 1e3, squats=stats["n"], squat_wg_us=stats["wg_us"],
                kernels=ops.rnn_last_kernels())
+    if trace:
+        res["trace"] = list(zip(tr_names, [int(v) for v in torch.stack(tr_vals).cpu().tolist()]))
     ran_in = ops.state_snapshot()
     ops.restore_state(dict(found, fallback_shapes=ran_in["fallback_shapes"], drop_counter=ran_in["drop_counter"]))
     if os.environ.get("CTCN_TRAJ_LOG"):               # one line per run: the trajectory next to the state it was computed in
         with open(os.environ["CTCN_TRAJ_LOG"], "a") as f:
-            f.write(json.dumps(dict(workload=workload, steps=steps, squat=bool(squat), seed=seed, losses=res["losses"], kernels=res["kernels"],
+            f.write(json.dumps(dict(workload=workload, steps=steps, squat=bool(squat), seed=seed, losses=res["losses"], kernels=res["kernels"], trace=res.get("trace"),
                                     state_found=found, state_ran_in=ran_in)) + "\n")
     return res
 
