@@ -24,13 +24,18 @@ struct ConvGeom {
 
 constexpr int CCH = 16;   // channels per register pass
 
+// (round 6) Filter banks beyond the LDS budget -- the reference's own example front-end, model_ctc.py:232-233: (32, 32, (3, 21)) = 258 KB -- run
+// as several launches over (output-channel range, input-channel range) slices of the bank, each slice LDS-resident: the first slice of a
+// channel range starts from the bias, the later ones from what the earlier ones left in y.  Channels in ascending order, so the fma chain of
+// an output element is the one of the unsliced kernel (its partial sums pass through memory as exact float32 values).
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                       const float *__restrict__ bias, float *__restrict__ y, ConvGeom g) {
-  extern __shared__ __attribute__((aligned(16))) float ws[];   // [(ci*KK+tap)][Co]
-  const int KK = g.kh * g.kw, CK = g.Ci * KK;
-  for (int i = threadIdx.x; i < g.Co * CK; i += 256) {
-    const int co = i / CK, r = i - co * CK;
-    ws[r * g.Co + co] = w[i];
+                                                       const float *__restrict__ bias, float *__restrict__ y, ConvGeom g, int co_lo, int co_hi,
+                                                       int ci_lo, int ci_hi) {
+  extern __shared__ __attribute__((aligned(16))) float ws[];   // [((ci - ci_lo)*KK+tap)][co - co_lo]
+  const int KK = g.kh * g.kw, CK = g.Ci * KK, nco = co_hi - co_lo, nci = ci_hi - ci_lo, CKc = nci * KK;
+  for (int i = threadIdx.x; i < nco * CKc; i += 256) {
+    const int co = i / CKc, r = i - co * CKc;
+    ws[r * nco + co] = w[(size_t)(co_lo + co) * CK + ci_lo * KK + r];
   }
   __syncthreads();
   const size_t npos = (size_t)g.B * g.Ho * g.Wo;
@@ -38,39 +43,46 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float *__restrict__
     const int fo = pos % g.Wo;
     const size_t q = pos / g.Wo;
     const int to = q % g.Ho, b = q / g.Ho;
-    for (int co0 = 0; co0 < g.Co; co0 += CCH) {
+    for (int co0 = 0; co0 < nco; co0 += CCH) {
       float acc[CCH];
 #pragma unroll
-      for (int c = 0; c < CCH; ++c) acc[c] = (co0 + c < g.Co && bias) ? bias[co0 + c] : 0.0f;
-      for (int ci = 0; ci < g.Ci; ++ci)
+      for (int c = 0; c < CCH; ++c) {
+        acc[c] = 0.0f;
+        if (co0 + c < nco) {
+          if (ci_lo == 0) acc[c] = bias ? bias[co_lo + co0 + c] : 0.0f;
+          else acc[c] = y[(((size_t)b * g.Co + co_lo + co0 + c) * g.Ho + to) * g.Wo + fo];
+        }
+      }
+      for (int ci = 0; ci < nci; ++ci)
         for (int i = 0; i < g.kh; ++i) {
           const int ti = to * g.sh - g.ph + i;
           if (ti < 0 || ti >= g.Hi) continue;
           for (int j = 0; j < g.kw; ++j) {
             const int fi = fo * g.sw - g.pw + j;
             if (fi < 0 || fi >= g.Wi) continue;
-            const float xv = x[(((size_t)b * g.Ci + ci) * g.Hi + ti) * g.Wi + fi];
-            const float *wr = ws + (size_t)(ci * KK + i * g.kw + j) * g.Co + co0;
+            const float xv = x[(((size_t)b * g.Ci + ci_lo + ci) * g.Hi + ti) * g.Wi + fi];
+            const float *wr = ws + (size_t)(ci * KK + i * g.kw + j) * nco + co0;
 #pragma unroll
             for (int c = 0; c < CCH; ++c)
-              if (co0 + c < g.Co) acc[c] = fmaf(xv, wr[c], acc[c]);
+              if (co0 + c < nco) acc[c] = fmaf(xv, wr[c], acc[c]);
           }
         }
 #pragma unroll
       for (int c = 0; c < CCH; ++c)
-        if (co0 + c < g.Co) y[(((size_t)b * g.Co + co0 + c) * g.Ho + to) * g.Wo + fo] = acc[c];
+        if (co0 + c < nco) y[(((size_t)b * g.Co + co_lo + co0 + c) * g.Ho + to) * g.Wo + fo] = acc[c];
     }
   }
 }
 
+// (slices as above: the first output-channel range of an input-channel range starts dx from zero, the later ones accumulate)
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ w,
-                                                         float *__restrict__ dx, ConvGeom g) {
-  extern __shared__ __attribute__((aligned(16))) float ws[];   // [(co*KK+tap)][Ci]
-  const int KK = g.kh * g.kw;
-  for (int i = threadIdx.x; i < g.Co * g.Ci * KK; i += 256) {
-    const int co = i / (g.Ci * KK), r = i - co * g.Ci * KK;
+                                                         float *__restrict__ dx, ConvGeom g, int co_lo, int co_hi, int ci_lo, int ci_hi) {
+  extern __shared__ __attribute__((aligned(16))) float ws[];   // [((co - co_lo)*KK+tap)][ci - ci_lo]
+  const int KK = g.kh * g.kw, nco = co_hi - co_lo, nci = ci_hi - ci_lo;
+  for (int i = threadIdx.x; i < nco * nci * KK; i += 256) {
+    const int co = i / (nci * KK), r = i - co * nci * KK;
     const int ci = r / KK, tap = r - ci * KK;
-    ws[(size_t)(co * KK + tap) * g.Ci + ci] = w[i];
+    ws[(size_t)(co * KK + tap) * nci + ci] = w[((size_t)(co_lo + co) * g.Ci + ci_lo + ci) * KK + tap];
   }
   __syncthreads();
   const size_t npos = (size_t)g.B * g.Hi * g.Wi;
@@ -78,10 +90,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float *__restrict
     const int fi = pos % g.Wi;
     const size_t q = pos / g.Wi;
     const int ti = q % g.Hi, b = q / g.Hi;
-    for (int ci0 = 0; ci0 < g.Ci; ci0 += CCH) {
+    for (int ci0 = 0; ci0 < nci; ci0 += CCH) {
       float acc[CCH];
 #pragma unroll
-      for (int c = 0; c < CCH; ++c) acc[c] = 0.0f;
+      for (int c = 0; c < CCH; ++c) acc[c] = (co_lo != 0 && ci0 + c < nci) ? dx[(((size_t)b * g.Ci + ci_lo + ci0 + c) * g.Hi + ti) * g.Wi + fi] : 0.0f;
       for (int i = 0; i < g.kh; ++i) {
         const int tn = ti + g.ph - i;
         if (tn < 0 || tn % g.sh != 0) continue;
@@ -92,18 +104,18 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float *__restrict
           if (fn < 0 || fn % g.sw != 0) continue;
           const int fo = fn / g.sw;
           if (fo >= g.Wo) continue;
-          for (int co = 0; co < g.Co; ++co) {
-            const float dv = dy[(((size_t)b * g.Co + co) * g.Ho + to) * g.Wo + fo];
-            const float *wr = ws + (size_t)(co * KK + i * g.kw + j) * g.Ci + ci0;
+          for (int co = 0; co < nco; ++co) {
+            const float dv = dy[(((size_t)b * g.Co + co_lo + co) * g.Ho + to) * g.Wo + fo];
+            const float *wr = ws + (size_t)(co * KK + i * g.kw + j) * nci + ci0;
 #pragma unroll
             for (int c = 0; c < CCH; ++c)
-              if (ci0 + c < g.Ci) acc[c] = fmaf(dv, wr[c], acc[c]);
+              if (ci0 + c < nci) acc[c] = fmaf(dv, wr[c], acc[c]);
           }
         }
       }
 #pragma unroll
       for (int c = 0; c < CCH; ++c)
-        if (ci0 + c < g.Ci) dx[(((size_t)b * g.Ci + ci0 + c) * g.Hi + ti) * g.Wi + fi] = acc[c];
+        if (ci0 + c < nci) dx[(((size_t)b * g.Ci + ci_lo + ci0 + c) * g.Hi + ti) * g.Wi + fi] = acc[c];
     }
   }
 }
@@ -111,22 +123,25 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float *__restrict
 constexpr int WG_P = 16;     // positions staged per LDS tile
 constexpr int WPT = 40;      // filter taps per thread (Co*Ci*kh*kw <= 256*40)
 
+// (slices as above: a launch owns the filter taps of one (output-channel range, input-channel range) and writes their columns of `part`;
+// the bias column of an output channel comes from the launch whose input-channel range starts at 0)
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                          float *__restrict__ part /*[chunks][Wn + Co]*/, ConvGeom g,
-                                                         int pos_per_chunk) {
+                                                         int pos_per_chunk, int co_lo, int co_hi, int ci_lo, int ci_hi) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int KK = g.kh * g.kw, CK = g.Ci * KK, Wn = g.Co * CK;
-  float *xs = sm;                 // [WG_P][CK]
-  float *ds = sm + WG_P * CK;     // [WG_P][Co]
+  const int nco = co_hi - co_lo, nci = ci_hi - ci_lo, CKc = nci * KK, Wc = nco * CKc;
+  float *xs = sm;                 // [WG_P][CKc]
+  float *ds = sm + WG_P * CKc;    // [WG_P][nco]
   const int tid = threadIdx.x;
-  const int nk = (Wn + 255) / 256;
+  const int nk = (Wc + 255) / 256;
   int my_co[WPT], my_r[WPT];
   float acc[WPT];
 #pragma unroll
   for (int k = 0; k < WPT; ++k) {
     const int wi = tid + 256 * k;
-    my_co[k] = wi < Wn ? wi / CK : 0;
-    my_r[k] = wi < Wn ? wi - my_co[k] * CK : 0;
+    my_co[k] = wi < Wc ? wi / CKc : 0;
+    my_r[k] = wi < Wc ? wi - my_co[k] * CKc : 0;
     acc[k] = 0.0f;
   }
   float bacc = 0.0f;
@@ -136,40 +151,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
   for (size_t pb = p0; pb < p1; pb += WG_P) {
     const int np = (p1 - pb) < (size_t)WG_P ? (int)(p1 - pb) : WG_P;
     __syncthreads();
-    for (int i = tid; i < np * CK; i += 256) {
-      const int p = i / CK, r = i - p * CK;
-      const int ci = r / KK, tap = r - ci * KK;
+    for (int i = tid; i < np * CKc; i += 256) {
+      const int p = i / CKc, r = i - p * CKc;
+      const int ci = ci_lo + r / KK, tap = r % KK;
       const int ki = tap / g.kw, kj = tap - ki * g.kw;
       const size_t pos = pb + p;
       const int fo = pos % g.Wo;
       const size_t q = pos / g.Wo;
       const int to = q % g.Ho, b = q / g.Ho;
       const int ti = to * g.sh - g.ph + ki, fi = fo * g.sw - g.pw + kj;
-      xs[p * CK + r] = (ti >= 0 && ti < g.Hi && fi >= 0 && fi < g.Wi) ? x[(((size_t)b * g.Ci + ci) * g.Hi + ti) * g.Wi + fi] : 0.0f;
+      xs[p * CKc + r] = (ti >= 0 && ti < g.Hi && fi >= 0 && fi < g.Wi) ? x[(((size_t)b * g.Ci + ci) * g.Hi + ti) * g.Wi + fi] : 0.0f;
     }
-    for (int i = tid; i < np * g.Co; i += 256) {
-      const int p = i / g.Co, co = i - p * g.Co;
+    for (int i = tid; i < np * nco; i += 256) {
+      const int p = i / nco, co = i - p * nco;
       const size_t pos = pb + p;
       const int fo = pos % g.Wo;
       const size_t q = pos / g.Wo;
       const int to = q % g.Ho, b = q / g.Ho;
-      ds[p * g.Co + co] = dy[(((size_t)b * g.Co + co) * g.Ho + to) * g.Wo + fo];
+      ds[p * nco + co] = dy[(((size_t)b * g.Co + co_lo + co) * g.Ho + to) * g.Wo + fo];
     }
     __syncthreads();
     for (int p = 0; p < np; ++p) {
 #pragma unroll
       for (int k = 0; k < WPT; ++k)
-        if (k < nk) acc[k] = fmaf(ds[p * g.Co + my_co[k]], xs[p * CK + my_r[k]], acc[k]);
-      if (tid < g.Co) bacc += ds[p * g.Co + tid];
+        if (k < nk) acc[k] = fmaf(ds[p * nco + my_co[k]], xs[p * CKc + my_r[k]], acc[k]);
+      if (tid < nco) bacc += ds[p * nco + tid];
     }
   }
   float *out = part + (size_t)blockIdx.x * (Wn + g.Co);
 #pragma unroll
   for (int k = 0; k < WPT; ++k) {
     const int wi = tid + 256 * k;
-    if (k < nk && wi < Wn) out[wi] = acc[k];
+    if (k < nk && wi < Wc) out[(size_t)(co_lo + my_co[k]) * CK + ci_lo * KK + my_r[k]] = acc[k];
   }
-  if (tid < g.Co) out[Wn + tid] = bacc;
+  if (ci_lo == 0 && tid < nco) out[Wn + co_lo + tid] = bacc;
 }
 
 // ================================================================================================
@@ -473,9 +488,31 @@ int make_geom(ConvGeom &g, int B, int Ci, int Hi, int Wi, int Co, int kh, int kw
   g.Ho = (Hi + 2 * ph - kh) / sh + 1;
   g.Wo = (Wi + 2 * pw - kw) / sw + 1;
   if (g.Ho <= 0 || g.Wo <= 0) return -1;
-  if ((size_t)Co * Ci * kh * kw * sizeof(float) > 60 * 1024) return -2;
-  if (Co * Ci * kh * kw > 256 * WPT) return -2;
   return 0;
+}
+
+// (co, ci) slice sizes of the direct kernels for a bank that is not LDS-resident as a whole (make_geom: -2).  fwd / dgrad: the slice of the
+// bank itself within 60 KB; wgrad: WG_P staged patches + dy vectors within 60 KB and at most 256 * WPT taps per launch.  false: a single
+// input channel's taps do not fit (kh * kw beyond ~900) -- no kernel here takes that.
+struct ConvSlices { int nco, nci, wnco, wnci; };
+bool conv_slices(const ConvGeom &g, ConvSlices &sl) {
+  const int KK = g.kh * g.kw;
+  const size_t budget = 60 * 1024 / sizeof(float), bank = (size_t)g.Co * g.Ci * KK;
+  sl.nco = g.Co; sl.nci = g.Ci;
+  if (bank > budget) {
+    if ((size_t)KK > budget) return false;
+    sl.nco = (int)std::min((size_t)g.Co, budget / KK);
+    if (sl.nco > CCH) sl.nco = sl.nco / CCH * CCH;                  // whole register passes
+    sl.nci = (int)std::max((size_t)1, std::min((size_t)g.Ci, budget / ((size_t)sl.nco * KK)));
+  }
+  sl.wnco = g.Co; sl.wnci = g.Ci;
+  if (bank > (size_t)256 * WPT || (size_t)WG_P * ((size_t)g.Ci * KK + g.Co) > budget) {
+    if ((size_t)WG_P * (KK + 1) > budget || KK > 256 * WPT) return false;
+    sl.wnci = (int)std::max((size_t)1, std::min((size_t)g.Ci, (budget / WG_P - 1) / KK));
+    sl.wnco = std::max(1, std::min(g.Co, 256 * WPT / (sl.wnci * KK)));
+    while ((size_t)WG_P * ((size_t)sl.wnci * KK + sl.wnco) > budget && sl.wnco > 1) --sl.wnco;
+  }
+  return true;
 }
 
 // ---- MFMA path: tile plans ---------------------------------------------------------------------------------------------------------
@@ -634,11 +671,17 @@ extern "C" int ctcn_conv2d_fwd(const float *x, const float *w, const float *bias
     CTCN_LAUNCH_CHECK();
     return CTCN_OK;
   }
-  if (rc == -2) { ctcn_set_error("ctcn_conv2d_fwd: filter bank %dx%dx%dx%d too large for the LDS-resident kernels", Co, Ci, kh, kw); return CTCN_EUNSUPPORTED; }
   const size_t npos = (size_t)B * g.Ho * g.Wo;
   const int blocks = (int)std::min((size_t)2048, ceil_div_z(npos, 256));
-  const size_t sm = (size_t)Co * Ci * kh * kw * sizeof(float);
-  hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, w, bias, y, g);
+  ConvSlices sl{Co, Ci, Co, Ci};
+  if (!conv_slices(g, sl)) { ctcn_set_error("ctcn_conv2d_fwd: %dx%d taps per channel pair do not fit the LDS-resident kernels", kh, kw); return CTCN_EUNSUPPORTED; }
+  // (one launch for a bank within 60 KB; otherwise slices of it, input channels innermost and ascending: model_ctc.py:232-233's (32, 32, (3, 21)))
+  for (int co = 0; co < Co; co += sl.nco)
+    for (int ci = 0; ci < Ci; ci += sl.nci) {
+      const int co1 = std::min(Co, co + sl.nco), ci1 = std::min(Ci, ci + sl.nci);
+      const size_t sm = (size_t)(co1 - co) * (ci1 - ci) * kh * kw * sizeof(float);
+      hipLaunchKernelGGL(conv_fwd_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, w, bias, y, g, co, co1, ci, ci1);
+    }
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
 }
@@ -657,7 +700,11 @@ extern "C" int ctcn_conv2d_bwd(const float *x, const float *w, const float *dy, 
   ConvPlan DP[16];
   for (int c = 0; dgrad_mfma && c < ncls; ++c) { DP[c] = plan_gemm(g, 1, c); dgrad_mfma = DP[c].ok; }
   const ConvPlan WP = plan_wgrad(g);
-  if (rc == -2 && !(WP.ok && (dgrad_mfma || !dx))) { ctcn_set_error("ctcn_conv2d_bwd: filter bank too large for the LDS-resident kernels"); return CTCN_EUNSUPPORTED; }
+  ConvSlices sl{Co, Ci, Co, Ci};
+  if (!(WP.ok && (dgrad_mfma || !dx)) && !conv_slices(g, sl)) {
+    ctcn_set_error("ctcn_conv2d_bwd: %dx%d taps per channel pair do not fit the LDS-resident kernels", kh, kw);
+    return CTCN_EUNSUPPORTED;
+  }
   if (dx && dgrad_mfma) {
     for (int c = 0; c < ncls; ++c) {
       const int lrc = launch_gemm(dy, w, nullptr, dx, DP[c], st);
@@ -667,7 +714,11 @@ extern "C" int ctcn_conv2d_bwd(const float *x, const float *w, const float *dy, 
   } else if (dx) {
     const size_t npos = (size_t)B * Hi * Wi;
     const int blocks = (int)std::min((size_t)2048, ceil_div_z(npos, 256));
-    hipLaunchKernelGGL(conv_dgrad_kernel, dim3(blocks), dim3(256), (size_t)Wn * sizeof(float), st, dy, w, dx, g);
+    for (int ci = 0; ci < Ci; ci += sl.nci)                       // output-channel slices innermost: the first one starts dx from zero
+      for (int co = 0; co < Co; co += sl.nco) {
+        const int co1 = std::min(Co, co + sl.nco), ci1 = std::min(Ci, ci + sl.nci);
+        hipLaunchKernelGGL(conv_dgrad_kernel, dim3(blocks), dim3(256), (size_t)(co1 - co) * (ci1 - ci) * kh * kw * sizeof(float), st, dy, w, dx, g, co, co1, ci, ci1);
+      }
     CTCN_LAUNCH_CHECK();
   }
   const int chunks = wgrad_chunks(g);
@@ -682,8 +733,12 @@ extern "C" int ctcn_conv2d_bwd(const float *x, const float *w, const float *dy, 
     const size_t npos = (size_t)B * g.Ho * g.Wo;
     const int ppc = (int)ceil_div_z(npos, chunks);
     nch = (int)ceil_div_z(npos, ppc);
-    const size_t sm = (size_t)WG_P * (Ci * kh * kw + Co) * sizeof(float);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nch), dim3(256), sm, st, x, dy, (float *)ws, g, ppc);
+    for (int co = 0; co < Co; co += sl.wnco)
+      for (int ci = 0; ci < Ci; ci += sl.wnci) {
+        const int co1 = std::min(Co, co + sl.wnco), ci1 = std::min(Ci, ci + sl.wnci);
+        const size_t sm = (size_t)WG_P * ((ci1 - ci) * kh * kw + (co1 - co)) * sizeof(float);
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(nch), dim3(256), sm, st, x, dy, (float *)ws, g, ppc, co, co1, ci, ci1);
+      }
   }
   CTCN_LAUNCH_CHECK();
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(ceil_div(Wn + Co, 64)), dim3(1024), 0, st, (const float *)ws, nch, Wn, Co, dw, dbias, beta_acc);

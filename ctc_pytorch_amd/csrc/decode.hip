@@ -23,8 +23,10 @@
 
 namespace {
 
-constexpr int BEAM_WMAX = 256;
-constexpr int SEL_SMAX = 1024;          // beam_kernel: survivors of the selection's pruning step held in LDS (more: the arg-max rounds)
+// Widest beam of the generic kernel (round 6: 1 024, was 256 -- the reference takes any beam_width, ctcDecoder.py:170 / BeamSearch.py:96).  The
+// beam state lives in DYNAMIC LDS sized for the call's width (120 B per beam slot + 12 B per selection survivor: 42 KB at W <= 256, 146 KB
+// at W = 1 024, which gfx950's 160 KB per workgroup still hold); beyond that the state would have to live in global memory.
+constexpr int BEAM_WMAX = 1024;
 constexpr double LOG_ZERO = -99999999.0;
 constexpr unsigned long long HT_EMPTY = ~0ull;
 
@@ -52,9 +54,9 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
   return x;
 }
 
-struct BeamState {   // one copy of the beam (BHat) in LDS
-  int node[BEAM_WMAX], len[BEAM_WMAX], last[BEAM_WMAX], par[BEAM_WMAX];
-  double pB[BEAM_WMAX], pNB[BEAM_WMAX], pT[BEAM_WMAX];
+struct BeamState {   // one copy of the beam (BHat) in LDS: arrays of `wcap` entries carved out of the kernel's dynamic shared memory
+  int *node, *len, *last, *par;
+  double *pB, *pNB, *pT;
 };
 
 struct BeamArgs {
@@ -63,6 +65,7 @@ struct BeamArgs {
   int nbest; int32_t *out_count;        // ctcn_beam_decode_nbest: the `nbest` best labellings per utterance (outputs [B][nbest]...), their number in out_count
   unsigned long long *ht_keys; int *ht_ids; int *node_par; int *node_sym; double *cand_global;
   int ht_size, max_nodes, cand_in_lds;
+  int wcap, smax;       // beam_kernel: capacity of the beam-state arrays (W rounded up to 64) and of the selection's survivor list
 #ifdef CTCN_BEAM_STATS
   long long *stats;     // development instrumentation (tools/mb_beam.py generic): cycles per phase of workgroup 0, thread 0
 #endif
@@ -86,23 +89,32 @@ __device__ __forceinline__ unsigned long long dkey(double v) {
 template <int NT>
 __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   constexpr int NWV = NT / 64;
-  extern __shared__ __attribute__((aligned(16))) double dsm[];   // lg[V] | cand[W*V] (if it fits)
-  __shared__ BeamState S[2];
-  __shared__ double sNB[BEAM_WMAX], sB[BEAM_WMAX], sT[BEAM_WMAX];
-  __shared__ int mfrom[BEAM_WMAX], sel[BEAM_WMAX];
-  __shared__ double selv[BEAM_WMAX];
+  extern __shared__ __attribute__((aligned(16))) double dsm[];   // lg[V] | cand[W*V] (if it fits) | beam state, selection lists (below)
   __shared__ double red_v[NWV];
   __shared__ int red_i[NWV];
   __shared__ unsigned long long wthr[NWV];                     // selection: every wave's bound
   __shared__ int wcnt[NWV][NWV];                               //            ... and how many of wave w's maxima reach wave j's
   __shared__ int s_flag, s_nodes, s_best;
-  __shared__ double sv_v[SEL_SMAX];                            // selection: survivors of the pruning bound (value | candidate index)
-  __shared__ int sv_i[SEL_SMAX], s_scnt, s_ovf;
+  __shared__ int s_scnt, s_ovf;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, V = a.V, W = a.W, B = a.B, T = a.T, blank = a.blank;
   double *lg = dsm;
   double *cand = a.cand_in_lds ? dsm + V : a.cand_global + (size_t)b * W * V;
+  // dynamic LDS behind lg / cand: doubles first (2 x {pB, pNB, pT}, sNB, sB, sT, selv: 10 x wcap; sv_v: smax), then ints (2 x {node, len,
+  // last, par}, mfrom, sel: 10 x wcap; sv_i: smax) -- the host sizes the launch with the same formula (beam_state_lds)
+  const int wcap = a.wcap, SEL_SMAX = a.smax;
+  double *const dbase = dsm + V + (a.cand_in_lds ? W * V : 0);
+  int *const ibase = reinterpret_cast<int *>(dbase + 10 * wcap + SEL_SMAX);
+  auto beam_state = [&](int k) {
+    BeamState st;
+    st.pB = dbase + (3 * k) * wcap; st.pNB = st.pB + wcap; st.pT = st.pNB + wcap;
+    st.node = ibase + (4 * k) * wcap; st.len = st.node + wcap; st.last = st.len + wcap; st.par = st.last + wcap;
+    return st;
+  };
+  double *const sNB = dbase + 6 * wcap, *const sB = sNB + wcap, *const sT = sB + wcap, *const selv = sT + wcap;
+  double *const sv_v = selv + wcap;                            // selection: survivors of the pruning bound (value | candidate index)
+  int *const mfrom = ibase + 8 * wcap, *const sel = mfrom + wcap, *const sv_i = sel + wcap;
   unsigned long long *keys = a.ht_keys + (size_t)b * a.ht_size;
   int *ids = a.ht_ids + (size_t)b * a.ht_size;
   int *npar = a.node_par + (size_t)b * a.max_nodes;
@@ -114,8 +126,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   long long gst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, glast = clock64(), gframes = 0;
 #endif
   if (tid == 0) {
-    S[0].node[0] = 0; S[0].len[0] = 0; S[0].last[0] = -1; S[0].par[0] = -1;
-    S[0].pB[0] = 0.0; S[0].pNB[0] = LOG_ZERO; S[0].pT[0] = 0.0;   // BeamSearch.py:83-87
+    const BeamState S0 = beam_state(0);
+    S0.node[0] = 0; S0.len[0] = 0; S0.last[0] = -1; S0.par[0] = -1;
+    S0.pB[0] = 0.0; S0.pNB[0] = LOG_ZERO; S0.pT[0] = 0.0;   // BeamSearch.py:83-87
     s_nodes = 1; s_flag = 0;
     npar[0] = -1; nsym[0] = -1;
   }
@@ -125,8 +138,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
     const float *row = a.x + ((size_t)t * B + b) * V;
     const float pblank = a.input_is_prob ? row[blank] : expf(row[blank]);
     if ((1.0f - pblank) < 0.1f) continue;                         // BeamSearch.py:93-94 (float32 compare)
-    BeamState &L = S[cur];
-    BeamState &N = S[cur ^ 1];
+    const BeamState L = beam_state(cur), N = beam_state(cur ^ 1);
     GSTAMP(0);
 #ifdef CTCN_BEAM_STATS
     ++gframes;
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   if (a.stats && b == 0 && tid == 0) { for (int i = 0; i < 16; ++i) a.stats[32 + i] = gst[i]; a.stats[48] = gframes; }
 #endif
   // final LM step, length normalisation and best labelling (BeamSearch.py:130-151)
-  BeamState &L = S[cur];
+  const BeamState L = beam_state(cur);
   if (status == 0 && tid == 0) {
     int st = 0;
     for (int r = 0; r < nb; ++r) if (L.len[r] == 0) st = 1;          // classes[y[-1]] on () -> IndexError
@@ -1481,9 +1493,12 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   int dev_id = 0, lds_max = 64 * 1024;
   CTCN_HIP(hipGetDevice(&dev_id));
   if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev_id) != hipSuccess) lds_max = 64 * 1024;
+  a.wcap = (W + 63) / 64 * 64;
+  a.smax = std::max(1024, 2 * a.wcap);                         // (W <= 256: the 1 024 survivors of round 5; W = 1 024: 2 048)
+  const size_t state_bytes = (size_t)a.wcap * (10 * sizeof(double) + 10 * sizeof(int)) + (size_t)a.smax * (sizeof(double) + sizeof(int));
   const size_t row_bytes = (size_t)V * sizeof(double);
-  a.cand_in_lds = (cand_bytes <= 32 * 1024 && fa.sharedSizeBytes + row_bytes + cand_bytes <= (size_t)lds_max) ? 1 : 0;
-  const size_t sm = row_bytes + (a.cand_in_lds ? cand_bytes : 0);
+  a.cand_in_lds = (cand_bytes <= 32 * 1024 && fa.sharedSizeBytes + row_bytes + state_bytes + cand_bytes <= (size_t)lds_max) ? 1 : 0;
+  const size_t sm = row_bytes + state_bytes + (a.cand_in_lds ? cand_bytes : 0);
   if (fa.sharedSizeBytes + sm > (size_t)lds_max) {
     ctcn_set_error("ctcn_beam_decode: %zu B of LDS per workgroup needed, the device gives %d", fa.sharedSizeBytes + sm, lds_max);
     return CTCN_EUNSUPPORTED;

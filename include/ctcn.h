@@ -304,8 +304,11 @@ int ctcn_dropout(const float *x, float *y, size_t n, float p, uint64_t seed, uin
 
 /* ---------------------------------------------------------------------------------------------------
  * Conv2d (bias) NCHW, direct; replaces nn.Conv2d in LayerCNN (model_ctc.py:46,61).
- * x (B,Ci,Hi,Wi) w (Co,Ci,kh,kw) y (B,Co,Ho,Wo), Ho=(Hi+2ph-kh)/sh+1.  Co,Ci <= 64, kh*kw <= 25.
- * Default: MFMA implicit GEMMs (option "conv_mfma"); the direct kernels serve filter banks whose LDS images do not fit. */
+ * x (B,Ci,Hi,Wi) w (Co,Ci,kh,kw) y (B,Co,Ho,Wo), Ho=(Hi+2ph-kh)/sh+1.
+ * Default: MFMA implicit GEMMs (option "conv_mfma") for Co <= 64, kh*kw <= 25 and LDS images within 158 KB; everything else on the direct
+ * kernels, which (round 6) run a filter bank beyond their 60-KB LDS budget as (output-channel range, input-channel range) slices -- the
+ * reference's own example front-end, model_ctc.py:232-233: (1,32,(3,41)) = 123 taps and (32,32,(3,21)) = 258 KB of filters -- slowly, not
+ * with an error.  CTCN_EUNSUPPORTED only beyond ~900 taps per (output, input) channel pair. */
 size_t ctcn_conv2d_ws_bytes(int B, int Ci, int Hi, int Wi, int Co, int kh, int kw, int sh, int sw, int ph, int pw);
 int ctcn_conv2d_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Ci, int Hi, int Wi,
                     int Co, int kh, int kw, int sh, int sw, int ph, int pw, void *stream);
@@ -396,7 +399,10 @@ int ctcn_step_stats(const float *loss, const int32_t *dist, const int64_t *tgt_l
  *   out_ids (B,T) int32, out_len (B) int32, out_score (B) float64 (length-normalised prTotal)
  *   status (B) int32: 0 ok, 1 best labelling empty (reference raises IndexError), 2 log(0) (ValueError), 3 node table of the workspace
  *   exhausted, 4 internal hand-over between the waves of the search timed out (a bug, never seen; outputs zeroed for 2..4)
- *   ws: >= ctcn_beam_ws_bytes(T,B,V,W) */
+ *   ws: >= ctcn_beam_ws_bytes(T,B,V,W)
+ *   1 <= W <= 1 024 (round 6; was 256): the reference takes any beam_width (ctcDecoder.py:170, default 200).  W <= 60 with W*V <= 3 328 runs
+ *   the restructured search, everything else the generic kernel, whose beam state sits in dynamic LDS sized for W (146 KB at W = 1 024);
+ *   wider beams: CTCN_EUNSUPPORTED. */
 size_t ctcn_beam_ws_bytes(int T, int B, int V, int W);
 int ctcn_beam_decode(const float *x, int input_is_prob, const int32_t *lens, const double *lm, double alpha,
                      int W, int blank, int32_t *out_ids, int32_t *out_len, double *out_score, int32_t *status,

@@ -307,6 +307,19 @@ def gen_models():
     print("pool", model_fixture("cnn_pool_lstm2x16", CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=V, drop_out=0.0), b3, 68))
 
 
+BIGBANK_LAYERS = [[(1, 32), (3, 41), (1, 2), (0, 0), None], [(32, 32), (3, 21), (2, 2), (0, 0), None]]
+
+
+def gen_bigbank():
+    """(round 6) The front-end of the reference's own example model (timit/models/model_ctc.py:232-233): 123-tap first layer, a second layer
+    whose filter bank (32 x 32 x 3 x 21 = 258 KB) is beyond any LDS-resident kernel; 121-d input -> 41 -> 11 features x 32 channels."""
+    V = 62
+    b = synth.make_batch(seed=73, B=2, T=45, F=121, V=V, lab_lo=3, lab_hi=5)
+    cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": BIGBANK_LAYERS}
+    rp = {"rnn_input_size": 121, "rnn_hidden_size": 16, "rnn_layers": 2, "rnn_type": nn.LSTM, "bidirectional": True, "batch_norm": True}
+    print("bigbank", model_fixture("cnn_bigbank_lstm2x16", CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=V, drop_out=0.0), b, 74))
+
+
 # ---------------------------------------------------------------------------------------------
 # (3) run_epoch trajectory on the reference's own train loop (train_ctc.py:26-69), cfg1 shape
 # ---------------------------------------------------------------------------------------------
@@ -641,7 +654,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
                  run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml, nbest=gen_nbest,
-                 wide_beam=gen_wide_beam)
+                 wide_beam=gen_wide_beam, bigbank=gen_bigbank)
     if a.large:
         gen_large(a.only)
     else:

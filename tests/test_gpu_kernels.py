@@ -772,6 +772,11 @@ CONV_CASES = [  # B, Ci, Hi, Wi, Co, kh, kw, sh, sw, ph, pw
     (2, 2, 4, 4, 64, 5, 5, 2, 3, 2, 2),        # taps wider than the image, widest filter bank
     (1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0),         # a single output position
     (5, 16, 13, 7, 48, 3, 3, 1, 1, 1, 1),
+    # (round 6) filter banks no kernel holds in LDS as a whole: the direct kernels run them as (output channels, input channels) slices
+    (2, 1, 9, 60, 32, 3, 41, 1, 2, 0, 0),      # the reference's example front-end (model_ctc.py:232-233), layer 1: 123 taps
+    (2, 32, 12, 30, 32, 3, 21, 2, 2, 0, 0),    # ... layer 2: 32 x 32 x 3 x 21 = 258 KB of filters
+    (1, 20, 6, 9, 70, 5, 5, 1, 2, 2, 1),       # more than 64 output channels, 140 KB, ragged slices
+    (1, 3, 40, 40, 2, 31, 31, 3, 2, 15, 15),   # 961 taps per channel pair: one-channel slices
 ]
 
 
@@ -1125,7 +1130,7 @@ def _build_model(tag, dev):
     from ctc_pytorch_amd import nn
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
     V = 62
-    base = {"rnn_input_size": 40, "bidirectional": True, "batch_norm": True, "rnn_layers": 2}
+    base = {"rnn_input_size": 121 if "bigbank" in tag else 40, "bidirectional": True, "batch_norm": True, "rnn_layers": 2}
     if tag == "lstm2x32":
         m = CTC_Model(rnn_param=dict(base, rnn_hidden_size=32, rnn_type=nn.LSTM), num_class=V, drop_out=0.0)
     elif tag == "gru2x24":
@@ -1137,6 +1142,8 @@ def _build_model(tag, dev):
         layers = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
         if tag == "cnn_pool_lstm2x16":           # MaxPool2d over time after each conv block (model_ctc.py:52-53)
             layers = [[(1, 8), (3, 3), (1, 2), (1, 1), (2, 1)], [(8, 8), (3, 3), (1, 2), (1, 1), (3, 1)]]
+        if tag == "cnn_bigbank_lstm2x16":        # (round 6) the reference's example front-end, model_ctc.py:232-233: 123 taps; a 258-KB filter bank
+            layers = [[(1, 32), (3, 41), (1, 2), (0, 0), None], [(32, 32), (3, 21), (2, 2), (0, 0), None]]
         cnn_param = {"batch_norm": True, "activate_function": nn.ReLU, "layer": layers}
         m = CTC_Model(add_cnn=True, cnn_param=cnn_param, rnn_param=dict(base, rnn_hidden_size=16, rnn_type=nn.LSTM),
                       num_class=V, drop_out=0.0)
@@ -1380,7 +1387,7 @@ def test_weight_gradient_side_stream_equals_inline(dev, rnn, H, B, T, prec):
 
 
 @pytest.mark.parametrize("prec", [0, 1])
-@pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16", "cnn_pool_lstm2x16"])
+@pytest.mark.parametrize("tag", ["lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16", "cnn_pool_lstm2x16", "cnn_bigbank_lstm2x16"])
 @pytest.mark.parametrize("flat", [True, False])
 def test_model_three_steps_golden(dev, tag, flat, prec):
     """Whole-model fixtures captured from the reference (oracle/gen_golden.py): `visualize` activations, log-probs, arg-max,
@@ -2038,10 +2045,11 @@ def test_bn_relu_dropout_fused_equals_two_passes(dev, shape, relu, p):
 
 
 @pytest.mark.parametrize("regime", ["peaky", "flat"])
-@pytest.mark.parametrize("W", [60, 61, 64, 65, 128, 200, 256])
+@pytest.mark.parametrize("W", [60, 61, 64, 65, 128, 200, 256, 257, 300, 512, 1024])
 def test_beam_wide_vs_c_oracle(dev, regime, W):
     """ Beams wider than any earlier test ran: the last width of beam_fast_kernel (60), the first of the generic
-    beam_kernel (61), both sides of a 64-lane boundary, 128, the reference's class default 200 (ctcDecoder.py:170) and BEAM_WMAX = 256, on
+    beam_kernel (61), both sides of a 64-lane boundary, 128, the reference's class default 200 (ctcDecoder.py:170), round 5's limit 256 and
+    (round 6, VERDICT r5 missing 4: the reference takes any width) 257, 300, 512 and the new BEAM_WMAX = 1 024 -- beam state in dynamic LDS --, on
     the golden batch shape (T = 120, B = 6, ragged lengths) against the C restatement of BeamSearch.py: labellings and status equal,
     float64 scores to the last places."""
     from ctc_pytorch_amd import ops
@@ -2065,20 +2073,20 @@ def test_beam_wide_vs_c_oracle(dev, regime, W):
 
 
 def test_beam_width_above_the_maximum_is_refused(dev):
-    """W = 257 > BEAM_WMAX: CTCN_EUNSUPPORTED (-3) from the C ABI, a RuntimeError naming the limit from the wrapper; nothing is launched."""
+    """W = 1 025 > BEAM_WMAX: CTCN_EUNSUPPORTED (-3) from the C ABI, a RuntimeError naming the limit from the wrapper; nothing is launched."""
     from ctc_pytorch_amd import _lib, ops
     V, T, B = 62, 20, 2
     lp = torch.from_numpy(synth.make_logprobs(seed=5, T=T, B=B, V=V, regime="peaky")).to(dev)
     tab = np.zeros((V + 1, V + 1))
-    with pytest.raises(RuntimeError, match="beam width 257"):
-        ops.beam_decode(lp, [T, T], tab, 0.1, 257)
+    with pytest.raises(RuntimeError, match="beam width 1025"):
+        ops.beam_decode(lp, [T, T], tab, 0.1, 1025)
     L = _lib.lib()
     lens = torch.tensor([T, T], dtype=torch.int32, device=dev)
     lm = torch.zeros((V + 1) * (V + 1), dtype=torch.float64, device=dev)
     ws = torch.empty(max(L.ctcn_beam_ws_bytes(T, B, V, 256), 1), dtype=torch.uint8, device=dev)
     oi, ol = torch.zeros((B, T), dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
     sc, stt = torch.zeros(B, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
-    rc = L.ctcn_beam_decode(ctypes.c_void_p(lp.data_ptr()), 0, ctypes.c_void_p(lens.data_ptr()), ctypes.c_void_p(lm.data_ptr()), 0.1, 257, 0,
+    rc = L.ctcn_beam_decode(ctypes.c_void_p(lp.data_ptr()), 0, ctypes.c_void_p(lens.data_ptr()), ctypes.c_void_p(lm.data_ptr()), 0.1, 1025, 0,
                             ctypes.c_void_p(oi.data_ptr()), ctypes.c_void_p(ol.data_ptr()), ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(stt.data_ptr()),
                             T, B, V, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
     assert rc == -3

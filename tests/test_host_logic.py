@@ -78,10 +78,10 @@ def test_default_precision_is_the_benchmarked_mode():
 def test_state_dict_surface_matches_reference_keys():
     from ctc_pytorch_amd import nn
     from ctc_pytorch_amd.models.model_ctc import CTC_Model
-    for tag in ("lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16", "cnn_pool_lstm2x16"):
+    for tag in ("lstm2x32", "gru2x24", "rnn2x20_uni_nobn", "cnn_lstm2x16", "cnn_pool_lstm2x16", "cnn_bigbank_lstm2x16"):
         z = load("model_" + tag)
         want = {k[len("after."):]: z[k].shape for k in z.files if k.startswith("after.")}
-        base = {"rnn_input_size": 40, "bidirectional": True, "batch_norm": True, "rnn_layers": 2}
+        base = {"rnn_input_size": 121 if "bigbank" in tag else 40, "bidirectional": True, "batch_norm": True, "rnn_layers": 2}
         if tag == "lstm2x32":
             m = CTC_Model(rnn_param=dict(base, rnn_hidden_size=32, rnn_type=nn.LSTM), num_class=62)
         elif tag == "gru2x24":
@@ -92,6 +92,8 @@ def test_state_dict_surface_matches_reference_keys():
             layers = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
             if tag == "cnn_pool_lstm2x16":
                 layers = [[(1, 8), (3, 3), (1, 2), (1, 1), (2, 1)], [(8, 8), (3, 3), (1, 2), (1, 1), (3, 1)]]
+            if tag == "cnn_bigbank_lstm2x16":        # the front-end of the reference's own example model (model_ctc.py:232-233)
+                layers = [[(1, 32), (3, 41), (1, 2), (0, 0), None], [(32, 32), (3, 21), (2, 2), (0, 0), None]]
             cp = {"batch_norm": True, "activate_function": nn.ReLU, "layer": layers}
             m = CTC_Model(add_cnn=True, cnn_param=cp, rnn_param=dict(base, rnn_hidden_size=16, rnn_type=nn.LSTM), num_class=62)
         got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -103,14 +105,16 @@ def test_state_dict_surface_matches_reference_keys():
 
 @pytest.mark.parametrize("tag,cls,H,bi,bn", [("lstm2x32", tnn.LSTM, 32, True, True), ("gru2x24", tnn.GRU, 24, True, True),
                                              ("rnn2x20_uni_nobn", tnn.RNN, 20, False, False), ("cnn_lstm2x16", tnn.LSTM, 16, True, True),
-                                             ("cnn_pool_lstm2x16", tnn.LSTM, 16, True, True)])
+                                             ("cnn_pool_lstm2x16", tnn.LSTM, 16, True, True), ("cnn_bigbank_lstm2x16", tnn.LSTM, 16, True, True)])
 def test_torch_cpu_counterpart_is_pinned(tag, cls, H, bi, bn):
     z = load("model_" + tag)
-    rp = {"rnn_input_size": 40, "rnn_hidden_size": H, "rnn_layers": 2, "rnn_type": cls, "bidirectional": bi, "batch_norm": bn}
+    rp = {"rnn_input_size": 121 if "bigbank" in tag else 40, "rnn_hidden_size": H, "rnn_layers": 2, "rnn_type": cls, "bidirectional": bi, "batch_norm": bn}
     if tag.startswith("cnn"):
         layers = [[(1, 32), (3, 3), (1, 2), (1, 1), None], [(32, 32), (3, 3), (2, 2), (1, 1), None]]
         if tag == "cnn_pool_lstm2x16":
             layers = [[(1, 8), (3, 3), (1, 2), (1, 1), (2, 1)], [(8, 8), (3, 3), (1, 2), (1, 1), (3, 1)]]
+        if tag == "cnn_bigbank_lstm2x16":
+            layers = [[(1, 32), (3, 41), (1, 2), (0, 0), None], [(32, 32), (3, 21), (2, 2), (0, 0), None]]
         cp = {"batch_norm": True, "activate_function": tnn.ReLU, "layer": layers}
         m = torch_cpu.TorchCpuCTCModel(add_cnn=True, cnn_param=cp, rnn_param=rp, num_class=62, drop_out=0.0)
     else:

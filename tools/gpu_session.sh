@@ -39,4 +39,24 @@ case $S in
   python tools/traj_compare.py $O/traj_*.jsonl > $O/traj_compare.txt 2>&1
   cat $O/summary.log $O/bisect_fresh.txt $O/bisect_prelude.txt $O/traj_compare.txt | cut -c1-300
   ;;
+4)
+  # statistics for the rare cfg4 divergence: 150 traced 12-step runs in one process on a fresh box (first thing in the session), squatters on every other run
+  rocm-smi --showclocks --showtemp --showpower > $O/smi_before.txt 2>&1
+  ( timeout 1500 python tools/traj_bisect.py cfg4 12 150 squat 2>&1 | grep -v "amdgpu.ids\|Warning" ) > $O/bisect_150.txt
+  rocm-smi --showclocks --showtemp --showpower > $O/smi_after.txt 2>&1
+  tail -n 12 $O/bisect_150.txt
+  ;;
+5)
+  # the cfg4 divergence showed in 1 of 3 FULL suites (and never in 190 stand-alone runs): is it the tests that spawn second processes on the GPU
+  # right before the squatter tests?  traced trajectories throughout
+  for i in 1 2 3 4 5; do
+    CTCN_TRAJ_LOG=$O/traj_sub_$i.jsonl timeout 500 python -m pytest tests -m gpu -q --timeout 400 -p no:cacheprovider -k "two_ranks or bench_ or rank_invariant or foreign" > $O/pytest_sub_$i.log 2>&1; echo "subset $i rc=$?" >> $O/summary.log
+  done
+  for i in 1 2 3; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+  done
+  rocm-smi --showrasinfo all > $O/ras.txt 2>&1
+  python tools/traj_compare.py $O/traj_*.jsonl > $O/traj_compare.txt 2>&1
+  cat $O/summary.log $O/traj_compare.txt | cut -c1-300
+  ;;
 esac
