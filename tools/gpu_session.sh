@@ -59,4 +59,16 @@ case $S in
   python tools/traj_compare.py $O/traj_*.jsonl > $O/traj_compare.txt 2>&1
   cat $O/summary.log $O/traj_compare.txt | cut -c1-300
   ;;
+6)
+  # the cfg4 divergence localised: full suites with the finer trace (layer-0 buffers per (timestep, direction), buffer addresses)
+  for i in 1 2 3 4; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    python tools/traj_compare.py $O/traj_full_$i.jsonl > $O/traj_compare_$i.txt 2>&1
+    tail -n 3 $O/pytest_full_$i.log | cut -c1-200
+  done
+  python tools/traj_compare.py $O/traj_*.jsonl > $O/traj_compare.txt 2>&1
+  cat $O/summary.log $O/traj_compare.txt | cut -c1-400
+  # keep the logs of the runs that deviated, drop the bulky rest
+  for i in 1 2 3 4; do grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl; done
+  ;;
 esac

@@ -69,7 +69,24 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
         tr_names.append(name)
         tr_vals.append(t.detach().reshape(-1).view(torch.int32).sum(dtype=torch.int64))
 
+    addrs, per_td = [], {"gates": [], "y": []}
     if trace:
+        layer_no = [0]
+
+        def rnn_note(tag, addresses, tensors):          # per recurrent-layer call: buffer addresses + checksums of what it read and wrote
+            l = layer_no[0] % c["L"]
+            layer_no[0] += 1
+            addrs.append(dict(addresses, layer=l))
+            for k in ("x", "gates", "aux", "y", "y_drop"):
+                if tensors.get(k) is not None:
+                    note("layer %d %s" % (l, k), tensors[k])
+            if l == 0:                                   # the bottom layer per (timestep, direction): where along the sequence does a run leave the others?
+                for k in ("gates", "y"):
+                    t_ = tensors[k]
+                    per_td[k].append(t_.detach().reshape(t_.shape[0], t_.shape[1], 2, -1).view(torch.int32).sum(dim=(1, 3), dtype=torch.int64))
+
+        ops._debug_note[0] = rnn_note
+        note("model-input", x)
         for name, mod in list(model.rnns.named_children()) + [("fc", model.fc)]:
             mod.register_forward_hook(lambda m, i, o, name=name: note("fwd %s" % name, o))
             mod.register_full_backward_pre_hook(lambda m, g, name=name: note("grad-of-output %s" % name, g[0]))
@@ -81,6 +98,8 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     t0 = time.perf_counter()
     for i in range(steps):
         maybe_squat(p)
+        if trace:
+            note("model-input", x)
         out = model(x)
         if in_len is None:
             in_len = torch.full((c["B"],), out.size(0), dtype=torch.int64, device=dev)
@@ -113,12 +132,16 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     res = dict(losses=[float(l) for l in losses], ms_per_step=dt / steps * 1e3, squats=stats["n"], squat_wg_us=stats["wg_us"],
                kernels=ops.rnn_last_kernels())
     if trace:
+        ops._debug_note[0] = None
         res["trace"] = list(zip(tr_names, [int(v) for v in torch.stack(tr_vals).cpu().tolist()]))
+        res["addresses"] = addrs
+        import base64
+        res["layer0_per_timestep"] = {k: base64.b64encode(torch.stack(v).cpu().numpy().tobytes()).decode() for k, v in per_td.items() if v}
     ran_in = ops.state_snapshot()
     ops.restore_state(dict(found, fallback_shapes=ran_in["fallback_shapes"], drop_counter=ran_in["drop_counter"]))
     if os.environ.get("CTCN_TRAJ_LOG"):               # one line per run: the trajectory next to the state it was computed in
         with open(os.environ["CTCN_TRAJ_LOG"], "a") as f:
-            f.write(json.dumps(dict(workload=workload, steps=steps, squat=bool(squat), seed=seed, losses=res["losses"], kernels=res["kernels"], trace=res.get("trace"),
+            f.write(json.dumps(dict(workload=workload, steps=steps, squat=bool(squat), seed=seed, losses=res["losses"], kernels=res["kernels"], trace=res.get("trace"), addresses=res.get("addresses"), layer0_per_timestep=res.get("layer0_per_timestep"),
                                     state_found=found, state_ran_in=ran_in)) + "\n")
     return res
 
