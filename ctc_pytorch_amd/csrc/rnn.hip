@@ -2589,33 +2589,68 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
   // three pairs: 13.78): the extra pair costs its 75 us here and takes only ~25 off the recurrence.  The slowdown goes with the TIME the bf16x3
   // chunk GEMMs run next to the recurrence, ~30 us per pair, and is gone with the single-product tiles of option "gemm_bf16_single" (1 186-
   // 1 190 us for all four layers) although they still run there for 70 % of the time: the matrix pipes' power, not the counter.)
+  // ORDER of the projection's row blocks (round 6, option "rnn_proj_order", default 1).  The reverse direction's first steps read the LAST
+  // time frames of the pre-activations within microseconds of the launch, and with one GEMM over rows in ascending time those are the rows the
+  // GEMM wrote last.  At cfg4's bottom layer (76 800 x 3 072 x 40: 943 MB written in 343 us, 2.75 TB/s) the traced trajectories of round 6
+  // (tools/traj_compare.py, profiles/r06_divergence_*.txt) caught the reverse direction of that layer starting from values other than the
+  // ones the GEMM produced -- 2 of 4 full parity suites, never the forward direction, never another layer, the error largest at t = T - 1 and
+  // decaying along the sequence -- i.e. reads of another XCD's freshest writes behind a kernel boundary.  The blocks are therefore issued so
+  // that the rows BOTH directions start on are written first and the block boundary written last is in the middle of the sequence, ~T/2
+  // dependent steps (a millisecond) away from its first reader: [T/2, T) before [0, T/2); in the pipelined form the last chunk before the
+  // first one.  Same products, same order per output element: bit-identical results.
+  const bool safe_order = ctcn_get_option("rnn_proj_order") != 0 && T >= 16;
   if (piped) {
-    int rc = project_chunk(0, ws, ws_bytes, stream, 0, pl_main);
+    int rc = project_chunk(safe_order ? NCHUNK - 1 : 0, ws, ws_bytes, stream, 0, pl_main);
     pl_main.same_b = true;                                // W_ih: split into planes once per stream (reused when the chunk has the same size)
-    if (!rc) rc = project_chunk(NCHUNK - 1, ws, ws_bytes, stream, 0, pl_main);
+    if (!rc) rc = project_chunk(safe_order ? 0 : NCHUNK - 1, ws, ws_bytes, stream, 0, pl_main);
     if (rc) return rc;
     proj_done = true;
   }
+  const int nblk_rows = safe_order ? 2 : 1;              // row blocks of the un-pipelined projection: [T/2, T) then [0, T/2), or all rows at once
+  auto block_rows = [&](int blk, int &t0, int &t1) {
+    if (nblk_rows == 1) { t0 = 0; t1 = T; }
+    else if (blk == 0) { t0 = T / 2; t1 = T; }
+    else { t0 = 0; t1 = T / 2; }
+  };
   if (!proj_done && dirs == 2) {
     const size_t wcat_bytes = align_up((size_t)2 * GH * I * sizeof(float), 256);
     if (w_ih1 == w_ih0 + (size_t)GH * I) {      // already one (2*GH, I) matrix (optim.FlatAdam places them so): no stacking copies
-      int rc = ctcn_gemm(0, 1, T * B, 2 * GH, I, x, I, w_ih0, I, gates, 2 * GH, 0.0f, precision, ws, ws_bytes, stream);
-      if (rc) return rc;
+      for (int blk = 0; blk < nblk_rows; ++blk) {
+        int t0, t1;
+        block_rows(blk, t0, t1);
+        if (blk > 0) pl_main.same_b = true;
+        int rc = ctcn_gemm_on_xcds(0, 1, (t1 - t0) * B, 2 * GH, I, x + (size_t)t0 * B * I, I, w_ih0, I, gates + (size_t)t0 * B * 2 * GH, 2 * GH, 0.0f, precision,
+                                   ws, ws_bytes, stream, 0u, &pl_main);
+        if (rc) return rc;
+      }
       proj_done = true;
     } else if (ws && ws_bytes > wcat_bytes + ((size_t)64 << 20)) {
       float *wcat = (float *)ws;
       CTCN_HIP(hipMemcpyAsync(wcat, w_ih0, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, st));
       CTCN_HIP(hipMemcpyAsync(wcat + (size_t)GH * I, w_ih1, (size_t)GH * I * sizeof(float), hipMemcpyDeviceToDevice, st));
-      int rc = ctcn_gemm(0, 1, T * B, 2 * GH, I, x, I, wcat, I, gates, 2 * GH, 0.0f, precision, (char *)ws + wcat_bytes, ws_bytes - wcat_bytes, stream);
-      if (rc) return rc;
+      GemmPlanes pl_cat;
+      for (int blk = 0; blk < nblk_rows; ++blk) {
+        int t0, t1;
+        block_rows(blk, t0, t1);
+        if (blk > 0) pl_cat.same_b = true;
+        int rc = ctcn_gemm_on_xcds(0, 1, (t1 - t0) * B, 2 * GH, I, x + (size_t)t0 * B * I, I, wcat, I, gates + (size_t)t0 * B * 2 * GH, 2 * GH, 0.0f, precision,
+                                   (char *)ws + wcat_bytes, ws_bytes - wcat_bytes, stream, 0u, &pl_cat);
+        if (rc) return rc;
+      }
       proj_done = true;
     }
   }
   for (int d = 0; d < dirs && !proj_done; ++d) {
-    if (d > 0) pl_main.same_a = true;                   // split x into planes once
-    int rc = ctcn_gemm_on_xcds(0, 1, T * B, GH, I, x, I, w_ih[d], I, gates + (size_t)d * GH, dirs * GH, 0.0f, precision, ws,
-                               ws_bytes, stream, 0u, &pl_main);
-    if (rc) return rc;
+    // (one direction per product: a forward-only layer starts on the rows written first; the reverse direction of a two-product layer gets the blocks)
+    const int nb_d = d == 1 ? nblk_rows : 1;
+    for (int blk = 0; blk < nb_d; ++blk) {
+      int t0 = 0, t1 = T;
+      if (nb_d > 1) block_rows(blk, t0, t1);
+      pl_main.same_a = false; pl_main.same_b = blk > 0;
+      int rc = ctcn_gemm_on_xcds(0, 1, (t1 - t0) * B, GH, I, x + (size_t)t0 * B * I, I, w_ih[d], I, gates + (size_t)t0 * B * dirs * GH + (size_t)d * GH, dirs * GH, 0.0f,
+                                 precision, ws, ws_bytes, stream, 0u, &pl_main);
+      if (rc) return rc;
+    }
   }
   RnnArgs a;
   a.cell = cell; a.T = T; a.B = B; a.H = H; a.D = dirs; a.G = G; a.step = 0;

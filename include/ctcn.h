@@ -90,6 +90,11 @@ int ctcn_device_xcds(void);
  * groups = XCDs) keeps group g on XCD g whatever the option says: there is nothing to place, and the one full parity run made while the order
  * applied to it too ended with a cfg4 loss trajectory that differed from step 4 on in the undisturbed AND the disturbed run of the squatter
  * test alike -- unreproduced since, unexplained, and therefore kept away from that launch.
+ * "rnn_proj_order" = 1 (default, round 6): the input projection of a recurrent layer is issued as the row blocks [T/2, T) then [0, T/2) (in the
+ * pipelined form: the last time chunk before the first) instead of one product over ascending time, so that the frames a recurrence STARTS on
+ * are never the rows the preceding kernel wrote last -- the reverse direction reads frame T - 1 within microseconds of its launch.  Same
+ * products, bit-identical results; closes the one trajectory divergence the traced parity suites of round 6 caught (cfg4, bottom layer, reverse
+ * direction: DESIGN.md section 8).  0: one product, ascending time (rounds 1-5).
  * "bn_rows4" = 1 (default, round 5): BatchNorm over (rows, C) with C % 4 == 0 forms its column sums with 16-B loads, sixteen row phases per
  * workgroup (colreduce_rows4_kernel); 0: the dword kernel.  Same chunks, same element values, float64 partials grouped differently: the float32
  * results agreed bit for bit wherever compared (tools/bn_rows_probe.py).  cfg2 13.33 -> 13.25 ms per step, cfg4 53.2 -> 52.8.

@@ -71,4 +71,17 @@ case $S in
   # keep the logs of the runs that deviated, drop the bulky rest
   for i in 1 2 3 4; do grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl; done
   ;;
+7)
+  # the mitigation under test (option rnn_proj_order = 1, default): full traced suites -- the divergence showed in 2 of 4 of them with the old order
+  for i in 1 2 3; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider --durations=12 > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    python tools/traj_compare.py $O/traj_full_$i.jsonl > $O/traj_compare_$i.txt 2>&1
+    tail -n 3 $O/pytest_full_$i.log | cut -c1-200
+  done
+  python tools/traj_compare.py $O/traj_*.jsonl > $O/traj_compare.txt 2>&1
+  cat $O/summary.log $O/traj_compare.txt | cut -c1-400
+  for i in 1 2 3; do grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl; done
+  timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  CTCN_OPT_RNN_PROJ_ORDER=0 timeout 600 python bench.py --no-cpu-baseline --no-decode --no-pmc --no-ragged --no-sync-bn-cost > $O/bench_order0.json 2> $O/bench_order0.err
+  ;;
 esac
