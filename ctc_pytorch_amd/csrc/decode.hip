@@ -66,6 +66,7 @@ struct BeamArgs {
   unsigned long long *ht_keys; int *ht_ids; int *node_par; int *node_sym; double *cand_global;
   int ht_size, max_nodes, cand_in_lds;
   int wcap, smax;       // beam_kernel: capacity of the beam-state arrays (W rounded up to 64) and of the selection's survivor list
+  int lm_in_lds;        // beam_kernel: the (V+1)^2 ln-prob table is copied into dynamic LDS behind the state arrays (when the launch's budget holds it)
 #ifdef CTCN_BEAM_STATS
   long long *stats;     // development instrumentation (tools/mb_beam.py generic): cycles per phase of workgroup 0, thread 0
 #endif
@@ -115,6 +116,14 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   double *const sNB = dbase + 6 * wcap, *const sB = sNB + wcap, *const sT = sB + wcap, *const selv = sT + wcap;
   double *const sv_v = selv + wcap;                            // selection: survivors of the pruning bound (value | candidate index)
   int *const mfrom = ibase + 8 * wcap, *const sel = mfrom + wcap, *const sv_i = sel + wcap;
+  // (round 6) the LM table in LDS when the launch has room for it: one LDS read instead of a global gather per candidate and frame; the raw
+  // ln-probs are copied, the product with alpha is formed per use exactly as before
+  const double *lmt = a.lm;
+  if (a.lm_in_lds) {
+    double *lml = reinterpret_cast<double *>(reinterpret_cast<char *>(sv_i + SEL_SMAX) + ((8 - ((size_t)(10 * wcap + SEL_SMAX) * 4) % 8) % 8));
+    for (int i = tid; i < (V + 1) * (V + 1); i += NT) lml[i] = a.lm[i];
+    lmt = lml;
+  }
   unsigned long long *keys = a.ht_keys + (size_t)b * a.ht_size;
   int *ids = a.ht_ids + (size_t)b * a.ht_size;
   int *npar = a.node_par + (size_t)b * a.max_nodes;
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
 #pragma unroll
       for (int u = 0; u < EU; ++u) {
         const int c1 = cln[u] > 0 ? cl[u] : V;
-        lmv[u] = a.lm[(size_t)c1 * (V + 1) + max(ck[u], 0)];
+        lmv[u] = lmt[(size_t)c1 * (V + 1) + max(ck[u], 0)];
       }
 #pragma unroll
       for (int u = 0; u < EU; ++u) {
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       // normalised scores (BeamSearch.py:147: prTotal / labelling length), then `last.sort()[0:nbest]` (:150, the reference keeps [0]): a stable
       // descending sort -- among equal scores the earlier entry (the order of BHat) comes first.  L.pT is reused for the scores, L.par as "taken"
       for (int r = 0; r < nb; ++r) {
-        const double pr = L.pT[r] + a.lm[(size_t)L.last[r] * (V + 1) + V] * a.alpha;
+        const double pr = L.pT[r] + lmt[(size_t)L.last[r] * (V + 1) + V] * a.alpha;
         const double tot = log_add_prob(LOG_ZERO, pr);
         const int ln = L.len[r];
         L.pT[r] = tot * (1.0 / (ln ? ln : 1));
@@ -1497,8 +1506,13 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   a.smax = std::max(1024, 2 * a.wcap);                         // (W <= 256: the 1 024 survivors of round 5; W = 1 024: 2 048)
   const size_t state_bytes = (size_t)a.wcap * (10 * sizeof(double) + 10 * sizeof(int)) + (size_t)a.smax * (sizeof(double) + sizeof(int));
   const size_t row_bytes = (size_t)V * sizeof(double);
-  a.cand_in_lds = (cand_bytes <= 32 * 1024 && fa.sharedSizeBytes + row_bytes + state_bytes + cand_bytes <= (size_t)lds_max) ? 1 : 0;
-  const size_t sm = row_bytes + state_bytes + (a.cand_in_lds ? cand_bytes : 0);
+  // (round 6) whatever the 160 KB hold: the candidate table first (three scans per frame: W = 200 at V = 62 is 99 KB -- in global memory until
+  // round 5, whose rule was 32 KB), then the LM table (31.7 KB at V = 62)
+  const size_t lm_bytes = (size_t)(V + 1) * (V + 1) * sizeof(double) + 8;
+  const size_t fixed = fa.sharedSizeBytes + row_bytes + state_bytes + 256;
+  a.cand_in_lds = fixed + cand_bytes <= (size_t)lds_max ? 1 : 0;
+  a.lm_in_lds = fixed + (a.cand_in_lds ? cand_bytes : 0) + lm_bytes <= (size_t)lds_max ? 1 : 0;
+  const size_t sm = row_bytes + state_bytes + (a.cand_in_lds ? cand_bytes : 0) + (a.lm_in_lds ? lm_bytes : 0);
   if (fa.sharedSizeBytes + sm > (size_t)lds_max) {
     ctcn_set_error("ctcn_beam_decode: %zu B of LDS per workgroup needed, the device gives %d", fa.sharedSizeBytes + sm, lds_max);
     return CTCN_EUNSUPPORTED;

@@ -84,4 +84,16 @@ case $S in
   timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
   CTCN_OPT_RNN_PROJ_ORDER=0 timeout 600 python bench.py --no-cpu-baseline --no-decode --no-pmc --no-ragged --no-sync-bn-cost > $O/bench_order0.json 2> $O/bench_order0.err
   ;;
+8)
+  # round-6 evidence (profiles/r06_*) + three more traced full suites with the projection order fix
+  bash tools/run_profiles_r6.sh > $O/run_profiles.log 2>&1
+  for i in 1 2 3; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider --durations=6 > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    python tools/traj_compare.py $O/traj_full_$i.jsonl > $O/traj_compare_$i.txt 2>&1
+    tail -n 3 $O/pytest_full_$i.log | cut -c1-200
+    grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl
+  done
+  cat $O/summary.log $O/traj_compare_*.txt | cut -c1-300
+  tail -n 12 $O/run_profiles.log | cut -c1-400
+  ;;
 esac
