@@ -156,7 +156,7 @@ def gemm_roofline(dev, c):
                 peak_note="f32 MFMA 157.3 TFLOP/s (dense)" if prec == 0 else "dense bf16 MFMA 2500 TFLOP/s; 3 bf16 MFMAs per algorithmic product (bf16x3)")
 
 
-PMC_FILE = next((f for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_hbm_traffic.json")
+PMC_FILE = next((f for f in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r02_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(kernel):

@@ -198,15 +198,24 @@ def check_status(device):
 
 
 _WS = {}
+_WS_LOCK = __import__("threading").Lock()
+# Size of a (device, stream tag) workspace: operand planes of the largest GEMM of a layer call (cfg4's dx product: 956 MB), split-K partials,
+# BN / conv partial sums, hand-off tiles.  CTCN_WORKSPACE_MB sizes it for smaller models (a call that does not fit answers CTCN_EWORKSPACE or
+# takes its plane-free path; nothing is silently truncated).  Allocated on first use of the tag, not at import.
+WORKSPACE_BYTES = int(os.environ.get("CTCN_WORKSPACE_MB", "1024")) << 20
 
 
-def workspace(device, nbytes=1 << 30, tag="main"):
+def workspace(device, nbytes=None, tag="main"):
     """Per-device scratch buffer (split-K partials, BN/conv partial sums).  Stream-ordered reuse: every
     library call consumes its partials before returning control to the same stream's next launch.  Calls issued on a
-    second stream use their own buffer (tag)."""
+    second stream use their own buffer (tag).  Creation is serialised (the autograd thread and the main thread may both get here first)."""
+    nbytes = WORKSPACE_BYTES if nbytes is None else nbytes
     key = (device.type, device.index, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WS[key] = buf
+        with _WS_LOCK:
+            buf = _WS.get(key)
+            if buf is None or buf.numel() < nbytes:
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                _WS[key] = buf
     return buf

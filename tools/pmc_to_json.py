@@ -22,8 +22,10 @@ ALGO = [   # (substring of the kernel name, label, algorithmic bytes per launch 
     ("bn_dx_", "bn_dx (rows of channels: four channels per lane) 25600x640", 196608000),
     ("beam_fast_kernel", "beam_fast_kernel cfg5 peaky (128 x 800 x 62, W=20): reads ln p (double) of the processed frames", None),
     ("beam_prep_kernel", "beam_prep_kernel cfg5 (128 x 800 x 62): lp f32 in, ln p f64 + p_blank + flags out", 800 * 128 * 62 * 12 + 800 * 128 * 5),
-    ("conv_mfma_kernel", "conv_mfma_kernel cfg3 layer 2 (32 -> 32, 3x3, stride 2x2; B=32, T=800): forward and the four dgrad classes", None),
-    ("conv_wgrad_mfma_kernel", "conv_wgrad_mfma_kernel cfg3 layer 2", None),
+    # x (32,32,800,20) = 65.536 MB, y = dy (32,32,400,10) = 16.384 MB.  The counters are averaged over the kernel's five launches of a forward + backward
+    # pass: forward (x in, y out) and four dgrad stride classes (dy in, a quarter of dx out each) -> (81.92 + 4 * 32.768) / 5 MB
+    ("conv_mfma_kernel", "conv_mfma_kernel cfg3 layer 2 (32 -> 32, 3x3, stride 2x2; B=32, T=800): forward and the four dgrad classes, averaged", (65536000 + 16384000 + 4 * (16384000 + 16384000)) // 5),
+    ("conv_wgrad_mfma_kernel", "conv_wgrad_mfma_kernel cfg3 layer 2 (dy and x in, per-chunk partials out)", 65536000 + 16384000 + 32 * 32 * 9 * 4),
 ]
 
 

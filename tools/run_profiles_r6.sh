@@ -1,5 +1,6 @@
 # Round-6 evidence in one box session (outputs under gpurun_out/r06/, copied to profiles/ by hand afterwards):
-#   1. rocprofv3 --kernel-trace --stats of the default driver command (python bench.py; --no-pmc: no profiler inside the profiler)
+#   1. rocprofv3 --kernel-trace --stats of the default driver command (python bench.py; --no-pmc: no profiler inside the profiler; --no-ragged: every
+#      recurrence launch of the pass is the T = 800 launch the roofline object times -- the ragged epochs' shorter launches would pull the average down)
 #      -> kernel stats + step timeline (main and side stream) of the cfg2 step and the cfg5 decode leg
 #   2. the same for cfg4 (every stream listed, so that who waits for whom can be read off the absolute times), cfg3, ref_yaml
 #   3. the default driver command as the driver runs it (roofline.traffic measured in-run by two rocprofv3 --pmc child passes, other_workloads)
@@ -8,7 +9,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o cfg2 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-others --no-pmc > $O/r06_bench_under_rocprof.json 2> $O/stats.log )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o cfg2 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-others --no-pmc --no-ragged --no-sync-bn-cost > $O/r06_bench_under_rocprof.json 2> $O/stats.log )
 db=$(find $O/stats -name "*.db" | head -1)
 [ -n "$db" ] && python tools/prof_timeline.py $db -1 all > $O/r06_cfg2_step_timeline.txt 2>&1
 [ -n "$db" ] && python tools/prof_stats.py $db > $O/r06_cfg2_train_decode_kernel_stats.txt 2>&1
