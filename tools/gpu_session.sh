@@ -113,4 +113,22 @@ case $S in
   python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
   cat $O/summary.log $O/traj_compare_*.txt | cut -c1-300
   ;;
+10)
+  # option rnn_early_sum (item waves sum the parked partial tiles as the exchange waves finish them): parity subset, then A/B of the step
+  timeout 900 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider -k "rnn or model_three or large_shape or lstm or gru or run_epoch or foreign or soak or stateless" > $O/pytest_sub.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 5 $O/pytest_sub.log | cut -c1-200
+  for rep in 1 2; do for v in 1 0; do
+    CTCN_OPT_RNN_EARLY_SUM=$v timeout 600 python bench.py --no-cpu-baseline --no-decode --no-pmc --no-ragged --no-sync-bn-cost > $O/bench_early${v}_$rep.json 2> $O/bench_early${v}_$rep.err
+  done; done
+  python - $O <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/bench_early*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], "cfg2 %.3f ms (median %.3f)  fwd %.3f bwd %.3f us/step" % (d["ms_per_step"], d["ms_per_step_median"], d["recurrence"]["fwd_us_per_timestep"], d["recurrence"]["bwd_us_per_timestep"]),
+              {k: (round(v["ms_per_step"], 3), round(v["fwd_us_per_timestep"], 3), round(v["bwd_us_per_timestep"], 3)) for k, v in d["other_workloads"].items()})
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+  cat $O/summary.log
+  ;;
 esac
