@@ -58,7 +58,6 @@ static int g_opt_beam_generic_threads = 0;  // generic beam kernel: 0 = 256 thre
 static int g_opt_beam_occ2 = 0;         // fast beam search compiled / launched for TWO workgroups per CU (<= 64 VGPRs, <= 80 KB LDS): 0 off, 1 on, 2 on with the LM in global memory
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
 static int g_opt_rnn_proj_order = 1;     // input projection of a recurrent layer as row blocks [T/2, T) then [0, T/2) (pipelined: last chunk before the first): the rows a recurrence starts on are never the rows written last (rnn.hip)
-static int g_opt_rnn_early_sum = 1;      // rnn_fwd_tagged / rnn_bwd_scatter: item waves add up the parked partial tiles as the exchange waves finish them (LDS flag per wave) instead of behind the barrier
 static int g_opt_xcd_interleave_force = 0;  // development / parity harness: apply "xcd_interleave" to a recurrence that takes EVERY XCD too (rnn.hip: xcd_order_for)
 static int *g_status_dev = nullptr;
 
@@ -101,7 +100,6 @@ static const OptionRow k_options[] = {
   {"gemm_dbg", &g_opt_gemm_dbg, [](int value) -> int { return value; }},
   {"gemm_tile256", &g_opt_gemm_tile256, [](int value) -> int { return value ? 1 : 0; }},
   {"rnn_proj_order", &g_opt_rnn_proj_order, [](int value) -> int { return value ? 1 : 0; }},
-  {"rnn_early_sum", &g_opt_rnn_early_sum, [](int value) -> int { return value ? 1 : 0; }},
   {"xcd_interleave_force", &g_opt_xcd_interleave_force, [](int value) -> int { return value ? 1 : 0; }},
 };
 static const int k_noptions = (int)(sizeof(k_options) / sizeof(k_options[0]));

@@ -401,8 +401,6 @@ struct PersistArgs {
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
   int rsv_nt;           // rnn_bwd_scatter2: reserve loads / stores carry the non-temporal hint (streaming data must not evict the exchange tiles from L2)
-  int early_sum;        // rnn_fwd_tagged / rnn_bwd_scatter (round 6, option "rnn_early_sum"): the item waves add up the parked partial tiles as the
-                        // exchange waves finish them (an LDS flag per exchange wave, fixed wave order: the same sums) instead of behind the barrier
   int tagmode;          // rnn_bwd_scatter: 1 = no flags, every float of a partial block carries the step tag in its LSB and the
                         // gathering wave polls the block itself; 0 = stores drained, then a flag per block
   float *ydrop;         // rnn_fwd_tagged: when set, the inverted dropout of y (Philox4x32-10, the dropout kernel's counters) is stored here as well
@@ -999,9 +997,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   __shared__ __attribute__((aligned(16))) float outq[RSV ? 2 : 1][RSV ? 7 : 1][RSV ? 256 : 4];   // RSV: values to store, by step parity
   __shared__ __attribute__((aligned(16))) float preq[RSV ? 3 : 1][RSV ? 4 : 1][RSV ? 256 : 4];   // RSV: pre-activations of three steps
   __shared__ int s_ticket;
-  __shared__ int ready[NGW];                       // early_sum: step + 1 of the partial tiles exchange wave g has parked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < NGW) ready[tid] = 0;
   const int r = lane & 15, q = lane >> 4;
   constexpr int G = CELL == CTCN_CELL_LSTM ? 4 : 3;
   const int H = p.H, D = p.D, B = p.B, T = p.T;
@@ -1086,7 +1082,6 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
 
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
-    float osum[4] = {0.f, 0.f, 0.f, 0.f};                       // early_sum: the item's four gate sums over the exchange waves' partial tiles
 #ifdef CTCN_PERSIST_STATS
     const long long z_a = clock64();
     long long z_p = z_a, z_m = z_a;
@@ -1154,24 +1149,10 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       // park: slot (wave, tile, unit q, row r) = the four gates of unit mt*4 + q for batch row r
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt) *reinterpret_cast<f32x4 *>(red + ((((gw * NMT + mt) * 4 + q) * PQ + r) << 2)) = acc[mt];
-      // (LDS executes a wave's instructions in order: the flag is written behind the tiles)
-      if (pa.early_sum && lane == 0) *reinterpret_cast<volatile int *>(&ready[gw]) = s + 1;
 #ifdef CTCN_PERSIST_STATS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       z_m = clock64();
 #endif
-    } else if (pa.early_sum) {
-      // item waves: the partial sums of the twelve exchange waves, in wave order (the order of the loop behind the barrier: the same float
-      // additions), each as soon as its wave has parked it -- the additions run in the shadow of the slowest exchange wave instead of
-      // behind the barrier that waits for it
-      const float *rp = red + ((((jl >> 2) * 4 + (jl & 3)) * PQ + bl) << 2);
-#pragma unroll
-      for (int w = 0; w < NGW; ++w) {
-        while (*reinterpret_cast<volatile int *>(&ready[w]) != s + 1) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + ((w * NMT * 4 * PQ) << 2));
-        osum[0] += v[0]; osum[1] += v[1]; osum[2] += v[2]; osum[3] += v[3];
-      }
     }
     if constexpr (RSV) { if (wave < G) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }   // this wave's pre-activation DMA of step s has landed (the youngest, s + 1, may be in flight)
     lds_barrier();
@@ -1185,14 +1166,12 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
         pre[0] = preq[pset][0][tid]; pre[1] = preq[pset][1][tid]; pre[2] = preq[pset][2][tid];
         if constexpr (G == 4) pre[3] = preq[pset][RSV ? 3 : 0][tid];
       }
-      float o[4] = {osum[0], osum[1], osum[2], osum[3]};
-      if (!pa.early_sum) {
-        const float *rp = red + ((((jl >> 2) * 4 + (jl & 3)) * PQ + bl) << 2);
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      const float *rp = red + ((((jl >> 2) * 4 + (jl & 3)) * PQ + bl) << 2);
 #pragma unroll
-        for (int w = 0; w < NGW; ++w) {
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + ((w * NMT * 4 * PQ) << 2));
-          o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
-        }
+      for (int w = 0; w < NGW; ++w) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + ((w * NMT * 4 * PQ) << 2));
+        o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
       }
 #ifdef CTCN_PERSIST_STATS
       if (o[0] + o[1] + o[2] + o[3] == 12345.678f) zi[5] += 1;
@@ -1648,7 +1627,6 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   __shared__ __attribute__((aligned(16))) float red[NW * RT_T];        // parked partial tiles (one per wave)
   __shared__ __attribute__((aligned(16))) float stage[1024];           // this workgroup's da block as MFMA A operand
   __shared__ uint4 dropw[4][64];                                       // fused dropout gradient: the Philox groups of an item wave's next four steps
-  __shared__ int ready[12];                                            // early_sum: step of the partial tile exchange wave g has parked
   __shared__ int s_abort;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -1664,7 +1642,6 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   const float *WT = d == 0 ? p.w0 : p.w1;                               // W_hh^T: row = hidden unit (output n), K columns
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   if (tid == 0) s_abort = 0;
-  if (tid < 12) ready[tid] = 0;
   for (int i = tid; i < 1024; i += 1024) stage[i] = 0.0f;              // rows / units nobody owns stay 0
 
   // Wave roles.  Waves 0..3 hold the (row, unit) items: gate math, the A-operand stage and ALL reserve traffic (loads two
@@ -1815,25 +1792,15 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
           }
         }
         park_tile(red, gw, lane, sum);
-        if (pa.early_sum && lane == 0) *reinterpret_cast<volatile int *>(&ready[gw]) = s;       // (in order behind the tile: LDS executes a wave's instructions in order)
       }
-      // early_sum: no barrier here -- an item wave adds the parked tiles in wave order, each as soon as its flag shows this step; what keeps
-      // the exchange waves from parking step s + 1 over them is the barrier behind the gate math (their next gather needs this workgroup's
-      // own scatter, which is behind that barrier)
-      if (!pa.early_sum) lds_barrier();
+      lds_barrier();
 #ifdef CTCN_PERSIST_STATS
       z_p = z_g = clock64();
 #endif
       if (tid < 256) {
         const float *rp = red + parked_at(bl, jl);
 #pragma unroll
-        for (int w = 0; w < NGW; ++w) {
-          if (pa.early_sum) {
-            while (*reinterpret_cast<volatile int *>(&ready[w]) != s) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-          }
-          rec += rp[w * RT_T];
-        }
+        for (int w = 0; w < NGW; ++w) rec += rp[w * RT_T];
       }
     }
 #ifdef CTCN_PERSIST_STATS
@@ -2741,7 +2708,6 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
         const int rsv_opt = ctcn_get_option("fwd_rsv_lds");
         const bool rsv = (rsv_opt == 1 || (rsv_opt == 2 && nsl > 24)) && ((uintptr_t)gates | (uintptr_t)aux | (uintptr_t)y | (uintptr_t)(drop_pending ? call.y_drop : nullptr)) % 16 == 0;
         pa.poll_depth = 1 | (rsv ? 256 : 0); pa.tagmode = 1; pa.poll_delay = ctcn_get_option("tag_poll_delay");
-        pa.early_sum = ctcn_get_option("rnn_early_sum") != 0;
         pa.tickets = (unsigned *)(tail + hx_bytes + fl_bytes - 256);
 #ifdef CTCN_PERSIST_STATS
         pa.stats = nullptr;
@@ -3029,7 +2995,6 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
       // flags + tickets, and the hand-off tiles where they start from zero (tags / partial sums): the two areas are contiguous -> one memset
       if (scatter) {
         pa.tagmode = ctcn_opt_handoff_tags();
-        pa.early_sum = ctcn_get_option("rnn_early_sum") != 0;
         if (pa.tagmode) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));
         else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         if (!dy_dropped && ctcn_get_option("rnn_fused_dropout") != 0) {

@@ -95,10 +95,6 @@ int ctcn_device_xcds(void);
  * are never the rows the preceding kernel wrote last -- the reverse direction reads frame T - 1 within microseconds of its launch.  Same
  * products, bit-identical results; closes the one trajectory divergence the traced parity suites of round 6 caught (cfg4, bottom layer, reverse
  * direction: DESIGN.md section 8).  0: one product, ascending time (rounds 1-5).
- * "rnn_early_sum" = 1 (default, round 6): in rnn_fwd_tagged / rnn_bwd_scatter the item waves add up the exchange waves' parked partial tiles
- * as each wave finishes (one LDS flag per exchange wave, fixed wave order: the same float additions as behind the barrier) instead of after the
- * barrier that waits for the slowest exchange wave; the backward kernel loses one of its two barriers per step.  Bit-identical results.  0: the
- * sums behind the barrier (rounds 2-5).
  * "bn_rows4" = 1 (default, round 5): BatchNorm over (rows, C) with C % 4 == 0 forms its column sums with 16-B loads, sixteen row phases per
  * workgroup (colreduce_rows4_kernel); 0: the dword kernel.  Same chunks, same element values, float64 partials grouped differently: the float32
  * results agreed bit for bit wherever compared (tools/bn_rows_probe.py).  cfg2 13.33 -> 13.25 ms per step, cfg4 53.2 -> 52.8.
