@@ -17,7 +17,8 @@ import torch  # noqa: F401  (must precede the dlopen, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(_HERE, "libctcn.so")
+# (CTCN_LIBCTCN: development only -- tools/flag_lottery.sh points it at a variant build of the same sources; the product loads the in-tree library)
+SO_PATH = os.environ.get("CTCN_LIBCTCN") or os.path.join(_HERE, "libctcn.so")
 _lib = None
 
 c_void_p, c_int, c_float, c_double, c_size_t, c_u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,

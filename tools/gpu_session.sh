@@ -131,4 +131,23 @@ for f in sorted(glob.glob(sys.argv[1] + "/bench_early*.json")):
 PY
   cat $O/summary.log
   ;;
+11)
+  # closing verification at HEAD: smoke, the full parity suite twice (traced), the driver's command
+  python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+  for i in 1 2; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    python tools/traj_compare.py $O/traj_full_$i.jsonl > $O/traj_compare_$i.txt 2>&1
+    tail -n 2 $O/pytest_full_$i.log | cut -c1-200
+    grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl
+  done
+  timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  cat $O/summary.log $O/traj_compare_*.txt | cut -c1-300
+  python - $O/bench_default.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("cfg2 %.3f ms (median %.3f) value %.0f; roofline frac %.4f us/launch %.1f traffic %s; decode %s; wide %s / %s ms" % (
+    d["ms_per_step"], d["ms_per_step_median"], d["value"], d["roofline"]["frac"], d["roofline"]["us_per_launch"], d["roofline"]["traffic"],
+    {k: round(v["value"]) for k, v in d["decode"]["regimes"].items()}, round(d["decode"]["wide_beam"]["peaky"]["ms_per_batch"], 2), round(d["decode"]["wide_beam"]["flat"]["ms_per_batch"], 2)))
+PY
+  ;;
 esac
