@@ -150,4 +150,7 @@ print("cfg2 %.3f ms (median %.3f) value %.0f; roofline frac %.4f us/launch %.1f 
     {k: round(v["value"]) for k, v in d["decode"]["regimes"].items()}, round(d["decode"]["wide_beam"]["peaky"]["ms_per_batch"], 2), round(d["decode"]["wide_beam"]["flat"]["ms_per_batch"], 2)))
 PY
   ;;
+12)
+  bash tools/flag_lottery.sh $O > $O/run.log 2>&1; cat $O/lottery.txt | cut -c1-250
+  ;;
 esac
