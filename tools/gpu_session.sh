@@ -153,4 +153,11 @@ PY
 12)
   bash tools/flag_lottery.sh $O > $O/run.log 2>&1; cat $O/lottery.txt | cut -c1-250
   ;;
+13)
+  # a reproducer of the stale first reads outside the parity suite? (tools/stale_probe.py)
+  { for args in "--iters 400" "--iters 300 --lag 0.02" "--iters 150 --lag 0.1" "--iters 200 --lag 0.05 --dirty 30" "--iters 100 --lag 0.3 --dirty 30" "--iters 200 --lag 0.05 --dirty 30 --order 1"; do
+      echo "== stale_probe $args"; timeout 300 python tools/stale_probe.py $args 2>&1 | grep -v amdgpu.ids | tail -n 8
+    done; } > $O/stale_probe.txt 2>&1
+  cat $O/stale_probe.txt | cut -c1-250
+  ;;
 esac
