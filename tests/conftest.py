@@ -96,3 +96,15 @@ def pytest_runtest_makereport(item, call):
                 st["end"] = {"error": repr(e)}
         rep.sections.append(("process state at the start of the test", json.dumps(st["start"], sort_keys=True)))
         rep.sections.append(("process state moved during the test", "; ".join(_diff(st["start"], st["end"])) or "nothing"))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """CTCN_AFTER_SUITE=<script.py>: run a script IN this process once the suite is over (tools/after_suite_ab.py: the projection-order A/B in the
+    long-lived process the cfg4 divergence needed).  Development aid; unset in every normal run."""
+    path = os.environ.get("CTCN_AFTER_SUITE")
+    if path:
+        import runpy
+        try:
+            runpy.run_path(path, run_name="__main__")
+        except SystemExit:
+            pass

@@ -160,4 +160,12 @@ PY
     done; } > $O/stale_probe.txt 2>&1
   cat $O/stale_probe.txt | cut -c1-250
   ;;
+14)
+  # the order fix A/B-ed IN the process that has just run the full suite (where the divergence lives), twice
+  for i in 1 2; do
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_suite_ab.json CTCN_AFTER_SUITE_N=25 timeout 1800 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider -s > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    grep "after_suite_ab" $O/pytest_full_$i.log | cut -c1-600
+  done
+  cat $O/summary.log
+  ;;
 esac
