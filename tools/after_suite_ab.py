@@ -1,31 +1,45 @@
-"""The projection-order A/B inside the process that has just run the full parity suite (tests/conftest.py: CTCN_AFTER_SUITE).  The cfg4 divergence of
-round 6 showed in 3 of 10 full suites and in none of ~200 fresh-process runs, so the order fix is A/B-ed where the event lives: `n` traced 12-step cfg4
-runs per order, interleaved, every trace compared with the majority; option rnn_proj_order 0 = one product over ascending time (rounds 1-5),
-1 = [T/2, T) then [0, T/2) (the fix).  Both orders are bit-identical by construction, so one reference trace serves both.
-Writes one JSON line to CTCN_AFTER_SUITE_OUT (default gpurun_out/after_suite_ab.json)."""
-import collections, json, os, sys
+"""Experiments inside the process that has just run the full parity suite (tests/conftest.py: CTCN_AFTER_SUITE), where the cfg4 divergence of round 6
+lives (8-10 % of traced 12-step runs there, 0 of ~200 in fresh processes).  Phases, each `n` traced cfg4 runs compared with the majority trace of ALL runs:
+  order0 / order1   option rnn_proj_order 0 | 1 (one product over ascending time | [T/2, T) then [0, T/2)); bit-identical by construction
+  nogc              the interpreter's cyclic collector off during the runs (a long-lived process pauses for tens of ms per generation-2 pass)
+  emptied           gc.collect() + torch.cuda.empty_cache() first: a fresh allocator pool, new addresses
+CTCN_AFTER_SUITE_PHASES selects them (default "order1,nogc,emptied,order1"), CTCN_AFTER_SUITE_N the runs per phase.  One JSON line to CTCN_AFTER_SUITE_OUT."""
+import collections, gc, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import squat_stress
 from ctc_pytorch_amd import ops
 
-n = int(os.environ.get("CTCN_AFTER_SUITE_N", "25"))
+n = int(os.environ.get("CTCN_AFTER_SUITE_N", "16"))
+phases = os.environ.get("CTCN_AFTER_SUITE_PHASES", "order1,nogc,emptied,order1").split(",")
 dev = torch.device("cuda", 0)
 found = ops.get_option("rnn_proj_order")
 runs = []
 try:
-    for i in range(n):
-        for order in (0, 1):
-            ops.set_option("rnn_proj_order", order)
-            r = squat_stress.run("cfg4", 12, squat=(i % 2 == 1), seed=i + 1, dev=dev, trace=True)
-            runs.append((order, json.dumps(r["trace"]), r["trace"]))
+    for pi, ph in enumerate(phases):
+        ops.set_option("rnn_proj_order", 0 if ph == "order0" else 1)
+        if ph == "nogc":
+            gc.collect()
+            gc.disable()
+        if ph == "emptied":
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        try:
+            for i in range(n):
+                r = squat_stress.run("cfg4", 12, squat=(i % 2 == 1), seed=i + 1, dev=dev, trace=True)
+                runs.append(("%d:%s" % (pi, ph), json.dumps(r["trace"]), r["trace"], r["addresses"][0]["gates"] if r.get("addresses") else 0))
+        finally:
+            if ph == "nogc":
+                gc.enable()
 finally:
     ops.set_option("rnn_proj_order", found)
-ref_j = collections.Counter(j for _, j, _ in runs).most_common(1)[0][0]
+ref_j = collections.Counter(j for _, j, _, _ in runs).most_common(1)[0][0]
 ref = json.loads(ref_j)
-out = {"runs_per_order": n, "deviating": {0: [], 1: []}}
-for k, (order, j, tr) in enumerate(runs):
+out = {"runs_per_phase": n, "phases": phases, "deviating": collections.OrderedDict(("%d:%s" % (pi, ph), []) for pi, ph in enumerate(phases)), "gates_addresses": {}}
+for k, (ph, j, tr, addr) in enumerate(runs):
+    out["gates_addresses"].setdefault(ph, sorted(set()))
     if j != ref_j:
         step, first = 0, None
         for (na, va), (nb, vb) in zip(tr, ref):
@@ -34,8 +48,9 @@ for k, (order, j, tr) in enumerate(runs):
             elif va != vb:
                 first = (step, na)
                 break
-        out["deviating"][order].append({"run": k, "first_difference": first})
-out["summary"] = "old order (0): %d of %d runs deviate; new order (1): %d of %d" % (len(out["deviating"][0]), n, len(out["deviating"][1]), n)
+        out["deviating"][ph].append({"run": k, "first_difference": first, "gates_at": hex(addr)})
+out["gates_addresses"] = {ph: sorted({hex(a) for p2, _, _, a in runs if p2 == ph}) for ph in out["deviating"]}
+out["summary"] = "; ".join("%s: %d of %d deviate" % (ph, len(v), n) for ph, v in out["deviating"].items())
 print("\n[after_suite_ab] " + json.dumps(out), flush=True)
 path = os.environ.get("CTCN_AFTER_SUITE_OUT", os.path.join(ROOT, "gpurun_out", "after_suite_ab.json"))
 os.makedirs(os.path.dirname(path), exist_ok=True)

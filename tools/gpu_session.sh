@@ -168,4 +168,10 @@ PY
   done
   cat $O/summary.log
   ;;
+15)
+  # which process condition does the cfg4 divergence need?  after the suite: as-is | GC off | emptied allocator pool | as-is again; and a FRESH process whose host lags
+  CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_suite_ab.json CTCN_AFTER_SUITE_N=16 timeout 1800 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider -s > $O/pytest_full_1.log 2>&1; echo "full rc=$?" >> $O/summary.log
+  grep "after_suite_ab" $O/pytest_full_1.log | cut -c1-1500
+  ( CTCN_STEP_LAG=0.04 timeout 600 python tools/traj_bisect.py cfg4 12 40 squat 2>&1 | grep -v "amdgpu.ids\|Warning" ) > $O/bisect_lag.txt; tail -n 6 $O/bisect_lag.txt | cut -c1-300
+  ;;
 esac

@@ -96,7 +96,11 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     ring = [torch.cuda.Event() for _ in range(3)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    lag = float(os.environ.get("CTCN_STEP_LAG", "0"))          # (round 6 experiment: a host that falls behind -- the GPU drains between steps)
+    lag_rs = np.random.RandomState(seed + 1000)
     for i in range(steps):
+        if lag > 0 and lag_rs.rand() < 0.4:
+            time.sleep(lag)
         maybe_squat(p)
         if trace:
             note("model-input", x)
