@@ -29,16 +29,34 @@ try:
         try:
             for i in range(n):
                 r = squat_stress.run("cfg4", 12, squat=(i % 2 == 1), seed=i + 1, dev=dev, trace=True)
-                runs.append(("%d:%s" % (pi, ph), json.dumps(r["trace"]), r["trace"], r["addresses"][0]["gates"] if r.get("addresses") else 0))
+                runs.append(("%d:%s" % (pi, ph), json.dumps(r["trace"]), r["trace"], r["addresses"][0]["gates"] if r.get("addresses") else 0, r.get("layer0_per_timestep")))
         finally:
             if ph == "nogc":
                 gc.enable()
 finally:
     ops.set_option("rnn_proj_order", found)
-ref_j = collections.Counter(j for _, j, _, _ in runs).most_common(1)[0][0]
+ref_j = collections.Counter(r_[1] for r_ in runs).most_common(1)[0][0]
+import base64
+import numpy as np
+ref_td = next(r_[4] for r_ in runs if r_[1] == ref_j)
+
+
+def td_pattern(td, step):
+    """layer 0 per (timestep, direction): which timesteps of which direction differ from the reference at `step`"""
+    pat = {}
+    for kk in ("gates", "y"):
+        a_ = np.frombuffer(base64.b64decode(td[kk]), dtype=np.int64).reshape(12, -1, 2)
+        b_ = np.frombuffer(base64.b64decode(ref_td[kk]), dtype=np.int64).reshape(12, -1, 2)
+        for dr in (0, 1):
+            ts = np.nonzero(a_[step, :, dr] != b_[step, :, dr])[0]
+            if len(ts):
+                mag = np.abs(a_[step, ts, dr] - b_[step, ts, dr]).astype(float)
+                pat["%s d%d" % (kk, dr)] = dict(count=int(len(ts)), first_t=int(ts.min()), last_t=int(ts.max()), largest_at_t=int(ts[int(np.argmax(mag))]))
+    return pat
+
 ref = json.loads(ref_j)
 out = {"runs_per_phase": n, "phases": phases, "deviating": collections.OrderedDict(("%d:%s" % (pi, ph), []) for pi, ph in enumerate(phases)), "gates_addresses": {}}
-for k, (ph, j, tr, addr) in enumerate(runs):
+for k, (ph, j, tr, addr, td) in enumerate(runs):
     out["gates_addresses"].setdefault(ph, sorted(set()))
     if j != ref_j:
         step, first = 0, None
@@ -48,8 +66,8 @@ for k, (ph, j, tr, addr) in enumerate(runs):
             elif va != vb:
                 first = (step, na)
                 break
-        out["deviating"][ph].append({"run": k, "first_difference": first, "gates_at": hex(addr)})
-out["gates_addresses"] = {ph: sorted({hex(a) for p2, _, _, a in runs if p2 == ph}) for ph in out["deviating"]}
+        out["deviating"][ph].append({"run": k, "first_difference": first, "gates_at": hex(addr), "layer0_pattern": td_pattern(td, first[0]) if (first and td) else None})
+out["gates_addresses"] = {ph: sorted({hex(r_[3]) for r_ in runs if r_[0] == ph}) for ph in out["deviating"]}
 out["summary"] = "; ".join("%s: %d of %d deviate" % (ph, len(v), n) for ph, v in out["deviating"].items())
 print("\n[after_suite_ab] " + json.dumps(out), flush=True)
 path = os.environ.get("CTCN_AFTER_SUITE_OUT", os.path.join(ROOT, "gpurun_out", "after_suite_ab.json"))

@@ -174,4 +174,14 @@ PY
   grep "after_suite_ab" $O/pytest_full_1.log | cut -c1-1500
   ( CTCN_STEP_LAG=0.04 timeout 600 python tools/traj_bisect.py cfg4 12 40 squat 2>&1 | grep -v "amdgpu.ids\|Warning" ) > $O/bisect_lag.txt; tail -n 6 $O/bisect_lag.txt | cut -c1-300
   ;;
+16)
+  # which tests put the process into the state where cfg4 trajectories deviate?  (24 traced runs after each subset, in the subset's process)
+  SPAWN="two_ranks or bench_ or rank_invariant or rank_failure or torchrun"
+  i=0
+  for sel in "not ($SPAWN)" "$SPAWN" "beam or decode or greedy or join" "rnn or lstm or gru"; do
+    i=$((i+1))
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=24 CTCN_AFTER_SUITE_PHASES=order1 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-100)" | tee -a $O/summary.log
+  done
+  ;;
 esac
