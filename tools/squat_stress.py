@@ -35,6 +35,18 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
     dev = dev or torch.device("cuda", 0)
     c = bench.WORKLOADS[workload]
     found = ops.state_snapshot()                      # (round 6) this function leaves the process-wide state as it found it, and says what it ran in
+    if os.environ.get("CTCN_WS_FILL"):                # (round 6 experiment: the library workspaces hold garbage / zeros when the run starts)
+        from ctc_pytorch_amd import _lib
+        _lib.workspace(dev)
+        _lib.workspace(dev, tag="side")
+        torch.cuda.synchronize()
+        for buf in _lib._WS.values():
+            f32 = buf.view(torch.float32)
+            if os.environ["CTCN_WS_FILL"] == "zero":
+                f32.zero_()
+            else:
+                f32.copy_(torch.randn(f32.shape, device=f32.device) * 3.0)
+        torch.cuda.synchronize()
     ops.set_precision(1)
     parallel.enable_overlap(True)
     torch.manual_seed(1)
