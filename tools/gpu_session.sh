@@ -194,4 +194,12 @@ PY
   done
   ( CTCN_WS_FILL=rand timeout 600 python tools/traj_bisect.py cfg4 12 30 2>&1 | grep -v "amdgpu.ids\|Warning" ) > $O/bisect_wsrand.txt; echo "fresh process, random workspaces: $(tail -n 1 $O/bisect_wsrand.txt)" | tee -a $O/summary.log
   ;;
+18)
+  i=0
+  for sel in "item_gather_equals or item_gather_edge" "persistent_equals or batch_chunks" "stateless or 4gb or unaligned" "xcd_order"; do
+    i=$((i+1))
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=30 CTCN_AFTER_SUITE_PHASES=order1 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-100)" | tee -a $O/summary.log
+  done
+  ;;
 esac
