@@ -202,4 +202,8 @@ PY
     echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-100)" | tee -a $O/summary.log
   done
   ;;
+19)
+  # does an earlier persistent launch of cfg4's geometry at another T poison the process?  (T mod 4 decides the tags it leaves in the hand-off tiles)
+  for T in 30 40 31 0; do ( timeout 400 python tools/prelude_ab.py $T 6 gru 30 2>&1 | grep -v "amdgpu.ids\|Warning" | tail -n 2 ) | tee -a $O/prelude.txt; done
+  ;;
 esac
