@@ -15,6 +15,10 @@ n = int(os.environ.get("CTCN_AFTER_SUITE_N", "16"))
 phases = os.environ.get("CTCN_AFTER_SUITE_PHASES", "order1,nogc,emptied,order1").split(",")
 dev = torch.device("cuda", 0)
 found = ops.get_option("rnn_proj_order")
+from ctc_pytorch_amd import _lib
+print("\n[after_suite_ab] process state: side live %r pending %r deferred %r events %r streams %r; workspaces %r; allocator reserved %.1f GB" % (
+    dict(ops._side["live"]), list(ops._side["pending"]), list(ops._side["deferred"]), list(ops._side["events"]), list(ops._side["streams"]),
+    {k: (hex(v.data_ptr()), v.numel() >> 20) for k, v in _lib._WS.items()}, torch.cuda.memory_reserved() / 2 ** 30), flush=True)
 runs = []
 try:
     for pi, ph in enumerate(phases):
@@ -22,6 +26,8 @@ try:
         if ph == "nogc":
             gc.collect()
             gc.disable()
+        if ph == "side_reset":
+            ops._side["live"].clear(); ops._side["pending"].clear(); ops._side["deferred"].clear()
         if ph == "emptied":
             gc.collect()
             torch.cuda.synchronize()

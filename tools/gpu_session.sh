@@ -206,4 +206,13 @@ PY
   # does an earlier persistent launch of cfg4's geometry at another T poison the process?  (T mod 4 decides the tags it leaves in the hand-off tiles)
   for T in 30 40 31 0; do ( timeout 400 python tools/prelude_ab.py $T 6 gru 30 2>&1 | grep -v "amdgpu.ids\|Warning" | tail -n 2 ) | tee -a $O/prelude.txt; done
   ;;
+20)
+  i=0
+  for sel in "item_gather_equals" "item_gather_edge" "persistent_equals" "batch_chunks_equal" "batch_chunks_into_flat" "xcd_order"; do
+    i=$((i+1))
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=30 CTCN_AFTER_SUITE_PHASES=order1 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-80)" | tee -a $O/summary.log
+    grep "process state" $O/pytest_$i.log | cut -c1-400 | tee -a $O/summary.log
+  done
+  ;;
 esac
