@@ -397,6 +397,7 @@ struct PersistArgs {
   int poll_delay;       // rnn_fwd_tagged: 64-cycle sleeps between the barrier and an exchange wave's first poll of a step
   int chunk_T, nchunk;  // rnn_fwd_tagged, pipelined input projection: frames per time chunk (0 = all pre-activations are there at launch)
   unsigned *chunk_ready; //   ... and the counter the side stream raises after each chunk PAIR (p covers chunks p and nchunk-1-p)
+  int dbg;               // option "rnn_dbg" (development)
   int xperm;             // option "xcd_interleave" (eight XCDs): which physical XCD is logical XCD g, i.e. hosts group g (persist_role)
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
@@ -1061,6 +1062,14 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       *reinterpret_cast<f32x4 *>(dst) = v;
     }
   };
+  if (pa.dbg & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (pa.dbg & 1) {
+    if (tid < 256) {
+      __builtin_amdgcn_raw_buffer_store_b32(0u, rs, tile_b[0] + pub_off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(0u, rs, tile_b[1] + pub_off, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   if constexpr (RSV) {
     if (wave < G) { pre_dma(0, 0); pre_dma(1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2718,7 +2727,10 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
           pa.ydrop = call.y_drop; pa.drop_p = call.drop_p; pa.drop_scale = 1.0f / (1.0f - call.drop_p);
           pa.drop_seed = call.drop_seed; pa.drop_off = call.drop_offset;
         }
+        pa.dbg = ctcn_get_option("rnn_dbg");
+        if (pa.dbg & 8) CTCN_HIP(hipStreamSynchronize(st));
         CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | chunk counter | role tickets
+        if (pa.dbg & 2) CTCN_HIP(hipStreamSynchronize(st));
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();

@@ -215,4 +215,9 @@ PY
     grep "process state" $O/pytest_$i.log | cut -c1-400 | tee -a $O/summary.log
   done
   ;;
+21)
+  # WHERE does a deviating bottom layer leave the others (element pattern), is it the projection or the recurrence, and which arm removes it
+  CTCN_AFTER_SUITE=$R/tools/first_rows_probe.py CTCN_PROBE_OUT=$O/probe.jsonl CTCN_PROBE_N=${PROBE_N:-1000} CTCN_PROBE_RUNS=${PROBE_RUNS:-30} timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s -k "item_gather_edge or batch_chunks_equal" > $O/pytest.log 2>&1
+  grep "^\[probe\]" $O/pytest.log | cut -c1-1800; tail -n 3 $O/pytest.log | cut -c1-300
+  ;;
 esac

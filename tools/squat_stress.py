@@ -24,7 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, squats_per_step=2.0, dev=None, log=None, trace=False):
+def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, squats_per_step=2.0, dev=None, log=None, trace=False, rows_capture=None):
     """`steps` training steps of `workload` (bench.py's model, batch and step); with `squat`, squatter launches at random host-side points
     of every step (before the forward pass, between forward and backward, inside the backward pass through a gradient hook on the
     output).  Returns dict(losses, ms_per_step, squats, squat_wg_us)."""
@@ -92,6 +92,9 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
             for k in ("x", "gates", "aux", "y", "y_drop"):
                 if tensors.get(k) is not None:
                     note("layer %d %s" % (l, k), tensors[k])
+            if l == 0 and rows_capture is not None:      # (tools/first_rows_probe.py) the bottom layer's reserve and output at chosen timesteps, kept per step
+                ridx = torch.tensor(rows_capture[0], device=dev)
+                rows_capture[1].append(dict(gates=tensors["gates"][ridx].clone(), y=tensors["y"][ridx].clone()))
             if l == 0:                                   # the bottom layer per (timestep, direction): where along the sequence does a run leave the others?
                 for k in ("gates", "y"):
                     t_ = tensors[k]
