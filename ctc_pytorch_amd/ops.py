@@ -494,7 +494,7 @@ class _RNNLayer(torch.autograd.Function):
         if _debug_note[0] is not None:              # development (tools/squat_stress.py trace): where this call's buffers live, what it read and wrote
             _debug_note[0]("rnn_fwd", dict(I=int(I), x=x.data_ptr(), gates=gates.data_ptr(), aux=aux.data_ptr() if aux is not None else 0, y=y.data_ptr(),
                                            y_drop=y_drop.data_ptr() if y_drop is not None else 0, ws=w.data_ptr(), w_ih=ws[0].data_ptr(), w_hh=ws[1].data_ptr()),
-                           dict(x=x, y=y, gates=gates, aux=aux, y_drop=y_drop))
+                           dict(x=x, y=y, gates=gates, aux=aux, y_drop=y_drop, w_ih=(ws[0], ws[2])))
         if piped:
             # by the time the recurrence ends the side stream's GEMMs have long finished (the kernel waited for their counter); the join
             # only tells the allocator and the following kernels so

@@ -129,6 +129,58 @@ if "rec" in parts or "layer" in parts:
             ops.set_option("rnn_recurrence_only", 0)
     del pre, gates, y_ref, g_ref, aux, y
 
+if "rec2" in parts or "layer2" in parts:
+    # two inputs A / B alternate: a stale read shows WHICH older content it returned (the other input's pre-activations, the activations the
+    # previous launch left in the reserve, or something else)
+    xs = [x, x * 1.7 + 0.3]
+    pres = [torch.empty(T, B, D, GH, device=dev) for _ in xs]
+    x_keep = x
+    for k_ in range(2):
+        x = xs[k_]; project(pres[k_])
+    gates = torch.empty_like(pres[0]); aux = torch.empty(T, B, D, H, device=dev); y = torch.empty(T, B, D * H, device=dev)
+    for part in ("rec2", "layer2"):
+        if part not in parts:
+            continue
+        ops.set_option("rnn_recurrence_only", 1 if part == "rec2" else 0)
+        try:
+            refs = []
+            for k_ in range(2):
+                x = xs[k_]
+                gates.copy_(pres[k_]); rnn_fwd(gates, y, aux); refs.append((y.clone(), gates.clone()))
+            bad = 0
+            t0_ = time.time()
+            for i in range(N):
+                k_ = i % 2
+                x = xs[k_]
+                if part == "rec2":
+                    gates.copy_(pres[k_])
+                rnn_fwd(gates, y, aux)
+                if not torch.equal(y.view(torch.int32), refs[k_][0].view(torch.int32)):
+                    bad += 1
+                    if bad <= 6:
+                        info = []
+                        for d, t in ((0, 0), (1, T - 1), (0, 1), (1, T - 2)):
+                            m = gates[t, :, d].view(torch.int32) != refs[k_][1][t, :, d].view(torch.int32)
+                            if not bool(m.any()):
+                                continue
+                            idx = torch.nonzero(m)
+                            bs = sorted(set(idx[:, 0].tolist())); cs = sorted(set((idx[:, 1] // 16).tolist()))
+                            # candidates for what a wrong element was computed from (step 0: r, z = sigmoid(pre), n = tanh(pre))
+                            def act(p_):
+                                a_ = p_[t, :, d].clone(); a_[:, :2 * H] = torch.sigmoid(a_[:, :2 * H]); a_[:, 2 * H:] = torch.tanh(a_[:, 2 * H:]); return a_
+                            got = gates[t, :, d][m]
+                            cand = dict(this_input=act(pres[k_])[m], other_input=act(pres[1 - k_])[m], act_of_prev_reserve=act(refs[1 - k_][1])[m], prev_reserve=refs[1 - k_][1][t, :, d][m],
+                                        this_next_t=act(pres[k_].roll(-1 if d == 0 else 1, 0))[m], other_next_t=act(pres[1 - k_].roll(-1 if d == 0 else 1, 0))[m])
+                            info.append(dict(t=t, d=d, n=int(m.sum()), batch_rows=bs, slices16=cs[:12], close_to={k2: float((v2 - got).abs().max()) for k2, v2 in cand.items()},
+                                             sample=[float(v_) for v_ in got[:3]], expected=[float(v_) for v_ in refs[k_][1][t, :, d][m][:3]]))
+                        emit(part=part, iteration=i, input=k_, detail=info)
+            ops.check_health(dev)
+            emit(part=part, n=N, deviating=bad, seconds=round(time.time() - t0_, 1), kernel=ops.rnn_last_kernels()[0])
+        finally:
+            ops.set_option("rnn_recurrence_only", 0)
+    x = x_keep
+    del pres, gates, aux, y
+
 if "runs" in parts:
     import squat_stress
     arms = []
@@ -146,7 +198,7 @@ if "runs" in parts:
                 ops.set_option(k, v)
             cap = []
             try:
-                r = squat_stress.run("cfg4", 12, squat=False, seed=i + 1, dev=dev, trace=True, rows_capture=(rows, cap))
+                r = squat_stress.run("cfg4", 12, squat=(os.environ.get("CTCN_PROBE_SQUAT") == "alt" and i % 2 == 1), seed=i + 1, dev=dev, trace=True, rows_capture=(rows, cap))
             finally:
                 for k, v in found:
                     ops.set_option(k, v)
@@ -161,6 +213,28 @@ if "runs" in parts:
                     gd = describe(a_["gates"], b_["gates"], TT, 64, 2, 1536, rows)
                     yd = describe(a_["y"].view(len(rows), 64, 2, 512), b_["y"].view(len(rows), 64, 2, 512), TT, 64, 2, 512, rows)
                     emit(part="runs", arm=name, run=i, step=step, gates=gd[:16], y=yd[:16], losses=r["losses"][:step + 2])
+                    # which pre-activation was a wrong first-step element computed from?  r, z = sigmoid(a): a_got = logit(got), compared with the pre-activations
+                    # (f32 matmul in the hook) of every kept timestep, both directions, this step and the previous one
+                    for d_, ti in ((0, 0), (1, len(rows) - 1)):
+                        m = (a_["gates"][ti, :, d_, :1024].view(torch.int32) != b_["gates"][ti, :, d_, :1024].view(torch.int32))
+                        if not bool(m.any()) or int(m.sum()) > 4096 or b_.get("pre") is None:
+                            continue
+                        got = b_["gates"][ti, :, d_, :1024][m].double()
+                        a_got = torch.log(got / (1 - got))
+                        cands = {}
+                        for nm, capk in (("this", cap[step]), ("prev", cap[step - 1] if step > 0 else rc[-1]), ("next", cap[step + 1] if step + 1 < len(cap) else None)):
+                            if capk is None or capk.get("pre") is None:
+                                continue
+                            for tj in range(len(rows)):
+                                for dj in (0, 1):
+                                    cands["%s t=%d d=%d" % (nm, rows[tj], dj)] = float((capk["pre"][tj, :, dj, :1024][m].double() - a_got).abs().max())
+                        best = sorted(cands.items(), key=lambda kv: kv[1])[:5]
+                        # GRU: aux = hn = the recurrent product of the n gate, exactly 0 at a direction's first step
+                        auxrow = b_["aux"][ti, :, d_] if b_.get("aux") is not None else None
+                        aux_info = dict(nonzero=int((auxrow != 0).sum()), maxabs=float(auxrow.abs().max()), rows=sorted(set(torch.nonzero(auxrow)[:, 0].tolist())),
+                                        slices16=sorted(set((torch.nonzero(auxrow)[:, 1] // 16).tolist())), sample=[float(v_) for v_ in auxrow[auxrow != 0][:6]]) if auxrow is not None else None
+                        emit(part="runs-source", arm=name, run=i, step=step, d=d_, t=rows[ti], n=int(m.sum()), best=best, aux_first_step=aux_info, expected=cands.get("this t=%d d=%d" % (rows[ti], d_)),
+                             sample_a_got=[float(v_) for v_ in a_got[:4]], sample_pre_this=[float(v_) for v_ in cap[step]["pre"][ti, :, d_, :1024][m][:4]])
                     if saved < 4:                     # the differing elements themselves (sparse)
                         m = torch.nonzero(a_["gates"].view(torch.int32) != b_["gates"].view(torch.int32))[:400000]
                         np.savez_compressed(os.path.join(os.path.dirname(OUT), "rows_%s_run%d_step%d.npz" % (name, i, step)), rows=np.array(rows), index=m.cpu().numpy(),

@@ -220,4 +220,43 @@ PY
   CTCN_AFTER_SUITE=$R/tools/first_rows_probe.py CTCN_PROBE_OUT=$O/probe.jsonl CTCN_PROBE_N=${PROBE_N:-1000} CTCN_PROBE_RUNS=${PROBE_RUNS:-30} timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s -k "item_gather_edge or batch_chunks_equal" > $O/pytest.log 2>&1
   grep "^\[probe\]" $O/pytest.log | cut -c1-1800; tail -n 3 $O/pytest.log | cut -c1-300
   ;;
+22)
+  # does session 20's condition come back with the rnn_dbg build (a) after_suite_ab as in session 20, (b) the probe's runs part alone, squatters on every other run
+  i=0
+  for sel in "item_gather_edge" "batch_chunks_equal"; do
+    i=$((i+1))
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=30 CTCN_AFTER_SUITE_PHASES=order1 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-80)" | tee -a $O/summary.log
+  done
+  CTCN_AFTER_SUITE=$R/tools/first_rows_probe.py CTCN_PROBE_OUT=$O/probe.jsonl CTCN_PROBE_PARTS=runs CTCN_PROBE_ARMS="base:" CTCN_PROBE_SQUAT=alt CTCN_PROBE_RUNS=40 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s -k "item_gather_edge or batch_chunks_equal" > $O/pytest.log 2>&1
+  grep "^\[probe\]" $O/pytest.log | cut -c1-2500; tail -n 1 $O/pytest.log | cut -c1-300
+  ;;
+23)
+  # is the condition a property of the BUILD?  the previous library (HEAD~rnn_dbg) and the rnn_dbg one, alternating on one box (tools/libctcn_{prev,dbg}.so are built by hand)
+  cp ctc_pytorch_amd/libctcn.so $O/libctcn_keep.so
+  i=0
+  for rep in 1 2; do for lib in prev dbg; do for sel in "item_gather_edge" "batch_chunks_equal"; do
+    i=$((i+1))
+    cp tools/libctcn_$lib.so ctc_pytorch_amd/libctcn.so
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=30 CTCN_AFTER_SUITE_PHASES=order1 timeout 600 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "$i lib $lib [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-80)" | tee -a $O/summary.log
+  done; done; done
+  cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
+  ;;
+24)
+  # the element pattern of a deviating bottom layer, with the library that shows the condition (tools/libctcn_prev.so)
+  cp ctc_pytorch_amd/libctcn.so $O/libctcn_keep.so
+  cp tools/libctcn_${LIBV:-prev}.so ctc_pytorch_amd/libctcn.so
+  CTCN_AFTER_SUITE=$R/tools/first_rows_probe.py CTCN_PROBE_OUT=$O/probe.jsonl CTCN_PROBE_PARTS=runs CTCN_PROBE_ARMS="${ARMS:-base:,rsv0:fwd_rsv_lds=0,order0:rnn_proj_order=0}" CTCN_PROBE_SQUAT=alt CTCN_PROBE_RUNS=${PROBE_RUNS:-40} timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s -k "batch_chunks_equal" > $O/pytest.log 2>&1
+  cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
+  grep "^\[probe\]" $O/pytest.log | cut -c1-3000; tail -n 1 $O/pytest.log | cut -c1-300
+  ;;
+25)
+  # a fast reproducer?  the stand-alone stress parts with the library that shows the condition, two alternating inputs (which older content does a stale read return)
+  cp ctc_pytorch_amd/libctcn.so $O/libctcn_keep.so
+  cp tools/libctcn_${LIBV:-prev}.so ctc_pytorch_amd/libctcn.so
+  CTCN_AFTER_SUITE=$R/tools/first_rows_probe.py CTCN_PROBE_OUT=$O/probe.jsonl CTCN_PROBE_PARTS=${PARTS:-gemm,rec2,layer2} CTCN_PROBE_N=${PROBE_N:-4000} timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s -k "batch_chunks_equal" > $O/pytest.log 2>&1
+  cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
+  grep "^\[probe\]" $O/pytest.log | cut -c1-3000; tail -n 1 $O/pytest.log | cut -c1-300
+  ;;
 esac

@@ -94,7 +94,9 @@ def run(workload="cfg2", steps=60, squat=True, seed=1, max_wgs=12, max_us=4000, 
                     note("layer %d %s" % (l, k), tensors[k])
             if l == 0 and rows_capture is not None:      # (tools/first_rows_probe.py) the bottom layer's reserve and output at chosen timesteps, kept per step
                 ridx = torch.tensor(rows_capture[0], device=dev)
-                rows_capture[1].append(dict(gates=tensors["gates"][ridx].clone(), y=tensors["y"][ridx].clone()))
+                xr = tensors["x"][ridx]                                    # (rows, B, I); the pre-activations the projection should have produced (f32 matmul, ~1e-6)
+                pre = torch.stack([xr @ w_.t() for w_ in tensors["w_ih"]], dim=2) if tensors.get("w_ih") and tensors["w_ih"][1] is not None else None
+                rows_capture[1].append(dict(gates=tensors["gates"][ridx].clone(), y=tensors["y"][ridx].clone(), pre=pre, aux=tensors["aux"][ridx].clone() if tensors.get("aux") is not None else None))
             if l == 0:                                   # the bottom layer per (timestep, direction): where along the sequence does a run leave the others?
                 for k in ("gates", "y"):
                     t_ = tensors[k]
