@@ -57,8 +57,8 @@ static int g_opt_tn_splits_xcd = 1;     // TN weight-gradient tile: split count 
 static int g_opt_beam_generic_threads = 0;  // generic beam kernel: 0 = 256 threads per utterance up to W = 64 and 1 024 beyond; 256 / 1024 = forced
 static int g_opt_beam_occ2 = 0;         // fast beam search compiled / launched for TWO workgroups per CU (<= 64 VGPRs, <= 80 KB LDS): 0 off, 1 on, 2 on with the LM in global memory
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
-static int g_opt_rnn_proj_order = 1;     // input projection of a recurrent layer as row blocks [T/2, T) then [0, T/2) (pipelined: last chunk before the first): the rows a recurrence starts on are never the rows written last (rnn.hip)
-static int g_opt_rnn_dbg = 0;             // development (round 6, the cfg4 divergence): bit 0 rnn_fwd_tagged clears its own tile dwords, bit 1 host synchronises between memset and launch, bit 2 agent acquire in the kernel prologue, bit 3 host synchronises behind the projection
+static int g_opt_rnn_proj_order = 0;     // 1: input projection of a recurrent layer as row blocks [T/2, T) then [0, T/2) (round 6 mitigation attempt; bit-identical; off: the cause was elsewhere, include/ctcn.h)
+static int g_opt_rnn_slow_items = 0;    // parity harness: > 0 = rnn_fwd_tagged runs its SLOW instantiation, the item waves sleeping this many x 64 cycles before they read the parked tiles (every step): results must not change
 static int g_opt_xcd_interleave_force = 0;  // development / parity harness: apply "xcd_interleave" to a recurrence that takes EVERY XCD too (rnn.hip: xcd_order_for)
 static int *g_status_dev = nullptr;
 
@@ -102,7 +102,7 @@ static const OptionRow k_options[] = {
   {"gemm_tile256", &g_opt_gemm_tile256, [](int value) -> int { return value ? 1 : 0; }},
   {"rnn_proj_order", &g_opt_rnn_proj_order, [](int value) -> int { return value ? 1 : 0; }},
   {"xcd_interleave_force", &g_opt_xcd_interleave_force, [](int value) -> int { return value ? 1 : 0; }},
-  {"rnn_dbg", &g_opt_rnn_dbg, [](int value) -> int { return value & 0xff; }},
+  {"rnn_slow_items", &g_opt_rnn_slow_items, [](int value) -> int { return value < 0 ? 0 : (value > 4096 ? 4096 : value); }},
 };
 static const int k_noptions = (int)(sizeof(k_options) / sizeof(k_options[0]));
 static const OptionRow *find_option(const char *name) {

@@ -397,7 +397,7 @@ struct PersistArgs {
   int poll_delay;       // rnn_fwd_tagged: 64-cycle sleeps between the barrier and an exchange wave's first poll of a step
   int chunk_T, nchunk;  // rnn_fwd_tagged, pipelined input projection: frames per time chunk (0 = all pre-activations are there at launch)
   unsigned *chunk_ready; //   ... and the counter the side stream raises after each chunk PAIR (p covers chunks p and nchunk-1-p)
-  int dbg;               // option "rnn_dbg" (development)
+  int slow;              // option "rnn_slow_items" (parity harness): the SLOW instantiation of rnn_fwd_tagged, whose item waves sleep this many x 64 cycles before they read the parked tiles
   int xperm;             // option "xcd_interleave" (eight XCDs): which physical XCD is logical XCD g, i.e. hosts group g (persist_role)
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
@@ -988,12 +988,22 @@ bool launch_fwd_persist(int prec, int nt, int kq4, dim3 grid, size_t lds, hipStr
 // c / hn, h and the dropped h as float32 [array][row][unit]; after the next barrier, in the pause before its first poll, exchange wave a
 // stores array a of the PREVIOUS step with ONE 16-B store per lane (64 B contiguous per row); item wave g brings gate g's pre-activations of
 // step s + 2 into a 3-deep LDS ring with ONE global_load_lds_dwordx4 (counted vmcnt wait before the barrier, as rnn_bwd_scatter2).
-template <int NBW, int CELL, bool RSV = false>
+// (round 6) The parked tiles are DOUBLE BUFFERED by step parity.  With one barrier per step the exchange waves enter step s + 1 while the item waves
+// still read the tiles of step s, and nothing but time kept a wave that found its blocks of h_s already published (by workgroups ahead of this one)
+// from parking step s + 1 over them: ~1 000 cycles of poll pause, round trip and MFMAs against ~300 of reading -- unless the item waves stall.  At a
+// direction's FIRST step they do (their code is not in the instruction cache yet): the cfg4 divergence of round 6 -- in ~1 % of the training steps
+// some item waves of one or a few bottom-layer workgroups added partial products of step 1 to their pre-activations of step 0 (the saved W_hn h of the
+// GRU, exactly 0 at that step, was not; profiles/r06_divergence_root_cause.txt), depending on where the code object lay in memory (per process) and on
+// the build.  With two buffers the tiles of step s are next written in step s + 2, behind barrier s + 1, which an item wave passes only after its reads.
+// SLOW: the parity harness's instantiation (option "rnn_slow_items"): the item waves sleep pa.slow x 64 cycles before they read the tiles, every step --
+// results must not change (tests/test_gpu_kernels.py:test_rnn_fwd_tagged_with_slow_item_waves).
+template <int NBW, int CELL, bool RSV = false, bool SLOW = false>
 __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
   constexpr int NGW = 12, NMT = 4;                           // exchange waves, MFMA tiles (4 units x 4 gates each) per workgroup
   constexpr int PQ = 17;                                     // parked slots per (tile, unit) row: 16 batch rows + 1 (bank spread)
+  constexpr int RED_N = NGW * NMT * 4 * PQ * 4;              // floats of one set of parked tiles
   const RnnArgs &p = pa.a;
-  __shared__ __attribute__((aligned(16))) float red[NGW * NMT * 4 * PQ * 4];
+  __shared__ __attribute__((aligned(16))) float red2[2 * RED_N];
   __shared__ uint4 dropw[4][64];                   // fused dropout: the Philox groups of an item wave's next four steps
   __shared__ __attribute__((aligned(16))) float outq[RSV ? 2 : 1][RSV ? 7 : 1][RSV ? 256 : 4];   // RSV: values to store, by step parity
   __shared__ __attribute__((aligned(16))) float preq[RSV ? 3 : 1][RSV ? 4 : 1][RSV ? 256 : 4];   // RSV: pre-activations of three steps
@@ -1062,14 +1072,6 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
       *reinterpret_cast<f32x4 *>(dst) = v;
     }
   };
-  if (pa.dbg & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (pa.dbg & 1) {
-    if (tid < 256) {
-      __builtin_amdgcn_raw_buffer_store_b32(0u, rs, tile_b[0] + pub_off, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(0u, rs, tile_b[1] + pub_off, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
   if constexpr (RSV) {
     if (wave < G) { pre_dma(0, 0); pre_dma(1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1091,6 +1093,11 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
 
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
+#ifndef CTCN_RED_SINGLE
+    float *const red = red2 + (s & 1) * RED_N;                // the parked tiles of this step
+#else
+    float *const red = red2;                                  // (tools: the single buffer of rounds 2-5, to show that the SLOW test catches it)
+#endif
 #ifdef CTCN_PERSIST_STATS
     const long long z_a = clock64();
     long long z_p = z_a, z_m = z_a;
@@ -1171,6 +1178,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
     long long z_i1 = z_b, z_i2 = z_b, z_i3 = z_b;
 #endif
     if (wave < 4) {
+      if constexpr (SLOW) { for (int i = 0; i < pa.slow; ++i) __builtin_amdgcn_s_sleep(1); }
       if constexpr (RSV) {
         pre[0] = preq[pset][0][tid]; pre[1] = preq[pset][1][tid]; pre[2] = preq[pset][2][tid];
         if constexpr (G == 4) pre[3] = preq[pset][RSV ? 3 : 0][tid];
@@ -1298,20 +1306,24 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
     }
 }
 
-template <int CELL>
-bool launch_fwd_tagged_c(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+template <int CELL, bool SLOW>
+bool launch_fwd_tagged_cs(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
   if (a.poll_depth & 256) {       // option "fwd_rsv_lds": reserve traffic through LDS (16-B aligned reserves)
     switch (nbw) {
-      case 1: return launch_resident(rnn_fwd_tagged<1, CELL, true>, grid, 1024, 0, st, a, wpx);
-      case 2: return launch_resident(rnn_fwd_tagged<2, CELL, true>, grid, 1024, 0, st, a, wpx);
+      case 1: return launch_resident(rnn_fwd_tagged<1, CELL, true, SLOW>, grid, 1024, 0, st, a, wpx);
+      case 2: return launch_resident(rnn_fwd_tagged<2, CELL, true, SLOW>, grid, 1024, 0, st, a, wpx);
       default: return false;
     }
   }
   switch (nbw) {
-    case 1: return launch_resident(rnn_fwd_tagged<1, CELL>, grid, 1024, 0, st, a, wpx);
-    case 2: return launch_resident(rnn_fwd_tagged<2, CELL>, grid, 1024, 0, st, a, wpx);
+    case 1: return launch_resident(rnn_fwd_tagged<1, CELL, false, SLOW>, grid, 1024, 0, st, a, wpx);
+    case 2: return launch_resident(rnn_fwd_tagged<2, CELL, false, SLOW>, grid, 1024, 0, st, a, wpx);
     default: return false;
   }
+}
+template <int CELL>
+bool launch_fwd_tagged_c(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  return a.slow > 0 ? launch_fwd_tagged_cs<CELL, true>(nbw, grid, st, a, wpx) : launch_fwd_tagged_cs<CELL, false>(nbw, grid, st, a, wpx);
 }
 bool launch_fwd_tagged(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
   if (a.a.cell == CTCN_CELL_LSTM) return launch_fwd_tagged_c<CTCN_CELL_LSTM>(nbw, grid, st, a, wpx);
@@ -2598,15 +2610,9 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
   // three pairs: 13.78): the extra pair costs its 75 us here and takes only ~25 off the recurrence.  The slowdown goes with the TIME the bf16x3
   // chunk GEMMs run next to the recurrence, ~30 us per pair, and is gone with the single-product tiles of option "gemm_bf16_single" (1 186-
   // 1 190 us for all four layers) although they still run there for 70 % of the time: the matrix pipes' power, not the counter.)
-  // ORDER of the projection's row blocks (round 6, option "rnn_proj_order", default 1).  The reverse direction's first steps read the LAST
-  // time frames of the pre-activations within microseconds of the launch, and with one GEMM over rows in ascending time those are the rows the
-  // GEMM wrote last.  At cfg4's bottom layer (76 800 x 3 072 x 40: 943 MB written in 343 us, 2.75 TB/s) the traced trajectories of round 6
-  // (tools/traj_compare.py, profiles/r06_divergence_*.txt) caught the reverse direction of that layer starting from values other than the
-  // ones the GEMM produced -- 2 of 4 full parity suites, never the forward direction, never another layer, the error largest at t = T - 1 and
-  // decaying along the sequence -- i.e. reads of another XCD's freshest writes behind a kernel boundary.  The blocks are therefore issued so
-  // that the rows BOTH directions start on are written first and the block boundary written last is in the middle of the sequence, ~T/2
-  // dependent steps (a millisecond) away from its first reader: [T/2, T) before [0, T/2); in the pipelined form the last chunk before the
-  // first one.  Same products, same order per output element: bit-identical results.
+  // ORDER of the projection's row blocks (option "rnn_proj_order", default 0 = one product over ascending time; 1 = [T/2, T) then [0, T/2), pipelined:
+  // the last chunk before the first).  Round 6 built the second order while it took the cfg4 divergence for stale reads of the rows a GEMM wrote last;
+  // both orders deviated alike in the after-suite A/Bs (the cause: the parked tiles of rnn_fwd_tagged, above).  Same products, bit-identical results.
   const bool safe_order = ctcn_get_option("rnn_proj_order") != 0 && T >= 16;
   if (piped) {
     int rc = project_chunk(safe_order ? NCHUNK - 1 : 0, ws, ws_bytes, stream, 0, pl_main);
@@ -2727,10 +2733,8 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
           pa.ydrop = call.y_drop; pa.drop_p = call.drop_p; pa.drop_scale = 1.0f / (1.0f - call.drop_p);
           pa.drop_seed = call.drop_seed; pa.drop_off = call.drop_offset;
         }
-        pa.dbg = ctcn_get_option("rnn_dbg");
-        if (pa.dbg & 8) CTCN_HIP(hipStreamSynchronize(st));
+        pa.slow = ctcn_get_option("rnn_slow_items");
         CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | chunk counter | role tickets
-        if (pa.dbg & 2) CTCN_HIP(hipStreamSynchronize(st));
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
           CTCN_LAUNCH_CHECK();

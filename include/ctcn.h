@@ -87,14 +87,16 @@ int ctcn_device_xcds(void);
  * derives its xcd_allow masks from the same order (ops._idle_xcd_mask).  Same results whatever the order.  Measured at cfg2 (two runs each):
  * order 0 13.19 / 13.20 ms per step; orders 1, 3, 4 -- ONE recurrence XCD and one GEMM XCD in every pair (2k, 2k + 1) -- 13.04-13.08; orders 2,
  * 5 -- both XCDs of a pair on the same side -- 13.26-13.31; cfg1 / cfg3 / shipped YAML unchanged.  A recurrence that takes EVERY XCD (cfg4:
- * groups = XCDs) keeps group g on XCD g whatever the option says: there is nothing to place, and the one full parity run made while the order
- * applied to it too ended with a cfg4 loss trajectory that differed from step 4 on in the undisturbed AND the disturbed run of the squatter
- * test alike -- unreproduced since, unexplained, and therefore kept away from that launch.
- * "rnn_proj_order" = 1 (default, round 6): the input projection of a recurrent layer is issued as the row blocks [T/2, T) then [0, T/2) (in the
- * pipelined form: the last time chunk before the first) instead of one product over ascending time, so that the frames a recurrence STARTS on
- * are never the rows the preceding kernel wrote last -- the reverse direction reads frame T - 1 within microseconds of its launch.  Same
- * products, bit-identical results; closes the one trajectory divergence the traced parity suites of round 6 caught (cfg4, bottom layer, reverse
- * direction: DESIGN.md section 8).  0: one product, ascending time (rounds 1-5).
+ * groups = XCDs) keeps group g on XCD g whatever the option says: there is nothing to place.  (The cfg4 trajectory divergence first seen while the
+ * order applied to that launch too had nothing to do with placement: round 6 traced it to the parked tiles of rnn_fwd_tagged)
+ * "rnn_proj_order" = 0 (default): 1 issues the input projection of a recurrent layer as the row blocks [T/2, T) then [0, T/2) (pipelined form:
+ * the last time chunk before the first) instead of one product over ascending time.  Same products, bit-identical results.  Built in round 6 as a
+ * mitigation while the cfg4 trajectory divergence was taken for a stale read behind a kernel boundary; the after-suite A/Bs showed both orders
+ * deviating alike and the cause turned out to be the single-buffered parked tiles of rnn_fwd_tagged (rnn.hip) -- kept as a
+ * switch for the record, off.
+ * "rnn_slow_items" = 0 (parity harness): N > 0 runs the SLOW instantiation of rnn_fwd_tagged, whose item waves sleep N x 64 cycles before they read
+ * the parked partial tiles, at every step.  Results must not change (test_rnn_fwd_tagged_with_slow_item_waves): the hand-off inside a workgroup may
+ * rest on barriers and buffer parity only, never on which wave is faster.
  * "bn_rows4" = 1 (default, round 5): BatchNorm over (rows, C) with C % 4 == 0 forms its column sums with 16-B loads, sixteen row phases per
  * workgroup (colreduce_rows4_kernel); 0: the dword kernel.  Same chunks, same element values, float64 partials grouped differently: the float32
  * results agreed bit for bit wherever compared (tools/bn_rows_probe.py).  cfg2 13.33 -> 13.25 ms per step, cfg4 53.2 -> 52.8.

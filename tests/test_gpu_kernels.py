@@ -530,6 +530,47 @@ def test_rnn_results_do_not_depend_on_the_xcd_order(dev, kind, T, B, I, H, bi, p
             assert torch.equal(a, b), "order %d repetition %d: tensor %d differs from order 0 (max |d| %.3e)" % (key[0], key[1], i, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("kind,T,B,I,H,bi,sleeps", [("gru", 40, 64, 24, 512, True, 48), ("lstm", 50, 32, 40, 320, True, 48), ("lstm", 30, 64, 16, 512, True, 24),
+                                                    ("gru", 25, 9, 16, 128, True, 96), ("lstm", 33, 40, 16, 384, False, 48)])
+def test_rnn_fwd_tagged_with_slow_item_waves(dev, kind, T, B, I, H, bi, sleeps):
+    """Round 6, the cfg4 trajectory divergence: rnn_fwd_tagged has ONE barrier per step, so its exchange waves enter step
+    s + 1 while the item waves still read the parked partial tiles of step s.  With a single set of tiles only time kept a fast exchange wave
+    from parking step s + 1 over them, and at a direction's first step (code not yet in the instruction cache) the item waves could lose that
+    race: their pre-activations of step 0 picked up partial products of step 1.  The tiles are double buffered by step parity now; option
+    "rnn_slow_items" runs the kernel's SLOW instantiation, whose item waves sleep N x 64 cycles before they read the tiles at EVERY step -- far
+    beyond the ~1 000 cycles an exchange wave needs to get there.  Outputs, saved state (through the gradients) and gradients must be
+    bit-identical to the undelayed run.  (tools/libctcn_single.so -- the same source with -DCTCN_RED_SINGLE, the single set of rounds 2-5 -- fails
+    this test on every shape: profiles/r06_divergence_root_cause.txt.)"""
+    from ctc_pytorch_amd import ops
+    ops.set_precision(1)
+    G = {"lstm": 4, "gru": 3}[kind]
+    torch.manual_seed(13)
+    x = torch.randn(T, B, I, device=dev)
+    w = [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)]
+    w += [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)] if bi else [None, None]
+    dy = torch.randn(T, B, (2 if bi else 1) * H, device=dev)
+    runs = []
+    try:
+        for slow in (0, sleeps, 0, sleeps):
+            ops.set_option("rnn_slow_items", slow)
+            xs = x.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) if t is not None else None for t in w]
+            y = ops.rnn_layer(xs, ws[0], ws[1], ws[2], ws[3], kind)
+            y.backward(dy)
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            ops.check_health(dev)
+            assert ops.rnn_last_kernels()[0] == "rnn_fwd_tagged", ops.rnn_last_kernels()
+            runs.append([y.detach().clone(), xs.grad.clone()] + [t.grad.clone() for t in ws if t is not None])
+    finally:
+        ops.set_option("rnn_slow_items", 0)
+    assert all(torch.isfinite(t).all() for t in runs[0])
+    for k, got in enumerate(runs[1:]):
+        for i, (a, b) in enumerate(zip(got, runs[0])):
+            assert torch.equal(a, b), "run %d (item waves %s): tensor %d differs from the undelayed run (max |d| %.3e)" % (
+                k + 1, "delayed" if k % 2 == 0 else "undelayed", i, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 2, 1, 4, 8, True), ("gru", 3, 17, 8, 40, True), ("rnn", 5, 3, 4, 16, False), ("lstm", 2, 64, 16, 512, True),
                                             ("gru", 7, 2, 4, 24, False)])
 def test_rnn_bwd_item_gather_edge_shapes(dev, kind, T, B, I, H, bi):

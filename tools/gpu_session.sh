@@ -259,4 +259,23 @@ PY
   cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
   grep "^\[probe\]" $O/pytest.log | cut -c1-3000; tail -n 1 $O/pytest.log | cut -c1-300
   ;;
+26)
+  # the root cause under test: the SLOW instantiation (item waves delayed at every step) on the single-buffer build (must FAIL) and on the shipped
+  # double-buffered one (must pass); then the after-suite statistics of session 23 for both
+  cp ctc_pytorch_amd/libctcn.so $O/libctcn_keep.so
+  for lib in single keep; do
+    [ $lib = single ] && cp tools/libctcn_single.so ctc_pytorch_amd/libctcn.so || cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so
+    timeout 600 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -k "slow_item_waves" > $O/pytest_slow_$lib.log 2>&1
+    echo "lib $lib, test_rnn_fwd_tagged_with_slow_item_waves: $(tail -n 1 $O/pytest_slow_$lib.log | cut -c1-120)" | tee -a $O/summary.log
+    grep "^E .*differs" $O/pytest_slow_$lib.log | cut -c1-200 | head -n 6 | tee -a $O/summary.log
+  done
+  i=0
+  for lib in keep single keep single; do for sel in "batch_chunks_equal"; do
+    i=$((i+1))
+    [ $lib = single ] && cp tools/libctcn_single.so ctc_pytorch_amd/libctcn.so || cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=40 CTCN_AFTER_SUITE_PHASES=order1 timeout 600 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "$i lib $lib [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-80)" | tee -a $O/summary.log
+  done; done
+  cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
+  ;;
 esac
