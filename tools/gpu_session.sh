@@ -278,4 +278,24 @@ PY
   done; done
   cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
   ;;
+27)
+  # verification at HEAD (double-buffered parked tiles): smoke, the full parity suite (traced), the driver's command
+  python -c 'import __graft_entry__ as g; g.smoke()' > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/summary.log
+  for i in 1; do
+    CTCN_TRAJ_LOG=$O/traj_full_$i.jsonl timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 --timeout 600 -p no:cacheprovider --durations=8 > $O/pytest_full_$i.log 2>&1; echo "full $i rc=$?" >> $O/summary.log
+    python tools/traj_compare.py $O/traj_full_$i.jsonl > $O/traj_compare_$i.txt 2>&1
+    tail -n 12 $O/pytest_full_$i.log | cut -c1-200
+    grep -q "first difference" $O/traj_compare_$i.txt || rm -f $O/traj_full_$i.jsonl
+  done
+  timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?" >> $O/summary.log
+  cat $O/summary.log $O/traj_compare_*.txt | cut -c1-300
+  python - $O/bench_default.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("cfg2 %.3f ms (median %.3f) value %.0f; roofline frac %.4f us/launch %.1f traffic %s; decode %s; wide %s / %s ms" % (
+    d["ms_per_step"], d["ms_per_step_median"], d["value"], d["roofline"]["frac"], d["roofline"]["us_per_launch"], d["roofline"]["traffic"],
+    {k: round(v["value"]) for k, v in d["decode"]["regimes"].items()}, round(d["decode"]["wide_beam"]["peaky"]["ms_per_batch"], 2), round(d["decode"]["wide_beam"]["flat"]["ms_per_batch"], 2)))
+print("recurrence", d["recurrence"], {k: (round(v["ms_per_step"], 3), round(v["fwd_us_per_timestep"], 3), round(v["bwd_us_per_timestep"], 3)) for k, v in d["other_workloads"].items()})
+PY
+  ;;
 esac
