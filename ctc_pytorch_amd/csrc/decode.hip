@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   __shared__ int s_flag, s_nodes, s_best;
   __shared__ int s_scnt, s_ovf;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: per-wave decisions are scalar branches)
   const int b = blockIdx.x, V = a.V, W = a.W, B = a.B, T = a.T, blank = a.blank;
   double *lg = dsm;
   double *cand = a.cand_in_lds ? dsm + V : a.cand_global + (size_t)b * W * V;
@@ -291,7 +291,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       {
         const int kth = (W + NWV - 1) / NWV;
         unsigned long long p = 0ull;
-        for (int bit = 63; bit >= 0; --bit) {
+        // (round 6: the low 20 bits of the key are not searched -- the result is a LOWER bound of the wave's k-th largest maximum either way, 2^-32
+        // relative below it at most: a survivor more once in a while, 20 ballot steps fewer every frame)
+        for (int bit = 63; bit >= 20; --bit) {
           const unsigned long long t = p | (1ull << bit);
           int cnt = __popcll(__ballot(tk[0] >= t));
           if (NH == 2) cnt += __popcll(__ballot(tk[NH - 1] >= t));
@@ -303,30 +305,36 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       __syncthreads();
       // the waves' values are NWV candidate bounds; the smallest is always valid, a larger one is valid whenever W of ALL the maxima still reach
       // it: every wave counts its own maxima against every candidate (NWV ballots), the largest candidate with a block-wide count >= W wins --
-      // the survivors drop from ~1.9 W to ~1.2 W at W = 200, and a wave that has no k candidates (narrow beam) no longer voids the bound
-#pragma nounroll
+      // the survivors drop from ~1.9 W to ~1.2 W at W = 200, and a wave that has no k candidates (narrow beam) no longer voids the bound.
+      // (round 6: lane j keeps candidate j in registers and v_readlane broadcasts it -- no chain of dependent LDS reads; every wave forms the
+      // block-wide counts itself from the waves' rows, so two barriers instead of three)
+      const unsigned long long tj = wthr[lane < NWV ? lane : 0];
+      const int tj_lo = (int)(unsigned)(tj & 0xffffffffull), tj_hi = (int)(unsigned)(tj >> 32);
+      int mycnt = 0;
       for (int j = 0; j < NWV; ++j) {
-        const unsigned long long t = wthr[j];
+        const unsigned long long t = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(tj_hi, j) << 32) | (unsigned)__builtin_amdgcn_readlane(tj_lo, j);
         int cnt = __popcll(__ballot(tk[0] >= t));
         if (NH == 2) cnt += __popcll(__ballot(tk[NH - 1] >= t));
-        if (lane == 0) wcnt[wave][j] = t != 0ull ? cnt : 0;
+        mycnt = lane == j ? (t != 0ull ? cnt : 0) : mycnt;
       }
+      if (lane < NWV) wcnt[wave][lane] = mycnt;
       __syncthreads();
-      if (tid < NWV) {                                   // thread j: how many of ALL the maxima reach candidate j
-        int reach = 0;
-#pragma nounroll
-        for (int w = 0; w < NWV; ++w) reach += wcnt[w][tid];
-        wcnt[0][tid] = reach;                            // (row 0 is read by its own column's thread only)
+      int reach = 0, total = 0;
+      {
+        const int jl = lane < NWV ? lane : 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) reach += wcnt[w][jl];
+        total = lane < NWV ? red_i[jl] : 0;
       }
-      __syncthreads();
-      int total = 0;
-      unsigned long long theta = 0ull;
-#pragma nounroll
-      for (int j = 0; j < NWV; ++j) {
-        total += red_i[j];
-        const unsigned long long t = wthr[j];
-        if (wcnt[0][j] >= W && t > theta) theta = t;
+      unsigned long long theta = (lane < NWV && reach >= W) ? tj : 0ull;
+#pragma unroll
+      for (int o = 1; o < NWV; o <<= 1) {
+        total += __shfl_xor(total, o, 64);
+        const unsigned long long ot = __shfl_xor(theta, o, 64);
+        theta = ot > theta ? ot : theta;
       }
+      total = __shfl(total, 0, 64);
+      theta = __shfl(theta, 0, 64);
       GSTAMP(9);
       // (no candidate bound that W maxima reach -- the first frames, when the beam is still narrow --: then everything valid is ranked, if it fits)
       const bool prune = total > W && theta != 0ull;

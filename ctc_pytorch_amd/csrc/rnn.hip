@@ -1063,13 +1063,22 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
     const int sc = min(step, T - 1), ts = d == 0 ? sc : T - 1 - sc;
     __builtin_amdgcn_global_load_lds((gptr_t)(p.gates + (size_t)ts * slab_g + xg + (size_t)wave * H), (lptr_t)&preq[set][RSV ? wave : 0][0], 16, 0, 0);
   };
+  // (round 6) the store goes through the tensors' loop-invariant buffer resources (SGPRs), a per-lane byte offset that never changes and the timestep as
+  // the scalar offset: with 64-bit pointers hipcc kept the per-array base addresses in a table in memory and in scratch, and every exchange wave that
+  // stores an array fetched them -- two dependent memory round trips -- in the pause in front of its first poll
+  // (array a on exchange wave a.  Measured and not kept: array a on wave 11 - a, so that the waves that own TWO blocks of the contraction at H = 512 -- waves
+  // 0 .. 3 -- keep their pause free: cfg4 forward 2.22 -> 2.36 us per step; their later first poll is the better one)
+  const int sa = gw;
+  const unsigned sv_off = (unsigned)((sa < 4 ? xg + (size_t)(sa < 0 ? 0 : sa) * H : xh) * 4);
   auto service_store = [&](int step) {             // exchange wave a: array a of `step`, one 16-B store per lane
-    const int ts = d == 0 ? step : T - 1 - step, a = gw;
+    const int ts = d == 0 ? step : T - 1 - step, a = sa;
     if (a < 7 && xvalid && (a < G || a == 4 || a == 5 || (a == 6 && pa.ydrop))) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(&outq[RSV ? step & 1 : 0][RSV ? a : 0][RSV ? lane * 4 : 0]);
-      float *dst = a < 4 ? p.gates + (size_t)ts * slab_g + xg + (size_t)a * H
-                         : (a == 4 ? p.aux : (a == 5 ? p.y : pa.ydrop)) + (size_t)ts * slab_h + xh;
-      *reinterpret_cast<f32x4 *>(dst) = v;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(&outq[RSV ? step & 1 : 0][RSV ? a : 0][RSV ? lane * 4 : 0]);
+      const unsigned og_ = __builtin_amdgcn_readfirstlane((unsigned)ts * sg_b), oh_ = __builtin_amdgcn_readfirstlane((unsigned)ts * sh_b);   // uniform: SGPR operands, no waterfall
+      if (a < 4) __builtin_amdgcn_raw_buffer_store_b128(v, rg, sv_off, og_, 0);
+      else if (a == 4) __builtin_amdgcn_raw_buffer_store_b128(v, ra, sv_off, oh_, 0);
+      else if (a == 5) __builtin_amdgcn_raw_buffer_store_b128(v, ry, sv_off, oh_, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(v, ryd, sv_off, oh_, 0);
     }
   };
   if constexpr (RSV) {

@@ -298,4 +298,37 @@ print("cfg2 %.3f ms (median %.3f) value %.0f; roofline frac %.4f us/launch %.1f 
 print("recurrence", d["recurrence"], {k: (round(v["ms_per_step"], 3), round(v["fwd_us_per_timestep"], 3), round(v["bwd_us_per_timestep"], 3)) for k, v in d["other_workloads"].items()})
 PY
   ;;
+28)
+  # A/B of a forward-recurrence edit: parity subset, then cfg4 / cfg2 steps (LIBB = the library to compare with, tools/libctcn_<LIBB>.so)
+  timeout 900 python -m pytest tests -m gpu -q --maxfail=8 --timeout 600 -p no:cacheprovider -k "rnn or model_three or large_shape or lstm or gru or run_epoch or foreign or soak or stateless or full_size" > $O/pytest_sub.log 2>&1; echo "pytest rc=$?" > $O/summary.log; tail -n 3 $O/pytest_sub.log | cut -c1-200
+  cp ctc_pytorch_amd/libctcn.so $O/libctcn_keep.so
+  for rep in 1 2; do for lib in keep ${LIBB:-base}; do
+    [ $lib = keep ] && cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so || cp tools/libctcn_$lib.so ctc_pytorch_amd/libctcn.so
+    for wl in cfg4 cfg2; do
+      timeout 400 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc --no-ragged --no-sync-bn-cost > $O/bench_${lib}_${wl}_$rep.json 2> $O/bench_${lib}_${wl}_$rep.err
+    done
+  done; done
+  cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
+  python - $O <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], "%.3f ms (median %.3f)  fwd %.3f bwd %.3f us/step" % (d["ms_per_step"], d["ms_per_step_median"], d["recurrence"]["fwd_us_per_timestep"], d["recurrence"]["bwd_us_per_timestep"]))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+  cat $O/summary.log
+  ;;
+29)
+  # cfg4 forward: sweep of the exchange waves' pause before their first poll (option tag_poll_delay, x 64 cycles; 8 was tuned at cfg2)
+  for v in ${SWEEP:-8 12 16 20 24 8}; do
+    CTCN_OPT_TAG_POLL_DELAY=$v timeout 400 python bench.py --workload ${WL:-cfg4} --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc --no-ragged --no-sync-bn-cost > $O/bench_$v.json 2> $O/bench_$v.err
+    python - $O/bench_$v.json $v <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("tag_poll_delay %s: %.3f ms (median %.3f)  fwd %.3f bwd %.3f us/step" % (sys.argv[2], d["ms_per_step"], d["ms_per_step_median"], d["recurrence"]["fwd_us_per_timestep"], d["recurrence"]["bwd_us_per_timestep"]))
+PY
+  done
+  ;;
 esac
