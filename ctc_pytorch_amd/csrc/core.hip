@@ -59,6 +59,7 @@ static int g_opt_beam_occ2 = 0;         // fast beam search compiled / launched 
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
 static int g_opt_rnn_proj_order = 0;     // 1: input projection of a recurrent layer as row blocks [T/2, T) then [0, T/2) (round 6 mitigation attempt; bit-identical; off: the cause was elsewhere, include/ctcn.h)
 static int g_opt_rnn_slow_items = 0;    // parity harness: > 0 = rnn_fwd_tagged runs its SLOW instantiation, the item waves sleeping this many x 64 cycles before they read the parked tiles (every step): results must not change
+static int g_opt_rnn_slow_exchange = 0; // parity harness: as rnn_slow_items, for the exchange waves (before their first LDS / global read of a step)
 static int g_opt_xcd_interleave_force = 0;  // development / parity harness: apply "xcd_interleave" to a recurrence that takes EVERY XCD too (rnn.hip: xcd_order_for)
 static int *g_status_dev = nullptr;
 
@@ -102,6 +103,7 @@ static const OptionRow k_options[] = {
   {"gemm_tile256", &g_opt_gemm_tile256, [](int value) -> int { return value ? 1 : 0; }},
   {"rnn_proj_order", &g_opt_rnn_proj_order, [](int value) -> int { return value ? 1 : 0; }},
   {"xcd_interleave_force", &g_opt_xcd_interleave_force, [](int value) -> int { return value ? 1 : 0; }},
+  {"rnn_slow_exchange", &g_opt_rnn_slow_exchange, [](int value) -> int { return value < 0 ? 0 : (value > 4096 ? 4096 : value); }},
   {"rnn_slow_items", &g_opt_rnn_slow_items, [](int value) -> int { return value < 0 ? 0 : (value > 4096 ? 4096 : value); }},
 };
 static const int k_noptions = (int)(sizeof(k_options) / sizeof(k_options[0]));

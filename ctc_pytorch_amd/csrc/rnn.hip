@@ -397,7 +397,7 @@ struct PersistArgs {
   int poll_delay;       // rnn_fwd_tagged: 64-cycle sleeps between the barrier and an exchange wave's first poll of a step
   int chunk_T, nchunk;  // rnn_fwd_tagged, pipelined input projection: frames per time chunk (0 = all pre-activations are there at launch)
   unsigned *chunk_ready; //   ... and the counter the side stream raises after each chunk PAIR (p covers chunks p and nchunk-1-p)
-  int slow;              // option "rnn_slow_items" (parity harness): the SLOW instantiation of rnn_fwd_tagged, whose item waves sleep this many x 64 cycles before they read the parked tiles
+  int slow, slow_x;      // options "rnn_slow_items" / "rnn_slow_exchange" (parity harness): the SLOW instantiations of the persistent kernels -- item / exchange waves sleep this many x 64 cycles at the start of their phase of every step
   int xperm;             // option "xcd_interleave" (eight XCDs): which physical XCD is logical XCD g, i.e. hosts group g (persist_role)
   int nbig, hsu_small;  // forward, mixed slices (nbig > 0): slices 0 .. nbig-1 own `hsu` units each, the others `hsu_small`
   int poll_depth;       // XCD-local mode: flag polls kept in flight (1..4)
@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(1024) void rnn_fwd_tagged(PersistArgs pa) {
     long long z_p = z_a, z_m = z_a;
 #endif
     if (wave >= 4) {
+      if constexpr (SLOW) { for (int i = 0; i < pa.slow_x; ++i) __builtin_amdgcn_s_sleep(1); }
       f32x4 acc[NMT];
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt) acc[mt] = zero;
@@ -1332,7 +1333,7 @@ bool launch_fwd_tagged_cs(int nbw, dim3 grid, hipStream_t st, const PersistArgs 
 }
 template <int CELL>
 bool launch_fwd_tagged_c(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
-  return a.slow > 0 ? launch_fwd_tagged_cs<CELL, true>(nbw, grid, st, a, wpx) : launch_fwd_tagged_cs<CELL, false>(nbw, grid, st, a, wpx);
+  return (a.slow > 0 || a.slow_x > 0) ? launch_fwd_tagged_cs<CELL, true>(nbw, grid, st, a, wpx) : launch_fwd_tagged_cs<CELL, false>(nbw, grid, st, a, wpx);
 }
 bool launch_fwd_tagged(int nbw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
   if (a.a.cell == CTCN_CELL_LSTM) return launch_fwd_tagged_c<CTCN_CELL_LSTM>(nbw, grid, st, a, wpx);
@@ -1650,7 +1651,9 @@ __global__ __launch_bounds__(1024) void rnn_bwd_persist(PersistArgs pa) {
 // ================================================================================================
 // CELL: the cell type as a compile-time constant (the gate math is then branch-free: with the run-time `p.cell` the item path
 // carried ~20 scalar branches and as many phi copies per step)
-template <int NTW, int PREC, bool TAGGED, int CELL>
+// SLOW: the parity harness's instantiation (options "rnn_slow_items" / "rnn_slow_exchange", as rnn_fwd_tagged): item waves sleep before they read the parked
+// tiles, exchange waves before they read the staged operand, every step -- results must not change (test_rnn_bwd_with_slow_waves)
+template <int NTW, int PREC, bool TAGGED, int CELL, bool SLOW = false>
 __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
   constexpr int NW = 16;
   const RnnArgs &p = pa.a;
@@ -1828,6 +1831,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
       z_p = z_g = clock64();
 #endif
       if (tid < 256) {
+        if constexpr (SLOW) { for (int i = 0; i < pa.slow; ++i) __builtin_amdgcn_s_sleep(1); }
         const float *rp = red + parked_at(bl, jl);
 #pragma unroll
         for (int w = 0; w < NGW; ++w) rec += rp[w * RT_T];
@@ -1901,6 +1905,7 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
 #endif
       const int par = s & 1;
       if (wave >= 4) {
+      if constexpr (SLOW) { for (int i = 0; i < pa.slow_x; ++i) __builtin_amdgcn_s_sleep(1); }
       f32x4 acc[NTW];
       if constexpr (PREC == 1) {
         const unsigned short *sp = reinterpret_cast<const unsigned short *>(stage);
@@ -2039,7 +2044,8 @@ __global__ __launch_bounds__(1024) void rnn_bwd_scatter(PersistArgs pa) {
 // W_hh fragments, tags, tile layout in the hand-off buffer and the role placement are those of rnn_bwd_scatter; an item lane group g sums
 // the blocks 4 i + g in ascending order, the four groups are combined lower group first.  NTE <= 5: up to 40 slices (H <= 640).
 // ================================================================================================
-template <int NEW, int NTE, int CELL>
+// SLOW: as rnn_bwd_scatter (item waves sleep at the start of their gather, exchange waves behind the barrier)
+template <int NEW, int NTE, int CELL, bool SLOW = false>
 __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs pa) {
   const RnnArgs &p = pa.a;
   constexpr int NTHR = 256 + 64 * NEW, NPL = (NEW * NTE + 3) / 4;       // NPL: 16-B poll loads per item lane (4 blocks each)
@@ -2142,6 +2148,7 @@ __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs p
 #endif
     if (wave < 4) {
       // ---------------- item waves: gather, gate math, stage ------------------------------------------------------------------
+      if constexpr (SLOW) { for (int i = 0; i < pa.slow; ++i) __builtin_amdgcn_s_sleep(1); }
       uint32_t dropword = 0;
       if (pa.drop_bwd) dropword = reinterpret_cast<const uint32_t *>(&dropw[wave][(s & 3) * 16 + (lane >> 4) * 4 + ((lane & 15) >> 2)])[lane & 3];
       const float *rv = &resv[set][0][0] + tid;
@@ -2261,6 +2268,7 @@ __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs p
 #endif
     if (wave >= 4) {
       // ---------------- exchange waves: multiply, scatter, reserve traffic ----------------------------------------------------
+      if constexpr (SLOW) { for (int i = 0; i < pa.slow_x; ++i) __builtin_amdgcn_s_sleep(1); }
       if (s + 1 < T) {
         const int par = s & 1;
         const unsigned short *sp = reinterpret_cast<const unsigned short *>(&stage[sb][0]);
@@ -2341,6 +2349,17 @@ __global__ __launch_bounds__(256 + 64 * NEW) void rnn_bwd_scatter2(PersistArgs p
 template <int NEW, int CELL>
 bool launch_bwd_scatter2_c(int nte, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
   constexpr int THR = 256 + 64 * NEW;
+  if constexpr (CELL != CTCN_CELL_TANH) {
+    if (a.slow > 0 || a.slow_x > 0)           // the parity harness's SLOW instantiations (LSTM / GRU)
+      switch (nte) {
+        case 1: return launch_resident(rnn_bwd_scatter2<NEW, 1, CELL, true>, grid, THR, 0, st, a, wpx);
+        case 2: return launch_resident(rnn_bwd_scatter2<NEW, 2, CELL, true>, grid, THR, 0, st, a, wpx);
+        case 3: return launch_resident(rnn_bwd_scatter2<NEW, 3, CELL, true>, grid, THR, 0, st, a, wpx);
+        case 4: return launch_resident(rnn_bwd_scatter2<NEW, 4, CELL, true>, grid, THR, 0, st, a, wpx);
+        case 5: return launch_resident(rnn_bwd_scatter2<NEW, 5, CELL, true>, grid, THR, 0, st, a, wpx);
+        default: return false;
+      }
+  }
   switch (nte) {
     case 1: return launch_resident(rnn_bwd_scatter2<NEW, 1, CELL>, grid, THR, 0, st, a, wpx);
     case 2: return launch_resident(rnn_bwd_scatter2<NEW, 2, CELL>, grid, THR, 0, st, a, wpx);
@@ -2363,6 +2382,14 @@ bool launch_bwd_scatter2(int nsl, dim3 grid, hipStream_t st, const PersistArgs &
 
 template <bool TAGGED, int CELL>
 bool launch_bwd_scatter_c(int ntw, dim3 grid, hipStream_t st, const PersistArgs &a, int wpx) {
+  if constexpr (TAGGED && CELL != CTCN_CELL_TANH) {
+    if (a.slow > 0 || a.slow_x > 0)           // the parity harness's SLOW instantiations (tagged hand-off, LSTM / GRU)
+      switch (ntw) {
+        case 1: return launch_resident(rnn_bwd_scatter<1, 1, TAGGED, CELL, true>, grid, 1024, 0, st, a, wpx);
+        case 2: return launch_resident(rnn_bwd_scatter<2, 1, TAGGED, CELL, true>, grid, 1024, 0, st, a, wpx);
+        default: return false;
+      }
+  }
   switch (ntw) {      // precision 1 only: the host never picks the scatter formulation for the f32 matmul
     case 1: return launch_resident(rnn_bwd_scatter<1, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
     case 2: return launch_resident(rnn_bwd_scatter<2, 1, TAGGED, CELL>, grid, 1024, 0, st, a, wpx);
@@ -2742,7 +2769,7 @@ static int rnn_fwd_impl(int cell, int T, int B, int I, int H, int dirs, const fl
           pa.ydrop = call.y_drop; pa.drop_p = call.drop_p; pa.drop_scale = 1.0f / (1.0f - call.drop_p);
           pa.drop_seed = call.drop_seed; pa.drop_off = call.drop_offset;
         }
-        pa.slow = ctcn_get_option("rnn_slow_items");
+        pa.slow = ctcn_get_option("rnn_slow_items"); pa.slow_x = ctcn_get_option("rnn_slow_exchange");
         CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));            // zeroed tiles (tag 0) | chunk counter | role tickets
         if (piped) CTCN_HIP(hipEventRecord((hipEvent_t)ov.event, st));
         if (launch_fwd_tagged(ceil_div(H / 32, 12), dim3(nxd * (wpx + std::max(2, wpx / 8)), 1, 1), st, pa, wpx)) {
@@ -3020,6 +3047,7 @@ extern "C" int ctcn_rnn_bwd_ex(int cell, int T, int B, int I, int H, int dirs, c
       // flags + tickets, and the hand-off tiles where they start from zero (tags / partial sums): the two areas are contiguous -> one memset
       if (scatter) {
         pa.tagmode = ctcn_opt_handoff_tags();
+        pa.slow = ctcn_get_option("rnn_slow_items"); pa.slow_x = ctcn_get_option("rnn_slow_exchange");
         if (pa.tagmode) CTCN_HIP(hipMemsetAsync(pa.hx, 0, hx_bytes + fl_bytes, st));
         else CTCN_HIP(hipMemsetAsync(pa.flags, 0, fl_bytes, st));
         if (!dy_dropped && ctcn_get_option("rnn_fused_dropout") != 0) {

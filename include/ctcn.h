@@ -96,7 +96,9 @@ int ctcn_device_xcds(void);
  * switch for the record, off.
  * "rnn_slow_items" = 0 (parity harness): N > 0 runs the SLOW instantiation of rnn_fwd_tagged, whose item waves sleep N x 64 cycles before they read
  * the parked partial tiles, at every step.  Results must not change (test_rnn_fwd_tagged_with_slow_item_waves): the hand-off inside a workgroup may
- * rest on barriers and buffer parity only, never on which wave is faster.
+ * rest on barriers and buffer parity only, never on which wave is faster.  "rnn_slow_exchange" = N: the same for the exchange waves; both options also select
+ * the SLOW instantiations of rnn_bwd_scatter / rnn_bwd_scatter2 (item waves sleep before they read the parked tiles / start their gather, exchange waves
+ * behind the barrier before they read the staged operand): test_rnn_bwd_with_slow_waves.
  * "bn_rows4" = 1 (default, round 5): BatchNorm over (rows, C) with C % 4 == 0 forms its column sums with 16-B loads, sixteen row phases per
  * workgroup (colreduce_rows4_kernel); 0: the dword kernel.  Same chunks, same element values, float64 partials grouped differently: the float32
  * results agreed bit for bit wherever compared (tools/bn_rows_probe.py).  cfg2 13.33 -> 13.25 ms per step, cfg4 53.2 -> 52.8.

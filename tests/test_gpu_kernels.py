@@ -551,8 +551,9 @@ def test_rnn_fwd_tagged_with_slow_item_waves(dev, kind, T, B, I, H, bi, sleeps):
     dy = torch.randn(T, B, (2 if bi else 1) * H, device=dev)
     runs = []
     try:
-        for slow in (0, sleeps, 0, sleeps):
+        for slow, slow_x in ((0, 0), (sleeps, 0), (0, sleeps), (sleeps // 2, sleeps)):
             ops.set_option("rnn_slow_items", slow)
+            ops.set_option("rnn_slow_exchange", slow_x)
             xs = x.clone().requires_grad_(True)
             ws = [t.clone().requires_grad_(True) if t is not None else None for t in w]
             y = ops.rnn_layer(xs, ws[0], ws[1], ws[2], ws[3], kind)
@@ -564,11 +565,59 @@ def test_rnn_fwd_tagged_with_slow_item_waves(dev, kind, T, B, I, H, bi, sleeps):
             runs.append([y.detach().clone(), xs.grad.clone()] + [t.grad.clone() for t in ws if t is not None])
     finally:
         ops.set_option("rnn_slow_items", 0)
+        ops.set_option("rnn_slow_exchange", 0)
     assert all(torch.isfinite(t).all() for t in runs[0])
     for k, got in enumerate(runs[1:]):
         for i, (a, b) in enumerate(zip(got, runs[0])):
-            assert torch.equal(a, b), "run %d (item waves %s): tensor %d differs from the undelayed run (max |d| %.3e)" % (
-                k + 1, "delayed" if k % 2 == 0 else "undelayed", i, float((a - b).abs().max()))
+            assert torch.equal(a, b), "run %d (%s waves delayed): tensor %d differs from the undelayed run (max |d| %.3e)" % (
+                k + 1, ("item", "exchange", "item and exchange")[k], i, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("kind,T,B,I,H,bi,gather,drop", [("lstm", 50, 32, 40, 320, True, 1, 0.0), ("gru", 40, 64, 24, 512, True, 1, 0.0), ("lstm", 30, 64, 16, 512, True, 1, 0.2),
+                                                         ("lstm", 50, 32, 40, 320, True, 2, 0.1), ("gru", 25, 9, 16, 128, True, 0, 0.0), ("lstm", 33, 40, 16, 384, False, 1, 0.0)])
+def test_rnn_bwd_with_slow_waves(dev, kind, T, B, I, H, bi, gather, drop):
+    """The backward recurrences under the same harness as test_rnn_fwd_tagged_with_slow_item_waves: rnn_bwd_scatter (two barriers per step: parked tiles,
+    staged operand) and rnn_bwd_scatter2 (one barrier; operand, float32 copy and reserve rings double / triple buffered) in their SLOW instantiations --
+    item waves sleep before they read the parked tiles / start their gather, exchange waves behind the barrier before they read the staged operand,
+    at every step; separately and together.  Input and weight gradients must be bit-identical to the undelayed run (`gather`: option bwd_item_gather --
+    0 rnn_bwd_scatter always, 1 the shipped rule, 2 rnn_bwd_scatter2 always)."""
+    from ctc_pytorch_amd import ops
+    ops.set_precision(1)
+    G = {"lstm": 4, "gru": 3}[kind]
+    torch.manual_seed(17)
+    x = torch.randn(T, B, I, device=dev)
+    w = [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)]
+    w += [torch.randn(G * H, I, device=dev) * 0.2, torch.randn(G * H, H, device=dev) * (1.0 / H ** 0.5)] if bi else [None, None]
+    dy = torch.randn(T, B, (2 if bi else 1) * H, device=dev)
+    runs, kernels = [], []
+    try:
+        ops.set_option("bwd_item_gather", gather)
+        for slow, slow_x in ((0, 0), (48, 0), (0, 48), (24, 64)):
+            ops._drop_counter[0] = 0
+            xs = x.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) if t is not None else None for t in w]
+            y = ops.rnn_layer(xs, ws[0], ws[1], ws[2], ws[3], kind, True, drop)
+            torch.cuda.synchronize()
+            ops.set_option("rnn_slow_items", slow)                 # (the delays apply to the backward pass only: the forward pass has its own test)
+            ops.set_option("rnn_slow_exchange", slow_x)
+            y.backward(dy)
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            ops.set_option("rnn_slow_items", 0)
+            ops.set_option("rnn_slow_exchange", 0)
+            ops.check_health(dev)
+            kernels.append(ops.rnn_last_kernels()[1])
+            runs.append([xs.grad.clone()] + [t.grad.clone() for t in ws if t is not None])
+    finally:
+        ops.set_option("rnn_slow_items", 0)
+        ops.set_option("rnn_slow_exchange", 0)
+        ops.set_option("bwd_item_gather", 1)
+    assert all(k in ("rnn_bwd_scatter", "rnn_bwd_scatter2") for k in kernels), kernels
+    assert all(torch.isfinite(t).all() for t in runs[0])
+    for k, got in enumerate(runs[1:]):
+        for i, (a, b) in enumerate(zip(got, runs[0])):
+            assert torch.equal(a, b), "%s, run %d (%s waves delayed): gradient %d differs from the undelayed run (max |d| %.3e)" % (
+                kernels[0], k + 1, ("item", "exchange", "item and exchange")[k], i, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("kind,T,B,I,H,bi", [("lstm", 2, 1, 4, 8, True), ("gru", 3, 17, 8, 40, True), ("rnn", 5, 3, 4, 16, False), ("lstm", 2, 64, 16, 512, True),
