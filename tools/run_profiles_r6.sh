@@ -34,7 +34,7 @@ fd=$(find $O/fetch -name "*.db" | head -1); wd=$(find $O/write -name "*.db" | he
 rm -rf $O/fetch $O/write $O/fetch2 $O/write2
 { echo "# tools/mb_step.bin (cfg2 layer: H 320, B 32, T 800): in-kernel clock64 stamps of the shipped forward / backward recurrences, round 6 HEAD"; timeout 200 ./tools/mb_step.bin; } > $O/r06_mb_step.txt 2>&1
 ( timeout 200 ./tools/mb_bwd2.bin 320 32 800 > $O/r06_mb_bwd2_cfg2.txt 2>&1 ); ( timeout 100 ./tools/mb_bwd2.bin 384 8 400 > $O/r06_mb_bwd2_ref_yaml.txt 2>&1 ); ( timeout 100 ./tools/mb_bwd2.bin 512 64 1200 > $O/r06_mb_bwd2_h512.txt 2>&1 )
-{ for r in peaky flat; do timeout 120 python tools/mb_beam.py run $r 2>&1 | grep -v amdgpu.ids; done; } > $O/r06_mb_beam.txt 2>&1
+{ for r in peaky flat; do timeout 120 python tools/mb_beam.py run $r 2>&1 | grep -v amdgpu.ids; done; for r in peaky flat; do timeout 200 python tools/mb_beam.py generic $r 200 2>&1 | grep -v amdgpu.ids; done; } > $O/r06_mb_beam.txt 2>&1
 { echo "# tools/conv_phase_probe.py: us per ctcn_conv2d_fwd launch with phases switched off (conv_dbg: 1 = no window load, 2 = no MFMA loop, 4 = no output phase)"; timeout 200 python tools/conv_phase_probe.py 2>&1 | grep -v amdgpu.ids; } > $O/r06_conv_phase_probe.txt
 timeout 900 python tools/soak.py --cfg2 600 --cfg4 300 --ref-yaml 600 --cfg1 600 --cfg3 400 --decode 100 --out $O/r06_soak.json > $O/soak.out 2> $O/soak.err; echo "soak rc=$?"
 ls -la $O
