@@ -540,7 +540,7 @@ def test_rnn_fwd_tagged_with_slow_item_waves(dev, kind, T, B, I, H, bi, sleeps):
     "rnn_slow_items" runs the kernel's SLOW instantiation, whose item waves sleep N x 64 cycles before they read the tiles at EVERY step -- far
     beyond the ~1 000 cycles an exchange wave needs to get there.  Outputs, saved state (through the gradients) and gradients must be
     bit-identical to the undelayed run.  (tools/libctcn_single.so -- the same source with -DCTCN_RED_SINGLE, the single set of rounds 2-5 -- fails
-    this test on every shape: profiles/r06_divergence_root_cause.txt.)"""
+    this test on cfg4's and cfg2's shapes on every box, on two more on some: profiles/r06_divergence_root_cause.txt.)"""
     from ctc_pytorch_amd import ops
     ops.set_precision(1)
     G = {"lstm": 4, "gru": 3}[kind]
