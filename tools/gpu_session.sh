@@ -331,4 +331,13 @@ print("tag_poll_delay %s: %.3f ms (median %.3f)  fwd %.3f bwd %.3f us/step" % (s
 PY
   done
   ;;
+36)
+  # after the fix: the statistics of session 20 (traced cfg4 runs in the process of the subsets that showed the divergence) at HEAD
+  i=0
+  for sel in "item_gather_equals" "item_gather_edge" "batch_chunks_equal" "xcd_order or batch_chunks_into_flat"; do
+    i=$((i+1))
+    CTCN_AFTER_SUITE=$R/tools/after_suite_ab.py CTCN_AFTER_SUITE_OUT=$O/after_$i.json CTCN_AFTER_SUITE_N=40 CTCN_AFTER_SUITE_PHASES=order1 timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s -k "$sel" > $O/pytest_$i.log 2>&1
+    echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-80)" | tee -a $O/summary.log
+  done
+  ;;
 esac
