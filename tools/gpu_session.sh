@@ -340,4 +340,24 @@ PY
     echo "subset $i [$sel]: $(grep -o '"summary": "[^"]*"' $O/pytest_$i.log)  $(tail -n 1 $O/pytest_$i.log | cut -c1-80)" | tee -a $O/summary.log
   done
   ;;
+37)
+  # code-placement lottery: rnn.hip rebuilt with block / function alignment switches, cfg2 step, alternating on one box
+  cp ctc_pytorch_amd/libctcn.so $O/libctcn_keep.so
+  for rep in 1 2; do for lib in keep ${LIBS:-fn4k nft6 nola}; do
+    [ $lib = keep ] && cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so || cp tools/libctcn_$lib.so ctc_pytorch_amd/libctcn.so
+    for wl in ${WLS:-cfg2}; do
+      timeout 400 python bench.py --workload $wl --steps 20 --warmup 3 --no-decode --no-cpu-baseline --no-others --no-pmc --no-ragged --no-sync-bn-cost > $O/bench_${lib}_${wl}_$rep.json 2> $O/bench_${lib}_${wl}_$rep.err
+    done
+  done; done
+  cp $O/libctcn_keep.so ctc_pytorch_amd/libctcn.so; rm -f $O/libctcn_keep.so
+  python - $O <<'PY'
+import json, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], "%.3f ms (median %.3f)  fwd %.3f bwd %.3f us/step  loss %r" % (d["ms_per_step"], d["ms_per_step_median"], d["recurrence"]["fwd_us_per_timestep"], d["recurrence"]["bwd_us_per_timestep"], d.get("final_loss")))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+  ;;
 esac
