@@ -23,7 +23,7 @@
 namespace {
 
 constexpr int CTC_THREADS = 256;
-constexpr int CTC_NS = 8;   // lattice states per thread -> S <= 2048 (L <= 1023)
+constexpr int CTC_NS = 16;  // lattice states per thread -> S <= 4096 (L <= 2047; 3 S floats of LDS = 48 KB)
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
@@ -483,7 +483,7 @@ extern "C" int ctcn_ctc_fwd(const float *lp, const int64_t *targets, const int64
   const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
   const int ns = ceil_div(2 * Lmax + 1, CTC_THREADS);
 #define CTC_LAUNCH(NS) hipLaunchKernelGGL((ctc_lattice_kernel<1, NS>), dim3(B), dim3(CTC_THREADS), sm, (hipStream_t)stream, lp, targets, in_len, tgt_len, alpha, nll, T, B, V, Lmax)
-  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
+  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else if (ns <= 8) CTC_LAUNCH(8); else CTC_LAUNCH(16);
 #undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;
@@ -498,7 +498,7 @@ extern "C" int ctcn_ctc_bwd(const float *lp, const int64_t *targets, const int64
   hipStream_t st = (hipStream_t)stream;
   const int ns = ceil_div(2 * Lmax + 1, CTC_THREADS);
 #define CTC_LAUNCH(NS) hipLaunchKernelGGL((ctc_lattice_kernel<-1, NS>), dim3(B), dim3(CTC_THREADS), sm, st, lp, targets, in_len, tgt_len, alpha, (float *)nullptr, T, B, V, Lmax)
-  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
+  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else if (ns <= 8) CTC_LAUNCH(8); else CTC_LAUNCH(16);
 #undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
   hipLaunchKernelGGL(ctc_grad_kernel<false>, dim3(ceil_div(T, GRAD_TCH), B), dim3(256), (size_t)(V + 1 + Lmax) * sizeof(int), st, lp, targets, in_len, tgt_len,
@@ -515,7 +515,7 @@ extern "C" int ctcn_ctc_fwd_both(const float *lp, const int64_t *targets, const 
   const size_t sm = (size_t)(3 * (2 * Lmax + 1)) * sizeof(float);
   const int ns = ceil_div(2 * Lmax + 1, CTC_THREADS);
 #define CTC_LAUNCH(NS) hipLaunchKernelGGL((ctc_lattices_kernel<NS>), dim3(B, 2), dim3(CTC_THREADS), sm, (hipStream_t)stream, lp, targets, in_len, tgt_len, alpha, beta, nll, T, B, V, Lmax)
-  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else CTC_LAUNCH(8);
+  if (ns <= 1) CTC_LAUNCH(1); else if (ns <= 2) CTC_LAUNCH(2); else if (ns <= 4) CTC_LAUNCH(4); else if (ns <= 8) CTC_LAUNCH(8); else CTC_LAUNCH(16);
 #undef CTC_LAUNCH
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;

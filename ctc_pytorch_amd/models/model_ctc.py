@@ -63,7 +63,8 @@ def _native_rnn(rnn_type):
 
 
 class LayerCNN(nn.Module):
-    """Conv2d(bias) -> BatchNorm2d -> activation -> [pool] -> dropout   (reference model_ctc.py:38-68).
+    """Conv2d(bias) -> BatchNorm2d -> activation -> [pool] -> dropout, or the Conv1d / BatchNorm1d / MaxPool1d stack for a one-element
+    kernel_size   (reference model_ctc.py:38-68).
 
     As in the reference only nn.ReLU can be constructed (it passes inplace=True to the activation class,
     which nn.Tanh / nn.Sigmoid reject); BN + ReLU run as one fused apply pass."""
@@ -71,12 +72,20 @@ class LayerCNN(nn.Module):
     def __init__(self, in_channel, out_channel, kernel_size, stride, padding, pooling_size=None, activation_function=nn.ReLU,
                  batch_norm=True, dropout=0.1):
         super().__init__()
-        if len(kernel_size) != 2:
-            raise NotImplementedError("only the Conv2d front-end is on the hot path (ctc_config.yaml:33-37)")
-        self.conv = nn.Conv2d(in_channel, out_channel, kernel_size=kernel_size, stride=stride, padding=padding)
-        self.batch_norm = nn.BatchNorm2d(out_channel) if batch_norm else None
+        if len(kernel_size) == 2:
+            self.conv = nn.Conv2d(in_channel, out_channel, kernel_size=kernel_size, stride=stride, padding=padding)
+            self.batch_norm = nn.BatchNorm2d(out_channel) if batch_norm else None
+        else:           # the reference's one-element kernel_size branch (model_ctc.py:48-50, 54-55): a stand-alone (B,C,L) layer --
+            # CTC_Model.forward feeds 4-D tensors, which nn.Conv1d refuses there as here
+            self.conv = nn.Conv1d(in_channel, out_channel, kernel_size=kernel_size, stride=stride, padding=padding)
+            self.batch_norm = nn.BatchNorm1d(out_channel) if batch_norm else None
         self.activation = _native_act(activation_function)(inplace=True)
-        self.pooling = nn.MaxPool2d(pooling_size) if pooling_size is not None else None
+        if pooling_size is not None and len(kernel_size) == 2:
+            self.pooling = nn.MaxPool2d(pooling_size)
+        elif len(kernel_size) == 1:
+            self.pooling = nn.MaxPool1d(pooling_size)
+        else:
+            self.pooling = None
         self.dropout = nn.Dropout(p=dropout)
         self._fused = isinstance(self.activation, nn.ReLU) and self.batch_norm is not None
         if self._fused:

@@ -209,7 +209,37 @@ class MaxPool2d(_tnn.Module):
         return "kernel_size=%s" % (self.kernel_size,)
 
 
+class Conv1d(_tnn.Conv1d):
+    """nn.Conv1d of LayerCNN's one-element kernel_size branch (model_ctc.py:48-50): (B,Ci,L) -> (B,Co,L').  Runs on the Conv2d kernels as
+    an image of height 1 (kernel (1,k), stride (1,s), padding (0,p)): the fma chain of an output element is the same one, and the parameter
+    keeps nn.Conv1d's (Co,Ci,k) shape, so state_dicts are interchangeable with the reference's."""
+
+    def forward(self, x):
+        if self.groups != 1 or tuple(self.dilation) != (1,) or self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise NotImplementedError("plain Conv1d (groups=1, dilation=1, zero padding) only (model_ctc.py:49)")
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise ValueError("Conv1d expects (B,C,L)")          # (a 4-D input -- what CTC_Model.forward feeds -- is refused by torch as well)
+        y = ops.conv2d(ops.contiguous(x).unsqueeze(2), self.weight.unsqueeze(2), self.bias, (1, self.stride[0]), (0, self.padding[0]))
+        return y.squeeze(2)
+
+
 class MaxPool1d(_tnn.Module):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("the Conv1d / MaxPool1d branch of LayerCNN cannot run in the reference either: CTC_Model.forward feeds "
-                                  "a 4-D tensor (model_ctc.py:148)")
+    """nn.MaxPool1d(pooling_size) of LayerCNN (model_ctc.py:54-55): stride = kernel, no padding, floor; (B,C,L) -> (B,C,L // k)."""
+
+    def __init__(self, kernel_size, stride=None, padding=0, dilation=1, return_indices=False, ceil_mode=False):
+        super().__init__()
+        if isinstance(kernel_size, (tuple, list)):
+            (kernel_size,) = kernel_size
+        if (stride not in (None, kernel_size, (kernel_size,))) or padding not in (0, (0,)) or dilation not in (1, (1,)) or return_indices or ceil_mode:
+            raise NotImplementedError("MaxPool1d(kernel_size) with its defaults only (model_ctc.py:55)")
+        self.kernel_size = kernel_size          # (None constructs, as in torch -- LayerCNN builds MaxPool1d(None) for pooling_size=None -- and fails in forward)
+
+    def forward(self, x):
+        if self.kernel_size is None:
+            raise TypeError("MaxPool1d: kernel_size is None (LayerCNN's one-element kernel_size branch needs a pooling_size, model_ctc.py:54-55)")
+        if x.dim() != 3:
+            raise ValueError("MaxPool1d expects (B,C,L)")
+        return ops.max_pool2d(ops.contiguous(x).unsqueeze(2), (1, int(self.kernel_size))).squeeze(2)
+
+    def extra_repr(self):
+        return "kernel_size=%s" % (self.kernel_size,)

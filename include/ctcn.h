@@ -340,7 +340,7 @@ int ctcn_argmax(const float *lp, int32_t *argmax, int rows, int V, void *stream)
  * CTC loss (blank = 0, zero_infinity = False); replaces nn.CTCLoss(reduction='sum') forward/backward
  * (train_ctc.py:144,47-48,63).  lp (T,B,V) log-probs; targets (B,Lmax) int64 zero-padded;
  * in_len/tgt_len (B) int64.  alpha: (T,B,2*Lmax+1) reserve.  nll (B): per-utterance negative
- * log-likelihood (+inf when no alignment exists).
+ * log-likelihood (+inf when no alignment exists).  Lmax <= 2047 (sixteen lattice states per thread), else CTCN_EUNSUPPORTED.
  * bwd: grad_lp[t,b,c] = gscale[0] * (exp(lp) - exp(logsum_{s:ext(s)=c}(alpha+beta) + nll - lp)) for
  * t < in_len[b], 0 beyond; gscale is a 1-element DEVICE float (the upstream gradient of the summed loss).
  * alpha is overwritten with alpha+beta. */

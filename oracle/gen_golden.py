@@ -176,6 +176,36 @@ def gen_conv():
         save("conv_front_" + actname, **out)
 
 
+def gen_conv1d():
+    """The reference's LayerCNN with a one-element kernel_size (model_ctc.py:48-50, 54-55): Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d -> Dropout(0)
+    on a (B, C, L) tensor -- the branch CTC_Model.forward cannot reach (it feeds 4-D tensors) but a user of LayerCNN can.  Two training steps
+    (forward, backward: the running statistics after both), then an eval pass; a second layer without BatchNorm."""
+    rs = np.random.RandomState(57)
+    out = {}
+    for tag, (cin, cout, k, s, p, pool, bn, L) in (("a", (5, 12, 7, 2, 3, 3, True, 83)), ("b", (3, 70, 41, 1, 0, 2, False, 64))):
+        layer = LayerCNN(cin, cout, (k,), (s,), (p,), pooling_size=pool, batch_norm=bn, dropout=0.0)
+        load_seeded(layer, 58 + cin)
+        layer.train()
+        for k_, v in layer.state_dict().items():
+            out["%s.before.%s" % (tag, k_)] = t2n(v)
+        for step in range(2):
+            x = torch.from_numpy(rs.standard_normal((3, cin, L)).astype(F32)).requires_grad_(True)
+            layer.zero_grad()
+            y = layer(x)
+            dy = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(F32))
+            y.backward(dy)
+            out.update({"%s.x%d" % (tag, step): t2n(x), "%s.y%d" % (tag, step): t2n(y), "%s.dy%d" % (tag, step): t2n(dy), "%s.dx%d" % (tag, step): t2n(x.grad)})
+            for k_, q in layer.named_parameters():
+                out["%s.g%d.%s" % (tag, step, k_)] = t2n(q.grad)
+        for k_, v in layer.state_dict().items():
+            out["%s.after.%s" % (tag, k_)] = t2n(v)
+        layer.eval()
+        with torch.no_grad():
+            out["%s.y_eval" % tag] = t2n(layer(x.detach()))
+        out["%s.cfg" % tag] = np.array([cin, cout, k, s, p, pool, int(bn), L], dtype=np.int64)
+    save("layer_cnn1d", **out)
+
+
 # ---------------------------------------------------------------------------------------------
 # (1d) fc = BN1d + Linear(no bias) + log_softmax (model_ctc.py:135-140,165-168)
 # ---------------------------------------------------------------------------------------------
@@ -654,7 +684,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     steps = dict(rnn=gen_rnn, bn=gen_bn, conv=gen_conv, fc=gen_fc, ctc=gen_ctc, models=gen_models,
                  run_epoch=gen_run_epoch, lengths=gen_lengths, decoders=gen_decoders, lm=gen_lm, ref_yaml=gen_ref_yaml, nbest=gen_nbest,
-                 wide_beam=gen_wide_beam, bigbank=gen_bigbank)
+                 wide_beam=gen_wide_beam, bigbank=gen_bigbank, conv1d=gen_conv1d)
     if a.large:
         gen_large(a.only)
     else:

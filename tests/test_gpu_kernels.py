@@ -951,6 +951,42 @@ def test_conv_front_golden(dev, prec):
     assert maxabs(ce, z["conv_out_eval"]) < 2e-5
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_layer_cnn_one_element_kernel_branch_golden(dev, tag):
+    """LayerCNN with a one-element kernel_size (reference model_ctc.py:48-50, 54-55: Conv1d -> BatchNorm1d -> ReLU -> MaxPool1d -> Dropout)
+    against tests/golden/layer_cnn1d.npz, which oracle/gen_golden.py captured from the reference's own LayerCNN: two training steps (outputs,
+    input / parameter gradients, running statistics after both) and an eval pass.  "a": 5 -> 12 channels, 7 taps, stride 2, padding 3,
+    pool 3, BatchNorm; "b": 3 -> 70 channels, 41 taps, pool 2, no BatchNorm (the separate ReLU module)."""
+    from ctc_pytorch_amd.models.model_ctc import LayerCNN
+    z = load("layer_cnn1d")
+    cin, cout, k, s, p, pool, bn, L = (int(v) for v in z[tag + ".cfg"])
+    layer = LayerCNN(cin, cout, (k,), (s,), (p,), pooling_size=pool, batch_norm=bool(bn), dropout=0.0)
+    before = {key[len(tag + ".before."):]: z[key] for key in z.files if key.startswith(tag + ".before.")}
+    assert list(layer.state_dict().keys()) == list(before.keys())
+    layer.load_state_dict({key: torch.from_numpy(v) for key, v in before.items()})
+    layer.to(dev).train()
+    for step in range(2):
+        x = gpu(z["%s.x%d" % (tag, step)], dev).requires_grad_(True)
+        layer.zero_grad()
+        y = layer(x)
+        want = z["%s.y%d" % (tag, step)]
+        assert tuple(y.shape) == want.shape and maxabs(y, want) < 2e-5
+        y.backward(gpu(z["%s.dy%d" % (tag, step)], dev))
+        assert maxabs(x.grad, z["%s.dx%d" % (tag, step)]) < 5e-5
+        for key, q in layer.named_parameters():
+            g = z["%s.g%d.%s" % (tag, step, key)]
+            assert tuple(q.grad.shape) == g.shape and maxabs(q.grad, g) < 5e-4 * max(1.0, float(np.abs(g).max())), key
+    for key, v in layer.state_dict().items():
+        w = z["%s.after.%s" % (tag, key)]
+        assert (int(v) == int(w)) if "num_batches" in key else (maxabs(v, w) < 1e-5), key
+    layer.eval()
+    with torch.no_grad():
+        ye = layer(x.detach())
+    assert maxabs(ye, z[tag + ".y_eval"]) < 2e-5
+    with pytest.raises((ValueError, RuntimeError)):          # what CTC_Model.forward would feed: nn.Conv1d refuses 4-D input in the reference as well
+        layer(x.detach().unsqueeze(1))
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 def test_fc_logsoftmax_golden(dev, prec):
     from ctc_pytorch_amd import ops
@@ -1058,9 +1094,9 @@ def test_ctc_one_launch_lattices_equal_two_pass_reserve(dev, T, B, V, lab):
     assert torch.equal(torch.isnan(g1), torch.isnan(g2))
 
 
-@pytest.mark.parametrize("T,B,V,Lmax", [(700, 5, 50, 200), (1200, 3, 30, 520), (9, 7, 12, 3)])
+@pytest.mark.parametrize("T,B,V,Lmax", [(700, 5, 50, 200), (1200, 3, 30, 520), (9, 7, 12, 3), (3400, 3, 20, 1500)])
 def test_ctc_long_labels_vs_torch_cpu(dev, T, B, V, Lmax):
-    """Label lengths that need 2 and 4+ lattice states per thread (S = 2L+1 > 256 / > 512), ragged input lengths incl.
+    """Label lengths that need 2, 4+ and (L = 1500: S = 3001) 16 lattice states per thread, ragged input lengths incl.
     a 1-frame utterance, repeated labels, and an empty target."""
     from ctc_pytorch_amd import nn, ops
     rs = np.random.RandomState(T + Lmax)

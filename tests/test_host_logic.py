@@ -103,6 +103,32 @@ def test_state_dict_surface_matches_reference_keys():
         assert set(pkg) == {"rnn_param", "add_cnn", "cnn_param", "num_class", "_drop_out", "state_dict", "epoch"}
 
 
+def test_layer_cnn_one_element_kernel_branch_surface():
+    """LayerCNN's Conv1d / BatchNorm1d / MaxPool1d branch (reference model_ctc.py:48-50, 54-55): the module tree and the state_dict (keys, order,
+    the (Co, Ci, k) weight shape) are the reference's -- tests/golden/layer_cnn1d.npz holds its state_dict -- and the torch-CPU stack of the
+    same modules reproduces the captured outputs (the fixture is what torch computes: the GPU test holds the HIP path to it)."""
+    from ctc_pytorch_amd import nn
+    from ctc_pytorch_amd.models.model_ctc import LayerCNN
+    z = load("layer_cnn1d")
+    for tag in ("a", "b"):
+        cin, cout, k, s, p, pool, bn, L = (int(v) for v in z[tag + ".cfg"])
+        layer = LayerCNN(cin, cout, (k,), (s,), (p,), pooling_size=pool, batch_norm=bool(bn), dropout=0.0)
+        assert isinstance(layer.conv, nn.Conv1d) and isinstance(layer.pooling, nn.MaxPool1d)
+        assert (layer.batch_norm is None) == (not bn) and (bn == 0 or isinstance(layer.batch_norm, nn.BatchNorm1d))
+        before = {key[len(tag + ".before."):]: z[key] for key in z.files if key.startswith(tag + ".before.")}
+        got = {key: tuple(v.shape) for key, v in layer.state_dict().items()}
+        assert list(got.keys()) == list(before.keys()) and all(got[key] == before[key].shape for key in got)
+        mods = [tnn.Conv1d(cin, cout, k, s, p)] + ([tnn.BatchNorm1d(cout)] if bn else []) + [tnn.ReLU(), tnn.MaxPool1d(pool)]
+        ref = tnn.Sequential(*mods)
+        ref[0].load_state_dict({"weight": torch.from_numpy(before["conv.weight"]), "bias": torch.from_numpy(before["conv.bias"])})
+        if bn:
+            ref[1].load_state_dict({key[len("batch_norm."):]: torch.from_numpy(v) for key, v in before.items() if key.startswith("batch_norm.")})
+        ref.train()
+        y = ref(torch.from_numpy(z[tag + ".x0"]))
+        assert tuple(y.shape) == z[tag + ".y0"].shape and float((y.detach() - torch.from_numpy(z[tag + ".y0"])).abs().max()) < 1e-5
+    assert isinstance(LayerCNN(1, 2, (3,), (1,), (0,), pooling_size=None).pooling, nn.MaxPool1d)      # MaxPool1d(None) constructs, as in the reference
+
+
 @pytest.mark.parametrize("tag,cls,H,bi,bn", [("lstm2x32", tnn.LSTM, 32, True, True), ("gru2x24", tnn.GRU, 24, True, True),
                                              ("rnn2x20_uni_nobn", tnn.RNN, 20, False, False), ("cnn_lstm2x16", tnn.LSTM, 16, True, True),
                                              ("cnn_pool_lstm2x16", tnn.LSTM, 16, True, True), ("cnn_bigbank_lstm2x16", tnn.LSTM, 16, True, True)])
