@@ -914,6 +914,31 @@ def decode_leg(dev, steps=5):
             got = dev_out[0][0, : int(dev_out[1][0])].cpu().tolist()
             wide[regime] = {"ms_per_batch": ms, "utt_per_s_one_batch_at_a_time": B / (ms * 1e-3), "first_utterance_matches_oracle": bool(list(map(int, want[0])) == got) and bool((dev_out[3] == 0).all()),
                             "cpu_oracle_utt_per_s": 1.0 / cdt}
+            # ... and as steps/test_ctc.decode_and_score runs any width: NS searches in flight on NS streams, every batch handed to the host and
+            # assembled into phone strings.  One batch is 128 workgroups of one CU each (99 KB of LDS per search) -- HALF the device -- and a
+            # workgroup whose utterance is short (lens U{400..800}) leaves its CU idle until the batch's longest search ends: batches in flight fill both
+            ids_w = [dev_out[0][k, : int(dev_out[1][k])].cpu().tolist() for k in range(B)]
+            nfl_w = 8 * NS
+            warm = []
+            for k in range(NS):
+                with torch.cuda.stream(streams[k % NS]):
+                    warm.append(ops.beam_decode_async(x, lens_dev, tab_dev, 0.01, 200))
+            for h in warm:
+                h.result()
+            del warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pend, strings = [], None
+            for k in range(nfl_w):
+                with torch.cuda.stream(streams[k % NS]):
+                    pend.append(ops.beam_decode_async(x, lens_dev, tab_dev, 0.01, 200))
+                if len(pend) == 2 * NS:
+                    strings = finish(pend.pop(0))
+            for h in pend:
+                strings = finish(h)
+            dtw = (time.perf_counter() - t0) / nfl_w
+            wide[regime].update(utt_per_s=B / dtw, ms_per_batch_in_flight=dtw * 1e3, batches_in_flight="%d on %d streams + %d queued behind them" % (NS, NS, NS),
+                                strings_match_the_one_at_a_time_run=bool(strings == [" ".join(map(phones.__getitem__, seq)) for seq in ids_w]))
         out["wide_beam"] = wide
     except Exception as e:      # noqa: BLE001
         out["wide_beam"] = {"error": repr(e)}
