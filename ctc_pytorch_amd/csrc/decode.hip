@@ -1500,8 +1500,9 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   const size_t cand_bytes = (size_t)W * V * sizeof(double);
   const int gthreads = ctcn_get_option("beam_generic_threads");          // 0 (default): by beam width; 256 / 1024: forced (measurements)
   // (measured, tools/beam_generic_probe.py, 128 x 800 batches: 3 720 candidates per frame 7.9 -> 6.3 ms with 1 024 threads, 12 000: 21 -> 16 ms; 1 240: 4.7 -> 4.9)
-  const bool wide = gthreads == 1024 || (gthreads != 256 && (W > 64 || (long)W * V > 3500));
-  const void *kern = wide ? reinterpret_cast<const void *>(beam_kernel<1024>) : reinterpret_cast<const void *>(beam_kernel<256>);
+  const bool wide = gthreads == 1024 || (gthreads != 256 && gthreads != 512 && (W > 64 || (long)W * V > 3500));
+  const bool mid = gthreads == 512;
+  const void *kern = wide ? reinterpret_cast<const void *>(beam_kernel<1024>) : mid ? reinterpret_cast<const void *>(beam_kernel<512>) : reinterpret_cast<const void *>(beam_kernel<256>);
   // The kernel's STATIC LDS is ~46 KB since the selection holds its survivors there; the candidate table joins it in LDS only if the
   // whole block then fits what this device gives one workgroup (160 KB on gfx950; a 64-KB device falls back to the global table
   // instead of failing the launch).
@@ -1518,7 +1519,7 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   // round 5, whose rule was 32 KB), then the LM table (31.7 KB at V = 62)
   const size_t lm_bytes = (size_t)(V + 1) * (V + 1) * sizeof(double) + 8;
   const size_t fixed = fa.sharedSizeBytes + row_bytes + state_bytes + 256;
-  a.cand_in_lds = fixed + cand_bytes <= (size_t)lds_max ? 1 : 0;
+  a.cand_in_lds = (fixed + cand_bytes <= (size_t)lds_max && !ctcn_get_option("beam_cand_global")) ? 1 : 0;
   a.lm_in_lds = fixed + (a.cand_in_lds ? cand_bytes : 0) + lm_bytes <= (size_t)lds_max ? 1 : 0;
   const size_t sm = row_bytes + state_bytes + (a.cand_in_lds ? cand_bytes : 0) + (a.lm_in_lds ? lm_bytes : 0);
   if (fa.sharedSizeBytes + sm > (size_t)lds_max) {
@@ -1527,6 +1528,7 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   }
   CTCN_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
   if (wide) hipLaunchKernelGGL(beam_kernel<1024>, dim3(B), dim3(1024), sm, st, a);
+  else if (mid) hipLaunchKernelGGL(beam_kernel<512>, dim3(B), dim3(512), sm, st, a);
   else hipLaunchKernelGGL(beam_kernel<256>, dim3(B), dim3(256), sm, st, a);
   CTCN_LAUNCH_CHECK();
   return CTCN_OK;

@@ -2201,6 +2201,34 @@ def test_beam_wide_vs_c_oracle(dev, regime, W):
     assert got2 == got and np.array_equal(np.asarray(score2), score) and list(st2) == list(st)
 
 
+@pytest.mark.parametrize("regime", ["peaky", "flat"])
+@pytest.mark.parametrize("W,threads,cand_global", [(200, 512, 1), (200, 512, 0), (200, 1024, 1), (61, 512, 1), (300, 512, 1), (200, 256, 1)])
+def test_beam_generic_kernel_occupancy_options(dev, regime, W, threads, cand_global):
+    """The generic search at other thread counts / candidate-table placements (options beam_generic_threads = 512, beam_cand_global: two
+    512-thread searches per CU -- tools/wide_beam_probe.py) returns the labellings, status words and float64 scores
+    of the C oracle and, bit for bit, of the default configuration."""
+    from ctc_pytorch_amd import ops
+    from ctc_pytorch_amd.utils.NgramLM import LanguageModel
+    V, T, B = 62, 120, 6
+    i2c = synth.int2char(V)
+    tab = LanguageModel(os.path.join(G, "lm_phone_bg.arpa")).table([i2c[i] for i in range(V)])
+    lp = synth.make_logprobs(seed=83 if regime == "peaky" else 84, T=T, B=B, V=V, regime=regime)
+    lens = [120, 97, 64, 110, 33, 81]
+    probs = torch.exp(torch.from_numpy(lp))
+    want, wscore, wst = beam_ref.decode_ids(probs.numpy().transpose(1, 0, 2), lens, tab, 0.01, W)
+    base = ops.beam_decode(probs.to(dev), lens, tab, 0.01, W, 0, input_is_prob=True)
+    ops.set_option("beam_generic_threads", threads)
+    ops.set_option("beam_cand_global", cand_global)
+    try:
+        got, score, st = ops.beam_decode(probs.to(dev), lens, tab, 0.01, W, 0, input_is_prob=True)
+    finally:
+        ops.set_option("beam_generic_threads", 0)
+        ops.set_option("beam_cand_global", 0)
+    assert list(st) == list(wst) and got == [list(map(int, s_)) for s_ in want]
+    assert np.all(np.abs(np.asarray(score) - np.asarray(wscore)) <= 4 * np.spacing(np.abs(np.asarray(wscore))))
+    assert got == base[0] and np.array_equal(np.asarray(score), np.asarray(base[1])) and list(st) == list(base[2])
+
+
 def test_beam_width_above_the_maximum_is_refused(dev):
     """W = 1 025 > BEAM_WMAX: CTCN_EUNSUPPORTED (-3) from the C ABI, a RuntimeError naming the limit from the wrapper; nothing is launched."""
     from ctc_pytorch_amd import _lib, ops
