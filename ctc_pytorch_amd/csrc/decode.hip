@@ -64,6 +64,7 @@ struct BeamArgs {
   int32_t *out_ids, *out_len; double *out_score; int32_t *status; int T, B, V;
   int nbest; int32_t *out_count;        // ctcn_beam_decode_nbest: the `nbest` best labellings per utterance (outputs [B][nbest]...), their number in out_count
   unsigned long long *ht_keys; int *ht_ids; int *node_par; int *node_sym; double *cand_global;
+  int *node_slot, *cand_owner;   // beam_kernel: beam slot of a trie node / beam slot whose labelling merges with a candidate (lookups that replace scans of the beam)
   int ht_size, max_nodes, cand_in_lds;
   int wcap, smax;       // beam_kernel: capacity of the beam-state arrays (W rounded up to 64) and of the selection's survivor list
   int lm_in_lds;        // beam_kernel: the (V+1)^2 ln-prob table is copied into dynamic LDS behind the state arrays (when the launch's budget holds it)
@@ -128,6 +129,14 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   int *ids = a.ht_ids + (size_t)b * a.ht_size;
   int *npar = a.node_par + (size_t)b * a.max_nodes;
   int *nsym = a.node_sym + (size_t)b * a.max_nodes;
+  // Lookups instead of scans of the beam (last session of round 6; both were ~200 LDS reads per thread and frame at the reference's W = 200):
+  //   nslot[node] = beam slot that holds trie node `node` -- written for every entry of a new beam, read by step 2 of the next frame;
+  //   cown[c]     = beam slot whose labelling merges with extension candidate c -- written by step 3b, read by step 5 of the same frame.
+  // Neither table is initialised or stamped: a value is USED only if the slot it names passes the very test the scan applied (L.node[s] ==
+  // pnode; mfrom[s] == i && L.last[s] == k), which at most one slot of a beam can pass -- and for a node / candidate that does have such a
+  // slot the table was written this frame.  Anything else (stale, never written) fails the test exactly as the scan found nothing.
+  int *nslot = a.node_slot + (size_t)b * a.max_nodes;
+  int *cown = a.cand_owner + (size_t)b * W * V;
   const int htmask = a.ht_size - 1;
 
   int cur = 0, nb = 1, status = 0;
@@ -140,12 +149,25 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
     S0.pB[0] = 0.0; S0.pNB[0] = LOG_ZERO; S0.pT[0] = 0.0;   // BeamSearch.py:83-87
     s_nodes = 1; s_flag = 0;
     npar[0] = -1; nsym[0] = -1;
+    nslot[0] = 0;
   }
   __syncthreads();
   const int nframes = min(max(a.lens[b], 0), T);
+  // p(blank) of 64 frames per load (lane j: frame chunk0 + j): the skip test of a frame that is not processed costs a register read, not a
+  // round trip to memory (peaky posteriors skip two frames of three); the previous frame's value (repeat rule) is carried along
+  float pb_lane = 0.0f, pb_before = 0.0f;
+  int chunk0 = -64;
   for (int t = 0; t < nframes; ++t) {
     const float *row = a.x + ((size_t)t * B + b) * V;
-    const float pblank = a.input_is_prob ? row[blank] : expf(row[blank]);
+    if (t >= chunk0 + 64) {
+      chunk0 = t;
+      const int tl = min(t + lane, nframes - 1);
+      const float *r = a.x + ((size_t)tl * B + b) * V;
+      pb_lane = a.input_is_prob ? r[blank] : expf(r[blank]);
+    }
+    const float pblank = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pb_lane), __builtin_amdgcn_readfirstlane(t - chunk0)));
+    const float pprev = pb_before;
+    pb_before = pblank;
     if ((1.0f - pblank) < 0.1f) continue;                         // BeamSearch.py:93-94 (float32 compare)
     const BeamState L = beam_state(cur), N = beam_state(cur ^ 1);
     GSTAMP(0);
@@ -158,26 +180,16 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       if (!(p > 0.0f)) s_flag = 2;
       lg[k] = log((double)p);
     }
-    bool rep_ok = false;
-    if (t > 0) {
-      const float *prow = a.x + ((size_t)(t - 1) * B + b) * V;
-      const float pprev = a.input_is_prob ? prow[blank] : expf(prow[blank]);
-      rep_ok = pprev < 0.9f;                                       // BeamSearch.py:63 (float32 compare)
-    }
+    const bool rep_ok = t > 0 && pprev < 0.9f;                     // BeamSearch.py:63 (float32 compare)
     // 2. which beam (if any) is the parent labelling of beam i' -> its extension by last(i') merges with i'
     if (tid < nb) {
       int m = -1;
       if (L.len[tid] > 0) {
         const int pnode = L.par[tid];
-        int i2 = 0;
-        for (; i2 + 8 <= nb; i2 += 8) {
-          int nd[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) nd[u] = L.node[i2 + u];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) if (nd[u] == pnode) m = i2 + u;
+        if ((unsigned)pnode < (unsigned)a.max_nodes) {
+          const int sl = nslot[pnode];
+          if ((unsigned)sl < (unsigned)nb && L.node[sl] == pnode) m = sl;
         }
-        for (; i2 < nb; ++i2) if (L.node[i2] == pnode) m = i2;
       }
       mfrom[tid] = m;
     }
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         const int k = L.last[ip];
         const int kk = (k < blank) ? k + 1 : k;
         const int ce = i * V + kk;
+        cown[ce] = ip;
         const double pr = cand[ce];
         if (i < ip) { apply_ext(e, pr); apply_stay(e, s_nb, s_b); cand[ce] = e.t; cand[ip * V] = -INFINITY; }
         else        { apply_stay(e, s_nb, s_b); apply_ext(e, pr); cand[ip * V] = e.t; cand[ce] = -INFINITY; }
@@ -293,11 +306,15 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         unsigned long long p = 0ull;
         // (round 6: the low 20 bits of the key are not searched -- the result is a LOWER bound of the wave's k-th largest maximum either way, 2^-32
         // relative below it at most: a survivor more once in a while, 20 ballot steps fewer every frame)
-        for (int bit = 63; bit >= 20; --bit) {
-          const unsigned long long t = p | (1ull << bit);
-          int cnt = __popcll(__ballot(tk[0] >= t));
-          if (NH == 2) cnt += __popcll(__ballot(tk[NH - 1] >= t));
-          if (cnt >= kth) p = t;
+        // (last session of round 6: two bits per step -- the three thresholds of a step are independent ballots, so a step costs one VALU -> SALU ->
+        // VALU turnaround instead of two -- and bits 63 .. 28 only: 2^-24 relative below the k-th largest at most)
+        for (int bit = 62; bit >= 28; bit -= 2) {
+          const unsigned long long t1 = p | (1ull << bit), t2 = p | (2ull << bit), t3 = p | (3ull << bit);
+          int c1 = __popcll(__ballot(tk[0] >= t1)), c2 = __popcll(__ballot(tk[0] >= t2)), c3 = __popcll(__ballot(tk[0] >= t3));
+          if (NH == 2) {
+            c1 += __popcll(__ballot(tk[NH - 1] >= t1)); c2 += __popcll(__ballot(tk[NH - 1] >= t2)); c3 += __popcll(__ballot(tk[NH - 1] >= t3));
+          }
+          p = c3 >= kth ? t3 : (c2 >= kth ? t2 : (c1 >= kth ? t1 : p));
         }
         if (lane == 0) wthr[wave] = p;
       }
@@ -429,16 +446,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       } else {
         const int k = (kk - 1 < blank) ? kk - 1 : kk;
         int ip = -1;
-        {                                                            // (eight slots read before they are tested: independent LDS reads)
-          int j = 0;
-          for (; j + 8 <= nb; j += 8) {
-            int mf[8], ls[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { mf[u] = mfrom[j + u]; ls[u] = L.last[j + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (mf[u] == i && ls[u] == k) ip = j + u;
-          }
-          for (; j < nb; ++j) if (mfrom[j] == i && L.last[j] == k) ip = j;
+        {
+          const int ow = cown[c];
+          if ((unsigned)ow < (unsigned)nb && mfrom[ow] == i && L.last[ow] == k) ip = ow;
         }
         if (ip >= 0) {   // this slot holds the merged entry of existing labelling ip (first touched as an extension)
           N.node[tid] = L.node[ip]; N.len[tid] = L.len[ip]; N.last[tid] = L.last[ip]; N.par[tid] = L.par[ip];
@@ -465,6 +475,8 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
           N.pNB[tid] = pr; N.pB[tid] = LOG_ZERO; N.pT[tid] = pr;
         }
       }
+      const int nd = N.node[tid];
+      if ((unsigned)nd < (unsigned)a.max_nodes) nslot[nd] = tid;     // (step 2 of the next frame finds a parent labelling's slot here)
     }
     __syncthreads();
     GSTAMP(5);
@@ -1355,7 +1367,7 @@ __global__ __launch_bounds__(FAST_NTH) void beam_fast_kernel(FastArgs a) { beam_
 template <int NPT, bool LM_LDS>
 __global__ __launch_bounds__(FAST_NTH) __attribute__((amdgpu_waves_per_eu(8, 8))) void beam_fast_kernel_occ2(FastArgs a) { beam_fast_body<NPT, LM_LDS>(a); }
 
-struct BeamLayout { size_t keys, ids, npar, nsym, cand, total; int ht_size, max_nodes; };
+struct BeamLayout { size_t keys, ids, npar, nsym, cand, nslot, cown, total; int ht_size, max_nodes; };
 BeamLayout beam_layout(int T, int B, int V, int W) {
   BeamLayout l;
   l.max_nodes = W * T + 2;
@@ -1368,6 +1380,8 @@ BeamLayout beam_layout(int T, int B, int V, int W) {
   l.npar = off; off += align_up((size_t)B * l.max_nodes * sizeof(int), 256);
   l.nsym = off; off += align_up((size_t)B * l.max_nodes * sizeof(int), 256);
   l.cand = off; off += align_up((size_t)B * W * V * sizeof(double), 256);
+  l.nslot = off; off += align_up((size_t)B * l.max_nodes * sizeof(int), 256);
+  l.cown = off; off += align_up((size_t)B * W * V * sizeof(int), 256);
   l.total = off;
   return l;
 }
@@ -1491,6 +1505,7 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
     a.nbest = nbest; a.out_count = out_count;
   a.ht_keys = (unsigned long long *)(base + l.keys); a.ht_ids = (int *)(base + l.ids);
   a.node_par = (int *)(base + l.npar); a.node_sym = (int *)(base + l.nsym); a.cand_global = (double *)(base + l.cand);
+  a.node_slot = (int *)(base + l.nslot); a.cand_owner = (int *)(base + l.cown);
   a.ht_size = l.ht_size; a.max_nodes = l.max_nodes;
 #ifdef CTCN_BEAM_STATS
   if (!g_beam_stats_dev) { CTCN_HIP(hipMalloc(&g_beam_stats_dev, 64 * sizeof(long long))); }
