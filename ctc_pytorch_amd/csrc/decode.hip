@@ -135,6 +135,11 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
   // Neither table is initialised or stamped: a value is USED only if the slot it names passes the very test the scan applied (L.node[s] ==
   // pnode; mfrom[s] == i && L.last[s] == k), which at most one slot of a beam can pass -- and for a node / candidate that does have such a
   // slot the table was written this frame.  Anything else (stale, never written) fails the test exactly as the scan found nothing.
+  // c / V for candidate indices c < W * V: one multiply-high by ceil(2^32 / V) (exact while c * V < 2^32: W * V * V = 2^20 at the reference's width and vocabulary) -- the runtime
+  // division hipcc emits is ~25 instructions, and step 3a pays it per candidate: the kernel's parallel phases are instruction-issue bound
+  const unsigned vmagic = 0xffffffffu / (unsigned)V + 1u;
+  const bool vmagic_ok = (unsigned long long)W * V * V < (1ull << 32);         // (a vocabulary of thousands: the plain division)
+  auto div_v = [&](int c) { return vmagic_ok ? (int)__umulhi((unsigned)c, vmagic) : c / V; };
   int *nslot = a.node_slot + (size_t)b * a.max_nodes;
   int *cown = a.cand_owner + (size_t)b * W * V;
   const int htmask = a.ht_size - 1;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
 #pragma unroll
       for (int u = 0; u < EU; ++u) {
         const int c = min(c0 + u * NT, ncand - 1);
-        ci[u] = c / V;
+        ci[u] = div_v(c);
         const int kk = c - ci[u] * V;
         ck[u] = kk == 0 ? -1 : ((kk - 1 < blank) ? kk - 1 : kk);
         cln[u] = L.len[ci[u]]; cl[u] = L.last[ci[u]];
@@ -285,18 +290,20 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       constexpr int NH = NT >= 1024 ? 1 : 2;                   // maxima per thread
       unsigned long long tk[NH];
       int nval = 0;
+      {
+        // (last session of round 6: the maxima in the double domain -- one v_max_f64 per candidate; fmax drops a NaN as "v > -inf" does -- and
+        // ONE conversion to the order-preserving key at the end: the scans are instruction-issue bound, ~25 -> ~8 instructions per candidate)
+        double mx[NH];
 #pragma unroll
-      for (int h = 0; h < NH; ++h) tk[h] = 0ull;               // (no candidate: below every key of a finite value)
-      scan([&](double v, int c) {
-        if (v > -INFINITY) {
-          ++nval;
-          const unsigned long long key = dkey(v);
-          const bool hi = NH == 2 && ((c / NT) & 1);
-          const unsigned long long cur = hi ? tk[NH - 1] : tk[0], nk = key > cur ? key : cur;
-          tk[0] = hi ? tk[0] : nk;
-          if (NH == 2) tk[NH - 1] = hi ? nk : tk[NH - 1];
-        }
-      });
+        for (int h = 0; h < NH; ++h) mx[h] = -INFINITY;
+        scan([&](double v, int c) {
+          nval += v > -INFINITY ? 1 : 0;
+          if (NH == 2 && ((c / NT) & 1)) mx[NH - 1] = fmax(mx[NH - 1], v);
+          else mx[0] = fmax(mx[0], v);
+        });
+#pragma unroll
+        for (int h = 0; h < NH; ++h) tk[h] = mx[h] > -INFINITY ? dkey(mx[h]) : 0ull;      // (no candidate: below every key of a finite value)
+      }
       GSTAMP(8);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) nval += __shfl_xor(nval, o, 64);
@@ -357,21 +364,29 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       const bool prune = total > W && theta != 0ull;
       if (prune || total <= SEL_SMAX) {
         // one scan: a thread's first two survivors wait in registers (it rarely has more than one), a second scan only for a thread with more
-        int cnt = 0;
-        double kv0 = 0.0, kv1 = 0.0; int kc0 = 0, kc1 = 0;
+        // The bound as a double: dkey is an order-preserving bijection of the finite values, so dkey(v) >= theta <=> v >= thd (one
+        // v_cmp_ge_f64; a NaN fails both; theta >= 2^52 > dkey(-inf) whenever a finite maximum produced it, so "v > -inf" is implied).  Without
+        // a bound every finite candidate is ranked: v >= -DBL_MAX.  Only the INDICES of a thread's first two survivors wait in registers; their
+        // values are read again when they are stored.
+        double thd = -1.7976931348623157e308;
+        if (prune) {
+          const unsigned long long tb = (theta >> 63) ? (theta & 0x7fffffffffffffffull) : ~theta;
+          thd = __longlong_as_double((long long)tb);
+        }
+        int cnt = 0, kc0 = 0, kc1 = 0;
         scan([&](double v, int c) {
-          if (v > -INFINITY && (!prune || dkey(v) >= theta)) {
-            kv0 = cnt == 0 ? v : kv0; kc0 = cnt == 0 ? c : kc0;          // (selects: an if-chain becomes an indexed store into a stack array)
-            kv1 = cnt == 1 ? v : kv1; kc1 = cnt == 1 ? c : kc1;
+          if (v >= thd) {
+            kc0 = cnt == 0 ? c : kc0;
+            kc1 = cnt == 1 ? c : kc1;
             ++cnt;
           }
         });
         int pos = cnt ? atomicAdd(&s_scnt, cnt) : 0;
         if (pos + cnt > SEL_SMAX) s_ovf = 1;
         else if (cnt <= 2) {
-          if (cnt > 0) { sv_v[pos] = kv0; sv_i[pos] = kc0; }
-          if (cnt > 1) { sv_v[pos + 1] = kv1; sv_i[pos + 1] = kc1; }
-        } else scan([&](double v, int c) { if (v > -INFINITY && (!prune || dkey(v) >= theta)) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
+          if (cnt > 0) { sv_v[pos] = cand[kc0]; sv_i[pos] = kc0; }
+          if (cnt > 1) { sv_v[pos + 1] = cand[kc1]; sv_i[pos + 1] = kc1; }
+        } else scan([&](double v, int c) { if (v >= thd) { sv_v[pos] = v; sv_i[pos] = c; ++pos; } });
         __syncthreads();
         GSTAMP(10);
 #ifdef CTCN_BEAM_STATS
@@ -381,10 +396,10 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
           // P threads per survivor (a power of two, neighbouring lanes), thread part p counts among the survivors p, p + P, ...; eight entries
           // are read before they are compared (a loop of dependent LDS reads costs a full LDS latency per entry); butterfly sum over the P lanes
           const int S = s_scnt;
-          int P = 1;
-          while (2 * P * S <= NT && P < 16) P *= 2;
-          for (int e0 = 0; e0 < S; e0 += NT / P) {
-            const int e = e0 + tid / P, part = tid & (P - 1);
+          int P = 1, lgP = 0;
+          while (2 * P * S <= NT && P < 16) { P *= 2; ++lgP; }
+          for (int e0 = 0; e0 < S; e0 += NT >> lgP) {
+            const int e = e0 + (tid >> lgP), part = tid & (P - 1);
             const bool have = e < S;
             const double mv = sv_v[have ? e : 0]; const int mi = sv_i[have ? e : 0];
             constexpr int RU = NT >= 1024 ? 4 : 8;
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
     // 5. materialise the new beam
     if (tid < m) {
       const int c = sel[tid];
-      const int i = c / V, kk = c - i * V;
+      const int i = div_v(c), kk = c - i * V;
       if (kk == 0) {
         N.node[tid] = L.node[i]; N.len[tid] = L.len[i]; N.last[tid] = L.last[i]; N.par[tid] = L.par[i];
         N.pNB[tid] = sNB[i]; N.pB[tid] = sB[i]; N.pT[tid] = sT[i];
