@@ -86,6 +86,34 @@ __device__ __forceinline__ unsigned long long dkey(double v) {
   return (bts >> 63) ? ~bts : (bts | 0x8000000000000000ull);
 }
 
+// Sum / 64-bit maximum over each row of 16 lanes by DPP (no LDS crossbar: a ds_bpermute butterfly is a chain of ~150-cycle hops under load);
+// afterwards every lane of a row holds the row's result
+__device__ __forceinline__ int row16_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);    // row_mirror
+  return v;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64_step(unsigned long long x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x & 0xffffffffull), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), CTRL, 0xf, 0xf, true);
+  const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+  return o > x ? o : x;
+}
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long x) {
+  x = dpp_max_u64_step<0xB1>(x);
+  x = dpp_max_u64_step<0x4E>(x);
+  x = dpp_max_u64_step<0x141>(x);
+  x = dpp_max_u64_step<0x140>(x);
+  return x;
+}
+__device__ __forceinline__ int wave_sum_rows(int v) {               // wave-wide sum, uniform result
+  v = row16_sum(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 // NT threads per utterance: 256 for small tables, 1 024 beyond W = 64 or 3 500 candidates per frame (round 5: every phase of a frame is a loop over nb * V candidates or over the beam, and the
 // kernel ran one wave per SIMD -- nothing hid an LDS or L2 latency)
 template <int NT>
@@ -305,8 +333,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         for (int h = 0; h < NH; ++h) tk[h] = mx[h] > -INFINITY ? dkey(mx[h]) : 0ull;      // (no candidate: below every key of a finite value)
       }
       GSTAMP(8);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) nval += __shfl_xor(nval, o, 64);
+      nval = wave_sum_rows(nval);
       if (lane == 0) red_i[wave] = nval;
       {
         const int kth = (W + NWV - 1) / NWV;
@@ -351,14 +378,11 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         total = lane < NWV ? red_i[jl] : 0;
       }
       unsigned long long theta = (lane < NWV && reach >= W) ? tj : 0ull;
-#pragma unroll
-      for (int o = 1; o < NWV; o <<= 1) {
-        total += __shfl_xor(total, o, 64);
-        const unsigned long long ot = __shfl_xor(theta, o, 64);
-        theta = ot > theta ? ot : theta;
-      }
-      total = __shfl(total, 0, 64);
-      theta = __shfl(theta, 0, 64);
+      static_assert(NWV <= 16, "the waves' bounds sit in the first row of 16 lanes");
+      total = __builtin_amdgcn_readfirstlane(row16_sum(total));
+      theta = row16_max_u64(theta);
+      theta = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(theta >> 32)) << 32) |
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(theta & 0xffffffffull));
       GSTAMP(9);
       // (no candidate bound that W maxima reach -- the first frames, when the beam is still narrow --: then everything valid is ranked, if it fits)
       const bool prune = total > W && theta != 0ull;
@@ -381,8 +405,22 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
             ++cnt;
           }
         });
-        int pos = cnt ? atomicAdd(&s_scnt, cnt) : 0;
-        if (pos + cnt > SEL_SMAX) s_ovf = 1;
+        // one atomic per WAVE (a thread rarely keeps more than two survivors: then its position follows from two ballots; a wave with such a
+        // thread takes the per-thread atomics) -- ~225 same-address LDS atomics per frame were a serial chain in front of the barrier
+        int pos = 0;
+        {
+          const unsigned long long b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3);
+          if (b3 == 0ull) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int wtot = __popcll(b1) + __popcll(b2);
+            int wbase = 0;
+            if (lane == 0 && wtot > 0) wbase = atomicAdd(&s_scnt, wtot);
+            pos = __builtin_amdgcn_readfirstlane(wbase) + __popcll(b1 & below) + __popcll(b2 & below);
+          } else {
+            pos = cnt ? atomicAdd(&s_scnt, cnt) : 0;
+          }
+        }
+        if (cnt && pos + cnt > SEL_SMAX) s_ovf = 1;
         else if (cnt <= 2) {
           if (cnt > 0) { sv_v[pos] = cand[kc0]; sv_i[pos] = kc0; }
           if (cnt > 1) { sv_v[pos + 1] = cand[kc1]; sv_i[pos + 1] = kc1; }
