@@ -55,6 +55,7 @@ static int g_opt_bn_rows4 = 1;          // BatchNorm over (T*B, C) rows: column 
 static int g_opt_tn_splits_force = 0;   // development (tools/gemm_tn_bench.py): split-K count of the TN tile, 0 = the rule of gemm.hip:tn_splits
 static int g_opt_tn_splits_xcd = 1;     // TN weight-gradient tile: split count sized for the CUs of xcd_allow (one round of items there), not for the whole device
 static int g_opt_beam_generic_threads = 0;  // generic beam kernel: 0 = 256 threads per utterance up to W = 64 and 1 024 beyond; 256 / 512 / 1024 = forced
+static int g_opt_beam_bitonic = 1;      // generic beam kernel: 1 = up to 256 survivors of the pruning bound are ranked by a bitonic sort; 0 = by counting pairs (rounds 5-6)
 static int g_opt_beam_cand_global = 0;  // generic beam kernel: 1 = the candidate table stays in global memory (L2) even where LDS would hold it (the LM table takes the room; two 512-thread searches per CU then fit)
 static int g_opt_beam_occ2 = 0;         // fast beam search compiled / launched for TWO workgroups per CU (<= 64 VGPRs, <= 80 KB LDS): 0 off, 1 on, 2 on with the LM in global memory
 static int g_opt_beam_fast = 1;         // 1: restructured beam search (W <= 60, W*V <= 3328); 0: the generic kernel always
@@ -86,6 +87,7 @@ static const OptionRow k_options[] = {
   {"gemm_bf16_single", &g_opt_gemm_bf16_single, [](int value) -> int { return value ? 1 : 0; }},
   {"beam_generic_threads", &g_opt_beam_generic_threads, [](int value) -> int { return (value == 256 || value == 512 || value == 1024) ? value : 0; }},
   {"beam_cand_global", &g_opt_beam_cand_global, [](int value) -> int { return value ? 1 : 0; }},
+  {"beam_bitonic", &g_opt_beam_bitonic, [](int value) -> int { return value ? 1 : 0; }},
   {"beam_occ2", &g_opt_beam_occ2, [](int value) -> int { return value < 0 ? 0 : (value > 2 ? 2 : value); }},
   {"fwd_pipe_min_input", &g_opt_fwd_pipe_min_input, [](int value) -> int { return value < 0 ? 0 : value; }},
   {"fwd_pipe_any_chunking", &g_opt_fwd_pipe_any_chunking, [](int value) -> int { return value ? 1 : 0; }},

@@ -67,6 +67,7 @@ struct BeamArgs {
   int *node_slot, *cand_owner;   // beam_kernel: beam slot of a trie node / beam slot whose labelling merges with a candidate (lookups that replace scans of the beam)
   int ht_size, max_nodes, cand_in_lds;
   int wcap, smax;       // beam_kernel: capacity of the beam-state arrays (W rounded up to 64) and of the selection's survivor list
+  int bitonic;          // beam_kernel: rank up to 256 survivors by a bitonic sort (option beam_bitonic, default 1) instead of counting pairs
   int lm_in_lds;        // beam_kernel: the (V+1)^2 ln-prob table is copied into dynamic LDS behind the state arrays (when the launch's budget holds it)
 #ifdef CTCN_BEAM_STATS
   long long *stats;     // development instrumentation (tools/mb_beam.py generic): cycles per phase of workgroup 0, thread 0
@@ -112,6 +113,36 @@ __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long x
 __device__ __forceinline__ int wave_sum_rows(int v) {               // wave-wide sum, uniform result
   v = row16_sum(v);
   return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+// Lane i <- lane i ^ J of a 32-bit value without the LDS crossbar: DPP quad permutes / row rotation inside a row of 16 lanes, the gfx950
+// v_permlane16_swap / v_permlane32_swap across rows and halves (swap(x, x): result 0 holds the lower partner's rows, result 1 the upper's).
+// J = 4 has no single pattern: both row shifts by 4 are taken and `pick_shl` (probed once by the caller: which of the two reads lane i ^ 4)
+// selects.
+template <int J>
+__device__ __forceinline__ unsigned xor_lane(unsigned x, int lane, bool pick_shl) {
+  if (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+  if (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+  if (J == 4) {
+    const unsigned a = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0xf, true);    // row_shl:4
+    const unsigned c = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    return pick_shl ? a : c;
+  }
+  if (J == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);      // row_ror:8
+  if (J == 16) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); return (lane & 16) ? r[0] : r[1]; }
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return (lane & 32) ? r[0] : r[1];
+}
+// one compare-exchange step of the bitonic network on (64-bit key descending, index ascending) elements, partner lane ^ J; `keep_better`:
+// this lane keeps the better element of the pair.  Equal elements (only the padding) may swap: they are identical.
+template <int J>
+__device__ __forceinline__ void bitonic_step(unsigned &khi, unsigned &klo, int &ix, bool keep_better, int lane, bool pick_shl) {
+  const unsigned ohi = xor_lane<J>(khi, lane, pick_shl), olo = xor_lane<J>(klo, lane, pick_shl);
+  const int oi = (int)xor_lane<J>((unsigned)ix, lane, pick_shl);
+  const unsigned long long k = ((unsigned long long)khi << 32) | klo, ok = ((unsigned long long)ohi << 32) | olo;
+  const bool other_better = ok > k || (ok == k && oi < ix);
+  const bool take = other_better == keep_better;
+  khi = take ? ohi : khi; klo = take ? olo : klo; ix = take ? oi : ix;
 }
 
 // NT threads per utterance: 256 for small tables, 1 024 beyond W = 64 or 3 500 candidates per frame (round 5: every phase of a frame is a loop over nb * V candidates or over the beam, and the
@@ -434,6 +465,49 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
           // P threads per survivor (a power of two, neighbouring lanes), thread part p counts among the survivors p, p + P, ...; eight entries
           // are read before they are compared (a loop of dependent LDS reads costs a full LDS latency per entry); butterfly sum over the P lanes
           const int S = s_scnt;
+          if (S <= 256 && a.bitonic) {
+            // (last session of round 6) Up to 256 survivors -- the reference's W = 200 leaves ~1.1 W -- are SORTED, one per thread of waves 0-3, by a
+            // bitonic network under the same strict order cand_better() (value descending, candidate index ascending; the padding compares
+            // equal to itself and worse than every survivor, so it never moves in front of one): 36 compare-exchange steps, 33 of them inside a
+            // wave, instead of S^2 = 50 000 comparisons through ~1 800 LDS reads per frame.  Position r of the sorted row IS rank r.
+            unsigned khi = 0u, klo = 0u; int ix = 0x7fffffff;       // (padding: key 0 is below the key of every finite value)
+            const bool act = wave < 4;                          // (scalar: the other waves only join the barriers of the three cross-wave steps)
+            if (act && tid < S) { const unsigned long long k0 = dkey(sv_v[tid]); khi = (unsigned)(k0 >> 32); klo = (unsigned)k0; ix = sv_i[tid]; }
+            const bool pick_shl = (unsigned)__builtin_amdgcn_update_dpp(-1, lane, 0x104, 0xf, 0xf, false) == (unsigned)(lane ^ 4);
+            unsigned *const xk = reinterpret_cast<unsigned *>(sv_v);     // cross-wave steps: (key hi, key lo) pairs | indices in the survivor arrays
+            // element tid of a K-block keeps the better of a pair iff (it is the lower partner) == (its block ends best-first)
+#define CTCN_BSTEP(J, K) bitonic_step<J>(khi, klo, ix, ((tid & (J)) == 0) == ((tid & (K)) == 0), lane, pick_shl)
+            auto lds_step = [&](int j, int k) {
+              if (act) { xk[2 * tid] = khi; xk[2 * tid + 1] = klo; sv_i[tid] = ix; }
+              __syncthreads();
+              if (act) {
+                const int pt = tid ^ j;
+                const unsigned ohi = xk[2 * pt], olo = xk[2 * pt + 1]; const int oi = sv_i[pt];
+                const unsigned long long kk = ((unsigned long long)khi << 32) | klo, ok = ((unsigned long long)ohi << 32) | olo;
+                const bool other_better = ok > kk || (ok == kk && oi < ix);
+                const bool take = other_better == (((tid & j) == 0) == ((tid & k) == 0));
+                khi = take ? ohi : khi; klo = take ? olo : klo; ix = take ? oi : ix;
+              }
+              __syncthreads();
+            };
+            auto tail = [&](int k) {                           // the in-wave steps j = 32 .. 1 of block size k >= 64
+              if (act) { CTCN_BSTEP(32, k); CTCN_BSTEP(16, k); CTCN_BSTEP(8, k); CTCN_BSTEP(4, k); CTCN_BSTEP(2, k); CTCN_BSTEP(1, k); }
+            };
+            if (act) {
+              CTCN_BSTEP(1, 2);
+              CTCN_BSTEP(2, 4); CTCN_BSTEP(1, 4);
+              CTCN_BSTEP(4, 8); CTCN_BSTEP(2, 8); CTCN_BSTEP(1, 8);
+              CTCN_BSTEP(8, 16); CTCN_BSTEP(4, 16); CTCN_BSTEP(2, 16); CTCN_BSTEP(1, 16);
+              CTCN_BSTEP(16, 32); CTCN_BSTEP(8, 32); CTCN_BSTEP(4, 32); CTCN_BSTEP(2, 32); CTCN_BSTEP(1, 32);
+            }
+            tail(64);
+            lds_step(64, 128); tail(128);
+            lds_step(128, 256); lds_step(64, 256); tail(256);
+#undef CTCN_BSTEP
+            // (lds_step ends with a barrier: the exchange area is free again; the value is read back from the candidate table, which this
+            // path leaves untouched -- bit for bit the double that was scored, where inverting the key would fold -0.0 onto +0.0)
+            if (act && tid < S && tid < W) { sel[tid] = ix; selv[tid] = cand[ix]; }
+          } else {
           int P = 1, lgP = 0;
           while (2 * P * S <= NT && P < 16) { P *= 2; ++lgP; }
           for (int e0 = 0; e0 < S; e0 += NT >> lgP) {
@@ -452,6 +526,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
             for (; q < S; q += P) rank += cand_better(sv_v[q], sv_i[q], mv, mi) ? 1 : 0;
             for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o, 64);
             if (have && part == 0 && rank < W) { sel[rank] = mi; selv[rank] = mv; }
+          }
           }
           m = min(W, total);
           ranked = true;
@@ -1587,6 +1662,7 @@ extern "C" int ctcn_beam_decode_nbest(const float *x, int input_is_prob, const i
   // round 5, whose rule was 32 KB), then the LM table (31.7 KB at V = 62)
   const size_t lm_bytes = (size_t)(V + 1) * (V + 1) * sizeof(double) + 8;
   const size_t fixed = fa.sharedSizeBytes + row_bytes + state_bytes + 256;
+  a.bitonic = ctcn_get_option("beam_bitonic");
   a.cand_in_lds = (fixed + cand_bytes <= (size_t)lds_max && !ctcn_get_option("beam_cand_global")) ? 1 : 0;
   a.lm_in_lds = fixed + (a.cand_in_lds ? cand_bytes : 0) + lm_bytes <= (size_t)lds_max ? 1 : 0;
   const size_t sm = row_bytes + state_bytes + (a.cand_in_lds ? cand_bytes : 0) + (a.lm_in_lds ? lm_bytes : 0);
