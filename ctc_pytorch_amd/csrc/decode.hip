@@ -133,15 +133,19 @@ __device__ __forceinline__ unsigned xor_lane(unsigned x, int lane, bool pick_shl
   const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
   return (lane & 32) ? r[0] : r[1];
 }
+// (key a, index ia) sorts before (key b, index ib): key descending, index ascending.  (A 96-bit subtract-with-borrow chain through
+// __builtin_subc was measured: slower than what hipcc makes of the two 64-bit compares.)
+__device__ __forceinline__ bool elem_before(unsigned ahi, unsigned alo, int ia, unsigned bhi, unsigned blo, int ib) {
+  const unsigned long long ka = ((unsigned long long)ahi << 32) | alo, kb = ((unsigned long long)bhi << 32) | blo;
+  return ka > kb || (ka == kb && ia < ib);
+}
 // one compare-exchange step of the bitonic network on (64-bit key descending, index ascending) elements, partner lane ^ J; `keep_better`:
 // this lane keeps the better element of the pair.  Equal elements (only the padding) may swap: they are identical.
 template <int J>
 __device__ __forceinline__ void bitonic_step(unsigned &khi, unsigned &klo, int &ix, bool keep_better, int lane, bool pick_shl) {
   const unsigned ohi = xor_lane<J>(khi, lane, pick_shl), olo = xor_lane<J>(klo, lane, pick_shl);
   const int oi = (int)xor_lane<J>((unsigned)ix, lane, pick_shl);
-  const unsigned long long k = ((unsigned long long)khi << 32) | klo, ok = ((unsigned long long)ohi << 32) | olo;
-  const bool other_better = ok > k || (ok == k && oi < ix);
-  const bool take = other_better == keep_better;
+  const bool take = elem_before(ohi, olo, oi, khi, klo, ix) == keep_better;
   khi = take ? ohi : khi; klo = take ? olo : klo; ix = take ? oi : ix;
 }
 
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
     const int ncand = nb * V;
     // (four candidates per trip with 256 threads -- two with 1 024 --: the slot reads, then the LM gathers -- global memory -- of all four are issued before the first is used; the same
     // expression per candidate)
-    constexpr int EU = NT >= 1024 ? 2 : 4;
+    constexpr int EU = 4;                 // (candidates per trip: a trip is one round trip to the LM table in L2; W = 200 at 1 024 threads: 4 trips, was 7 with two per trip)
     for (int c0 = tid; c0 < ncand; c0 += EU * NT) {
       int ci[EU], ck[EU], cl[EU], cln[EU];
       double lmv[EU];
@@ -483,9 +487,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
               if (act) {
                 const int pt = tid ^ j;
                 const unsigned ohi = xk[2 * pt], olo = xk[2 * pt + 1]; const int oi = sv_i[pt];
-                const unsigned long long kk = ((unsigned long long)khi << 32) | klo, ok = ((unsigned long long)ohi << 32) | olo;
-                const bool other_better = ok > kk || (ok == kk && oi < ix);
-                const bool take = other_better == (((tid & j) == 0) == ((tid & k) == 0));
+                const bool take = elem_before(ohi, olo, oi, khi, klo, ix) == (((tid & j) == 0) == ((tid & k) == 0));
                 khi = take ? ohi : khi; klo = take ? olo : klo; ix = take ? oi : ix;
               }
               __syncthreads();

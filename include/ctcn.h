@@ -118,11 +118,13 @@ int ctcn_device_xcds(void);
  * as an experiment switch.
  * "beam_generic_threads" = 0 (default): the generic beam kernel runs 256 threads per utterance, 1 024 beyond W = 64 or 3 500 candidates per frame;
  * 256 / 512 / 1024 force one (measurements).
+ * "beam_bitonic" = 1 (default): the generic beam kernel ranks up to 256 survivors of its pruning bound (the reference's W = 200 leaves ~1.1 W) by a
+ * bitonic sort on waves 0-3 (DPP / v_permlane swaps); 0 = by counting pairs, as it does for more survivors.  Same labellings and scores.
  * "beam_cand_global" = 0 (default): 1 keeps the generic kernel's candidate table in global memory (L2) even where the LDS would hold it; the LM
  * table takes the room.  With "beam_generic_threads" = 512 two searches of the reference-default width then share a CU (116 VGPRs, 77 KB of
- * LDS each).  Same results bit for bit (test_beam_generic_kernel_occupancy_options).  Measured (cfg5, W = 200, profiles/r06_wide_beam_probe.txt):
- * +13 % / +22 % utterances/s (peaky / flat) with twelve searches in flight, -13 % with three, one batch 14 % slower -- an opt-in for offline
- * decoding with many batches in flight, not the default.
+ * LDS each).  Same results bit for bit (test_beam_generic_kernel_occupancy_options).  Measured on the kernel as it stood at the start of the
+ * round's last session (cfg5, W = 200, profiles/r06_wide_beam_probe.txt): +13 % / +22 % utterances/s (peaky / flat) with twelve searches in
+ * flight, -13 % with three, one batch 14 % slower -- an opt-in for offline decoding with many batches in flight, not the default.
  * "rnn_rsv_nt" = 0 (default): 1 puts the non-temporal hint on rnn_bwd_scatter2's reserve loads / stores (experiment: -15 % L2 write-backs at H = 512, no
  * change of the step).
  * "conv_dbg" = 0 (default): development only (tools/conv_phase_probe.py) -- conv_mfma_kernel skips its window load (1), MFMA loop (2) and /

@@ -2202,11 +2202,13 @@ def test_beam_wide_vs_c_oracle(dev, regime, W):
 
 
 @pytest.mark.parametrize("regime", ["peaky", "flat"])
-@pytest.mark.parametrize("W,threads,cand_global", [(200, 512, 1), (200, 512, 0), (200, 1024, 1), (61, 512, 1), (300, 512, 1), (200, 256, 1)])
-def test_beam_generic_kernel_occupancy_options(dev, regime, W, threads, cand_global):
+@pytest.mark.parametrize("W,threads,cand_global,bitonic", [(200, 512, 1, 1), (200, 512, 0, 1), (200, 1024, 1, 1), (61, 512, 1, 1), (300, 512, 1, 1), (200, 256, 1, 1),
+                                                             (200, 0, 0, 0), (128, 0, 0, 0), (200, 512, 1, 0)])
+def test_beam_generic_kernel_occupancy_options(dev, regime, W, threads, cand_global, bitonic):
     """The generic search at other thread counts / candidate-table placements (options beam_generic_threads = 512, beam_cand_global: two
-    512-thread searches per CU -- tools/wide_beam_probe.py) returns the labellings, status words and float64 scores
-    of the C oracle and, bit for bit, of the default configuration."""
+    512-thread searches per CU -- tools/wide_beam_probe.py) and with its survivors ranked by pair counts instead of
+    the bitonic sort (beam_bitonic = 0) returns the labellings, status words and float64 scores of the C oracle and, bit for bit, of the
+    default configuration."""
     from ctc_pytorch_amd import ops
     from ctc_pytorch_amd.utils.NgramLM import LanguageModel
     V, T, B = 62, 120, 6
@@ -2219,11 +2221,13 @@ def test_beam_generic_kernel_occupancy_options(dev, regime, W, threads, cand_glo
     base = ops.beam_decode(probs.to(dev), lens, tab, 0.01, W, 0, input_is_prob=True)
     ops.set_option("beam_generic_threads", threads)
     ops.set_option("beam_cand_global", cand_global)
+    ops.set_option("beam_bitonic", bitonic)
     try:
         got, score, st = ops.beam_decode(probs.to(dev), lens, tab, 0.01, W, 0, input_is_prob=True)
     finally:
         ops.set_option("beam_generic_threads", 0)
         ops.set_option("beam_cand_global", 0)
+        ops.set_option("beam_bitonic", 1)
     assert list(st) == list(wst) and got == [list(map(int, s_)) for s_ in want]
     assert np.all(np.abs(np.asarray(score) - np.asarray(wscore)) <= 4 * np.spacing(np.abs(np.asarray(wscore))))
     assert got == base[0] and np.array_equal(np.asarray(score), np.asarray(base[1])) and list(st) == list(base[2])
