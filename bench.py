@@ -803,11 +803,11 @@ def decode_leg(dev, steps=5):
     i2c = synth.int2char(V)
     arpa = os.path.join(ROOT, "tests", "golden", "lm_phone_bg.arpa")
     tab = LanguageModel(arpa).table([i2c[i] for i in range(V)])
-    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM alpha=0.1, 128 x 800 x 62 log-probs in HBM; two batches in flight, results handed to the host and assembled into phone strings)", "unit": "utt/s", "n_gpus": 1,
+    NS = int(os.environ.get("CTCN_DECODE_STREAMS", "3"))              # searches in flight, one stream each, as steps/test_ctc.decode_and_score runs them
+    out = {"metric": "utterances/sec beam-decode (W=20, bigram LM alpha=0.1, 128 x 800 x 62 log-probs in HBM; %d searches in flight, results handed to the host and assembled into phone strings)" % NS, "unit": "utt/s", "n_gpus": 1,
            "config": {"workload": "cfg5: BeamDecoder W=20 + phone bigram LM over 128 utterances x 800 frames x 62 classes, lens U{400..800}"},
            "regimes": {}}
     tab_dev = torch.as_tensor(tab, dtype=torch.float64).to(dev)
-    NS = int(os.environ.get("CTCN_DECODE_STREAMS", "3"))              # searches in flight, one stream each, as steps/test_ctc.decode_and_score runs them
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     for regime in ("peaky", "flat"):
         lp = synth.make_logprobs(seed=7, T=T, B=B, V=V, regime=regime)
@@ -826,7 +826,7 @@ def decode_leg(dev, steps=5):
         ids_c, len_c = dev_out[0].cpu(), dev_out[1].cpu()                   # host hand-over of the last batch (synchronises)
         dt1 = (time.perf_counter() - t0) / steps
         kernel_us = e0.elapsed_time(e1) * 1e3 / steps
-        # ... and the way steps/test_ctc.decode_and_score runs it: two batches in flight on two streams (a batch is one workgroup per
+        # ... and the way steps/test_ctc.decode_and_score runs it: NS batches in flight on NS streams (a batch is one workgroup per
         # utterance = half of the CUs), every batch handed to the host through pinned memory (ops.beam_decode_async)
         nfl = 16 * max(steps, 4)
         warm = []
