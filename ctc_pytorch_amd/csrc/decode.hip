@@ -373,11 +373,11 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
       {
         const int kth = (W + NWV - 1) / NWV;
         unsigned long long p = 0ull;
-        // (round 6: the low 20 bits of the key are not searched -- the result is a LOWER bound of the wave's k-th largest maximum either way, 2^-32
-        // relative below it at most: a survivor more once in a while, 20 ballot steps fewer every frame)
-        // (last session of round 6: two bits per step -- the three thresholds of a step are independent ballots, so a step costs one VALU -> SALU ->
-        // VALU turnaround instead of two -- and bits 63 .. 28 only: 2^-24 relative below the k-th largest at most)
-        for (int bit = 62; bit >= 28; bit -= 2) {
+        // Bitwise search, two bits per step (the three thresholds of a step are independent ballots), bits 63 .. 36 only: the result is a LOWER
+        // bound of the wave's k-th largest maximum either way, 2^-16 relative below it at most -- the survivor count did not move (225 | 207 per
+        // frame at W = 200) while the search is the most instruction-heavy part of the bound phase, which is issue-bound (sixteen waves at once:
+        // the first barrier waits ~3 000 cycles for the slowest wave's scan + search): 14 steps instead of 18, 44 in round 5.
+        for (int bit = 62; bit >= 36; bit -= 2) {
           const unsigned long long t1 = p | (1ull << bit), t2 = p | (2ull << bit), t3 = p | (3ull << bit);
           int c1 = __popcll(__ballot(tk[0] >= t1)), c2 = __popcll(__ballot(tk[0] >= t2)), c3 = __popcll(__ballot(tk[0] >= t3));
           if (NH == 2) {
@@ -388,7 +388,9 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         if (lane == 0) wthr[wave] = p;
       }
       if (tid == 0) { s_scnt = 0; s_ovf = 0; }
+      GSTAMP(12);
       __syncthreads();
+      GSTAMP(13);
       // the waves' values are NWV candidate bounds; the smallest is always valid, a larger one is valid whenever W of ALL the maxima still reach
       // it: every wave counts its own maxima against every candidate (NWV ballots), the largest candidate with a block-wide count >= W wins --
       // the survivors drop from ~1.9 W to ~1.2 W at W = 200, and a wave that has no k candidates (narrow beam) no longer voids the bound.
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(NT) void beam_kernel(BeamArgs a) {
         mycnt = lane == j ? (t != 0ull ? cnt : 0) : mycnt;
       }
       if (lane < NWV) wcnt[wave][lane] = mycnt;
+      GSTAMP(14);
       __syncthreads();
       int reach = 0, total = 0;
       {

@@ -93,12 +93,14 @@ def run_generic(regime, W):
     nfl = max(st[48], 1)
     names = ["loop top (skip test, pointers)", "ln p of the frame + parent slots (table lookup) + barrier", "extension scores + barrier", "stay entries / merges + barrier",
              "selection (maxima, bound, compaction, rank count | arg-max rounds)", "new beam (trie lookups / inserts) + barrier"]
-    print("%s W=%d generic kernel, workgroup 0: %d processed frames, %.0f cycles per frame" % (regime, W, nfl, (sum(st[32 + i] for i in range(6)) + sum(st[40 + i] for i in range(4))) / nfl))
+    print("%s W=%d generic kernel, workgroup 0: %d processed frames, %.0f cycles per frame" % (regime, W, nfl, (sum(st[32 + i] for i in range(6)) + sum(st[40 + i] for i in range(7))) / nfl))
     for i, n in enumerate(names):
         print("    %-70s %9.0f cycles/frame" % (n, st[32 + i] / nfl))
-    for i, n in enumerate(["selection: scan for the maxima per thread", "selection: wave-local k-th largest (ballot search) -> bound (+ two barriers)", "selection: count + compact the survivors (two scans, + barrier)",
+    for i, n in enumerate(["selection: scan for the maxima per thread", "selection: bound, rest (second barrier, block-wide counts, theta; the three parts below come on top)", "selection: count + compact the survivors (two scans, + barrier)",
                            "selection: survivors sorted (bitonic, <= 256) | pair counts (+ barrier)"]):
         print("    %-70s %9.0f cycles/frame" % (n, st[40 + i] / nfl))
+    for i, n in enumerate(["  bound: wave sum of the counts + the wave's ballot search", "  bound: waiting at the first barrier (the slowest wave's scan + search)", "  bound: the waves' bounds against this wave's maxima (16 ballots)"]):
+        print("    %-70s %9.0f cycles/frame" % (n, st[44 + i] / nfl))
     print("    survivors of the pruning bound per frame %.0f; frames whose survivors overflowed into the arg-max rounds %d" % (st[38] / nfl, st[39]))
 
 
