@@ -893,14 +893,16 @@ def relu(x):
 # dropout
 # --------------------------------------------------------------------------------------------------
 _drop_counter = [0]
+_drop_lock = __import__("threading").Lock()
 
 
 def _next_dropout_stream(n):
     """(seed, offset): seed follows torch.manual_seed (+ rank so that DP shards decorrelate); the offset
     advances by the number of Philox groups consumed so that successive calls never reuse counters."""
     seed = (torch.initial_seed() ^ (0x9E3779B97F4A7C15 * (1 + _rank()))) & 0xFFFFFFFFFFFFFFFF
-    off = _drop_counter[0]
-    _drop_counter[0] += (n + 3) // 4
+    with _drop_lock:        # (two models stepping in two threads of one process share the stream: no two calls may take the same offsets)
+        off = _drop_counter[0]
+        _drop_counter[0] += (n + 3) // 4
     return seed, off
 
 

@@ -103,6 +103,30 @@ def test_state_dict_surface_matches_reference_keys():
         assert set(pkg) == {"rnn_param", "add_cnn", "cnn_param", "num_class", "_drop_out", "state_dict", "epoch"}
 
 
+def test_dropout_stream_offsets_are_disjoint_across_threads():
+    """The Philox offsets of the dropout calls of one process (ops._next_dropout_stream) come from ONE counter: calls racing from several threads
+    (two models in one process; the autograd thread next to the main thread) must never be handed overlapping counter ranges -- the same
+    mask twice (the Python layer's process-wide state)."""
+    import threading
+    from ctc_pytorch_amd import ops
+    snap = ops._drop_counter[0]
+    try:
+        ops._drop_counter[0] = 0
+        got, sizes = [[] for _ in range(8)], [7, 64, 1001, 4, 13, 250, 3, 96]
+        def work(k):
+            for i in range(4000):
+                n = sizes[(k + i) % 8]
+                got[k].append((ops._next_dropout_stream(n)[1], (n + 3) // 4))
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        spans = sorted(sp for g in got for sp in g)
+        assert all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))          # contiguous, none handed out twice
+        assert spans[0][0] == 0 and spans[-1][0] + spans[-1][1] == ops._drop_counter[0]
+    finally:
+        ops._drop_counter[0] = snap
+
+
 def test_layer_cnn_one_element_kernel_branch_surface():
     """LayerCNN's Conv1d / BatchNorm1d / MaxPool1d branch (reference model_ctc.py:48-50, 54-55): the module tree and the state_dict (keys, order,
     the (Co, Ci, k) weight shape) are the reference's -- tests/golden/layer_cnn1d.npz holds its state_dict -- and the torch-CPU stack of the
